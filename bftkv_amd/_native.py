@@ -1,0 +1,243 @@
+"""ctypes binding of libbftkv_gpu.so (include/bftkv_gpu.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is present, loading /
+``Context()`` raises.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbftkv_gpu.so")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class PubKey(C.Structure):
+    _fields_ = [("key_id", C.c_uint64), ("entity_id", C.c_uint64), ("pk_algo", C.c_uint8),
+                ("usable_sign", C.c_uint8), ("reserved", C.c_uint8 * 6),
+                ("n", C.c_void_p), ("n_len", C.c_uint32), ("e", C.c_void_p), ("e_len", C.c_uint32),
+                ("g", C.c_void_p), ("g_len", C.c_uint32), ("y", C.c_void_p), ("y_len", C.c_uint32)]
+
+
+class QC(C.Structure):
+    _fields_ = [("f", C.c_int32), ("min", C.c_int32), ("threshold", C.c_int32), ("suff", C.c_int32),
+                ("node_ids", C.c_void_p), ("n_nodes", C.c_uint32)]
+
+
+EXPORTS = [
+    "bftkv_gpu_init", "bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string",
+    "bftkv_gpu_keyring_set", "bftkv_gpu_quorum_create", "bftkv_gpu_quorum_destroy",
+    "bftkv_gpu_collective_verify", "bftkv_gpu_collective_verify_dev", "bftkv_gpu_sync",
+    "bftkv_gpu_signature_verify", "bftkv_gpu_last_statuses", "bftkv_gpu_last_counters",
+    "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
+    "bftkv_gpu_stream",
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; raises NativeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("%s not built -- run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64p, u8p = C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p
+    lib.bftkv_gpu_init.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.bftkv_gpu_destroy.argtypes = [vp]
+    lib.bftkv_gpu_destroy.restype = None
+    lib.bftkv_gpu_last_error.argtypes = [vp]
+    lib.bftkv_gpu_last_error.restype = C.c_char_p
+    lib.bftkv_gpu_error_string.argtypes = [C.c_int]
+    lib.bftkv_gpu_error_string.restype = C.c_char_p
+    lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
+    lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
+    lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
+    lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p]
+    lib.bftkv_gpu_collective_verify_dev.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, C.c_uint64, u8p, vp, u8p]
+    lib.bftkv_gpu_sync.argtypes = [vp]
+    lib.bftkv_gpu_signature_verify.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p]
+    lib.bftkv_gpu_last_statuses.argtypes = [vp, u8p, vp, u32, C.POINTER(u32)]
+    lib.bftkv_gpu_last_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.bftkv_gpu_signers.argtypes = [vp, u32, u8p, u64p, u64p, u64p, C.c_uint64]
+    lib.bftkv_gpu_quorum_tally.argtypes = [vp, C.c_int, u32, u64p, u64p, u8p]
+    lib.bftkv_gpu_modexp.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u32, u8p]
+    lib.bftkv_gpu_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.bftkv_gpu_stream.argtypes = [vp]
+    lib.bftkv_gpu_stream.restype = vp
+    for name in EXPORTS:
+        if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One verifier context = one GPU + one HIP stream (bftkv_gpu_init)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.bftkv_gpu_init(device, C.byref(h))
+        if rc != 0:
+            raise NativeError("bftkv_gpu_init(device=%d) failed with %d: no usable MI355X / HIP runtime "
+                              "(there is no CPU fallback)" % (device, rc))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.bftkv_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise NativeError("%s failed (%d): %s" % (what, rc, self.lib.bftkv_gpu_last_error(self.h).decode()))
+
+    # ---- keyring
+    def keyring_set(self, keys):
+        """keys: iterable of dicts {key_id, entity_id, pk_algo, usable_sign, n, e[, g, y]} with
+        big-endian ``bytes`` material, in keyring order."""
+        keys = list(keys)
+        arr = (PubKey * max(1, len(keys)))()
+        bufs = []
+        for i, k in enumerate(keys):
+            arr[i].key_id = k["key_id"]
+            arr[i].entity_id = k.get("entity_id", k["key_id"])
+            arr[i].pk_algo = k["pk_algo"]
+            arr[i].usable_sign = 1 if k.get("usable_sign", True) else 0
+            for name in ("n", "e", "g", "y"):
+                b = k.get(name) or b""
+                cb = C.create_string_buffer(b, len(b)) if b else None
+                bufs.append(cb)
+                setattr(arr[i], name, C.cast(cb, C.c_void_p) if cb is not None else None)
+                setattr(arr[i], name + "_len", len(b))
+        self._check(self.lib.bftkv_gpu_keyring_set(self.h, arr, len(keys)), "keyring_set")
+
+    # ---- quorum
+    def quorum_create(self, qcs) -> int:
+        """qcs: iterable of (f, min, threshold, suff, [node ids])."""
+        qcs = list(qcs)
+        arr = (QC * max(1, len(qcs)))()
+        keep = []
+        for i, (f, mn, thr, suff, nodes) in enumerate(qcs):
+            ids = np.ascontiguousarray(np.array(list(nodes), dtype=np.uint64))
+            keep.append(ids)
+            arr[i].f, arr[i].min, arr[i].threshold, arr[i].suff = f, mn, thr, suff
+            arr[i].node_ids = ids.ctypes.data if len(ids) else None
+            arr[i].n_nodes = len(ids)
+        out = C.c_int(-1)
+        self._check(self.lib.bftkv_gpu_quorum_create(self.h, arr, len(qcs), C.byref(out)), "quorum_create")
+        return out.value
+
+    def quorum_destroy(self, q: int):
+        self._check(self.lib.bftkv_gpu_quorum_destroy(self.h, q), "quorum_destroy")
+
+    # ---- verification
+    def collective_verify(self, quorum: int, tbs_blob, tbs_off, ss_blob, ss_off):
+        n = len(tbs_off) - 1
+        tbs_blob, ss_blob = _u8(tbs_blob), _u8(ss_blob)
+        tbs_off, ss_off = _u64(tbs_off), _u64(ss_off)
+        err = np.zeros(n, dtype=np.uint8)
+        nver = np.zeros(n, dtype=np.uint32)
+        verdict = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_collective_verify(self.h, quorum, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(ss_blob),
+                                                         _ptr(ss_off), _ptr(err), _ptr(nver), _ptr(verdict)),
+                    "collective_verify")
+        return err, nver, verdict
+
+    def collective_verify_dev(self, quorum: int, n_items: int, tbs_ptr: int, tbs_off_ptr: int, ss_ptr: int, ss_off_ptr: int,
+                              ss_len: int, err_ptr: int, nver_ptr: int, verdict_ptr: int):
+        self._check(self.lib.bftkv_gpu_collective_verify_dev(self.h, quorum, n_items, tbs_ptr, tbs_off_ptr, ss_ptr, ss_off_ptr,
+                                                             ss_len, err_ptr, nver_ptr, verdict_ptr), "collective_verify_dev")
+
+    def sync(self):
+        self._check(self.lib.bftkv_gpu_sync(self.h), "sync")
+
+    def signature_verify(self, tbs_blob, tbs_off, sig_blob, sig_off, cert_key_id=None):
+        n = len(tbs_off) - 1
+        tbs_blob, sig_blob = _u8(tbs_blob), _u8(sig_blob)
+        tbs_off, sig_off = _u64(tbs_off), _u64(sig_off)
+        ck = None if cert_key_id is None else _u64(cert_key_id)
+        err = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_signature_verify(self.h, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(sig_blob), _ptr(sig_off),
+                                                        _ptr(ck), _ptr(err)), "signature_verify")
+        return err
+
+    def last_statuses(self):
+        n = C.c_uint32(0)
+        self._check(self.lib.bftkv_gpu_last_statuses(self.h, None, None, 0, C.byref(n)), "last_statuses")
+        st = np.zeros(max(1, n.value), dtype=np.uint8)
+        item = np.zeros(max(1, n.value), dtype=np.uint32)
+        self._check(self.lib.bftkv_gpu_last_statuses(self.h, _ptr(st), _ptr(item), n.value, C.byref(n)), "last_statuses")
+        return st[:n.value], item[:n.value]
+
+    def last_counters(self):
+        c = (C.c_uint64 * 4)()
+        self._check(self.lib.bftkv_gpu_last_counters(self.h, c), "last_counters")
+        return {"packets": c[0], "pubkey_ops": c[1], "items": c[2]}
+
+    def last_timing(self):
+        ms = (C.c_float * 8)()
+        self._check(self.lib.bftkv_gpu_last_timing(self.h, ms), "last_timing")
+        return {"total": ms[0], "parse": ms[1], "hash": ms[2], "rsa": ms[3], "tally": ms[4]}
+
+    def signers(self, ss_blob, ss_off):
+        n = len(ss_off) - 1
+        ss_blob, ss_off = _u8(ss_blob), _u64(ss_off)
+        cap = max(1, int(len(ss_blob) // 12) + 1)
+        ids = np.zeros(cap, dtype=np.uint64)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self._check(self.lib.bftkv_gpu_signers(self.h, n, _ptr(ss_blob), _ptr(ss_off), _ptr(ids), _ptr(off), cap), "signers")
+        return ids[:int(off[n])], off
+
+    def quorum_tally(self, quorum: int, ids, list_off):
+        n = len(list_off) - 1
+        ids, list_off = _u64(ids), _u64(list_off)
+        v = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_quorum_tally(self.h, quorum, n, _ptr(ids), _ptr(list_off), _ptr(v)), "quorum_tally")
+        return v
+
+    def modexp(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
+        """base [n, nbytes] u8 BE; mods [m, nbytes]; exps [m, exp_len] -> [n, nbytes]."""
+        base, mods, exps = _u8(base), _u8(mods), _u8(exps)
+        mod_idx = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros_like(base)
+        self._check(self.lib.bftkv_gpu_modexp(self.h, base.shape[0], _ptr(base), base.shape[1], _ptr(mod_idx), mods.shape[0],
+                                              _ptr(mods), _ptr(exps), exps.shape[1], _ptr(out)), "modexp")
+        return out
+
+
+def _u8(a) -> np.ndarray:
+    if isinstance(a, (bytes, bytearray)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint8)[:0].copy()
+    return a
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)

@@ -1,0 +1,675 @@
+// C ABI of the bftkv MI355X verifier (include/bftkv_gpu.h) -- host side: context, key table,
+// quorum descriptors, grow-only device arena, kernel pipeline.
+#include "../../include/bftkv_gpu.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "host_bignum.h"
+#include "kernels.hip"
+
+using namespace bftkv;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct QuorumHost {
+  bool live = false;
+  int n_qcs = 0;
+  int32_t f[MAX_QC], mn[MAX_QC], thr[MAX_QC], suff[MAX_QC];
+  std::vector<std::vector<uint64_t>> nodes;
+  DevBuf member;          // [n_qcs][n_entities] bytes, keyed to the keyring generation below
+  uint64_t keyring_gen = ~0ull;
+  DevBuf ids;             // concatenated node ids
+  uint32_t ids_off[MAX_QC + 1];
+};
+
+}  // namespace
+
+struct bftkv_gpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+
+  // key table
+  uint64_t keyring_gen = 0;
+  uint32_t n_keys = 0, n_entities = 0;
+  std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
+  std::vector<uint32_t> h_key_entity;
+  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0;
+  KeyTableDev kt{};
+
+  std::vector<QuorumHost> quorums;
+
+  // per-call arena
+  DevBuf counts, base, total, item_flags, cert_ent, mid, recs, x, em, xr, rsa_list, rsa_count;
+  DevBuf o_err, o_nver, o_verdict;
+  DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
+  DevBuf st_tmp, item_tmp;
+  uint32_t last_total = 0, last_rsa = 0, last_items = 0;
+  hipEvent_t ev[6] = {};
+  bool have_timing = false;
+};
+
+namespace {
+
+int fail(bftkv_gpu_ctx* c, int rc, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  c->err = buf;
+  return rc;
+}
+
+#define HIPCHK(c, call)                                                    \
+  do {                                                                     \
+    hipError_t _e = (call);                                                \
+    if (_e != hipSuccess) return fail((c), BFTKV_E_DEVICE, #call, _e);     \
+  } while (0)
+
+template <typename T>
+int upload(bftkv_gpu_ctx* c, DevBuf& b, const std::vector<T>& v) {
+  size_t bytes = v.size() * sizeof(T);
+  HIPCHK(c, b.ensure(bytes ? bytes : 16));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int build_member(bftkv_gpu_ctx* c, QuorumHost& q) {
+  if (q.keyring_gen == c->keyring_gen && q.member.p) return 0;
+  std::vector<uint8_t> m((size_t)q.n_qcs * (c->n_entities ? c->n_entities : 1), 0);
+  for (int qc = 0; qc < q.n_qcs; ++qc)
+    for (uint32_t e = 0; e < c->n_entities; ++e)
+      for (uint64_t id : q.nodes[qc])
+        if (id == c->h_entity_id[e]) { m[(size_t)qc * c->n_entities + e] = 1; break; }
+  int rc = upload(c, q.member, m);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  q.keyring_gen = c->keyring_gen;
+  return 0;
+}
+
+QuorumDev quorum_dev(const bftkv_gpu_ctx* c, const QuorumHost& q) {
+  QuorumDev d{};
+  d.n_qcs = q.n_qcs;
+  for (int i = 0; i < q.n_qcs; ++i) { d.f[i] = q.f[i]; d.min[i] = q.mn[i]; d.threshold[i] = q.thr[i]; d.suff[i] = q.suff[i]; }
+  d.member = q.member.as<uint8_t>();
+  d.n_entities = c->n_entities;
+  return d;
+}
+
+// per-item fold of Signature.Verify semantics (crypto_pgp.go:319-330)
+__global__ void k_sigverify_fold(const SigRec* __restrict__ recs, const uint32_t* __restrict__ base,
+                                 const uint32_t* __restrict__ counts, const uint8_t* __restrict__ item_flags,
+                                 uint32_t n_items, uint8_t* __restrict__ err_out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  uint32_t n_ok = 0;
+  bool bad = false;
+  for (uint32_t k = 0; k < counts[i]; ++k) {
+    uint8_t st = recs[base[i] + k].status;
+    if (st == ST_OK) ++n_ok;
+    else if (st != ST_UNKNOWN_ISSUER) bad = true;
+  }
+  // a call that runs into EOF after only skipped packets returns ErrUnknownIssuer
+  if (item_flags[i] & 1) bad = true;
+  err_out[i] = (!bad && n_ok >= 1) ? BFTKV_ERR_NONE : BFTKV_ERR_INVALID_SIGNATURE;
+}
+
+// quorum predicates over explicit node-id lists: one wave per list (wotqs.go:144-206)
+__global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ ids, const uint64_t* __restrict__ list_off,
+                                                   uint32_t n_lists, const uint64_t* __restrict__ qc_ids,
+                                                   const uint32_t* __restrict__ qc_off, QuorumDev q,
+                                                   uint8_t* __restrict__ verdict) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (wave >= n_lists) return;
+  uint32_t cq[MAX_QC];
+#pragma unroll
+  for (int c = 0; c < MAX_QC; ++c) cq[c] = 0;
+  const uint64_t lo = list_off[wave], hi = list_off[wave + 1];
+  for (uint64_t off = lo; off < hi; off += 64) {
+    const bool in = off + lane < hi;
+    const uint64_t id = in ? ids[off + lane] : 0;
+#pragma unroll
+    for (int c = 0; c < MAX_QC; ++c) {
+      if (c < q.n_qcs) {
+        bool mem = false;
+        if (in)
+          for (uint32_t k = qc_off[c]; k < qc_off[c + 1]; ++k)
+            if (qc_ids[k] == id) { mem = true; break; }
+        cq[c] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mem));
+      }
+    }
+  }
+  if (lane == 0) {
+    bool is_quorum = q.n_qcs > 0, is_thr = q.n_qcs > 0, is_suff = false, reject = true;
+    for (int c = 0; c < q.n_qcs; ++c) {
+      if (q.f[c] > 0 && (int32_t)cq[c] < q.min[c]) is_quorum = false;
+      if (q.threshold[c] > 0 && (int32_t)cq[c] < q.threshold[c]) is_thr = false;
+      if (q.suff[c] > 0 && (int32_t)cq[c] >= q.suff[c]) is_suff = true;
+      if (q.f[c] == 0 || (int32_t)cq[c] <= q.f[c]) reject = false;
+    }
+    verdict[wave] = (is_quorum ? V_IS_QUORUM : 0) | (is_thr ? V_IS_THRESHOLD : 0) | (is_suff ? V_IS_SUFFICIENT : 0) |
+                    (reject ? V_REJECT : 0);
+  }
+}
+
+// Shared pipeline: parse -> hash -> public-key operations.  Leaves SigRec statuses final.
+int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
+                 const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent) {
+  hipStream_t s = c->stream;
+  if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+  HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
+  HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
+  HIPCHK(c, c->total.ensure(16));
+  HIPCHK(c, c->item_flags.ensure(n_items + 16));
+  HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * (size_t)n_items + 16));
+  HIPCHK(c, c->rsa_count.ensure(16));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  const uint32_t nb = (n_items + 255) / 256;
+  hipLaunchKernelGGL(k_parse<false>, dim3(nb), dim3(256), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->kt, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
+                     c->total.as<uint32_t>());
+  uint32_t total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->last_total = total;
+  c->last_items = n_items;
+  const size_t tr = total ? total : 1;
+  HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
+  HIPCHK(c, c->x.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->em.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->rsa_list.ensure(sizeof(uint32_t) * tr));
+  hipLaunchKernelGGL(k_parse<true>, dim3(nb), dim3(256), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->kt, d_cert_ent, c->item_flags.as<uint8_t>());
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, s, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
+  HIPCHK(c, hipMemsetAsync(c->rsa_count.p, 0, 4, s));
+  if (total) {
+    hipLaunchKernelGGL(k_digest_em, dim3((total + 255) / 256), dim3(256), 0, s, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+                       c->recs.as<SigRec>(), total, c->kt, c->x.as<uint32_t>(), c->em.as<uint32_t>(),
+                       c->rsa_list.as<uint32_t>(), c->rsa_count.as<uint32_t>());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], s));
+  if (total) {
+    hipLaunchKernelGGL(k_rsa_verify, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                       c->recs.as<SigRec>(), c->rsa_list.as<uint32_t>(), c->rsa_count.as<uint32_t>(), c->kt,
+                       c->x.as<uint32_t>(), c->em.as<uint32_t>(), c->xr.as<uint32_t>());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[3], s));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int check_quorum(bftkv_gpu_ctx* c, int quorum) {
+  if (quorum < 0 || (size_t)quorum >= c->quorums.size() || !c->quorums[quorum].live) return fail(c, BFTKV_E_INVALID, "bad quorum handle");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
+  if (!out) return BFTKV_E_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BFTKV_E_DEVICE;   // no GPU: fail loudly, no CPU fallback
+  if (device_ordinal < 0 || device_ordinal >= n) return BFTKV_E_INVALID;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return BFTKV_E_DEVICE;
+  bftkv_gpu_ctx* c = new bftkv_gpu_ctx();
+  c->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
+  *out = c;
+  return BFTKV_OK;
+}
+
+void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0,
+                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->recs, &c->x, &c->em, &c->xr,
+                    &c->rsa_list, &c->rsa_count, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
+    b->release();
+  for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* bftkv_gpu_last_error(const bftkv_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+const char* bftkv_gpu_error_string(int e) {
+  switch (e) {
+    case BFTKV_ERR_NONE: return "";
+    case BFTKV_ERR_INVALID_SIGNATURE: return "crypto: invalid signature";                          // crypto/crypto.go:20
+    case BFTKV_ERR_INSUFFICIENT_SIGNATURES: return "crypto: insufficient number of signatures";    // crypto/crypto.go:19
+    default: return "unknown";
+  }
+}
+
+void* bftkv_gpu_stream(bftkv_gpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
+  if (!c) return BFTKV_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32_t n_keys) {
+  if (!c || (!keys && n_keys)) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint64_t> key_id;
+  std::vector<uint32_t> entity, bits, e32, nl, r2, n0;
+  std::vector<uint8_t> algo, flags;
+  std::vector<uint64_t> entity_ids;
+  std::vector<std::string> material;
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    const bftkv_gpu_pubkey& k = keys[i];
+    std::string mat;
+    mat.push_back((char)k.pk_algo);
+    mat.push_back((char)k.usable_sign);
+    auto app = [&](const uint8_t* p, uint32_t l) {
+      uint32_t z = 0;
+      while (z < l && p[z] == 0) ++z;
+      mat.append((const char*)p + z, l - z);
+      mat.push_back('|');
+    };
+    app(k.n, k.n_len); app(k.e, k.e_len); app(k.g, k.g_len); app(k.y, k.y_len);
+    bool dup = false;
+    for (size_t j = 0; j < key_id.size(); ++j) {
+      if (key_id[j] == k.key_id) {
+        if (material[j] == mat) { dup = true; break; }
+        return fail(c, BFTKV_E_UNSUPPORTED, "two different keys share one 64-bit key id");
+      }
+    }
+    if (dup) continue;
+    uint32_t ent = 0;
+    for (; ent < entity_ids.size(); ++ent) if (entity_ids[ent] == k.entity_id) break;
+    if (ent == entity_ids.size()) entity_ids.push_back(k.entity_id);
+    key_id.push_back(k.key_id);
+    material.push_back(mat);
+    entity.push_back(ent);
+    algo.push_back(k.pk_algo);
+    uint8_t fl = 0;
+    if (k.usable_sign) fl |= KEYF_USABLE_SIGN;
+    if (k.pk_algo != PK_RSA_ENCRYPT_ONLY && k.pk_algo != PK_ELGAMAL) fl |= KEYF_CAN_SIGN;   // PublicKey.CanSign
+    if (k.key_id == k.entity_id) fl |= KEYF_PRIMARY;
+    uint32_t nbits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
+    uint32_t ev = 0;
+    size_t o = nl.size();
+    nl.resize(o + MONT_N, 0); r2.resize(o + MONT_N, 0);
+    uint32_t n0i = 0;
+    if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
+      int ebits = hostbn::bit_length(k.e, k.e_len);
+      if (ebits > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
+      for (uint32_t j = 0; j < k.e_len; ++j) ev = (ev << 8) | k.e[j];
+      if (nbits > 2048) {
+        nbits = 0xFFFFFFFFu;   // k_digest_em reports ST_UNSUPPORTED for this key
+      } else if (!hostbn::mont_setup(k.n, k.n_len, MONT_N, &nl[o], &r2[o], &n0i)) {
+        nbits = 0xFFFFFFFFu;   // even / zero modulus: no Montgomery form (never a real key)
+      }
+    }
+    flags.push_back(fl);
+    bits.push_back(nbits);
+    e32.push_back(ev);
+    n0.push_back(n0i);
+  }
+  int rc;
+  if ((rc = upload(c, c->k_id, key_id))) return rc;
+  if ((rc = upload(c, c->k_entity, entity))) return rc;
+  if ((rc = upload(c, c->k_algo, algo))) return rc;
+  if ((rc = upload(c, c->k_flags, flags))) return rc;
+  if ((rc = upload(c, c->k_bits, bits))) return rc;
+  if ((rc = upload(c, c->k_e, e32))) return rc;
+  if ((rc = upload(c, c->k_n, nl))) return rc;
+  if ((rc = upload(c, c->k_r2, r2))) return rc;
+  if ((rc = upload(c, c->k_n0, n0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_keys = (uint32_t)key_id.size();
+  c->n_entities = (uint32_t)entity_ids.size();
+  c->h_key_id = key_id;
+  c->h_entity_id = entity_ids;
+  c->h_key_entity = entity;
+  c->kt.n_keys = c->n_keys;
+  c->kt.key_id = c->k_id.as<uint64_t>();
+  c->kt.entity = c->k_entity.as<uint32_t>();
+  c->kt.pk_algo = c->k_algo.as<uint8_t>();
+  c->kt.flags = c->k_flags.as<uint8_t>();
+  c->kt.mod_bits = c->k_bits.as<uint32_t>();
+  c->kt.rsa_e = c->k_e.as<uint32_t>();
+  c->kt.n_limbs = c->k_n.as<uint32_t>();
+  c->kt.r2_limbs = c->k_r2.as<uint32_t>();
+  c->kt.n0inv = c->k_n0.as<uint32_t>();
+  ++c->keyring_gen;
+  return 0;
+}
+
+int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t n_qcs, int* out) {
+  if (!c || !out || (!qcs && n_qcs)) return BFTKV_E_INVALID;
+  if (n_qcs > MAX_QC) return fail(c, BFTKV_E_UNSUPPORTED, "more than MAX_QC cliques in one quorum");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  QuorumHost q;
+  q.live = true;
+  q.n_qcs = (int)n_qcs;
+  std::vector<uint64_t> all;
+  q.ids_off[0] = 0;
+  for (uint32_t i = 0; i < n_qcs; ++i) {
+    q.f[i] = qcs[i].f; q.mn[i] = qcs[i].min; q.thr[i] = qcs[i].threshold; q.suff[i] = qcs[i].suff;
+    q.nodes.emplace_back(qcs[i].node_ids, qcs[i].node_ids + qcs[i].n_nodes);
+    all.insert(all.end(), qcs[i].node_ids, qcs[i].node_ids + qcs[i].n_nodes);
+    q.ids_off[i + 1] = (uint32_t)all.size();
+  }
+  // device copy: ids followed by the offsets (as uint32)
+  std::vector<uint64_t> blob = all;
+  size_t ids_words = blob.size();
+  blob.resize(ids_words + (MAX_QC + 2) / 2 + 1, 0);
+  memcpy(&blob[ids_words], q.ids_off, sizeof(uint32_t) * (n_qcs + 1));
+  int rc = upload(c, q.ids, blob);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  q.ids_off[MAX_QC] = (uint32_t)ids_words;   // remember where the offsets live
+  int h = -1;
+  for (size_t i = 0; i < c->quorums.size(); ++i) if (!c->quorums[i].live) { h = (int)i; break; }
+  if (h < 0) { c->quorums.emplace_back(); h = (int)c->quorums.size() - 1; }
+  c->quorums[h] = std::move(q);
+  *out = h;
+  return 0;
+}
+
+int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
+  if (!c) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = check_quorum(c, quorum);
+  if (rc) return rc;
+  c->quorums[quorum].member.release();
+  c->quorums[quorum].ids.release();
+  c->quorums[quorum] = QuorumHost();
+  return 0;
+}
+
+int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                    const uint8_t* ss, const uint64_t* ss_off, uint64_t ss_len, uint8_t* err_out,
+                                    uint32_t* nver_out, uint8_t* verdict_out) {
+  (void)ss_len;
+  if (!c) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = check_quorum(c, quorum);
+  if (rc) return rc;
+  if (n_items == 0) return 0;
+  QuorumHost& q = c->quorums[quorum];
+  if ((rc = build_member(c, q))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr))) return rc;
+  HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
+  HIPCHK(c, c->o_verdict.ensure(n_items));
+  uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
+  uint8_t* vd = verdict_out ? verdict_out : c->o_verdict.as<uint8_t>();
+  hipLaunchKernelGGL(k_tally, dim3((n_items + 3) / 4), dim3(256), 0, c->stream, c->recs.as<SigRec>(), c->base.as<uint32_t>(),
+                     c->counts.as<uint32_t>(), n_items, c->kt, quorum_dev(c, q), vd, nv, (uint32_t*)nullptr);
+  if (err_out) {
+    // err = IsSufficient ? nil : ErrInsufficientNumberOfSignatures
+    hipLaunchKernelGGL(k_err_from_verdict, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, vd, n_items, err_out);
+  }
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->have_timing = true;
+  return 0;
+}
+
+int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                uint8_t* verdict_out) {
+  if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
+  if (n_items == 0) return 0;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
+    HIPCHK(c, c->in_tbs.ensure(tl + 64));
+    HIPCHK(c, c->in_ss.ensure(sl + 64));
+    HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+    HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+    HIPCHK(c, c->o_err.ensure(n_items));
+    HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
+    HIPCHK(c, c->o_verdict.ensure(n_items));
+    if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, c->stream));
+    if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ss, sl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = bftkv_gpu_collective_verify_dev(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(),
+                                           c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), ss_off[n_items],
+                                           c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>());
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
+  if (nver_out) HIPCHK(c, hipMemcpyAsync(nver_out, c->o_nver.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, c->stream));
+  if (verdict_out) HIPCHK(c, hipMemcpyAsync(verdict_out, c->o_verdict.p, n_items, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                               const uint8_t* sig, const uint64_t* sig_off, const uint64_t* cert_key_id, uint8_t* err_out) {
+  if (!c || (n_items && (!tbs_off || !sig_off || !err_out))) return BFTKV_E_INVALID;
+  if (n_items == 0) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t tl = tbs_off[n_items], sl = sig_off[n_items];
+  HIPCHK(c, c->in_tbs.ensure(tl + 64));
+  HIPCHK(c, c->in_ss.ensure(sl + 64));
+  HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  HIPCHK(c, c->o_err.ensure(n_items));
+  if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, c->stream));
+  if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, sig, sl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, sig_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+  const uint32_t* d_cert = nullptr;
+  std::vector<uint32_t> ce;
+  if (cert_key_id) {
+    ce.resize(n_items);
+    for (uint32_t i = 0; i < n_items; ++i) {
+      uint32_t e = 0xFFFFFFFEu;   // an entity that is not in the table: nothing matches
+      for (uint32_t k = 0; k < c->n_entities; ++k) if (c->h_entity_id[k] == cert_key_id[i]) { e = k; break; }
+      ce[i] = e;
+    }
+    int rc = upload(c, c->cert_ent, ce);
+    if (rc) return rc;
+    d_cert = c->cert_ent.as<uint32_t>();
+  }
+  int rc = run_pipeline(c, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
+                        c->in_ss_off.as<uint64_t>(), d_cert);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sigverify_fold, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(),
+                     c->base.as<uint32_t>(), c->counts.as<uint32_t>(), c->item_flags.as<uint8_t>(), n_items, c->o_err.as<uint8_t>());
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->have_timing = true;
+  return 0;
+}
+
+int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint32_t cap, uint32_t* n_out) {
+  if (!c || !n_out) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  *n_out = c->last_total;
+  uint32_t n = c->last_total < cap ? c->last_total : cap;
+  if (!n || !st) return 0;
+  HIPCHK(c, c->st_tmp.ensure(n));
+  HIPCHK(c, c->item_tmp.ensure(sizeof(uint32_t) * n));
+  hipLaunchKernelGGL(k_export_status, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(), n,
+                     c->st_tmp.as<uint8_t>(), c->item_tmp.as<uint32_t>());
+  HIPCHK(c, hipMemcpyAsync(st, c->st_tmp.p, n, hipMemcpyDeviceToHost, c->stream));
+  if (item) HIPCHK(c, hipMemcpyAsync(item, c->item_tmp.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
+  if (!c || !counters) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t rsa = 0;
+  if (c->rsa_count.p) HIPCHK(c, hipMemcpy(&rsa, c->rsa_count.p, 4, hipMemcpyDeviceToHost));
+  counters[0] = c->last_total;
+  counters[1] = rsa;
+  counters[2] = c->last_items;
+  counters[3] = 0;
+  return 0;
+}
+
+int bftkv_gpu_last_timing(bftkv_gpu_ctx* c, float ms[8]) {
+  if (!c || !ms) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_timing) return fail(c, BFTKV_E_STATE, "no timed call yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->ev[4]));
+  for (int i = 0; i < 8; ++i) ms[i] = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[4]));
+  HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]));
+  HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[1], c->ev[2]));
+  HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[2], c->ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));
+  return 0;
+}
+
+int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* c, int quorum, uint32_t n_lists, const uint64_t* ids, const uint64_t* list_off,
+                           uint8_t* verdict_out) {
+  if (!c || (n_lists && (!list_off || !verdict_out))) return BFTKV_E_INVALID;
+  if (n_lists == 0) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = check_quorum(c, quorum);
+  if (rc) return rc;
+  QuorumHost& q = c->quorums[quorum];
+  const uint64_t n_ids = list_off[n_lists];
+  HIPCHK(c, c->in_ss.ensure(sizeof(uint64_t) * (n_ids + 1)));
+  HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_lists + 1)));
+  HIPCHK(c, c->o_verdict.ensure(n_lists));
+  if (n_ids) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ids, sizeof(uint64_t) * n_ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, list_off, sizeof(uint64_t) * (n_lists + 1), hipMemcpyHostToDevice, c->stream));
+  QuorumDev qd = quorum_dev(c, q);
+  const uint64_t* d_ids = q.ids.as<uint64_t>();
+  const uint32_t* d_off = (const uint32_t*)(d_ids + q.ids_off[MAX_QC]);
+  hipLaunchKernelGGL(k_tally_ids, dim3((n_lists + 3) / 4), dim3(256), 0, c->stream, c->in_ss.as<uint64_t>(),
+                     c->in_ss_off.as<uint64_t>(), n_lists, d_ids, d_off, qd, c->o_verdict.as<uint8_t>());
+  HIPCHK(c, hipMemcpyAsync(verdict_out, c->o_verdict.p, n_lists, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, const uint64_t* ss_off, uint64_t* ids_out,
+                      uint64_t* ids_off_out, uint64_t cap) {
+  // parse-only walk: reuse the parse kernels with no hashing; issuers resolved against PRIMARY
+  // key ids only (getCertById, crypto_pgp.go:206-219).
+  if (!c || (n_items && (!ss_off || !ids_off_out))) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  ids_off_out[0] = 0;
+  if (n_items == 0) return 0;
+  hipStream_t s = c->stream;
+  const uint64_t sl = ss_off[n_items];
+  HIPCHK(c, c->in_ss.ensure(sl + 64));
+  HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ss, sl, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
+  HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
+  HIPCHK(c, c->total.ensure(16));
+  const uint32_t nb = (n_items + 255) / 256;
+  hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(256), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
+                     c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
+                     c->total.as<uint32_t>());
+  uint32_t total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, c->total.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (total > cap) return fail(c, BFTKV_E_NOMEM, "ids_out too small");
+  HIPCHK(c, c->x.ensure(sizeof(uint64_t) * (total + 1)));
+  hipLaunchKernelGGL(k_signers<true>, dim3(nb), dim3(256), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
+                     c->counts.as<uint32_t>(), c->base.as<uint32_t>(), c->x.as<uint64_t>(), c->kt);
+  std::vector<uint32_t> hb(n_items);
+  HIPCHK(c, hipMemcpyAsync(hb.data(), c->base.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, s));
+  if (total && ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->x.p, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  for (uint32_t i = 0; i < n_items; ++i) ids_off_out[i] = hb[i];
+  ids_off_out[n_items] = total;
+  return 0;
+}
+
+int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
+                     uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
+  if (!c || nbytes == 0 || nbytes > 256 || (n_ops && (!base || !mod_idx || !mods || !exps || !out))) return BFTKV_E_INVALID;
+  if (n_ops == 0) return 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  std::vector<uint32_t> nl((size_t)n_mods * MONT_N), r2((size_t)n_mods * MONT_N), n0(n_mods);
+  const uint32_t ew = (exp_len + 3) / 4;
+  std::vector<uint32_t> ex((size_t)n_mods * ew, 0);
+  for (uint32_t m = 0; m < n_mods; ++m) {
+    if (hostbn::bit_length(mods + (size_t)m * nbytes, nbytes) > 2048) return fail(c, BFTKV_E_UNSUPPORTED, "modulus wider than 2048 bits");
+    if (!hostbn::mont_setup(mods + (size_t)m * nbytes, nbytes, MONT_N, &nl[(size_t)m * MONT_N], &r2[(size_t)m * MONT_N], &n0[m]))
+      return fail(c, BFTKV_E_UNSUPPORTED, "even modulus");
+    hostbn::from_be(exps + (size_t)m * exp_len, exp_len, &ex[(size_t)m * ew], (int)ew);
+  }
+  for (uint32_t i = 0; i < n_ops; ++i) if (mod_idx[i] >= n_mods) return fail(c, BFTKV_E_INVALID, "mod_idx out of range");
+  DevBuf d_nl, d_r2, d_n0, d_ex, d_mi, d_in, d_inl, d_outl, d_out;
+  struct Guard { std::vector<DevBuf*> v; ~Guard() { for (auto* b : v) b->release(); } } g{{&d_nl, &d_r2, &d_n0, &d_ex, &d_mi, &d_in, &d_inl, &d_outl, &d_out}};
+  HIPCHK(c, d_nl.ensure(nl.size() * 4)); HIPCHK(c, d_r2.ensure(r2.size() * 4)); HIPCHK(c, d_n0.ensure(n0.size() * 4));
+  HIPCHK(c, d_ex.ensure(ex.size() * 4 + 16)); HIPCHK(c, d_mi.ensure((size_t)n_ops * 4));
+  HIPCHK(c, d_in.ensure((size_t)n_ops * nbytes)); HIPCHK(c, d_inl.ensure((size_t)n_ops * MONT_N * 4));
+  HIPCHK(c, d_outl.ensure((size_t)n_ops * MONT_N * 4)); HIPCHK(c, d_out.ensure((size_t)n_ops * nbytes));
+  HIPCHK(c, hipMemcpyAsync(d_nl.p, nl.data(), nl.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(d_r2.p, r2.data(), r2.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(d_n0.p, n0.data(), n0.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(d_ex.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(d_mi.p, mod_idx, (size_t)n_ops * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(d_in.p, base, (size_t)n_ops * nbytes, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_bytes_to_limbs, dim3((n_ops * MONT_N + 255) / 256), dim3(256), 0, s, d_in.as<uint8_t>(), nbytes, n_ops,
+                     d_inl.as<uint32_t>());
+  hipLaunchKernelGGL(k_modexp, dim3((n_ops + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s, n_ops,
+                     d_inl.as<uint32_t>(), d_mi.as<uint32_t>(), d_nl.as<uint32_t>(), d_r2.as<uint32_t>(), d_n0.as<uint32_t>(),
+                     d_ex.as<uint32_t>(), ew, d_outl.as<uint32_t>());
+  hipLaunchKernelGGL(k_limbs_to_bytes, dim3((n_ops * nbytes + 255) / 256), dim3(256), 0, s, d_outl.as<uint32_t>(), nbytes, n_ops,
+                     d_out.as<uint8_t>());
+  HIPCHK(c, hipMemcpyAsync(out, d_out.p, (size_t)n_ops * nbytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Shared host/device plain-data types of the bftkv GPU verifier.
+#pragma once
+#include <stdint.h>
+
+namespace bftkv {
+
+// Per-packet outcome of one CheckDetachedSignature-equivalent step.  Numeric values are part of the
+// C ABI (include/bftkv_gpu.h BFTKV_ST_*) and mirror oracle/openpgp.py ST_*.
+enum SigStatus : uint8_t {
+  ST_OK = 0,
+  ST_UNKNOWN_ISSUER = 1,
+  ST_PARSE_ERROR = 2,
+  ST_NOT_SIGNATURE = 3,
+  ST_NO_ISSUER = 4,
+  ST_HASH_UNSUPPORTED = 5,
+  ST_HASH_TAG = 6,
+  ST_ALGO_MISMATCH = 7,
+  ST_BAD_SIG = 8,
+  ST_KEY_CANNOT_SIGN = 9,
+  ST_UNSUPPORTED = 10,
+  // internal, never returned:
+  ST_PENDING_HASH = 100,   // parsed, key found; digest not computed yet
+  ST_PENDING_RSA = 101,    // digest + tag OK; waiting for the modexp
+  ST_PENDING_DSA = 102,
+};
+
+constexpr int PK_RSA = 1, PK_RSA_ENCRYPT_ONLY = 2, PK_RSA_SIGN_ONLY = 3, PK_ELGAMAL = 16, PK_DSA = 17, PK_ECDSA = 19;
+constexpr int HASH_MD5 = 1, HASH_SHA1 = 2, HASH_RIPEMD160 = 3, HASH_SHA256 = 8, HASH_SHA384 = 9,
+              HASH_SHA512 = 10, HASH_SHA224 = 11;
+
+// One record per packet event of an item's signature stream (40 bytes).
+struct SigRec {
+  uint64_t body_off;      // offset of the signature body (version byte) in the signature blob
+  uint32_t item;          // index of the item (write / reply) the packet belongs to
+  int32_t key_slot;       // slot in the device key table, -1 if none
+  uint32_t mpi_off[2];    // offsets of the MPI *value* bytes relative to body_off
+  uint16_t mpi_bits[2];   // bit counts as written in the packet
+  uint16_t hashed_len;    // length of the hashed-subpacket area (hash suffix = 6+hl body bytes + 6 trailer)
+  uint8_t hash_tag[2];
+  uint8_t pk_algo, hash_id, sig_type, status;
+  uint32_t pad;
+};
+
+// Device key table (structure of arrays, [limb][key] would also do; [key][limb] keeps a key's
+// limbs contiguous for the quad's 4x19 loads).
+struct KeyTableDev {
+  uint32_t n_keys;
+  const uint64_t* key_id;     // [n_keys] 64-bit OpenPGP key id (primary or subkey)
+  const uint32_t* entity;     // [n_keys] index of the owning entity (node) in the node table
+  const uint8_t* pk_algo;     // [n_keys]
+  const uint8_t* flags;       // [n_keys] bit0: usable for signing per KeysByIdUsage; bit1: CanSign(); bit2: primary key of its entity
+  const uint32_t* mod_bits;   // [n_keys] RSA: bits(n); DSA: bits(p)
+  const uint32_t* rsa_e;      // [n_keys]
+  const uint32_t* n_limbs;    // [n_keys][76] modulus (RSA n / DSA p), radix 2^28
+  const uint32_t* r2_limbs;   // [n_keys][76] R^2 mod n
+  const uint32_t* n0inv;      // [n_keys] -n^-1 mod 2^28
+};
+
+constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;
+
+// Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.
+constexpr int MAX_QC = 8;
+struct QuorumDev {
+  int32_t n_qcs;
+  int32_t f[MAX_QC], min[MAX_QC], threshold[MAX_QC], suff[MAX_QC];
+  const uint8_t* member;   // [n_qcs][n_entities]
+  uint32_t n_entities;
+};
+
+// verdict bits (one byte per item)
+constexpr uint8_t V_IS_QUORUM = 1, V_IS_THRESHOLD = 2, V_IS_SUFFICIENT = 4, V_REJECT = 8;
+
+}  // namespace bftkv

@@ -1,0 +1,90 @@
+// Minimal host-side big integers for key-table precomputation (R^2 mod n, -n^-1 mod 2^28,
+// radix-2^28 limb conversion).  Runs once per uploaded key; not on the verification path.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+namespace bftkv {
+namespace hostbn {
+
+constexpr int W28 = 28;
+constexpr uint32_t MASK28 = (1u << W28) - 1;
+
+// big-endian bytes -> little-endian 32-bit words (nwords entries)
+inline void from_be(const uint8_t* be, uint32_t len, uint32_t* w, int nwords) {
+  memset(w, 0, sizeof(uint32_t) * nwords);
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t k = len - 1 - i;  // byte index from the LSB
+    if ((int)(k >> 2) < nwords) w[k >> 2] |= (uint32_t)be[i] << (8 * (k & 3));
+  }
+}
+
+inline int bit_length(const uint8_t* be, uint32_t len) {
+  uint32_t i = 0;
+  while (i < len && be[i] == 0) ++i;
+  if (i == len) return 0;
+  int top = 8;
+  while (!((be[i] >> (top - 1)) & 1)) --top;
+  return (int)(len - i - 1) * 8 + top;
+}
+
+inline int cmp(const uint32_t* a, const uint32_t* b, int n) {
+  for (int i = n - 1; i >= 0; --i) {
+    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  }
+  return 0;
+}
+inline void sub(uint32_t* a, const uint32_t* b, int n) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < n; ++i) {
+    uint64_t d = (uint64_t)a[i] - b[i] - borrow;
+    a[i] = (uint32_t)d;
+    borrow = (d >> 63) & 1;
+  }
+}
+// a = 2a mod m, a < m, top word of m has headroom
+inline void dbl_mod(uint32_t* a, const uint32_t* m, int n) {
+  uint32_t c = 0;
+  for (int i = 0; i < n; ++i) {
+    uint32_t nc = a[i] >> 31;
+    a[i] = (a[i] << 1) | c;
+    c = nc;
+  }
+  if (cmp(a, m, n) >= 0) sub(a, m, n);
+}
+
+// 32-bit words -> radix-2^28 limbs
+inline void to_limbs28(const uint32_t* w, int nwords, uint32_t* limbs, int nlimbs) {
+  for (int j = 0; j < nlimbs; ++j) {
+    uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
+    uint64_t v = 0;
+    if ((int)wi < nwords) v = w[wi];
+    if ((int)wi + 1 < nwords) v |= (uint64_t)w[wi + 1] << 32;
+    limbs[j] = (uint32_t)(v >> sh) & MASK28;
+  }
+}
+
+// Montgomery constants for an odd modulus n < 2^(28*nlimbs - 2).
+//   r2[] = (2^(28*nlimbs))^2 mod n as limbs, n0inv = -n^-1 mod 2^28.  false if n is even or zero.
+inline bool mont_setup(const uint8_t* n_be, uint32_t n_len, int nlimbs, uint32_t* n_limbs, uint32_t* r2_limbs,
+                       uint32_t* n0inv) {
+  const int nwords = (28 * nlimbs + 31) / 32 + 1;
+  std::vector<uint32_t> n(nwords), r(nwords);
+  from_be(n_be, n_len, n.data(), nwords);
+  if ((n[0] & 1) == 0) return false;
+  r.assign(nwords, 0);
+  r[0] = 1;
+  if (cmp(r.data(), n.data(), nwords) >= 0) { r[0] = 0; }  // n == 1
+  for (int i = 0; i < 2 * 28 * nlimbs; ++i) dbl_mod(r.data(), n.data(), nwords);
+  to_limbs28(n.data(), nwords, n_limbs, nlimbs);
+  to_limbs28(r.data(), nwords, r2_limbs, nlimbs);
+  uint32_t n0 = n[0], inv = n0;            // inv = n0^-1 mod 2^32 by Newton iteration
+  for (int i = 0; i < 5; ++i) inv *= 2u - n0 * inv;
+  *n0inv = (0u - inv) & MASK28;
+  return true;
+}
+
+}  // namespace hostbn
+}  // namespace bftkv

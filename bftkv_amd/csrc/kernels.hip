@@ -1,0 +1,750 @@
+// HIP kernels of the bftkv batched quorum verifier (gfx950 / MI355X only).
+//
+//   k_parse<COUNT|FILL>   walk each item's OpenPGP signature stream (x/crypto packet.Read +
+//                         Signature.parse semantics) -> SigRec per packet event
+//   k_scan_counts         exclusive scan of per-item record counts
+//   k_sha256_mid          SHA-256 midstate of every item's signed payload, computed ONCE per item
+//                         (the reference re-hashes the whole payload per signature,
+//                          crypto/pgp/crypto_pgp.go:490)
+//   k_digest_em           per signature: finish the hash with the hash suffix, hash-tag check,
+//                         algorithm checks, build EMSA-PKCS1-v1_5 and the signature value as
+//                         radix-2^28 limbs
+//   k_rsa_verify          s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h), compare
+//   k_modexp              generic b^x mod n (corpus signing, threshold-RSA partial signatures)
+//   k_tally               per item: wavefront ballots over the verified signers -> per-clique
+//                         counts -> IsSufficient / IsThreshold / IsQuorum / Reject bits
+//                         (quorum/wotqs/wotqs.go:144-185) and the early-exit position of
+//                         PGPCollectiveSignature.Verify (crypto_pgp.go:485-500)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "mont28.h"
+#include "sha256.h"
+
+namespace bftkv {
+
+// ------------------------------------------------------------------------------------------------
+// OpenPGP packet walk (oracle/openpgp.py next_packet / parse_signature_body are the spec)
+// ------------------------------------------------------------------------------------------------
+struct ParsedPacket {
+  uint64_t next;       // stream position after this event
+  bool event;          // false: silently skipped (unknown packet type)
+  SigRec rec;
+};
+
+__device__ __forceinline__ bool known_tag(uint32_t tag) {
+  // packet types packet.Read constructs; anything else is an UnknownPacketTypeError that
+  // Reader.Next skips
+  return tag < 32 && ((0x00066BFEu >> tag) & 1u);  // {1..9,11,13,14,17,18}
+}
+
+// subpacket area walk; returns false on structural/unsupported error
+__device__ bool parse_subpackets(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
+                                 bool& have_issuer, uint64_t& issuer, int depth);
+
+__device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
+                               uint64_t& issuer, int depth) {
+  if (blen < 1) return false;
+  if (body[0] != 4) return false;  // v3 handled by the caller, others unsupported
+  if (blen < 6) return false;
+  rec.sig_type = body[1];
+  rec.pk_algo = body[2];
+  rec.hash_id = body[3];
+  if (!(rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY || rec.pk_algo == PK_DSA || rec.pk_algo == PK_ECDSA))
+    return false;
+  uint32_t h = rec.hash_id;
+  if (!(h == 1 || h == 2 || h == 3 || (h >= 8 && h <= 11))) return false;
+  uint32_t hl = ((uint32_t)body[4] << 8) | body[5];
+  if (6 + hl > blen) return false;
+  rec.hashed_len = (uint16_t)hl;
+  bool have_ctime = false;
+  have_issuer = false;
+  if (!parse_subpackets(body + 6, hl, true, have_ctime, have_issuer, issuer, depth)) return false;
+  if (!have_ctime) return false;
+  uint32_t p = 6 + hl;
+  if (p + 2 > blen) return false;
+  uint32_t ul = ((uint32_t)body[p] << 8) | body[p + 1];
+  p += 2;
+  if (p + ul > blen) return false;
+  if (!parse_subpackets(body + p, ul, false, have_ctime, have_issuer, issuer, depth)) return false;
+  p += ul;
+  if (p + 2 > blen) return false;
+  rec.hash_tag[0] = body[p];
+  rec.hash_tag[1] = body[p + 1];
+  p += 2;
+  int n_mpi = (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) ? 1 : 2;
+  rec.mpi_off[1] = 0;
+  rec.mpi_bits[1] = 0;
+  for (int i = 0; i < n_mpi; ++i) {
+    if (p + 2 > blen) return false;
+    uint32_t bits = ((uint32_t)body[p] << 8) | body[p + 1];
+    uint32_t nb = (bits + 7) >> 3;
+    p += 2;
+    if (p + nb > blen) return false;
+    rec.mpi_off[i] = p;
+    rec.mpi_bits[i] = (uint16_t)bits;
+    p += nb;
+  }
+  return true;
+}
+
+__device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
+                                 bool& have_issuer, uint64_t& issuer, int depth) {
+  uint32_t p = 0;
+  while (p < len) {
+    uint32_t b = a[p], ln;
+    if (b < 192) { ln = b; p += 1; }
+    else if (b < 255) {
+      if (p + 2 > len) return false;
+      ln = ((b - 192) << 8) + a[p + 1] + 192; p += 2;
+    } else {
+      if (p + 5 > len) return false;
+      ln = ((uint32_t)a[p + 1] << 24) | ((uint32_t)a[p + 2] << 16) | ((uint32_t)a[p + 3] << 8) | a[p + 4]; p += 5;
+    }
+    if (ln > len - p) return false;
+    if (ln == 0) return false;
+    uint32_t typ = a[p] & 0x7F;
+    bool critical = (a[p] & 0x80) != 0;
+    const uint8_t* body = a + p + 1;
+    uint32_t bl = ln - 1;
+    p += ln;
+    switch (typ) {
+      case 2:
+        if (!hashed) break;
+        if (bl != 4) return false;
+        have_ctime = true;
+        break;
+      case 3: case 9:
+        if (!hashed) break;
+        if (bl != 4) return false;
+        break;
+      case 11: case 21: case 22: case 30:
+        break;
+      case 16:
+        if (bl != 8) return false;
+        issuer = 0;
+        for (int i = 0; i < 8; ++i) issuer = (issuer << 8) | body[i];
+        have_issuer = true;
+        break;
+      case 25:
+        if (!hashed) break;
+        if (bl != 1) return false;
+        break;
+      case 27: case 29:
+        if (!hashed) break;
+        if (bl == 0) return false;
+        break;
+      case 32: {
+        if (!hashed) break;
+        // embedded signature: the reference parses it recursively and fails the outer parse on error
+        if (depth >= 2) return false;  // bounded recursion on the device (fenced)
+        SigRec tmp; bool hi; uint64_t iss;
+        if (!parse_sig_body(body, bl, tmp, hi, iss, depth + 1)) return false;
+        break;
+      }
+      default:
+        if (critical) return false;
+    }
+  }
+  return true;
+}
+
+// One packet.Read step at stream position pos of [base, base+end).
+__device__ ParsedPacket parse_next(const uint8_t* base, uint64_t pos, uint64_t end) {
+  ParsedPacket r;
+  r.event = true;
+  r.rec.key_slot = -1;
+  r.rec.status = ST_PARSE_ERROR;
+  r.rec.body_off = pos;
+  r.rec.mpi_off[0] = r.rec.mpi_off[1] = 0;
+  r.rec.mpi_bits[0] = r.rec.mpi_bits[1] = 0;
+  r.rec.hashed_len = 0;
+  r.rec.hash_tag[0] = r.rec.hash_tag[1] = 0;
+  r.rec.pk_algo = r.rec.hash_id = r.rec.sig_type = 0;
+  r.rec.pad = 0;
+  uint32_t b0 = base[pos];
+  if ((b0 & 0x80) == 0) { r.next = pos + 1; return r; }  // "tag byte does not have MSB set"
+  uint32_t tag;
+  uint64_t start, ln;
+  if ((b0 & 0x40) == 0) {
+    tag = (b0 & 0x3F) >> 2;
+    uint32_t lt = b0 & 3;
+    if (lt == 3) { r.next = end; r.rec.status = ST_UNSUPPORTED; return r; }  // indeterminate length: fenced
+    uint32_t nb = 1u << lt;
+    if (pos + 1 + nb > end) { r.next = end; return r; }
+    ln = 0;
+    for (uint32_t i = 0; i < nb; ++i) ln = (ln << 8) | base[pos + 1 + i];
+    start = pos + 1 + nb;
+  } else {
+    tag = b0 & 0x3F;
+    if (pos + 1 >= end) { r.next = end; return r; }
+    uint32_t b1 = base[pos + 1];
+    if (b1 < 192) { ln = b1; start = pos + 2; }
+    else if (b1 < 224) {
+      if (pos + 2 >= end) { r.next = end; return r; }
+      ln = ((b1 - 192) << 8) + base[pos + 2] + 192; start = pos + 3;
+    } else if (b1 == 255) {
+      if (pos + 6 > end) { r.next = end; return r; }
+      ln = ((uint64_t)base[pos + 2] << 24) | ((uint64_t)base[pos + 3] << 16) | ((uint64_t)base[pos + 4] << 8) | base[pos + 5];
+      start = pos + 6;
+    } else { r.next = end; r.rec.status = ST_UNSUPPORTED; return r; }  // partial body length: fenced
+  }
+  if (start + ln > end) { r.next = end; return r; }  // truncated
+  r.next = start + ln;
+  r.rec.body_off = start;
+  if (tag != 2) {
+    if (known_tag(tag)) r.rec.status = ST_NOT_SIGNATURE;
+    else r.event = false;
+    return r;
+  }
+  if (ln >= 1 && base[start] < 4) { r.rec.status = ST_UNSUPPORTED; return r; }  // SignatureV3: fenced
+  bool have_issuer = false;
+  uint64_t issuer = 0;
+  if (!parse_sig_body(base + start, (uint32_t)ln, r.rec, have_issuer, issuer, 0)) { r.rec.status = ST_PARSE_ERROR; return r; }
+  if (!have_issuer) { r.rec.status = ST_NO_ISSUER; return r; }
+  r.rec.status = ST_PENDING_HASH;
+  // stash the issuer in mpi fields' neighbour: returned through pad (low) + key_slot (high) is
+  // awkward; the caller re-reads it from this struct instead
+  r.rec.pad = (uint32_t)issuer;
+  r.rec.key_slot = (int32_t)(issuer >> 32);
+  return r;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_parse(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
+                                               uint32_t n_items, uint32_t* __restrict__ counts,
+                                               const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
+                                               KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
+                                               uint8_t* __restrict__ item_flags) {
+  uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  uint64_t pos = sig_off[item], end = sig_off[item + 1];
+  uint32_t n = 0;
+  uint32_t base = FILL ? rec_base[item] : 0;
+  // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
+  const uint32_t only_ent = (FILL && cert_ent) ? cert_ent[item] : 0xFFFFFFFFu;
+  bool dangling = false;   // bytes consumed after the last call-terminating event
+  while (pos < end) {
+    ParsedPacket pp = parse_next(sig_blob, pos, end);
+    pos = pp.next;
+    if (!pp.event) { dangling = true; continue; }
+    if (FILL) {
+      SigRec rec = pp.rec;
+      rec.item = item;
+      if (rec.status == ST_PENDING_HASH) {
+        uint64_t issuer = ((uint64_t)(uint32_t)rec.key_slot << 32) | rec.pad;
+        rec.pad = 0;
+        rec.key_slot = -1;
+        // KeysByIdUsage(issuer, KeyFlagSign): first usable key with that id (ids are unique in the
+        // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
+        for (uint32_t k = 0; k < kt.n_keys; ++k) {
+          if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) &&
+              (only_ent == 0xFFFFFFFFu || kt.entity[k] == only_ent)) { rec.key_slot = (int32_t)k; break; }
+        }
+        if (rec.key_slot < 0) rec.status = ST_UNKNOWN_ISSUER;
+        else if (rec.sig_type != 0x00) rec.status = ST_HASH_UNSUPPORTED;       // hashForSignature: binary only (text: fenced)
+        else if (rec.hash_id != HASH_SHA256) rec.status = ST_HASH_UNSUPPORTED;  // TODO(next): SHA-1/224/384/512
+      }
+      dangling = (rec.status == ST_UNKNOWN_ISSUER);
+      recs[base + n] = rec;
+    }
+    ++n;
+  }
+  if (!FILL) counts[item] = n;
+  else if (item_flags) item_flags[item] = dangling ? 1 : 0;
+}
+
+// PGPSignature.Signers (crypto_pgp.go:373-390): parse-only walk, issuers looked up among PRIMARY
+// key ids (getCertById, :206-219); the walk ends at the first Reader.Next error.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_signers(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
+                                                 uint32_t n_items, uint32_t* __restrict__ counts,
+                                                 const uint32_t* __restrict__ out_base, uint64_t* __restrict__ ids_out,
+                                                 KeyTableDev kt) {
+  uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  uint64_t pos = sig_off[item], end = sig_off[item + 1];
+  uint32_t n = 0;
+  uint32_t base = FILL ? out_base[item] : 0;
+  while (pos < end) {
+    ParsedPacket pp = parse_next(sig_blob, pos, end);
+    pos = pp.next;
+    if (!pp.event) continue;                              // unknown packet type: skipped by Next
+    const uint8_t st = pp.rec.status;
+    if (st == ST_NOT_SIGNATURE) continue;                 // other packet types fall through the type switch
+    if (st == ST_UNSUPPORTED && pos < end) continue;      // SignatureV3 is a different Go type (fenced framings end the stream)
+    if (st != ST_PENDING_HASH) break;                     // parse error => Next returns err => loop ends; no issuer: fenced
+    uint64_t issuer = ((uint64_t)(uint32_t)pp.rec.key_slot << 32) | pp.rec.pad;
+    for (uint32_t k = 0; k < kt.n_keys; ++k) {
+      if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY)) {
+        if (FILL) ids_out[base + n] = issuer;
+        ++n;
+        break;
+      }
+    }
+  }
+  if (!FILL) counts[item] = n;
+}
+
+// single-block exclusive scan (n up to a few million): each thread scans a contiguous chunk
+__global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict__ counts, uint32_t n,
+                                                      uint32_t* __restrict__ base, uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[1024];
+  uint32_t t = threadIdx.x;
+  uint32_t chunk = (n + 1023) / 1024;
+  uint32_t lo = t * chunk, hi = min(n, lo + chunk);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = (t == 0) ? 0 : part[t - 1];
+  for (uint32_t i = lo; i < hi; ++i) { base[i] = run; run += counts[i]; }
+  if (t == 1023) *total = part[1023];
+}
+
+// ------------------------------------------------------------------------------------------------
+// hashing
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_be32(const uint8_t* p) {
+  if ((((uintptr_t)p) & 3) == 0) return __builtin_bswap32(*(const uint32_t*)p);
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+__global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                   uint32_t n_items, uint32_t* __restrict__ mid /*[n][8]*/) {
+  uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const uint8_t* p = tbs_blob + tbs_off[item];
+  uint64_t len = tbs_off[item + 1] - tbs_off[item];
+  uint32_t s[8];
+  sha256_init(s);
+  for (uint64_t blk = 0; blk < (len >> 6); ++blk) {
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = load_be32(p + blk * 64 + i * 4);
+    sha256_compress(s, w);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mid[(uint64_t)item * 8 + i] = s[i];
+}
+
+// DigestInfo prefix of SHA-256 (Go crypto/rsa hashPrefixes; reference copy crypto/threshold/rsa/rsa.go:349)
+__device__ __constant__ const uint8_t SHA256_DI[19] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01,
+                                                       0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+
+struct TailSrc {
+  const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
+  const uint8_t* body; uint32_t pre_len;      // first 6+hl bytes of the signature body
+  uint64_t total_len;                         // bytes hashed in all = len(signed) + pre_len + 6
+};
+__device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j, uint32_t rem_len) {
+  if (j < t.tail_len) return t.tail[j];
+  j -= t.tail_len;
+  if (j < t.pre_len) return t.body[j];
+  j -= t.pre_len;
+  if (j < 6) {
+    if (j == 0) return 0x04;
+    if (j == 1) return 0xFF;
+    return (t.pre_len >> (8 * (5 - j))) & 0xFF;
+  }
+  j -= 6;
+  if (j == 0) return 0x80;
+  (void)rem_len;
+  return 0;
+}
+
+// value of a big-endian byte string as radix-2^28 limb j
+template <typename F>
+__device__ __forceinline__ uint32_t limb28(F byte_from_lsb, int j) {
+  uint32_t bit = 28u * (uint32_t)j;
+  uint32_t b0 = bit >> 3, sh = bit & 7;
+  uint64_t v = 0;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) v |= (uint64_t)byte_from_lsb(b0 + t) << (8 * t);
+  return (uint32_t)(v >> sh) & MONT_MASK;
+}
+
+__global__ void __launch_bounds__(256) k_digest_em(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                   const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid,
+                                                   SigRec* __restrict__ recs, uint32_t n_recs, KeyTableDev kt,
+                                                   uint32_t* __restrict__ x_limbs, uint32_t* __restrict__ em_limbs,
+                                                   uint32_t* __restrict__ rsa_list, uint32_t* __restrict__ rsa_count) {
+  uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= n_recs) return;
+  SigRec rec = recs[ri];
+  if (rec.status != ST_PENDING_HASH) return;
+  const uint8_t* body = sig_blob + rec.body_off;
+  uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
+  TailSrc ts;
+  ts.tail_len = (uint32_t)(tlen & 63);
+  ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
+  ts.body = body;
+  ts.pre_len = 6u + rec.hashed_len;
+  ts.total_len = tlen + ts.pre_len + 6;
+  uint32_t rem = ts.tail_len + ts.pre_len + 6;     // message bytes still to hash
+  uint32_t nblk = (rem + 9 + 63) >> 6;
+  uint32_t s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = mid[(uint64_t)rec.item * 8 + i];
+  for (uint32_t blk = 0; blk < nblk; ++blk) {
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t j = blk * 64 + i * 4;
+      w[i] = (tail_byte(ts, j, rem) << 24) | (tail_byte(ts, j + 1, rem) << 16) | (tail_byte(ts, j + 2, rem) << 8) |
+             tail_byte(ts, j + 3, rem);
+    }
+    if (blk == nblk - 1) {
+      uint64_t bits = ts.total_len * 8;
+      w[14] = (uint32_t)(bits >> 32);
+      w[15] = (uint32_t)bits;
+    }
+    sha256_compress(s, w);
+  }
+  // PublicKey.VerifySignature order of checks: CanSign, hash tag, algorithm match, then the math
+  uint32_t k = (uint32_t)rec.key_slot;
+  uint8_t kflags = kt.flags[k];
+  uint8_t st;
+  if (!(kflags & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;
+  else if ((uint8_t)(s[0] >> 24) != rec.hash_tag[0] || (uint8_t)(s[0] >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
+  else if (kt.pk_algo[k] != rec.pk_algo) st = ST_ALGO_MISMATCH;
+  else if (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) {
+    uint32_t kbytes = (kt.mod_bits[k] + 7) >> 3;
+    const uint32_t hlen = 32, plen = 19, tl = hlen + plen;
+    // value of the signature MPI
+    uint32_t nb = (rec.mpi_bits[0] + 7u) >> 3;
+    const uint8_t* mp = body + rec.mpi_off[0];
+    uint32_t lead = 0;
+    while (lead < nb && mp[lead] == 0) ++lead;
+    uint32_t vbytes = nb - lead;
+    if (kbytes < tl + 11) st = ST_BAD_SIG;                 // rsa.VerifyPKCS1v15: k < tLen+11
+    else if (kt.mod_bits[k] > 2048) st = ST_UNSUPPORTED;   // TODO(next): 3072/4096-bit instantiations
+    else if (vbytes > 266) st = ST_BAD_SIG;                // value >= R: fenced, never a valid s
+    else {
+      auto sig_b = [&](uint32_t i) -> uint32_t { return i < nb ? mp[nb - 1 - i] : 0u; };
+      auto em_b = [&](uint32_t i) -> uint32_t {
+        if (i < hlen) return (s[7 - (i >> 2)] >> (8 * (i & 3))) & 0xFF;
+        if (i < tl) return SHA256_DI[plen - 1 - (i - hlen)];
+        if (i == tl) return 0;
+        if (i < kbytes - 2) return 0xFF;
+        if (i == kbytes - 2) return 1;
+        return 0;
+      };
+      uint32_t* xo = x_limbs + (uint64_t)ri * MONT_N;
+      uint32_t* eo = em_limbs + (uint64_t)ri * MONT_N;
+      for (int j = 0; j < MONT_N; ++j) {
+        xo[j] = limb28(sig_b, j);
+        eo[j] = limb28(em_b, j);
+      }
+      rec.pad = (vbytes > kbytes) ? 1u : 0u;   // bit0: signature value may be >= 2^(8k): no x-shortcut
+      st = ST_PENDING_RSA;
+      uint32_t slot = atomicAdd(rsa_count, 1u);
+      rsa_list[slot] = ri;
+    }
+  } else {
+    st = ST_UNSUPPORTED;   // DSA / ECDSA: DSA lands in k_dsa (next milestone)
+  }
+  rec.status = st;
+  recs[ri].status = st;
+  recs[ri].pad = rec.pad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RSA verify: 4 lanes per signature
+// ------------------------------------------------------------------------------------------------
+constexpr int RSA_BLOCK = 256;
+constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
+
+enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
+
+__global__ void __launch_bounds__(RSA_BLOCK) k_rsa_verify(SigRec* __restrict__ recs, const uint32_t* __restrict__ rsa_list,
+                                                          const uint32_t* __restrict__ rsa_count, KeyTableDev kt,
+                                                          const uint32_t* __restrict__ x_limbs,
+                                                          const uint32_t* __restrict__ em_limbs,
+                                                          uint32_t* __restrict__ xr_scratch) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  constexpr int L = MONT_L;
+  const uint32_t count = *rsa_count;
+  if (blockIdx.x * QUADS_PER_BLOCK >= count) return;   // whole block idle
+  const uint32_t quad = threadIdx.x >> 2;
+  const int qlane = threadIdx.x & 3;
+  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const bool active = gq < count;
+  const uint32_t ri = rsa_list[active ? gq : (count - 1)];
+  const SigRec rec = recs[ri];
+  const uint32_t key = (uint32_t)rec.key_slot;
+  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;     // this lane's slice of the quad's operand
+  const uint32_t* a_rd = a_sh + quad * MONT_N;
+
+  uint32_t n[L], b[L], y[L];
+  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
+  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_N + qlane * L;
+  const uint32_t* xp = x_limbs + (uint64_t)ri * MONT_N + qlane * L;
+  uint32_t* xrp = xr_scratch + (uint64_t)ri * MONT_N + qlane * L;
+#pragma unroll
+  for (int k = 0; k < L; ++k) n[k] = np[k];
+  const uint32_t n0inv = kt.n0inv[key];
+  const uint32_t e = kt.rsa_e[key];
+  // x-shortcut: the last multiplication of an odd exponent uses plain x instead of xR, which also
+  // leaves the Montgomery domain.  Only when x < 2^(8k) so that the result stays below n(1+2^-79).
+  const uint32_t cls = (e << 1) | (((e & 1u) && e > 1u && !(rec.pad & 1u)) ? 1u : 0u);
+  bool ok_final = false;
+
+  // Exponent schedules are wave-uniform per (e, shortcut) class; a wave whose 16 signatures use
+  // different public exponents runs the schedule once per class (all real keys use 65537).
+  uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+  while (todo) {
+    const int lead = __builtin_ctzll(todo);
+    const uint32_t cls_u = (uint32_t)__builtin_amdgcn_readlane((int)cls, lead);
+    const bool live = (cls == cls_u);
+    const uint32_t e_u = cls_u >> 1;
+    const bool sc_u = cls_u & 1u;
+    const int top = 31 - __builtin_clz(e_u | 1u);
+    int kind = OP_TO_MONT, bitpos = top;
+    while (true) {
+      // ---- operands of this step
+      if (kind == OP_TO_MONT) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) { b[k] = rp[k]; a_lds[k] = xp[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < L; ++k) b[k] = y[k];
+        if (kind == OP_SQR) {
+#pragma unroll
+          for (int k = 0; k < L; ++k) a_lds[k] = y[k];
+        } else if (kind == OP_MULX) {
+#pragma unroll
+          for (int k = 0; k < L; ++k) a_lds[k] = xrp[k];
+        } else if (kind == OP_MULP) {
+#pragma unroll
+          for (int k = 0; k < L; ++k) a_lds[k] = xp[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      mont_mul(y, a_rd, b, n, n0inv, qlane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // ---- next step (scalar control flow)
+      if (kind == OP_TO_MONT && (e_u & (e_u - 1u)) != 0 && !(sc_u && __builtin_popcount(e_u) == 2)) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) xrp[k] = y[k];   // xR is needed again by OP_MULX
+      }
+      if (kind == OP_MULP || kind == OP_MUL1) break;
+      if (kind == OP_SQR && ((e_u >> bitpos) & 1u)) { kind = (bitpos == 0 && sc_u) ? OP_MULP : OP_MULX; continue; }
+      --bitpos;
+      kind = (bitpos >= 0) ? OP_SQR : OP_MUL1;
+    }
+    // y = s^e mod n (+ possibly n): canonicalise and compare with EM, then with EM + n
+    canonicalize(y, qlane);
+    const uint32_t* ep = em_limbs + (uint64_t)ri * MONT_N + qlane * L;
+    uint32_t em[L];
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) { em[k] = ep[k]; diff |= em[k] ^ y[k]; }
+    diff = quad_or(diff);
+    bool ok = (diff == 0);
+    if (__any(!ok)) {
+      uint32_t diff2 = 0;
+#pragma unroll
+      for (int k = 0; k < L; ++k) em[k] += n[k];
+      canonicalize(em, qlane);
+#pragma unroll
+      for (int k = 0; k < L; ++k) diff2 |= em[k] ^ y[k];
+      diff2 = quad_or(diff2);
+      ok = ok || (diff2 == 0);
+    }
+    if (e_u == 0) ok = false;   // x^0 = 1 is never a PKCS#1 encoding
+    if (live) ok_final = ok;
+    todo &= ~__builtin_amdgcn_ballot_w64(live);
+  }
+  if (active && qlane == 0) recs[ri].status = ok_final ? ST_OK : ST_BAD_SIG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic modular exponentiation  out = base^exp mod n   (corpus signing; threshold-RSA partials,
+// crypto/threshold/rsa/rsa.go:161-171).  Square-and-always-multiply with a per-lane select on the
+// exponent bit, so signatures with different exponents share a wave without divergence.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RSA_BLOCK) k_modexp(uint32_t n_ops, const uint32_t* __restrict__ base_limbs /*[n_ops][76]*/,
+                                                      const uint32_t* __restrict__ mod_idx, const uint32_t* __restrict__ n_limbs,
+                                                      const uint32_t* __restrict__ r2_limbs, const uint32_t* __restrict__ n0inv_tab,
+                                                      const uint32_t* __restrict__ exp_words /*[n_mods][exp_nwords] little-endian*/,
+                                                      uint32_t exp_nwords, uint32_t* __restrict__ out_limbs) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  __shared__ uint32_t x_sh[QUADS_PER_BLOCK * MONT_N];
+  constexpr int L = MONT_L;
+  const uint32_t quad = threadIdx.x >> 2;
+  const int qlane = threadIdx.x & 3;
+  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const bool active = gq < n_ops;
+  const uint32_t op = active ? gq : (n_ops - 1);
+  const uint32_t mi = mod_idx[op];
+  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
+  uint32_t* x_lds = x_sh + quad * MONT_N + qlane * L;
+  const uint32_t* a_rd = a_sh + quad * MONT_N;
+  const uint32_t* x_rd = x_sh + quad * MONT_N;
+  uint32_t n[L], b[L], y[L], t[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) n[k] = n_limbs[(uint64_t)mi * MONT_N + qlane * L + k];
+  const uint32_t n0inv = n0inv_tab[mi];
+  const uint32_t* ew = exp_words + (uint64_t)mi * exp_nwords;
+  // steps: -2: xR = mont(x, R^2); -1: y = mont(1, R^2) = R mod n; then per exponent bit a
+  // squaring (even step) and a multiplication by xR (odd step); last: mont(y, 1).
+  const int nbits = (int)exp_nwords * 32;
+  for (int step = -2; step <= 2 * nbits; ++step) {
+    const uint32_t* ard = a_rd;
+    if (step == -2) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) { b[k] = r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; a_lds[k] = base_limbs[(uint64_t)op * MONT_N + qlane * L + k]; }
+    } else if (step == -1 || step == 2 * nbits) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+      if (step >= 0) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) b[k] = y[k];
+      }
+    } else if ((step & 1) == 0) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < L; ++k) b[k] = y[k];
+      ard = x_rd;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    mont_mul(t, ard, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (step == -2) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) x_lds[k] = t[k];
+    } else if (step >= 0 && step < 2 * nbits && (step & 1)) {
+      const int bi = nbits - 1 - (step >> 1);
+      const bool bit = (ew[bi >> 5] >> (bi & 31)) & 1u;
+      if (bit) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) y[k] = t[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < L; ++k) y[k] = t[k];
+    }
+  }
+  canonicalize(y, qlane);
+  // y <= n, and y == n only when the value is 0 mod n
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < L; ++k) diff |= y[k] ^ n[k];
+  diff = quad_or(diff);
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) out_limbs[(uint64_t)op * MONT_N + qlane * L + k] = (diff == 0) ? 0u : y[k];
+  }
+}
+
+// big-endian bytes <-> radix-2^28 limbs (one thread per limb / per byte)
+__global__ void k_bytes_to_limbs(const uint8_t* __restrict__ src, uint32_t nbytes, uint32_t n_nums, uint32_t* __restrict__ dst) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nums * MONT_N) return;
+  uint32_t num = i / MONT_N, j = i % MONT_N;
+  const uint8_t* p = src + (uint64_t)num * nbytes;
+  auto bf = [&](uint32_t k) -> uint32_t { return k < nbytes ? p[nbytes - 1 - k] : 0u; };
+  dst[i] = limb28(bf, (int)j);
+}
+__global__ void k_limbs_to_bytes(const uint32_t* __restrict__ src, uint32_t nbytes, uint32_t n_nums, uint8_t* __restrict__ dst) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nums * nbytes) return;
+  uint32_t num = i / nbytes, k = i % nbytes;      // k: byte index from the LSB
+  uint32_t bit = k * 8, j = bit / 28, sh = bit % 28;
+  const uint32_t* l = src + (uint64_t)num * MONT_N;
+  uint64_t v = (j < MONT_N ? l[j] : 0u);
+  if (j + 1 < MONT_N) v |= (uint64_t)l[j + 1] << 28;
+  dst[(uint64_t)num * nbytes + (nbytes - 1 - k)] = (uint8_t)(v >> sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// quorum tally: one wave per item
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tally(const SigRec* __restrict__ recs, const uint32_t* __restrict__ rec_base,
+                                               const uint32_t* __restrict__ counts, uint32_t n_items, KeyTableDev kt,
+                                               QuorumDev q, uint8_t* __restrict__ verdict, uint32_t* __restrict__ n_verified,
+                                               uint32_t* __restrict__ clique_counts /*[n_items][MAX_QC] or null*/) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (wave >= n_items) return;
+  const uint32_t base = rec_base[wave], cnt = counts[wave];
+  uint32_t cq[MAX_QC];
+#pragma unroll
+  for (int c = 0; c < MAX_QC; ++c) cq[c] = 0;
+  uint32_t total_ok = 0;
+  uint32_t first_suff = 0xFFFFFFFFu;   // number of verified signers consumed when IsSufficient first held
+  for (uint32_t off = 0; off < cnt; off += 64) {
+    const uint32_t i = off + lane;
+    bool ok = false;
+    uint32_t ent = 0;
+    if (i < cnt) {
+      const SigRec r = recs[base + i];
+      ok = (r.status == ST_OK);
+      if (ok) ent = kt.entity[r.key_slot];
+    }
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    bool reached = false;
+#pragma unroll
+    for (int c = 0; c < MAX_QC; ++c) {
+      if (c < q.n_qcs) {
+        const bool mem = ok && q.member[(uint64_t)c * q.n_entities + ent];
+        const uint64_t mm = __builtin_amdgcn_ballot_w64(mem);
+        // inclusive running count of clique-c members among verified signers up to this lane
+        const uint32_t run = cq[c] + (uint32_t)__builtin_popcountll(mm & below) + (mem ? 1u : 0u);
+        if (ok && q.suff[c] > 0 && run >= (uint32_t)q.suff[c]) reached = true;
+        cq[c] += (uint32_t)__builtin_popcountll(mm);
+      }
+    }
+    const uint64_t rm = __builtin_amdgcn_ballot_w64(reached);
+    if (rm != 0 && first_suff == 0xFFFFFFFFu) {
+      const uint32_t fl = (uint32_t)__builtin_ctzll(rm);
+      first_suff = total_ok + (uint32_t)__builtin_popcountll(okm & ((fl == 63) ? ~0ull : ((1ull << (fl + 1)) - 1)));
+    }
+    total_ok += (uint32_t)__builtin_popcountll(okm);
+  }
+  if (lane == 0) {
+    // wotqs.go:144-185 over the full verified list (counts are monotone, so the early exit of
+    // crypto_pgp.go:493 fires iff IsSufficient holds for the full list)
+    bool is_quorum = q.n_qcs > 0, is_thr = q.n_qcs > 0, is_suff = false, reject = true;
+    for (int c = 0; c < q.n_qcs; ++c) {
+      if (q.f[c] > 0 && (int32_t)cq[c] < q.min[c]) is_quorum = false;
+      if (q.threshold[c] > 0 && (int32_t)cq[c] < q.threshold[c]) is_thr = false;
+      if (q.suff[c] > 0 && (int32_t)cq[c] >= q.suff[c]) is_suff = true;
+      if (q.f[c] == 0 || (int32_t)cq[c] <= q.f[c]) reject = false;
+    }
+    verdict[wave] = (is_quorum ? V_IS_QUORUM : 0) | (is_thr ? V_IS_THRESHOLD : 0) | (is_suff ? V_IS_SUFFICIENT : 0) |
+                    (reject ? V_REJECT : 0);
+    n_verified[wave] = is_suff ? first_suff : total_ok;
+    if (clique_counts)
+      for (int c = 0; c < MAX_QC; ++c) clique_counts[(uint64_t)wave * MAX_QC + c] = cq[c];
+  }
+}
+
+__global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, uint8_t* __restrict__ e) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) e[i] = (v[i] & V_IS_SUFFICIENT) ? 0 : 2;   // BFTKV_ERR_NONE : BFTKV_ERR_INSUFFICIENT_SIGNATURES
+}
+
+// per-record status export (diagnostics / parity tests)
+__global__ void k_export_status(const SigRec* __restrict__ recs, uint32_t n, uint8_t* __restrict__ st, uint32_t* __restrict__ item) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st[i] = recs[i].status;
+  if (item) item[i] = recs[i].item;
+}
+
+}  // namespace bftkv

@@ -1,0 +1,159 @@
+/*
+ * bftkv_gpu.h -- C ABI of the MI355X batched quorum verifier for yahoo/bftkv.
+ *
+ * The reference has no FFI today; its plug-in seam for this path is the Go interface bundle
+ * crypto.Crypto (crypto/crypto.go:103-111), specifically crypto.Signature (crypto/crypto.go:50-58),
+ * crypto.CollectiveSignature (crypto/crypto.go:66-71) and quorum.Quorum (quorum/quorum.go:18-25),
+ * implemented by crypto/pgp/crypto_pgp.go:319-344, 373-390, 485-519 and
+ * quorum/wotqs/wotqs.go:144-193.  Every entry point below names the reference function(s) it
+ * replaces; INTEGRATION.md shows the cgo package (crypto/pgpgpu) a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative BFTKV_E_* infrastructure error;
+ *     cryptographic outcomes are DATA (status / verdict bytes), never return codes;
+ *   - all pointers are host pointers unless the function name ends in _dev; buffers are only read
+ *     for the duration of the call (cgo rule: no pointer is retained);
+ *   - the library is re-entrant per context; calls on one context are serialised internally.
+ *   - offsets arrays have n+1 entries: item i occupies blob[off[i] .. off[i+1]).
+ */
+#ifndef BFTKV_GPU_H
+#define BFTKV_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bftkv_gpu_ctx bftkv_gpu_ctx;
+
+/* infrastructure errors */
+#define BFTKV_OK 0
+#define BFTKV_E_INVALID (-1)       /* bad argument */
+#define BFTKV_E_DEVICE (-2)        /* HIP runtime failure (message via bftkv_gpu_last_error) */
+#define BFTKV_E_NOMEM (-3)
+#define BFTKV_E_UNSUPPORTED (-4)   /* e.g. two different keys sharing one 64-bit key id, modulus > 2048 bits */
+#define BFTKV_E_STATE (-5)         /* keyring / quorum not set */
+
+/* per-packet status (one CheckDetachedSignature-equivalent step) */
+#define BFTKV_ST_OK 0
+#define BFTKV_ST_UNKNOWN_ISSUER 1
+#define BFTKV_ST_PARSE_ERROR 2
+#define BFTKV_ST_NOT_SIGNATURE 3
+#define BFTKV_ST_NO_ISSUER 4
+#define BFTKV_ST_HASH_UNSUPPORTED 5
+#define BFTKV_ST_HASH_TAG 6
+#define BFTKV_ST_ALGO_MISMATCH 7
+#define BFTKV_ST_BAD_SIG 8
+#define BFTKV_ST_KEY_CANNOT_SIGN 9
+#define BFTKV_ST_UNSUPPORTED 10
+
+/* error identities of crypto/crypto.go:16-33 the shim maps verdicts to */
+#define BFTKV_ERR_NONE 0
+#define BFTKV_ERR_INVALID_SIGNATURE 1          /* crypto.ErrInvalidSignature */
+#define BFTKV_ERR_INSUFFICIENT_SIGNATURES 2    /* crypto.ErrInsufficientNumberOfSignatures */
+
+/* quorum predicate bits (quorum/wotqs/wotqs.go:144-185) */
+#define BFTKV_V_IS_QUORUM 1
+#define BFTKV_V_IS_THRESHOLD 2
+#define BFTKV_V_IS_SUFFICIENT 4
+#define BFTKV_V_REJECT 8
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out);
+void bftkv_gpu_destroy(bftkv_gpu_ctx* ctx);
+const char* bftkv_gpu_last_error(const bftkv_gpu_ctx* ctx);
+/* "crypto: invalid signature" etc. -- the strings that travel in the X-error header
+ * (transport/http/http.go:145, bftkv.go:34-48) */
+const char* bftkv_gpu_error_string(int bftkv_err);
+
+/* ---- keyring: replaces PGPKeyring.getKeyring()/KeysByIdUsage (crypto_pgp.go:195-219) ---------- */
+typedef struct {
+  uint64_t key_id;        /* 64-bit OpenPGP key id of this (sub)key */
+  uint64_t entity_id;     /* primary key id of the owning entity = node.Node.Id() (crypto_pgp.go:43-45) */
+  uint8_t pk_algo;        /* 1 RSA, 3 RSA-sign-only, 17 DSA, ... as in the public-key packet */
+  uint8_t usable_sign;    /* KeysByIdUsage(id, KeyFlagSign) would return it: entity not revoked, self-signature
+                             not a revocation, key flags absent or containing Sign */
+  uint8_t reserved[6];
+  const uint8_t* n; uint32_t n_len;   /* RSA modulus, big-endian       | DSA p */
+  const uint8_t* e; uint32_t e_len;   /* RSA public exponent           | DSA q */
+  const uint8_t* g; uint32_t g_len;   /* DSA g */
+  const uint8_t* y; uint32_t y_len;   /* DSA y */
+} bftkv_gpu_pubkey;
+
+/* keys[] in keyring order (secring entities first, crypto_pgp.go:195-197).  Identical material
+ * under one key id (the node's own key appears in both rings) is de-duplicated; different
+ * material under one id is BFTKV_E_UNSUPPORTED. */
+int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint32_t n_keys);
+
+/* ---- quorum: replaces wotq / qc (quorum/wotqs/wotqs.go:16-26) ------------------------------- */
+typedef struct {
+  int32_t f, min, threshold, suff;       /* as computed by wot.newQC (wotqs.go:36-70) */
+  const uint64_t* node_ids; uint32_t n_nodes;
+} bftkv_gpu_qc;
+int bftkv_gpu_quorum_create(bftkv_gpu_ctx* ctx, const bftkv_gpu_qc* qcs, uint32_t n_qcs, int* quorum_out);
+int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
+
+/* ---- CollectiveSignature.Verify, batched (crypto_pgp.go:485-500) ----------------------------- */
+/* For item i: tbs = tbs_blob[tbs_off[i]..], ss.Data = ss_blob[ss_off[i]..], quorum q.
+ *   err_out[i]        BFTKV_ERR_NONE (=> the shim sets ss.Completed = true, crypto_pgp.go:494) or
+ *                     BFTKV_ERR_INSUFFICIENT_SIGNATURES
+ *   n_verified_out[i] (optional) len(verified) when the reference returned
+ *   verdict_out[i]    (optional) BFTKV_V_* bits of the full verified-signer list */
+int bftkv_gpu_collective_verify(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
+                                const uint8_t* tbs_blob, const uint64_t* tbs_off,
+                                const uint8_t* ss_blob, const uint64_t* ss_off,
+                                uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out);
+/* same, every pointer a DEVICE pointer (inputs already resident in HBM); asynchronous on the
+ * context's stream until bftkv_gpu_sync */
+int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
+                                    const uint8_t* tbs_blob, const uint64_t* tbs_off,
+                                    const uint8_t* ss_blob, const uint64_t* ss_off, uint64_t ss_blob_len,
+                                    uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out);
+int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
+
+/* ---- Signature.Verify / VerifyWithCertificate, batched (crypto_pgp.go:319-344) ---------------- */
+/* err_out[i] = BFTKV_ERR_NONE iff sig.Data holds >= 1 packet and every CheckDetachedSignature call
+ * succeeds, else BFTKV_ERR_INVALID_SIGNATURE.  cert_key_id == NULL: keyring = the node keyring;
+ * otherwise the keyring of item i is the single entity whose primary key id is cert_key_id[i]
+ * (it must have been uploaded with bftkv_gpu_keyring_set; subkeys of that entity match too). */
+int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
+                               const uint8_t* tbs_blob, const uint64_t* tbs_off,
+                               const uint8_t* sig_blob, const uint64_t* sig_off,
+                               const uint64_t* cert_key_id, uint8_t* err_out);
+
+/* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */
+int bftkv_gpu_last_statuses(bftkv_gpu_ctx* ctx, uint8_t* status_out, uint32_t* item_out, uint32_t cap, uint32_t* n_out);
+/* counters of the last verify call: [0] packets parsed, [1] public-key operations performed */
+int bftkv_gpu_last_counters(bftkv_gpu_ctx* ctx, uint64_t counters[4]);
+
+/* ---- Signers (parse only) (crypto_pgp.go:373-390, 517-519) ------------------------------------ */
+/* ids_out receives, per item, the entity ids of issuers present in the keyring, in packet order;
+ * ids_off_out[n_items+1] delimits them.  cap = capacity of ids_out. */
+int bftkv_gpu_signers(bftkv_gpu_ctx* ctx, uint32_t n_items, const uint8_t* ss_blob, const uint64_t* ss_off,
+                      uint64_t* ids_out, uint64_t* ids_off_out, uint64_t cap);
+
+/* ---- quorum predicates over node lists, batched (wotqs.go:144-193) ---------------------------- */
+/* verdict_out[i] = BFTKV_V_* bits for nodes = ids[list_off[i]..list_off[i+1]) (duplicates count
+ * repeatedly, wotqs.go:195-206). */
+int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_lists,
+                           const uint64_t* ids, const uint64_t* list_off, uint8_t* verdict_out);
+
+/* ---- modular exponentiation, batched ---------------------------------------------------------- */
+/* out[i] = base[i] ^ exp[mod_idx[i]] mod mod[mod_idx[i]]; numbers big-endian, nbytes each (<= 256),
+ * exponents exp_len bytes each.  Replaces the per-fragment m^d_i mod N of threshold RSA
+ * (crypto/threshold/rsa/rsa.go:161-171); also used to sign synthetic corpora. */
+int bftkv_gpu_modexp(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, uint32_t nbytes,
+                     const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
+                     const uint8_t* exps, uint32_t exp_len, uint8_t* out);
+
+/* ---- timing of the last *_dev verify call (HIP events on the context's stream) ---------------- */
+/* ms[0] total, ms[1] parse, ms[2] hash, ms[3] rsa, ms[4] tally */
+int bftkv_gpu_last_timing(bftkv_gpu_ctx* ctx, float ms[8]);
+void* bftkv_gpu_stream(bftkv_gpu_ctx* ctx);   /* hipStream_t of the context */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFTKV_GPU_H */

@@ -1,0 +1,610 @@
+"""Oracle restatement of the OpenPGP arithmetic the bftkv hot path reaches through
+golang.org/x/crypto/openpgp (pinned v0.0.0-20191227163750-53104e6ec876, go.mod:8; source NOT in
+/root/reference -- PARITY UNPINNED, see oracle/__init__.py) and the Go 1.12/1.13 standard library
+(crypto/rsa, crypto/dsa, math/big, crypto/sha*).
+
+TEST INFRASTRUCTURE ONLY.  Reference call sites this file answers for:
+  openpgp.CheckDetachedSignature      crypto/pgp/crypto_pgp.go:324, :338, :490
+  packet.NewReader / Reader.Next      crypto/pgp/crypto_pgp.go:375-377
+  openpgp.ReadEntity / ReadKeyRing    crypto/pgp/crypto_pgp.go:242, :252   (key material + flags only)
+Published behaviour restated (RFC 4880):
+  B.1 packet header  B.2 Signature.parse  B.3 CheckDetachedSignature
+  B.4 RSA PKCS#1 v1.5 verify  B.5 DSA verify
+Pinned against GnuPG 2.2.27 / OpenSSL 3 through tests/golden/gpg_vectors.json.
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+# ---- status codes of one CheckDetachedSignature-equivalent step (shared with include/bftkv_gpu.h)
+ST_OK = 0                # verified; signer entity returned
+ST_UNKNOWN_ISSUER = 1    # no sign-capable key with that id in the keyring (packet skipped in-call)
+ST_PARSE_ERROR = 2       # structural / unsupported error while parsing the packet (packet consumed)
+ST_NOT_SIGNATURE = 3     # a well-formed packet that is not a signature
+ST_NO_ISSUER = 4         # v4 signature without issuer subpacket
+ST_HASH_UNSUPPORTED = 5  # hashForSignature failed (hash not linked in / sig type unsupported)
+ST_HASH_TAG = 6          # "hash tag doesn't match"
+ST_ALGO_MISMATCH = 7     # "public key and signature use different algorithms"
+ST_BAD_SIG = 8           # RSA/DSA verification failure
+ST_KEY_CANNOT_SIGN = 9   # "public key cannot generate signatures"
+ST_UNSUPPORTED = 10      # fenced-off input: oversize MPI, partial lengths, v3 ...
+
+PK_RSA = 1
+PK_RSA_ENCRYPT_ONLY = 2
+PK_RSA_SIGN_ONLY = 3
+PK_ELGAMAL = 16
+PK_DSA = 17
+PK_ECDH = 18
+PK_ECDSA = 19
+
+# s2k.HashIdToHash table; "available" = linked into a bftkv binary through x/crypto/openpgp's
+# imports (crypto/md5, sha1, sha256, sha512, x/crypto/ripemd160).
+HASH_BY_ID = {1: "md5", 2: "sha1", 3: "ripemd160", 8: "sha256", 9: "sha384", 10: "sha512", 11: "sha224"}
+
+# DigestInfo prefixes, Go crypto/rsa hashPrefixes (the reference carries a copy at
+# crypto/threshold/rsa/rsa.go:345-354).
+HASH_PREFIXES = {
+    "md5": bytes.fromhex("3020300c06082a864886f70d020505000410"),
+    "sha1": bytes.fromhex("3021300906052b0e03021a05000414"),
+    "sha224": bytes.fromhex("302d300d06096086480165030402040500041c"),
+    "sha256": bytes.fromhex("3031300d060960864801650304020105000420"),
+    "sha384": bytes.fromhex("3041300d060960864801650304020205000430"),
+    "sha512": bytes.fromhex("3051300d060960864801650304020305000440"),
+    "ripemd160": bytes.fromhex("3020300706052b240302010414"),
+}
+
+
+class StructuralError(Exception):
+    pass
+
+
+class UnsupportedError(Exception):
+    pass
+
+
+class UnknownPacketType(Exception):
+    pass
+
+
+class _Truncated(Exception):
+    """io.ErrUnexpectedEOF / io.EOF in the middle of a packet."""
+
+
+# ------------------------------------------------------------------------------------------------
+# B.1 packet framing
+# ------------------------------------------------------------------------------------------------
+def read_header(buf: bytes, pos: int) -> Tuple[int, int, int]:
+    """openpgp/packet.readHeader.  Returns (tag, body_start, body_len).
+    body_len == -1: indeterminate length (old format type 3); -2: partial body length (new format)."""
+    if pos >= len(buf):
+        raise EOFError()
+    b0 = buf[pos]
+    if b0 & 0x80 == 0:
+        raise StructuralError("tag byte does not have MSB set")
+    if b0 & 0x40 == 0:  # old format
+        tag = (b0 & 0x3F) >> 2
+        lt = b0 & 3
+        if lt == 3:
+            return tag, pos + 1, -1
+        nb = 1 << lt
+        if pos + 1 + nb > len(buf):
+            raise _Truncated()
+        ln = int.from_bytes(buf[pos + 1:pos + 1 + nb], "big")
+        return tag, pos + 1 + nb, ln
+    tag = b0 & 0x3F
+    if pos + 1 >= len(buf):
+        raise _Truncated()
+    b1 = buf[pos + 1]
+    if b1 < 192:
+        return tag, pos + 2, b1
+    if b1 < 224:
+        if pos + 2 >= len(buf):
+            raise _Truncated()
+        return tag, pos + 3, ((b1 - 192) << 8) + buf[pos + 2] + 192
+    if b1 == 255:
+        if pos + 6 > len(buf):
+            raise _Truncated()
+        return tag, pos + 6, int.from_bytes(buf[pos + 2:pos + 6], "big")
+    return tag, pos + 2, -2
+
+
+@dataclass
+class Signature:
+    """What Signature.parse keeps (openpgp/packet/signature.go) -- only the fields the path uses."""
+    version: int = 4
+    sig_type: int = 0
+    pk_algo: int = 0
+    hash_id: int = 0
+    hash_suffix: bytes = b""
+    hash_tag: bytes = b"\0\0"
+    issuer: Optional[int] = None
+    creation_time: Optional[int] = None
+    mpis: List[Tuple[int, bytes]] = field(default_factory=list)  # (bit length as written, bytes)
+    flags_valid: bool = False
+    flag_certify: bool = False
+    flag_sign: bool = False
+    is_primary_id: Optional[bool] = None
+    revocation_reason: Optional[int] = None
+
+
+def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
+    """parseSignatureSubpackets / parseSignatureSubpacket (B.2)."""
+    p = 0
+    while p < len(area):
+        b = area[p]
+        if b < 192:
+            ln, p = b, p + 1
+        elif b < 255:
+            if p + 2 > len(area):
+                raise StructuralError("subpacket truncated")
+            ln, p = ((b - 192) << 8) + area[p + 1] + 192, p + 2
+        else:
+            if p + 5 > len(area):
+                raise StructuralError("subpacket truncated")
+            ln, p = int.from_bytes(area[p + 1:p + 5], "big"), p + 5
+        if ln > len(area) - p:
+            raise StructuralError("subpacket truncated")
+        if ln == 0:
+            raise StructuralError("zero length signature subpacket")
+        sub = area[p:p + ln]
+        p += ln
+        typ = sub[0] & 0x7F
+        critical = sub[0] & 0x80 != 0
+        body = sub[1:]
+        if typ == 2:  # creation time
+            if not hashed:
+                continue
+            if len(body) != 4:
+                raise StructuralError("signature creation time not four bytes")
+            sig.creation_time = int.from_bytes(body, "big")
+        elif typ == 3:  # signature expiry
+            if not hashed:
+                continue
+            if len(body) != 4:
+                raise StructuralError("expiration subpacket with bad length")
+        elif typ == 9:  # key lifetime
+            if not hashed:
+                continue
+            if len(body) != 4:
+                raise StructuralError("key expiration subpacket with bad length")
+        elif typ in (11, 21, 22):  # preferences
+            if not hashed:
+                continue
+        elif typ == 16:  # issuer: accepted from either area
+            if len(body) != 8:
+                raise StructuralError("issuer subpacket with bad length")
+            sig.issuer = int.from_bytes(body, "big")
+        elif typ == 25:  # primary user id
+            if not hashed:
+                continue
+            if len(body) != 1:
+                raise StructuralError("primary user id subpacket with bad length")
+            sig.is_primary_id = body[0] != 0
+        elif typ == 27:  # key flags
+            if not hashed:
+                continue
+            if len(body) == 0:
+                raise StructuralError("empty key flags subpacket")
+            sig.flags_valid = True
+            sig.flag_certify = bool(body[0] & 0x01)
+            sig.flag_sign = bool(body[0] & 0x02)
+        elif typ == 29:  # reason for revocation
+            if not hashed:
+                continue
+            if len(body) == 0:
+                raise StructuralError("empty revocation reason subpacket")
+            sig.revocation_reason = body[0]
+        elif typ == 30:  # features
+            if not hashed:
+                continue
+        elif typ == 32:  # embedded signature: parsed recursively by the reference
+            if not hashed:
+                continue
+            parse_signature_body(body)
+        else:
+            if critical:
+                raise UnsupportedError("unknown critical signature subpacket type %d" % typ)
+
+
+def parse_signature_body(body: bytes) -> Signature:
+    """Signature.parse for a version-4 body (B.2).  Raises StructuralError/UnsupportedError."""
+    if len(body) < 1:
+        raise _Truncated()
+    if body[0] != 4:
+        raise UnsupportedError("signature packet version %d" % body[0])
+    if len(body) < 6:
+        raise _Truncated()
+    sig = Signature(version=4, sig_type=body[1], pk_algo=body[2], hash_id=body[3])
+    if sig.pk_algo not in (PK_RSA, PK_RSA_SIGN_ONLY, PK_DSA, PK_ECDSA):
+        raise UnsupportedError("public key algorithm %d" % sig.pk_algo)
+    if sig.hash_id not in HASH_BY_ID:
+        raise UnsupportedError("hash function %d" % sig.hash_id)
+    hl = (body[4] << 8) | body[5]
+    if 6 + hl > len(body):
+        raise _Truncated()
+    hashed = body[6:6 + hl]
+    l = 6 + hl
+    sig.hash_suffix = body[0:l] + bytes([4, 0xFF]) + struct.pack(">I", l)
+    _parse_subpackets(sig, hashed, True)
+    if sig.creation_time is None:
+        raise StructuralError("no creation time in signature")
+    p = l
+    if p + 2 > len(body):
+        raise _Truncated()
+    ul = (body[p] << 8) | body[p + 1]
+    p += 2
+    if p + ul > len(body):
+        raise _Truncated()
+    _parse_subpackets(sig, body[p:p + ul], False)
+    p += ul
+    if p + 2 > len(body):
+        raise _Truncated()
+    sig.hash_tag = body[p:p + 2]
+    p += 2
+    n_mpi = 1 if sig.pk_algo in (PK_RSA, PK_RSA_SIGN_ONLY) else 2
+    for _ in range(n_mpi):
+        if p + 2 > len(body):
+            raise _Truncated()
+        bits = (body[p] << 8) | body[p + 1]
+        nb = (bits + 7) // 8
+        p += 2
+        if p + nb > len(body):
+            raise _Truncated()
+        sig.mpis.append((bits, body[p:p + nb]))
+        p += nb
+    return sig
+
+
+@dataclass
+class RawPacket:
+    tag: int
+    body: bytes
+    end: int  # stream position after the packet
+
+
+def next_packet(buf: bytes, pos: int) -> RawPacket:
+    """One packet.Read step on an unbuffered stream.  Raises EOFError at a clean end,
+    StructuralError for a bad tag byte (1 byte consumed: ``.consumed``), _Truncated mid-packet."""
+    try:
+        tag, start, ln = read_header(buf, pos)
+    except StructuralError as e:
+        e.consumed = pos + 1
+        raise
+    if ln < 0:
+        # indeterminate / partial body lengths: legal OpenPGP, never produced by the path's
+        # writers (DetachSign emits definite lengths).  FENCED: the whole rest of the
+        # stream is treated as unsupported.
+        u = UnsupportedError("indeterminate/partial packet length")
+        u.consumed = len(buf)
+        raise u
+    if start + ln > len(buf):
+        raise _Truncated()
+    return RawPacket(tag, buf[start:start + ln], start + ln)
+
+
+# ------------------------------------------------------------------------------------------------
+# Keys and keyrings
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PublicKey:
+    key_id: int
+    pk_algo: int
+    # RSA
+    n: int = 0
+    e: int = 0
+    # DSA
+    p: int = 0
+    q: int = 0
+    g: int = 0
+    y: int = 0
+    fingerprint: bytes = b""
+    is_subkey: bool = False
+
+    def can_sign(self) -> bool:  # PublicKey.CanSign
+        return self.pk_algo not in (PK_RSA_ENCRYPT_ONLY, PK_ELGAMAL)
+
+
+@dataclass
+class Entity:
+    """openpgp.Entity reduced to what KeysByIdUsage and bftkv's node wrapper read."""
+    primary: PublicKey
+    name: str = ""
+    # self-signature facts of the (first / primary) identity
+    flags_valid: bool = True
+    flag_sign: bool = True
+    flag_certify: bool = True
+    self_sig_revoked: bool = False
+    revoked: bool = False                      # len(Entity.Revocations) > 0
+    subkeys: List[Tuple[PublicKey, bool, bool]] = field(default_factory=list)  # (key, flags_valid, flag_sign)
+    certifiers: List[int] = field(default_factory=list)   # issuer key ids of 3rd-party certifications
+    serialized: bytes = b""
+
+    @property
+    def id(self) -> int:  # PGPCertificateInstance.Id, crypto_pgp.go:43-45
+        return self.primary.key_id
+
+
+def keys_by_id_usage_sign(keyring: List[Entity], key_id: int) -> List[Tuple[Entity, PublicKey]]:
+    """EntityList.KeysByIdUsage(id, KeyFlagSign) (B.3)."""
+    out = []
+    for e in keyring:
+        cands = []
+        if e.primary.key_id == key_id:
+            cands.append((e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked))
+        for sk, fv, fs in e.subkeys:
+            if sk.key_id == key_id:
+                cands.append((sk, fv, fs, False))
+        for k, fv, fs, rr in cands:
+            if e.revoked or rr:
+                continue
+            if fv and not fs:
+                continue
+            out.append((e, k))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# B.4 / B.5 public-key verification
+# ------------------------------------------------------------------------------------------------
+def rsa_verify_pkcs1v15(n: int, e: int, hash_name: str, digest: bytes, sig: bytes) -> bool:
+    """Go 1.12/1.13 rsa.VerifyPKCS1v15 after openpgp's padToKeySize: no len(sig)==k check and no
+    s<n check (math/big.Exp reduces) in those releases (B.4)."""
+    prefix = HASH_PREFIXES[hash_name]
+    t_len = len(prefix) + len(digest)
+    k = (n.bit_length() + 7) // 8
+    if k < t_len + 11:
+        return False
+    c = int.from_bytes(sig, "big")
+    m = pow(c, e, n)
+    em = m.to_bytes(k, "big")
+    expect = b"\x00\x01" + b"\xff" * (k - t_len - 3) + b"\x00" + prefix + digest
+    return em == expect
+
+
+def dsa_verify(p: int, q: int, g: int, y: int, digest: bytes, r: int, s: int) -> bool:
+    """Go crypto/dsa.Verify (B.5); ``digest`` already truncated by openpgp to ceil(bits(q)/8)."""
+    if p == 0:  # pub.P.Sign() == 0
+        return False
+    if r < 1 or r >= q:
+        return False
+    if s < 1 or s >= q:
+        return False
+    n = q.bit_length()
+    if n & 7 != 0:
+        return False
+    w = pow(s, -1, q) if _gcd(s, q) == 1 else 0   # ModInverse returns nil on failure -> treated as 0
+    if w == 0:
+        return False
+    z = int.from_bytes(digest[:n // 8] if len(digest) > n // 8 else digest, "big")
+    u1 = (z * w) % q
+    u2 = (r * w) % q
+    v = (pow(g, u1, p) * pow(y, u2, p)) % p % q
+    return v == r
+
+
+def _gcd(a: int, b: int) -> int:
+    while b:
+        a, b = b, a % b
+    return a
+
+
+def hash_for_signature(hash_id: int, sig_type: int):
+    """hashForSignature: binary (0x00) hashes raw bytes; text (0x01) canonicalises line endings
+    (not produced on this path -> fenced as unsupported); others unsupported."""
+    name = HASH_BY_ID.get(hash_id)
+    if name is None:
+        return None
+    if sig_type != 0x00:
+        return None
+    try:
+        return hashlib.new(name)
+    except ValueError:
+        return None
+
+
+def verify_signature(key: PublicKey, hash_id: int, digest: bytes, sig: Signature) -> int:
+    """PublicKey.VerifySignature after the hash has been finalised (B.4)."""
+    if not key.can_sign():
+        return ST_KEY_CANNOT_SIGN
+    if digest[0] != sig.hash_tag[0] or digest[1] != sig.hash_tag[1]:
+        return ST_HASH_TAG
+    if key.pk_algo != sig.pk_algo:
+        return ST_ALGO_MISMATCH
+    if key.pk_algo in (PK_RSA, PK_RSA_SIGN_ONLY):
+        ok = rsa_verify_pkcs1v15(key.n, key.e, HASH_BY_ID[hash_id], digest, sig.mpis[0][1])
+        return ST_OK if ok else ST_BAD_SIG
+    if key.pk_algo == PK_DSA:
+        sub = (key.q.bit_length() + 7) // 8
+        hb = digest[:sub] if len(digest) > sub else digest
+        ok = dsa_verify(key.p, key.q, key.g, key.y, hb,
+                        int.from_bytes(sig.mpis[0][1], "big"), int.from_bytes(sig.mpis[1][1], "big"))
+        return ST_OK if ok else ST_BAD_SIG
+    return ST_UNSUPPORTED  # ECDSA: out of scope
+
+
+@dataclass
+class StepResult:
+    status: int
+    signer: Optional[Entity]
+    pos: int                # stream position after the call
+    statuses: List[int]     # one status per packet consumed by this call (diagnostics / GPU parity)
+
+
+def check_detached_signature(keyring: List[Entity], signed: bytes, sigdata: bytes, pos: int) -> StepResult:
+    """openpgp.CheckDetachedSignature(keyring, signed, signature) where ``signature`` is the shared
+    bytes.Reader positioned at ``pos`` (crypto_pgp.go:321-329, 486-498).  B.3."""
+    per_packet: List[int] = []
+    while True:
+        try:
+            pkt = next_packet(sigdata, pos)
+        except EOFError:
+            return StepResult(ST_UNKNOWN_ISSUER, None, pos, per_packet)  # io.EOF => ErrUnknownIssuer
+        except StructuralError as e:
+            per_packet.append(ST_PARSE_ERROR)
+            return StepResult(ST_PARSE_ERROR, None, e.consumed, per_packet)
+        except UnsupportedError as e:
+            per_packet.append(ST_UNSUPPORTED)
+            return StepResult(ST_UNSUPPORTED, None, e.consumed, per_packet)
+        except _Truncated:
+            per_packet.append(ST_PARSE_ERROR)
+            return StepResult(ST_PARSE_ERROR, None, len(sigdata), per_packet)
+        pos = pkt.end   # bufio inside peekVersion/consumeAll drains the whole body (<= 4096 B)
+        if pkt.tag != 2:
+            if pkt.tag in _KNOWN_TAGS:
+                per_packet.append(ST_NOT_SIGNATURE)
+                return StepResult(ST_NOT_SIGNATURE, None, pos, per_packet)
+            continue  # Reader.Next silently skips unknown packet types
+        if len(pkt.body) >= 1 and pkt.body[0] < 4:
+            # SignatureV3: legal for the reference, never produced by DetachSign.  FENCED.
+            per_packet.append(ST_UNSUPPORTED)
+            return StepResult(ST_UNSUPPORTED, None, pos, per_packet)
+        try:
+            sig = parse_signature_body(pkt.body)
+        except (StructuralError, UnsupportedError, _Truncated):
+            per_packet.append(ST_PARSE_ERROR)
+            return StepResult(ST_PARSE_ERROR, None, pos, per_packet)
+        if sig.issuer is None:
+            per_packet.append(ST_NO_ISSUER)
+            return StepResult(ST_NO_ISSUER, None, pos, per_packet)
+        keys = keys_by_id_usage_sign(keyring, sig.issuer)
+        if not keys:
+            per_packet.append(ST_UNKNOWN_ISSUER)
+            continue
+        h = hash_for_signature(sig.hash_id, sig.sig_type)
+        if h is None:
+            per_packet.append(ST_HASH_UNSUPPORTED)
+            return StepResult(ST_HASH_UNSUPPORTED, None, pos, per_packet)
+        h.update(signed)
+        st = ST_BAD_SIG
+        for ent, key in keys:
+            # VerifySignature writes HashSuffix into the *shared* hash object each time it is
+            # called, so candidate j sees the suffix j+1 times.
+            h.update(sig.hash_suffix)
+            st = verify_signature(key, sig.hash_id, h.copy().digest(), sig)
+            if st == ST_OK:
+                per_packet.append(ST_OK)
+                return StepResult(ST_OK, ent, pos, per_packet)
+        per_packet.append(st)
+        return StepResult(st, None, pos, per_packet)
+
+
+# packet tags packet.Read knows how to construct (anything else => UnknownPacketTypeError)
+_KNOWN_TAGS = {1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 14, 17, 18}
+
+
+# ------------------------------------------------------------------------------------------------
+# Building blocks used by the corpus generator and the gpg pinning tests
+# ------------------------------------------------------------------------------------------------
+def mpi(x: int) -> bytes:
+    """Canonical MPI (true bit count)."""
+    nb = (x.bit_length() + 7) // 8
+    return struct.pack(">H", x.bit_length()) + x.to_bytes(nb, "big")
+
+
+def new_format_header(tag: int, ln: int) -> bytes:
+    """serializeHeader: new-format packet header."""
+    if ln < 192:
+        return bytes([0xC0 | tag, ln])
+    if ln < 8384:
+        ln -= 192
+        return bytes([0xC0 | tag, 192 + (ln >> 8), ln & 0xFF])
+    return bytes([0xC0 | tag, 255]) + struct.pack(">I", ln)
+
+
+def public_key_body(key: PublicKey, creation_time: int) -> bytes:
+    body = bytes([4]) + struct.pack(">I", creation_time) + bytes([key.pk_algo])
+    if key.pk_algo in (PK_RSA, PK_RSA_SIGN_ONLY, PK_RSA_ENCRYPT_ONLY):
+        body += mpi(key.n) + mpi(key.e)
+    elif key.pk_algo == PK_DSA:
+        body += mpi(key.p) + mpi(key.q) + mpi(key.g) + mpi(key.y)
+    else:
+        raise ValueError("algo")
+    return body
+
+
+def fingerprint_v4(body: bytes) -> bytes:
+    """SHA-1(0x99 || u16(len) || body)."""
+    return hashlib.sha1(b"\x99" + struct.pack(">H", len(body)) + body).digest()
+
+
+def parse_public_key_body(body: bytes, is_subkey: bool = False) -> PublicKey:
+    if body[0] != 4:
+        raise UnsupportedError("public key version")
+    algo = body[5]
+    p = 6
+
+    def rd():
+        nonlocal p
+        bits = (body[p] << 8) | body[p + 1]
+        nb = (bits + 7) // 8
+        v = int.from_bytes(body[p + 2:p + 2 + nb], "big")
+        p += 2 + nb
+        return v
+
+    fp = fingerprint_v4(body)
+    kid = int.from_bytes(fp[12:20], "big")
+    if algo in (PK_RSA, PK_RSA_SIGN_ONLY, PK_RSA_ENCRYPT_ONLY):
+        n = rd()
+        e = rd()
+        return PublicKey(kid, algo, n=n, e=e, fingerprint=fp, is_subkey=is_subkey)
+    if algo == PK_DSA:
+        pp, q, g, y = rd(), rd(), rd(), rd()
+        return PublicKey(kid, algo, p=pp, q=q, g=g, y=y, fingerprint=fp, is_subkey=is_subkey)
+    raise UnsupportedError("public key algorithm %d" % algo)
+
+
+def read_entities(blob: bytes) -> List[Entity]:
+    """ReadKeyRing / repeated ReadEntity reduced to key material, self-signature key flags and the
+    list of third-party certifier ids (B.6).  Self-signature *verification* (which ReadEntity
+    performs) is row 8(f)-1 of SURVEY.md, not part of this restatement yet."""
+    ents: List[Entity] = []
+    pos = 0
+    cur: Optional[Entity] = None
+    last_pub: Optional[PublicKey] = None
+    in_sub = False
+    while pos < len(blob):
+        try:
+            pkt = next_packet(blob, pos)
+        except (EOFError, _Truncated, StructuralError, UnsupportedError):
+            break
+        start, pos = pos, pkt.end
+        if pkt.tag == 6:  # public key
+            cur = Entity(primary=parse_public_key_body(pkt.body), flags_valid=False, flag_sign=False,
+                         flag_certify=False)
+            cur._start = start
+            ents.append(cur)
+            in_sub = False
+            cur._have_self = False
+        elif cur is None:
+            continue
+        elif pkt.tag == 13:
+            cur.name = cur.name or pkt.body.decode("utf-8", "replace")
+            in_sub = False
+        elif pkt.tag == 14:
+            last_pub = parse_public_key_body(pkt.body, True)
+            cur.subkeys.append((last_pub, False, False))
+            in_sub = True
+        elif pkt.tag == 2:
+            try:
+                s = parse_signature_body(pkt.body)
+            except Exception:
+                continue
+            if in_sub:
+                if s.sig_type == 0x18 and cur.subkeys:
+                    k, _, _ = cur.subkeys[-1]
+                    cur.subkeys[-1] = (k, s.flags_valid, s.flag_sign)
+            elif s.sig_type in (0x10, 0x11, 0x12, 0x13):
+                if s.issuer == cur.primary.key_id:
+                    if not cur._have_self:
+                        cur.flags_valid, cur.flag_sign, cur.flag_certify = s.flags_valid, s.flag_sign, s.flag_certify
+                        cur.self_sig_revoked = s.revocation_reason is not None
+                        cur._have_self = True
+                elif s.issuer is not None:
+                    cur.certifiers.append(s.issuer)
+            elif s.sig_type == 0x20:
+                cur.revoked = True
+        cur.serialized = blob[cur._start:pos]
+    return ents
