@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on BASELINE.json configs[1]:
+"64-replica quorum, 10k RSA-2048 signed writes, single MI355X batched verify".
+
+One "step" = one pass of the whole hot path (packet parse -> SHA-256 -> RSA-2048 verify -> quorum
+tally) over one batch of synthetic signed writes that is ALREADY RESIDENT IN HBM when the timed
+region starts.  N>1: one process per GPU, every rank verifies its own shard of writes (weak scaling)
+and the per-write verdict bitmaps are all-gathered over RCCL inside every step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+INT_MAC_PEAK = 29.1e12         # measured v_mad_u64_u32 lane-ops/s on MI355X (tools/microbench, profiles/)
+RSA_BYTES = 291                # algorithmic bytes per RSA-2048 signature verify
+MADS_PER_VERIFY = 18 * 2 * 76 * 76   # 18 Montgomery products x (76x76 a*b + 76x76 m*n) limb MACs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--items", type=int, default=10000, help="signed writes per GPU per step")
+    ap.add_argument("--replicas", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from bftkv_amd import Context
+    from corpus import build as cb
+
+    ctx = Context(local_rank)
+    n = args.replicas
+    cl = cb.make_cluster(n)
+
+    # ---- synthetic signed writes; RSA signatures made on this GPU (generic modexp kernel)
+    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+
+    def gpu_signer(em, key_index):
+        return ctx.modexp(em, key_index.astype(np.uint32), mods, exps)
+
+    t0 = time.time()
+    corpus = cb.make_write_corpus(cl, args.items, seed=cb.MASTER_SEED + rank, batch_signer=gpu_signer, with_client_sig=True)
+    t_corpus = time.time() - t0
+
+    # keyring + quorum through the C ABI (clique of all replicas, AUTH rule: wotqs.go:36-70)
+    keys = [{"key_id": r.key_id, "entity_id": r.key_id, "pk_algo": r.algo, "usable_sign": True,
+             "n": r.n.to_bytes(256, "big"), "e": r.e.to_bytes(3, "big")} for r in cl.replicas]
+    ctx.keyring_set(keys)
+    f, mn, thr, suff = cb.quorum_numbers(n)
+    qh = ctx.quorum_create([(f, mn, thr, suff, [r.key_id for r in cl.replicas])])
+
+    d_tbs = torch.from_numpy(corpus.tbss_blob).to(dev)
+    d_tbs_off = torch.from_numpy(corpus.tbss_off.astype(np.int64)).to(dev)
+    d_ss = torch.from_numpy(corpus.ss_blob).to(dev)
+    d_ss_off = torch.from_numpy(corpus.ss_off.astype(np.int64)).to(dev)
+    d_err = torch.zeros(args.items, dtype=torch.uint8, device=dev)
+    d_nver = torch.zeros(args.items, dtype=torch.int32, device=dev)
+    d_verdict = torch.zeros(args.items, dtype=torch.uint8, device=dev)
+    nbits = (args.items + 7) // 8
+    d_bits_all = torch.zeros(world * nbits, dtype=torch.uint8, device=dev) if world > 1 else None
+    weights = (2 ** torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.collective_verify_dev(qh, args.items, d_tbs.data_ptr(), d_tbs_off.data_ptr(), d_ss.data_ptr(), d_ss_off.data_ptr(),
+                                  int(corpus.ss_off[-1]), d_err.data_ptr(), d_nver.data_ptr(), d_verdict.data_ptr())
+        ctx.sync()
+        if world > 1:
+            # per-write verdict bitmap (1 bit per write), all-gathered over RCCL/xGMI so that every
+            # rank holds every verdict -- as every replica of the reference reaches every decision
+            ok = (d_err == 0).to(torch.uint8)
+            pad = torch.zeros(nbits * 8, dtype=torch.uint8, device=dev)
+            pad[:args.items] = ok
+            bits = (pad.view(nbits, 8) * weights).sum(dim=1).to(torch.uint8)
+            dist.all_gather_into_tensor(d_bits_all, bits)
+
+    for _ in range(args.warmup):
+        step()
+    rsa_ms, tot_ms = [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = ctx.last_timing()
+        rsa_ms.append(tm["rsa"])
+        tot_ms.append(tm["total"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([corpus.n_sigs, args.items], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_sigs, total_items = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        total_sigs, total_items = corpus.n_sigs, args.items
+
+    counters = ctx.last_counters()
+    err = d_err.cpu().numpy()
+    nver = d_nver.cpu().numpy()
+
+    if rank == 0:
+        verifies_per_s = total_sigs * args.steps / elapsed
+        verdicts_per_s = total_items * args.steps / elapsed
+        rsa_avg_s = float(np.mean(rsa_ms)) * 1e-3
+        alg_bytes = int(corpus.tbss_off[-1]) + corpus.n_sigs * RSA_BYTES + (args.items + 7) // 8
+        achieved = alg_bytes / rsa_avg_s / 1e9
+        out = {
+            "metric": "pgp_rsa2048_signature_verifies_per_sec",
+            "value": verifies_per_s,
+            "unit": "verifies/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%d-replica quorum, %d RSA-2048 signed writes per GPU (cfg2 of BASELINE.json), "
+                                   "%d signature packets per GPU, 1.0%% corrupt / 0.5%% unknown issuer / 0.5%% duplicate / "
+                                   "1.0%% one-short" % (n, args.items, corpus.n_sigs),
+                       "replicas": n, "writes_per_gpu": args.items, "sigs_per_gpu": corpus.n_sigs,
+                       "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps" % world},
+            "quorum_verdicts_per_sec": verdicts_per_s,
+            "sufficient_fraction": float((err == 0).mean()),
+            "pubkey_ops_per_step_per_gpu": int(counters["pubkey_ops"]),
+            "kernel_ms": {"pipeline_total": float(np.mean(tot_ms)), "k_rsa_verify": float(np.mean(rsa_ms))},
+            "roofline": {"bound": "hbm", "kernel": "k_rsa_verify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"},
+            "int_mac": {"achieved": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s, "peak": INT_MAC_PEAK,
+                        "frac": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s / INT_MAC_PEAK,
+                        "unit": "u32xu32+u64 MAC/s (v_mad_u64_u32 lanes)"},
+            "corpus_build_s": t_corpus,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cl, corpus, err, nver)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(cl, corpus, gpu_err, gpu_nver):
+    """The reference-shaped CPU path (oracle/c/oracle.c, 'port') on this box's host cores, on the same
+    writes; also the bit-exact verdict check of the GPU results (checker role only)."""
+    from oracle.cbind import COracle
+    from tests import helpers as H
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    cores = os.cpu_count() or 1
+    n = corpus.n_items
+    # single-thread rate on a bounded sample (~5 s of CPU work), then all cores on the whole batch
+    m1 = min(n, 2000)
+    sub = (corpus.tbss_blob, corpus.tbss_off[:m1 + 1], corpus.ss_blob, corpus.ss_off[:m1 + 1])
+    t0 = time.perf_counter()
+    _, _, ops1 = co.collective_verify(*sub, n_threads=1)
+    t1 = time.perf_counter() - t0
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cerr, cnver, ops = co.collective_verify(corpus.tbss_blob, corpus.tbss_off, corpus.ss_blob, corpus.ss_off, n_threads=cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    identical = bool((cerr == gpu_err).all() and (cnver == gpu_nver).all())
+    return {"value": ops / best, "unit": "verifies/s", "cores": cores, "kind": "port",
+            "sample": "all %d writes of the GPU batch (%d public-key ops after the reference's early exit at suff=%d), "
+                      "%d threads, best of 3; OpenSSL libcrypto bignum/SHA (faster than Go math/big)" % (n, ops, cl.suff, cores),
+            "verdicts_per_sec": n / best,
+            "single_thread_verifies_per_sec": ops1 / t1,
+            "gpu_verdicts_identical_to_cpu": identical}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,453 @@
+/*
+ * oracle.c -- plain-C restatement of the reference's CPU path for the quorum-verification hot
+ * path, in the reference's ALGORITHMIC SHAPE: per signature packet a fresh hash of the WHOLE signed
+ * payload (crypto/pgp/crypto_pgp.go:490 -> openpgp.CheckDetachedSignature), one RSA/DSA public-key
+ * operation, append the signer, then quorum.IsSufficient with the O(k*n) multiset intersection
+ * (quorum/wotqs/wotqs.go:168-175, 195-206), early exit on sufficiency (crypto_pgp.go:493-496).
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): used by tests/ to cross-check the Python oracle
+ * and by bench.py's cpu_baseline leg ("kind": "port").  Big integers and hashes come from OpenSSL
+ * (libcrypto) -- hand-tuned assembly, i.e. a FASTER baseline than the reference's Go math/big.
+ * PARITY UNPINNED against the reference itself (no Go toolchain, x/crypto not vendored); pinned
+ * against the Python oracle, which is pinned against GnuPG (tests/golden).
+ *
+ * Follows: SURVEY.md Appendix B.1-B.5 (x/crypto openpgp packet.Read, Signature.parse,
+ * CheckDetachedSignature, PublicKey.VerifySignature; Go crypto/rsa.VerifyPKCS1v15, crypto/dsa.Verify).
+ */
+#include <openssl/bn.h>
+#include <openssl/evp.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ST_OK = 0, ST_UNKNOWN_ISSUER, ST_PARSE_ERROR, ST_NOT_SIGNATURE, ST_NO_ISSUER, ST_HASH_UNSUPPORTED,
+       ST_HASH_TAG, ST_ALGO_MISMATCH, ST_BAD_SIG, ST_KEY_CANNOT_SIGN, ST_UNSUPPORTED };
+
+typedef struct {
+  uint64_t key_id, entity_id;
+  int pk_algo, usable_sign;
+  BIGNUM *n, *e;          /* RSA */
+  BIGNUM *p, *q, *g, *y;  /* DSA */
+} okey;
+
+typedef struct {
+  int f, min, threshold, suff;
+  uint64_t* nodes;
+  int n_nodes;
+} oqc;
+
+typedef struct {
+  okey* keys;
+  int n_keys;
+  oqc* qcs;
+  int n_qcs;
+} oracle;
+
+void* oracle_new(void) { return calloc(1, sizeof(oracle)); }
+
+void oracle_free(void* h) {
+  oracle* o = (oracle*)h;
+  if (!o) return;
+  for (int i = 0; i < o->n_keys; ++i) {
+    BN_free(o->keys[i].n); BN_free(o->keys[i].e); BN_free(o->keys[i].p);
+    BN_free(o->keys[i].q); BN_free(o->keys[i].g); BN_free(o->keys[i].y);
+  }
+  free(o->keys);
+  for (int i = 0; i < o->n_qcs; ++i) free(o->qcs[i].nodes);
+  free(o->qcs);
+  free(o);
+}
+
+/* keys in keyring order (secring first, crypto_pgp.go:195-197).  RSA: a=n, b=e.  DSA: a=p, b=q, g, y. */
+void oracle_add_key(void* h, uint64_t key_id, uint64_t entity_id, int pk_algo, int usable_sign, const uint8_t* a, int alen,
+                    const uint8_t* b, int blen, const uint8_t* g, int glen, const uint8_t* y, int ylen) {
+  oracle* o = (oracle*)h;
+  o->keys = (okey*)realloc(o->keys, sizeof(okey) * (o->n_keys + 1));
+  okey* k = &o->keys[o->n_keys++];
+  memset(k, 0, sizeof *k);
+  k->key_id = key_id; k->entity_id = entity_id; k->pk_algo = pk_algo; k->usable_sign = usable_sign;
+  if (pk_algo == 17) {
+    k->p = BN_bin2bn(a, alen, NULL); k->q = BN_bin2bn(b, blen, NULL);
+    k->g = BN_bin2bn(g, glen, NULL); k->y = BN_bin2bn(y, ylen, NULL);
+  } else {
+    k->n = BN_bin2bn(a, alen, NULL); k->e = BN_bin2bn(b, blen, NULL);
+  }
+}
+
+void oracle_set_quorum(void* h, int n_qcs, const int32_t* f, const int32_t* mn, const int32_t* thr, const int32_t* suff,
+                       const uint64_t* ids, const int32_t* counts) {
+  oracle* o = (oracle*)h;
+  for (int i = 0; i < o->n_qcs; ++i) free(o->qcs[i].nodes);
+  free(o->qcs);
+  o->qcs = (oqc*)calloc(n_qcs ? n_qcs : 1, sizeof(oqc));
+  o->n_qcs = n_qcs;
+  for (int i = 0; i < n_qcs; ++i) {
+    o->qcs[i].f = f[i]; o->qcs[i].min = mn[i]; o->qcs[i].threshold = thr[i]; o->qcs[i].suff = suff[i];
+    o->qcs[i].n_nodes = counts[i];
+    o->qcs[i].nodes = (uint64_t*)malloc(sizeof(uint64_t) * (counts[i] ? counts[i] : 1));
+    memcpy(o->qcs[i].nodes, ids, sizeof(uint64_t) * counts[i]);
+    ids += counts[i];
+  }
+}
+
+/* wotqs.go:195-206 + :168-175 -- deliberately the reference's nested loops */
+static int is_sufficient(const oracle* o, const uint64_t* nodes, int n) {
+  for (int c = 0; c < o->n_qcs; ++c) {
+    const oqc* qc = &o->qcs[c];
+    int cnt = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < qc->n_nodes; ++j)
+        if (nodes[i] == qc->nodes[j]) { ++cnt; break; }
+    if (qc->suff > 0 && cnt >= qc->suff) return 1;
+  }
+  return 0;
+}
+
+/* ---- OpenPGP parsing (Appendix B.1, B.2) ---------------------------------------------------- */
+typedef struct {
+  int sig_type, pk_algo, hash_id;
+  const uint8_t* prefix; int prefix_len;      /* first 6+hl body bytes */
+  uint8_t tag[2];
+  int have_issuer; uint64_t issuer; int have_ctime;
+  const uint8_t* mpi[2]; int mpi_len[2];
+} psig;
+
+static int parse_body(const uint8_t* b, int n, psig* s, int depth);
+
+static int parse_subpackets(const uint8_t* a, int len, int hashed, psig* s, int depth) {
+  int p = 0;
+  while (p < len) {
+    int ln;
+    int b = a[p];
+    if (b < 192) { ln = b; p += 1; }
+    else if (b < 255) { if (p + 2 > len) return 0; ln = ((b - 192) << 8) + a[p + 1] + 192; p += 2; }
+    else { if (p + 5 > len) return 0; ln = (int)(((uint32_t)a[p + 1] << 24) | (a[p + 2] << 16) | (a[p + 3] << 8) | a[p + 4]); p += 5; }
+    if (ln < 0 || ln > len - p) return 0;
+    if (ln == 0) return 0;
+    int typ = a[p] & 0x7F, critical = a[p] & 0x80;
+    const uint8_t* body = a + p + 1;
+    int bl = ln - 1;
+    p += ln;
+    switch (typ) {
+      case 2: if (!hashed) break; if (bl != 4) return 0; s->have_ctime = 1; break;
+      case 3: case 9: if (!hashed) break; if (bl != 4) return 0; break;
+      case 11: case 21: case 22: case 30: break;
+      case 16:
+        if (bl != 8) return 0;
+        s->issuer = 0;
+        for (int i = 0; i < 8; ++i) s->issuer = (s->issuer << 8) | body[i];
+        s->have_issuer = 1;
+        break;
+      case 25: if (!hashed) break; if (bl != 1) return 0; break;
+      case 27: case 29: if (!hashed) break; if (bl == 0) return 0; break;
+      case 32: {
+        if (!hashed) break;
+        if (depth >= 2) return 0;
+        psig tmp;
+        if (!parse_body(body, bl, &tmp, depth + 1)) return 0;
+        break;
+      }
+      default: if (critical) return 0;
+    }
+  }
+  return 1;
+}
+
+static int parse_body(const uint8_t* b, int n, psig* s, int depth) {
+  memset(s, 0, sizeof *s);
+  if (n < 1 || b[0] != 4 || n < 6) return 0;
+  s->sig_type = b[1]; s->pk_algo = b[2]; s->hash_id = b[3];
+  if (!(s->pk_algo == 1 || s->pk_algo == 3 || s->pk_algo == 17 || s->pk_algo == 19)) return 0;
+  int h = s->hash_id;
+  if (!(h == 1 || h == 2 || h == 3 || (h >= 8 && h <= 11))) return 0;
+  int hl = (b[4] << 8) | b[5];
+  if (6 + hl > n) return 0;
+  s->prefix = b; s->prefix_len = 6 + hl;
+  if (!parse_subpackets(b + 6, hl, 1, s, depth)) return 0;
+  if (!s->have_ctime) return 0;
+  int p = 6 + hl;
+  if (p + 2 > n) return 0;
+  int ul = (b[p] << 8) | b[p + 1];
+  p += 2;
+  if (p + ul > n) return 0;
+  if (!parse_subpackets(b + p, ul, 0, s, depth)) return 0;
+  p += ul;
+  if (p + 2 > n) return 0;
+  s->tag[0] = b[p]; s->tag[1] = b[p + 1];
+  p += 2;
+  int nm = (s->pk_algo == 1 || s->pk_algo == 3) ? 1 : 2;
+  for (int i = 0; i < nm; ++i) {
+    if (p + 2 > n) return 0;
+    int bits = (b[p] << 8) | b[p + 1];
+    int nb = (bits + 7) / 8;
+    p += 2;
+    if (p + nb > n) return 0;
+    s->mpi[i] = b + p; s->mpi_len[i] = nb;
+    p += nb;
+  }
+  return 1;
+}
+
+static const EVP_MD* md_for(int hash_id) {
+  switch (hash_id) {   /* md5 / ripemd160: fenced as unavailable */
+    case 2: return EVP_sha1();
+    case 8: return EVP_sha256();
+    case 9: return EVP_sha384();
+    case 10: return EVP_sha512();
+    case 11: return EVP_sha224();
+    default: return NULL;
+  }
+}
+
+static const uint8_t PFX_SHA1[] = {0x30, 0x21, 0x30, 0x09, 0x06, 0x05, 0x2b, 0x0e, 0x03, 0x02, 0x1a, 0x05, 0x00, 0x04, 0x14};
+static const uint8_t PFX_SHA224[] = {0x30, 0x2d, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x04, 0x05, 0x00, 0x04, 0x1c};
+static const uint8_t PFX_SHA256[] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+static const uint8_t PFX_SHA384[] = {0x30, 0x41, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x02, 0x05, 0x00, 0x04, 0x30};
+static const uint8_t PFX_SHA512[] = {0x30, 0x51, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x03, 0x05, 0x00, 0x04, 0x40};
+
+static const uint8_t* prefix_for(int hash_id, int* len) {
+  switch (hash_id) {
+    case 2: *len = sizeof PFX_SHA1; return PFX_SHA1;
+    case 8: *len = sizeof PFX_SHA256; return PFX_SHA256;
+    case 9: *len = sizeof PFX_SHA384; return PFX_SHA384;
+    case 10: *len = sizeof PFX_SHA512; return PFX_SHA512;
+    case 11: *len = sizeof PFX_SHA224; return PFX_SHA224;
+    default: *len = 0; return NULL;
+  }
+}
+
+/* B.4: Go 1.12/1.13 rsa.VerifyPKCS1v15 (no length check, no s<n check) */
+static int rsa_verify(const okey* k, int hash_id, const uint8_t* digest, int dlen, const uint8_t* sig, int slen, BN_CTX* ctx) {
+  int plen;
+  const uint8_t* pfx = prefix_for(hash_id, &plen);
+  int tlen = plen + dlen;
+  int kb = (BN_num_bits(k->n) + 7) / 8;
+  if (kb < tlen + 11) return 0;
+  int ok = 0;
+  BN_CTX_start(ctx);
+  BIGNUM* c = BN_CTX_get(ctx);
+  BIGNUM* m = BN_CTX_get(ctx);
+  BN_bin2bn(sig, slen, c);
+  if (BN_is_odd(k->n) && BN_cmp(c, k->n) < 0) {
+    if (!BN_mod_exp(m, c, k->e, k->n, ctx)) goto done;
+  } else {
+    /* math/big.Exp reduces the base and accepts any modulus */
+    BIGNUM* cr = BN_CTX_get(ctx);
+    if (!BN_nnmod(cr, c, k->n, ctx)) goto done;
+    if (!BN_mod_exp_simple(m, cr, k->e, k->n, ctx)) goto done;
+  }
+  {
+    uint8_t em[1024], want[1024];
+    if (kb > (int)sizeof em || BN_num_bytes(m) > kb) goto done;
+    BN_bn2binpad(m, em, kb);
+    want[0] = 0; want[1] = 1;
+    memset(want + 2, 0xFF, kb - tlen - 3);
+    want[kb - tlen - 1] = 0;
+    memcpy(want + kb - tlen, pfx, plen);
+    memcpy(want + kb - dlen, digest, dlen);
+    ok = memcmp(em, want, kb) == 0;
+  }
+done:
+  BN_CTX_end(ctx);
+  return ok;
+}
+
+/* B.5: Go crypto/dsa.Verify */
+static int dsa_verify(const okey* k, const uint8_t* digest, int dlen, const uint8_t* rb, int rlen, const uint8_t* sb, int slen,
+                      BN_CTX* ctx) {
+  int ok = 0;
+  BN_CTX_start(ctx);
+  BIGNUM *r = BN_CTX_get(ctx), *s = BN_CTX_get(ctx), *w = BN_CTX_get(ctx), *z = BN_CTX_get(ctx), *u1 = BN_CTX_get(ctx),
+         *u2 = BN_CTX_get(ctx), *v1 = BN_CTX_get(ctx), *v2 = BN_CTX_get(ctx);
+  BN_bin2bn(rb, rlen, r); BN_bin2bn(sb, slen, s);
+  if (BN_is_zero(k->p)) goto done;
+  if (BN_is_zero(r) || BN_cmp(r, k->q) >= 0) goto done;
+  if (BN_is_zero(s) || BN_cmp(s, k->q) >= 0) goto done;
+  int nq = BN_num_bits(k->q);
+  if (nq & 7) goto done;
+  if (!BN_mod_inverse(w, s, k->q, ctx)) goto done;
+  if (dlen > nq / 8) dlen = nq / 8;
+  BN_bin2bn(digest, dlen, z);
+  BN_mod_mul(u1, z, w, k->q, ctx);
+  BN_mod_mul(u2, r, w, k->q, ctx);
+  BN_mod_exp(v1, k->g, u1, k->p, ctx);
+  BN_mod_exp(v2, k->y, u2, k->p, ctx);
+  BN_mod_mul(v1, v1, v2, k->p, ctx);
+  BN_nnmod(v1, v1, k->q, ctx);
+  ok = BN_cmp(v1, r) == 0;
+done:
+  BN_CTX_end(ctx);
+  return ok;
+}
+
+static int known_tag(int tag) { return tag < 32 && ((0x00066BFEu >> tag) & 1u); }
+
+/* One openpgp.CheckDetachedSignature(keyring, signed, sigstream@pos) call (B.3).
+ * Returns the call's status; *signer = entity id on ST_OK; *pos advanced; per-packet statuses
+ * appended to trace (if non-NULL). */
+static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sd, uint64_t end, uint64_t* pos,
+                          uint64_t* signer, uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, EVP_MD_CTX* mdctx,
+                          uint64_t* n_pk_ops) {
+#define TRACE(st) do { if (trace && *ntrace < cap) trace[(*ntrace)++] = (uint8_t)(st); } while (0)
+  for (;;) {
+    uint64_t p = *pos;
+    if (p >= end) return ST_UNKNOWN_ISSUER;   /* io.EOF => ErrUnknownIssuer */
+    int b0 = sd[p];
+    if (!(b0 & 0x80)) { *pos = p + 1; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+    int tag; uint64_t start, ln;
+    if (!(b0 & 0x40)) {
+      tag = (b0 & 0x3F) >> 2;
+      int lt = b0 & 3;
+      if (lt == 3) { *pos = end; TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
+      int nb = 1 << lt;
+      if (p + 1 + nb > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+      ln = 0;
+      for (int i = 0; i < nb; ++i) ln = (ln << 8) | sd[p + 1 + i];
+      start = p + 1 + nb;
+    } else {
+      tag = b0 & 0x3F;
+      if (p + 1 >= end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+      int b1 = sd[p + 1];
+      if (b1 < 192) { ln = b1; start = p + 2; }
+      else if (b1 < 224) {
+        if (p + 2 >= end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+        ln = ((uint64_t)(b1 - 192) << 8) + sd[p + 2] + 192; start = p + 3;
+      } else if (b1 == 255) {
+        if (p + 6 > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+        ln = ((uint64_t)sd[p + 2] << 24) | ((uint64_t)sd[p + 3] << 16) | ((uint64_t)sd[p + 4] << 8) | sd[p + 5];
+        start = p + 6;
+      } else { *pos = end; TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
+    }
+    if (start + ln > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+    *pos = start + ln;
+    if (tag != 2) {
+      if (known_tag(tag)) { TRACE(ST_NOT_SIGNATURE); return ST_NOT_SIGNATURE; }
+      continue;
+    }
+    if (ln >= 1 && sd[start] < 4) { TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
+    psig s;
+    if (!parse_body(sd + start, (int)ln, &s, 0)) { TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+    if (!s.have_issuer) { TRACE(ST_NO_ISSUER); return ST_NO_ISSUER; }
+    /* KeysByIdUsage(issuer, KeyFlagSign) */
+    int found = 0;
+    for (int i = 0; i < o->n_keys; ++i) if (o->keys[i].key_id == s.issuer && o->keys[i].usable_sign) { found = 1; break; }
+    if (!found) { TRACE(ST_UNKNOWN_ISSUER); continue; }
+    const EVP_MD* md = md_for(s.hash_id);
+    if (!md || s.sig_type != 0) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
+    /* the reference hashes the WHOLE payload again for every signature packet */
+    EVP_DigestInit_ex(mdctx, md, NULL);
+    EVP_DigestUpdate(mdctx, tbs, tbs_len);
+    int st = ST_BAD_SIG;
+    for (int i = 0; i < o->n_keys; ++i) {
+      const okey* k = &o->keys[i];
+      if (k->key_id != s.issuer || !k->usable_sign) continue;
+      /* VerifySignature appends the suffix to the shared hash on every candidate */
+      if (k->pk_algo == 2 || k->pk_algo == 16) { st = ST_KEY_CANNOT_SIGN; continue; }   /* checked before the hash is touched */
+      uint8_t trailer[6] = {4, 0xFF, 0, 0, (uint8_t)(s.prefix_len >> 8), (uint8_t)s.prefix_len};
+      EVP_DigestUpdate(mdctx, s.prefix, s.prefix_len);
+      EVP_DigestUpdate(mdctx, trailer, 6);
+      EVP_MD_CTX* cp = EVP_MD_CTX_new();
+      EVP_MD_CTX_copy_ex(cp, mdctx);
+      uint8_t dg[64]; unsigned dl = 0;
+      EVP_DigestFinal_ex(cp, dg, &dl);
+      EVP_MD_CTX_free(cp);
+      if (dg[0] != s.tag[0] || dg[1] != s.tag[1]) { st = ST_HASH_TAG; continue; }
+      if (k->pk_algo != s.pk_algo) { st = ST_ALGO_MISMATCH; continue; }
+      if (n_pk_ops) ++*n_pk_ops;
+      int ok;
+      if (k->pk_algo == 1 || k->pk_algo == 3) ok = rsa_verify(k, s.hash_id, dg, (int)dl, s.mpi[0], s.mpi_len[0], ctx);
+      else if (k->pk_algo == 17) {
+        int sub = (BN_num_bits(k->q) + 7) / 8;
+        ok = dsa_verify(k, dg, (int)dl > sub ? sub : (int)dl, s.mpi[0], s.mpi_len[0], s.mpi[1], s.mpi_len[1], ctx);
+      } else { st = ST_UNSUPPORTED; continue; }
+      if (ok) { *signer = k->entity_id; TRACE(ST_OK); return ST_OK; }
+      st = ST_BAD_SIG;
+    }
+    TRACE(st);
+    return st;
+  }
+#undef TRACE
+}
+
+/* PGPCollectiveSignature.Verify for one item (crypto_pgp.go:485-500) */
+static int collective_one(const oracle* o, const uint8_t* tbs, uint64_t tl, const uint8_t* sd, uint64_t sl, uint32_t* nver,
+                          uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, EVP_MD_CTX* mdctx, uint64_t* ops) {
+  uint64_t pos = 0;
+  uint64_t verified[4096];
+  int nv = 0;
+  while (pos < sl) {
+    uint64_t signer = 0;
+    int st = check_detached(o, tbs, tl, sd, sl, &pos, &signer, trace, ntrace, cap, ctx, mdctx, ops);
+    if (st == ST_OK) {
+      if (nv < 4096) verified[nv++] = signer;
+      if (is_sufficient(o, verified, nv)) { *nver = (uint32_t)nv; return 0; }
+    }
+  }
+  *nver = (uint32_t)nv;
+  return 2;   /* ErrInsufficientNumberOfSignatures */
+}
+
+int oracle_trace_item(void* h, const uint8_t* tbs, uint64_t tl, const uint8_t* sd, uint64_t sl, uint8_t* trace, int cap,
+                      uint32_t* nver, int* err) {
+  BN_CTX* ctx = BN_CTX_new();
+  EVP_MD_CTX* md = EVP_MD_CTX_new();
+  int nt = 0;
+  uint64_t ops = 0;
+  *err = collective_one((oracle*)h, tbs, tl, sd, sl, nver, trace, &nt, cap, ctx, md, &ops);
+  EVP_MD_CTX_free(md);
+  BN_CTX_free(ctx);
+  return nt;
+}
+
+typedef struct {
+  const oracle* o;
+  uint32_t lo, hi;
+  const uint8_t* tbs; const uint64_t* tbs_off; const uint8_t* ss; const uint64_t* ss_off;
+  uint8_t* err; uint32_t* nver;
+  uint64_t ops;
+} job;
+
+static void* worker(void* arg) {
+  job* j = (job*)arg;
+  BN_CTX* ctx = BN_CTX_new();
+  EVP_MD_CTX* md = EVP_MD_CTX_new();
+  for (uint32_t i = j->lo; i < j->hi; ++i) {
+    int nt = 0;
+    uint32_t nv = 0;
+    int e = collective_one(j->o, j->tbs + j->tbs_off[i], j->tbs_off[i + 1] - j->tbs_off[i], j->ss + j->ss_off[i],
+                           j->ss_off[i + 1] - j->ss_off[i], &nv, NULL, &nt, 0, ctx, md, &j->ops);
+    if (j->err) j->err[i] = (uint8_t)e;
+    if (j->nver) j->nver[i] = nv;
+  }
+  EVP_MD_CTX_free(md);
+  BN_CTX_free(ctx);
+  return NULL;
+}
+
+/* Batched collective verify over n_items with n_threads host threads (items split evenly).
+ * Returns the number of public-key operations performed (the reference's early exit included). */
+uint64_t oracle_collective_verify(void* h, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* ss,
+                                  const uint64_t* ss_off, uint8_t* err, uint32_t* nver, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if ((uint32_t)n_threads > n_items) n_threads = n_items ? (int)n_items : 1;
+  job* jobs = (job*)calloc(n_threads, sizeof(job));
+  pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+  for (int t = 0; t < n_threads; ++t) {
+    jobs[t].o = (oracle*)h;
+    jobs[t].lo = (uint32_t)((uint64_t)n_items * t / n_threads);
+    jobs[t].hi = (uint32_t)((uint64_t)n_items * (t + 1) / n_threads);
+    jobs[t].tbs = tbs; jobs[t].tbs_off = tbs_off; jobs[t].ss = ss; jobs[t].ss_off = ss_off;
+    jobs[t].err = err; jobs[t].nver = nver;
+    if (n_threads == 1) worker(&jobs[t]);
+    else pthread_create(&th[t], NULL, worker, &jobs[t]);
+  }
+  uint64_t ops = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    if (n_threads > 1) pthread_join(th[t], NULL);
+    ops += jobs[t].ops;
+  }
+  free(jobs);
+  free(th);
+  return ops;
+}

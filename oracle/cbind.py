@@ -1,0 +1,86 @@
+"""ctypes binding of oracle/liboracle.so (oracle/c/oracle.c).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "c", "oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c")])
+    return LIB
+
+
+def _nb(x: int) -> bytes:
+    return x.to_bytes(max(1, (x.bit_length() + 7) // 8), "big")
+
+
+class COracle:
+    def __init__(self):
+        if not os.path.exists(LIB):
+            build()
+        self.lib = C.CDLL(LIB)
+        self.lib.oracle_new.restype = C.c_void_p
+        self.lib.oracle_free.argtypes = [C.c_void_p]
+        self.lib.oracle_add_key.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int] + [C.c_char_p, C.c_int] * 4
+        self.lib.oracle_set_quorum.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        self.lib.oracle_collective_verify.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6 + [C.c_int]
+        self.lib.oracle_collective_verify.restype = C.c_uint64
+        self.lib.oracle_trace_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_void_p, C.c_int,
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        self.h = C.c_void_p(self.lib.oracle_new())
+
+    def __del__(self):
+        try:
+            self.lib.oracle_free(self.h)
+        except Exception:
+            pass
+
+    def set_keyring(self, keyring):
+        """keyring: oracle.collective.Keyring"""
+        for e in keyring.get_keyring():
+            cands = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + [(k, fv, fs, False) for k, fv, fs in e.subkeys]
+            for k, fv, fs, rr in cands:
+                usable = int(not (e.revoked or rr) and not (fv and not fs))
+                if k.pk_algo == 17:
+                    a, b, g, y = _nb(k.p), _nb(k.q), _nb(k.g), _nb(k.y)
+                else:
+                    a, b, g, y = _nb(k.n), _nb(k.e), b"", b""
+                self.lib.oracle_add_key(self.h, k.key_id, e.id, k.pk_algo, usable, a, len(a), b, len(b), g, len(g), y, len(y))
+
+    def set_quorum(self, q):
+        """q: oracle.wotqs.WotQ"""
+        n = len(q.qcs)
+        arr = lambda xs: np.ascontiguousarray(np.array(xs, dtype=np.int32))
+        f, mn, thr, su = arr([c.f for c in q.qcs]), arr([c.min for c in q.qcs]), arr([c.threshold for c in q.qcs]), arr([c.suff for c in q.qcs])
+        ids = np.ascontiguousarray(np.array([i for c in q.qcs for i in c.nodes], dtype=np.uint64))
+        cnt = arr([len(c.nodes) for c in q.qcs])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.oracle_set_quorum(self.h, n, p(f), p(mn), p(thr), p(su), p(ids), p(cnt))
+
+    def collective_verify(self, tbs_blob, tbs_off, ss_blob, ss_off, n_threads: int = 1):
+        n = len(tbs_off) - 1
+        tbs_blob = np.ascontiguousarray(tbs_blob, dtype=np.uint8)
+        ss_blob = np.ascontiguousarray(ss_blob, dtype=np.uint8)
+        tbs_off = np.ascontiguousarray(tbs_off, dtype=np.uint64)
+        ss_off = np.ascontiguousarray(ss_off, dtype=np.uint64)
+        err = np.zeros(n, dtype=np.uint8)
+        nver = np.zeros(n, dtype=np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        ops = self.lib.oracle_collective_verify(self.h, n, p(tbs_blob), p(tbs_off), p(ss_blob), p(ss_off), p(err), p(nver), n_threads)
+        return err, nver, int(ops)
+
+    def trace_item(self, tbs: bytes, ss: bytes):
+        tr = np.zeros(8192, dtype=np.uint8)
+        nver = C.c_uint32(0)
+        err = C.c_int(0)
+        nt = self.lib.oracle_trace_item(self.h, tbs, len(tbs), ss, len(ss), tr.ctypes.data_as(C.c_void_p), len(tr),
+                                        C.byref(nver), C.byref(err))
+        return list(tr[:nt]), nver.value, err.value

@@ -395,7 +395,9 @@ def hash_for_signature(hash_id: int, sig_type: int):
     """hashForSignature: binary (0x00) hashes raw bytes; text (0x01) canonicalises line endings
     (not produced on this path -> fenced as unsupported); others unsupported."""
     name = HASH_BY_ID.get(hash_id)
-    if name is None:
+    if name is None or name in ("md5", "ripemd160"):
+        # whether MD5 / RIPEMD-160 are linked into a bftkv binary cannot be established without the
+        # x/crypto source: FENCED as unavailable (DESIGN.md), identically in oracle.c and the HIP path
         return None
     if sig_type != 0x00:
         return None
@@ -482,6 +484,9 @@ def check_detached_signature(keyring: List[Entity], signed: bytes, sigdata: byte
         for ent, key in keys:
             # VerifySignature writes HashSuffix into the *shared* hash object each time it is
             # called, so candidate j sees the suffix j+1 times.
+            if not key.can_sign():          # checked before the suffix is written
+                st = ST_KEY_CANNOT_SIGN
+                continue
             h.update(sig.hash_suffix)
             st = verify_signature(key, sig.hash_id, h.copy().digest(), sig)
             if st == ST_OK:

@@ -47,6 +47,8 @@ def main():
         payloads = [b"", b"tbs", bytes(range(256)) * 5, b"x" * 64, b"y" * 119, b"z" * 120]
         for uid in ("a01@gpg.example", "a02@gpg.example"):
             for digest in ("SHA256", "SHA512", "SHA1", "SHA384", "SHA224"):
+                if uid.startswith("a02") and digest in ("SHA1", "SHA224"):
+                    continue  # gpg refuses digests shorter than q (256 bits) for DSA-2048
                 for pl in payloads[:3] if digest != "SHA256" else payloads:
                     sig = gpg(home, "--faked-system-time", "20200102T000000", "--digest-algo", digest, "-u", uid,
                               "--detach-sign", "-o", "-", inp=pl).stdout
