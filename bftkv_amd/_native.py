@@ -202,7 +202,7 @@ class Context:
     def last_timing(self):
         ms = (C.c_float * 8)()
         self._check(self.lib.bftkv_gpu_last_timing(self.h, ms), "last_timing")
-        return {"total": ms[0], "parse": ms[1], "hash": ms[2], "rsa": ms[3], "tally": ms[4]}
+        return {"total": ms[0], "parse": ms[1], "hash": ms[2], "rsa": ms[3], "tally": ms[4], "compare": ms[5]}
 
     def signers(self, ss_blob, ss_off):
         n = len(ss_off) - 1

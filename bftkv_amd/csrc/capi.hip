@@ -48,7 +48,8 @@ struct QuorumHost {
 
 struct bftkv_gpu_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // main stream: walk, parse, modexp, compare, tally
+  hipStream_t stream_h = nullptr;    // hashing stream: runs beside the modexp
   std::mutex mu;
   std::string err;
 
@@ -63,12 +64,12 @@ struct bftkv_gpu_ctx {
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, cert_ent, mid, recs, x, em, xr, rsa_list, rsa_count;
+  DevBuf counts, base, total, item_flags, cert_ent, mid, recs, digests, r, xr, pk_list, pk_count, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};   // 0 start, 1 parsed, 2 modexp done, 3 compare done, 4 end, 5 hash start, 6 hash done
   bool have_timing = false;
 };
 
@@ -132,8 +133,10 @@ __global__ void k_sigverify_fold(const SigRec* __restrict__ recs, const uint32_t
     if (st == ST_OK) ++n_ok;
     else if (st != ST_UNKNOWN_ISSUER) bad = true;
   }
-  // a call that runs into EOF after only skipped packets returns ErrUnknownIssuer
+  // a final call that only skips packets (unknown issuers / unknown packet types) runs into EOF
+  // and returns ErrUnknownIssuer
   if (item_flags[i] & 1) bad = true;
+  if (counts[i] && recs[base[i] + counts[i] - 1].status == ST_UNKNOWN_ISSUER) bad = true;
   err_out[i] = (!bad && n_ok >= 1) ? BFTKV_ERR_NONE : BFTKV_ERR_INVALID_SIGNATURE;
 }
 
@@ -176,49 +179,66 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
   }
 }
 
-// Shared pipeline: parse -> hash -> public-key operations.  Leaves SigRec statuses final.
+// Shared pipeline.  Main stream: walk -> parse -> RSA modexp -> compare.  Hash stream (forked after
+// the parse): SHA-256 midstates -> per-signature digests; joined before the compare.  Leaves SigRec
+// statuses final.
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent) {
-  hipStream_t s = c->stream;
+  hipStream_t s = c->stream, sh = c->stream_h;
   if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
   HIPCHK(c, c->item_flags.ensure(n_items + 16));
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * (size_t)n_items + 16));
-  HIPCHK(c, c->rsa_count.ensure(16));
+  HIPCHK(c, c->pk_count.ensure(16));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
-  const uint32_t nb = (n_items + 255) / 256;
-  hipLaunchKernelGGL(k_parse<false>, dim3(nb), dim3(256), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->kt, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+  // the payload midstates do not depend on the parse: start them right away on the hash stream
+  HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
+  HIPCHK(c, hipEventRecord(c->ev[5], sh));
+  hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
+  const uint32_t nb = (n_items + 63) / 64;
+  hipLaunchKernelGGL(k_walk<false>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+                     (const uint32_t*)nullptr, (SigRec*)nullptr, (uint8_t*)nullptr);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>());
   uint32_t total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 4, s));
   HIPCHK(c, hipStreamSynchronize(s));
   c->last_total = total;
   c->last_items = n_items;
   const size_t tr = total ? total : 1;
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
-  HIPCHK(c, c->x.ensure(sizeof(uint32_t) * MONT_N * tr));
-  HIPCHK(c, c->em.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 8 * tr));
+  HIPCHK(c, c->r.ensure(sizeof(uint32_t) * MONT_N * tr));
   HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * MONT_N * tr));
-  HIPCHK(c, c->rsa_list.ensure(sizeof(uint32_t) * tr));
-  hipLaunchKernelGGL(k_parse<true>, dim3(nb), dim3(256), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->kt, d_cert_ent, c->item_flags.as<uint8_t>());
-  HIPCHK(c, hipEventRecord(c->ev[1], s));
-  hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, s, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
-  HIPCHK(c, hipMemsetAsync(c->rsa_count.p, 0, 4, s));
+  HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
+  hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>());
   if (total) {
-    hipLaunchKernelGGL(k_digest_em, dim3((total + 255) / 256), dim3(256), 0, s, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                       c->recs.as<SigRec>(), total, c->kt, c->x.as<uint32_t>(), c->em.as<uint32_t>(),
-                       c->rsa_list.as<uint32_t>(), c->rsa_count.as<uint32_t>());
+    hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, c->recs.as<SigRec>(), total, c->kt,
+                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  // hash stream: digests need the parsed records
+  HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
+  if (total) {
+    hipLaunchKernelGGL(k_digest, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+                       c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[6], sh));
+  // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
+  if (total) {
+    hipLaunchKernelGGL(k_rsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s, d_ss,
+                       c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(),
+                       c->xr.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
+  HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
   if (total) {
-    hipLaunchKernelGGL(k_rsa_verify, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
-                       c->recs.as<SigRec>(), c->rsa_list.as<uint32_t>(), c->rsa_count.as<uint32_t>(), c->kt,
-                       c->x.as<uint32_t>(), c->em.as<uint32_t>(), c->xr.as<uint32_t>());
+    hipLaunchKernelGGL(k_rsa_compare, dim3((total * 4 + 255) / 256), dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+                       c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipGetLastError());
@@ -242,7 +262,8 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   if (hipSetDevice(device_ordinal) != hipSuccess) return BFTKV_E_DEVICE;
   bftkv_gpu_ctx* c = new bftkv_gpu_ctx();
   c->device = device_ordinal;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   *out = c;
   return BFTKV_OK;
 }
@@ -251,14 +272,16 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream_h);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0,
-                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->recs, &c->x, &c->em, &c->xr,
-                    &c->rsa_list, &c->rsa_count, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->recs, &c->digests, &c->r, &c->xr,
+                    &c->pk_list, &c->pk_count, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->stream_h);
   delete c;
 }
 
@@ -541,7 +564,7 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t rsa = 0;
-  if (c->rsa_count.p) HIPCHK(c, hipMemcpy(&rsa, c->rsa_count.p, 4, hipMemcpyDeviceToHost));
+  if (c->pk_count.p) HIPCHK(c, hipMemcpy(&rsa, c->pk_count.p, 4, hipMemcpyDeviceToHost));
   counters[0] = c->last_total;
   counters[1] = rsa;
   counters[2] = c->last_items;
@@ -556,11 +579,12 @@ int bftkv_gpu_last_timing(bftkv_gpu_ctx* c, float ms[8]) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventSynchronize(c->ev[4]));
   for (int i = 0; i < 8; ++i) ms[i] = 0;
-  HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[4]));
-  HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]));
-  HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[1], c->ev[2]));
-  HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[2], c->ev[3]));
-  HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));
+  HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[4]));   // whole call
+  HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]));   // walk + scan + parse (incl. the host read of the count)
+  HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[5], c->ev[6]));   // hash stream: midstates + digests (overlaps the modexp)
+  HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[1], c->ev[2]));   // k_rsa_modexp on its own stream
+  HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));   // tally
+  HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[2], c->ev[3]));   // compare (incl. waiting for the hash stream)
   return 0;
 }
 
@@ -608,8 +632,8 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
-  const uint32_t nb = (n_items + 255) / 256;
-  hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(256), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
+  const uint32_t nb = (n_items + 63) / 64;
+  hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
                      c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>());
@@ -617,12 +641,12 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (total > cap) return fail(c, BFTKV_E_NOMEM, "ids_out too small");
-  HIPCHK(c, c->x.ensure(sizeof(uint64_t) * (total + 1)));
-  hipLaunchKernelGGL(k_signers<true>, dim3(nb), dim3(256), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
-                     c->counts.as<uint32_t>(), c->base.as<uint32_t>(), c->x.as<uint64_t>(), c->kt);
+  HIPCHK(c, c->ids_tmp.ensure(sizeof(uint64_t) * (total + 1)));
+  hipLaunchKernelGGL(k_signers<true>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
+                     c->counts.as<uint32_t>(), c->base.as<uint32_t>(), c->ids_tmp.as<uint64_t>(), c->kt);
   std::vector<uint32_t> hb(n_items);
   HIPCHK(c, hipMemcpyAsync(hb.data(), c->base.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, s));
-  if (total && ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->x.p, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
+  if (total && ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->ids_tmp.p, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   for (uint32_t i = 0; i < n_items; ++i) ids_off_out[i] = hb[i];

@@ -19,6 +19,7 @@ enum SigStatus : uint8_t {
   ST_KEY_CANNOT_SIGN = 9,
   ST_UNSUPPORTED = 10,
   // internal, never returned:
+  ST_PENDING_PARSE = 99,   // signature packet located, body not parsed yet
   ST_PENDING_HASH = 100,   // parsed, key found; digest not computed yet
   ST_PENDING_RSA = 101,    // digest + tag OK; waiting for the modexp
   ST_PENDING_DSA = 102,
@@ -28,9 +29,10 @@ constexpr int PK_RSA = 1, PK_RSA_ENCRYPT_ONLY = 2, PK_RSA_SIGN_ONLY = 3, PK_ELGA
 constexpr int HASH_MD5 = 1, HASH_SHA1 = 2, HASH_RIPEMD160 = 3, HASH_SHA256 = 8, HASH_SHA384 = 9,
               HASH_SHA512 = 10, HASH_SHA224 = 11;
 
-// One record per packet event of an item's signature stream (40 bytes).
+// One record per packet event of an item's signature stream (48 bytes).
 struct SigRec {
-  uint64_t body_off;      // offset of the signature body (version byte) in the signature blob
+  uint64_t body_off;      // offset of the packet body (version byte for signatures) in the signature blob
+  uint32_t body_len;
   uint32_t item;          // index of the item (write / reply) the packet belongs to
   int32_t key_slot;       // slot in the device key table, -1 if none
   uint32_t mpi_off[2];    // offsets of the MPI *value* bytes relative to body_off
@@ -38,8 +40,12 @@ struct SigRec {
   uint16_t hashed_len;    // length of the hashed-subpacket area (hash suffix = 6+hl body bytes + 6 trailer)
   uint8_t hash_tag[2];
   uint8_t pk_algo, hash_id, sig_type, status;
-  uint32_t pad;
+  uint8_t after_tag;      // status once the hash tag has matched; AFTER_TAG_PUBKEY: the public-key operation decides
+  uint8_t flags;          // bit0: signature value may be >= 2^(8k) (no x-shortcut in the exponent ladder)
+  uint8_t pad[2];
+  uint32_t pk_idx;        // index in the public-key work list
 };
+constexpr uint8_t AFTER_TAG_PUBKEY = 0xFF;
 
 // Device key table (structure of arrays, [limb][key] would also do; [key][limb] keeps a key's
 // limbs contiguous for the quad's 4x19 loads).

@@ -1,15 +1,17 @@
 // HIP kernels of the bftkv batched quorum verifier (gfx950 / MI355X only).
 //
-//   k_parse<COUNT|FILL>   walk each item's OpenPGP signature stream (x/crypto packet.Read +
-//                         Signature.parse semantics) -> SigRec per packet event
+//   k_walk<COUNT|FILL>    per item: walk the OpenPGP packet HEADERS of the signature stream
+//                         (x/crypto packet.Read framing) -> one SigRec per packet event
 //   k_scan_counts         exclusive scan of per-item record counts
+//   k_parse_body          per packet: Signature.parse (subpackets, MPIs), KeysByIdUsage lookup, every
+//                         check that does not need the digest; queues public-key work
 //   k_sha256_mid          SHA-256 midstate of every item's signed payload, computed ONCE per item
 //                         (the reference re-hashes the whole payload per signature,
 //                          crypto/pgp/crypto_pgp.go:490)
-//   k_digest_em           per signature: finish the hash with the hash suffix, hash-tag check,
-//                         algorithm checks, build EMSA-PKCS1-v1_5 and the signature value as
-//                         radix-2^28 limbs
-//   k_rsa_verify          s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h), compare
+//   k_digest              per signature: finish the hash with the hash suffix, hash-tag check
+//   k_rsa_modexp          s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h);
+//                         runs CONCURRENTLY with the two hash kernels (separate HIP stream)
+//   k_rsa_compare         EMSA-PKCS1-v1_5 from the digest, compare with s^e mod n
 //   k_modexp              generic b^x mod n (corpus signing, threshold-RSA partial signatures)
 //   k_tally               per item: wavefront ballots over the verified signers -> per-clique
 //                         counts -> IsSufficient / IsThreshold / IsQuorum / Reject bits
@@ -150,19 +152,21 @@ __device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool hashed, bo
   return true;
 }
 
-// One packet.Read step at stream position pos of [base, base+end).
-__device__ ParsedPacket parse_next(const uint8_t* base, uint64_t pos, uint64_t end) {
-  ParsedPacket r;
+// One packet.Read framing step at stream position pos of [.., end): header only.
+struct WalkStep {
+  uint64_t next;       // stream position after the packet
+  uint64_t body_off;
+  uint32_t body_len;
+  bool event;          // false: silently skipped (unknown packet type)
+  uint8_t status;      // ST_PENDING_PARSE for signature packets, final otherwise
+};
+
+__device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
+  WalkStep r;
   r.event = true;
-  r.rec.key_slot = -1;
-  r.rec.status = ST_PARSE_ERROR;
-  r.rec.body_off = pos;
-  r.rec.mpi_off[0] = r.rec.mpi_off[1] = 0;
-  r.rec.mpi_bits[0] = r.rec.mpi_bits[1] = 0;
-  r.rec.hashed_len = 0;
-  r.rec.hash_tag[0] = r.rec.hash_tag[1] = 0;
-  r.rec.pk_algo = r.rec.hash_id = r.rec.sig_type = 0;
-  r.rec.pad = 0;
+  r.status = ST_PARSE_ERROR;
+  r.body_off = pos;
+  r.body_len = 0;
   uint32_t b0 = base[pos];
   if ((b0 & 0x80) == 0) { r.next = pos + 1; return r; }  // "tag byte does not have MSB set"
   uint32_t tag;
@@ -170,7 +174,7 @@ __device__ ParsedPacket parse_next(const uint8_t* base, uint64_t pos, uint64_t e
   if ((b0 & 0x40) == 0) {
     tag = (b0 & 0x3F) >> 2;
     uint32_t lt = b0 & 3;
-    if (lt == 3) { r.next = end; r.rec.status = ST_UNSUPPORTED; return r; }  // indeterminate length: fenced
+    if (lt == 3) { r.next = end; r.status = ST_UNSUPPORTED; return r; }  // indeterminate length: fenced
     uint32_t nb = 1u << lt;
     if (pos + 1 + nb > end) { r.next = end; return r; }
     ln = 0;
@@ -188,94 +192,146 @@ __device__ ParsedPacket parse_next(const uint8_t* base, uint64_t pos, uint64_t e
       if (pos + 6 > end) { r.next = end; return r; }
       ln = ((uint64_t)base[pos + 2] << 24) | ((uint64_t)base[pos + 3] << 16) | ((uint64_t)base[pos + 4] << 8) | base[pos + 5];
       start = pos + 6;
-    } else { r.next = end; r.rec.status = ST_UNSUPPORTED; return r; }  // partial body length: fenced
+    } else { r.next = end; r.status = ST_UNSUPPORTED; return r; }  // partial body length: fenced
   }
   if (start + ln > end) { r.next = end; return r; }  // truncated
   r.next = start + ln;
-  r.rec.body_off = start;
+  r.body_off = start;
+  r.body_len = (uint32_t)ln;
   if (tag != 2) {
-    if (known_tag(tag)) r.rec.status = ST_NOT_SIGNATURE;
+    if (known_tag(tag)) r.status = ST_NOT_SIGNATURE;
     else r.event = false;
     return r;
   }
-  if (ln >= 1 && base[start] < 4) { r.rec.status = ST_UNSUPPORTED; return r; }  // SignatureV3: fenced
-  bool have_issuer = false;
-  uint64_t issuer = 0;
-  if (!parse_sig_body(base + start, (uint32_t)ln, r.rec, have_issuer, issuer, 0)) { r.rec.status = ST_PARSE_ERROR; return r; }
-  if (!have_issuer) { r.rec.status = ST_NO_ISSUER; return r; }
-  r.rec.status = ST_PENDING_HASH;
-  // stash the issuer in mpi fields' neighbour: returned through pad (low) + key_slot (high) is
-  // awkward; the caller re-reads it from this struct instead
-  r.rec.pad = (uint32_t)issuer;
-  r.rec.key_slot = (int32_t)(issuer >> 32);
+  r.status = ST_PENDING_PARSE;
   return r;
 }
 
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_parse(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
-                                               uint32_t n_items, uint32_t* __restrict__ counts,
-                                               const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
-                                               KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
-                                               uint8_t* __restrict__ item_flags) {
+__global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
+                                             uint32_t n_items, uint32_t* __restrict__ counts,
+                                             const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
+                                             uint8_t* __restrict__ item_flags) {
   uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   uint64_t pos = sig_off[item], end = sig_off[item + 1];
   uint32_t n = 0;
   uint32_t base = FILL ? rec_base[item] : 0;
-  // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
-  const uint32_t only_ent = (FILL && cert_ent) ? cert_ent[item] : 0xFFFFFFFFu;
-  bool dangling = false;   // bytes consumed after the last call-terminating event
+  bool trailing_skip = false;   // silently skipped packet(s) after the last event
   while (pos < end) {
-    ParsedPacket pp = parse_next(sig_blob, pos, end);
-    pos = pp.next;
-    if (!pp.event) { dangling = true; continue; }
+    WalkStep w = walk_next(sig_blob, pos, end);
+    pos = w.next;
+    if (!w.event) { trailing_skip = true; continue; }
+    trailing_skip = false;
     if (FILL) {
-      SigRec rec = pp.rec;
-      rec.item = item;
-      if (rec.status == ST_PENDING_HASH) {
-        uint64_t issuer = ((uint64_t)(uint32_t)rec.key_slot << 32) | rec.pad;
-        rec.pad = 0;
-        rec.key_slot = -1;
-        // KeysByIdUsage(issuer, KeyFlagSign): first usable key with that id (ids are unique in the
-        // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
-        for (uint32_t k = 0; k < kt.n_keys; ++k) {
-          if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) &&
-              (only_ent == 0xFFFFFFFFu || kt.entity[k] == only_ent)) { rec.key_slot = (int32_t)k; break; }
-        }
-        if (rec.key_slot < 0) rec.status = ST_UNKNOWN_ISSUER;
-        else if (rec.sig_type != 0x00) rec.status = ST_HASH_UNSUPPORTED;       // hashForSignature: binary only (text: fenced)
-        else if (rec.hash_id != HASH_SHA256) rec.status = ST_HASH_UNSUPPORTED;  // TODO(next): SHA-1/224/384/512
-      }
-      dangling = (rec.status == ST_UNKNOWN_ISSUER);
+      SigRec rec;
+      rec.body_off = w.body_off; rec.body_len = w.body_len; rec.item = item; rec.key_slot = -1;
+      rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
+      rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
+      rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = w.status;
+      rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
       recs[base + n] = rec;
     }
     ++n;
   }
   if (!FILL) counts[item] = n;
-  else if (item_flags) item_flags[item] = dangling ? 1 : 0;
+  else if (item_flags) item_flags[item] = trailing_skip ? 1 : 0;
+}
+
+// hash parameters by OpenPGP hash id (digest length, DigestInfo prefix length)
+__device__ __forceinline__ bool hash_supported(uint32_t hash_id, uint32_t& hlen, uint32_t& plen) {
+  if (hash_id == HASH_SHA256) { hlen = 32; plen = 19; return true; }
+  return false;   // TODO(next): SHA-1/224/384/512 (needed for certification signatures)
+}
+
+// Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
+__global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs, uint32_t n_recs,
+                                                    KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
+                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count) {
+  uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= n_recs) return;
+  SigRec rec = recs[ri];
+  if (rec.status != ST_PENDING_PARSE) return;
+  const uint8_t* body = sig_blob + rec.body_off;
+  uint8_t st;
+  if (rec.body_len >= 1 && body[0] < 4) st = ST_UNSUPPORTED;   // SignatureV3: fenced
+  else {
+    bool have_issuer = false;
+    uint64_t issuer = 0;
+    if (!parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, 0)) st = ST_PARSE_ERROR;
+    else if (!have_issuer) st = ST_NO_ISSUER;
+    else {
+      // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
+      const uint32_t only_ent = cert_ent ? cert_ent[rec.item] : 0xFFFFFFFFu;
+      // KeysByIdUsage(issuer, KeyFlagSign): first usable key with that id (ids are unique in the
+      // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
+      int32_t slot = -1;
+      for (uint32_t k = 0; k < kt.n_keys; ++k) {
+        if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) && (only_ent == 0xFFFFFFFFu || kt.entity[k] == only_ent)) {
+          slot = (int32_t)k;
+          break;
+        }
+      }
+      rec.key_slot = slot;
+      uint32_t hlen = 0, plen = 0;
+      if (slot < 0) st = ST_UNKNOWN_ISSUER;
+      else if (rec.sig_type != 0x00) st = ST_HASH_UNSUPPORTED;            // hashForSignature: binary only (text: fenced)
+      else if (!hash_supported(rec.hash_id, hlen, plen)) st = ST_HASH_UNSUPPORTED;
+      else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
+      else {
+        // everything below is only reached when the hash tag matches (k_digest decides)
+        st = ST_PENDING_HASH;
+        if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
+        else if (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) {
+          const uint32_t mod_bits = kt.mod_bits[slot];
+          const uint32_t kbytes = (mod_bits + 7) >> 3;
+          const uint32_t nb = (rec.mpi_bits[0] + 7u) >> 3;
+          const uint8_t* mp = body + rec.mpi_off[0];
+          uint32_t lead = 0;
+          while (lead < nb && mp[lead] == 0) ++lead;
+          const uint32_t vbytes = nb - lead;
+          if (mod_bits == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;          // > 2048 bits or no Montgomery form
+          else if (kbytes < hlen + plen + 11) rec.after_tag = ST_BAD_SIG;       // rsa.VerifyPKCS1v15: k < tLen+11
+          else if (vbytes > 266) rec.after_tag = ST_BAD_SIG;                    // value >= R: fenced
+          else {
+            rec.after_tag = AFTER_TAG_PUBKEY;
+            rec.flags = (vbytes > kbytes) ? 1 : 0;
+            rec.pk_idx = atomicAdd(pk_count, 1u);
+            pk_list[rec.pk_idx] = ri;
+          }
+        } else rec.after_tag = ST_UNSUPPORTED;   // DSA: k_dsa (next milestone); ECDSA out of scope
+      }
+    }
+  }
+  rec.status = st;
+  recs[ri] = rec;
 }
 
 // PGPSignature.Signers (crypto_pgp.go:373-390): parse-only walk, issuers looked up among PRIMARY
 // key ids (getCertById, :206-219); the walk ends at the first Reader.Next error.
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_signers(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
-                                                 uint32_t n_items, uint32_t* __restrict__ counts,
-                                                 const uint32_t* __restrict__ out_base, uint64_t* __restrict__ ids_out,
-                                                 KeyTableDev kt) {
+__global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
+                                                uint32_t n_items, uint32_t* __restrict__ counts,
+                                                const uint32_t* __restrict__ out_base, uint64_t* __restrict__ ids_out,
+                                                KeyTableDev kt) {
   uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   uint64_t pos = sig_off[item], end = sig_off[item + 1];
   uint32_t n = 0;
   uint32_t base = FILL ? out_base[item] : 0;
   while (pos < end) {
-    ParsedPacket pp = parse_next(sig_blob, pos, end);
-    pos = pp.next;
-    if (!pp.event) continue;                              // unknown packet type: skipped by Next
-    const uint8_t st = pp.rec.status;
-    if (st == ST_NOT_SIGNATURE) continue;                 // other packet types fall through the type switch
-    if (st == ST_UNSUPPORTED && pos < end) continue;      // SignatureV3 is a different Go type (fenced framings end the stream)
-    if (st != ST_PENDING_HASH) break;                     // parse error => Next returns err => loop ends; no issuer: fenced
-    uint64_t issuer = ((uint64_t)(uint32_t)pp.rec.key_slot << 32) | pp.rec.pad;
+    WalkStep w = walk_next(sig_blob, pos, end);
+    pos = w.next;
+    if (!w.event) continue;                               // unknown packet type: skipped by Next
+    if (w.status == ST_NOT_SIGNATURE) continue;           // other packet types fall through the type switch
+    if (w.status != ST_PENDING_PARSE) break;              // framing error => Next returns err => loop ends
+    const uint8_t* body = sig_blob + w.body_off;
+    if (w.body_len >= 1 && body[0] < 4) continue;         // SignatureV3 is a different Go type
+    SigRec tmp;
+    bool have_issuer = false;
+    uint64_t issuer = 0;
+    if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, 0)) break;   // parse error => Next returns err
+    if (!have_issuer) break;                              // nil dereference in the reference: fenced
     for (uint32_t k = 0; k < kt.n_keys; ++k) {
       if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY)) {
         if (FILL) ids_out[base + n] = issuer;
@@ -312,9 +368,18 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // hashing
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load_be32(const uint8_t* p) {
-  if ((((uintptr_t)p) & 3) == 0) return __builtin_bswap32(*(const uint32_t*)p);
-  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+// 64-byte block at an arbitrarily aligned address as 16 big-endian words: 17 aligned dword loads
+// funnel-shifted with v_alignbyte_b32 (the bytes before/after the block inside the same aligned
+// dwords are readable: they belong to the same allocation).
+__device__ __forceinline__ void load_block_be(const uint8_t* p, uint32_t (&w)[16]) {
+  const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
+  const uint32_t* ap = (const uint32_t*)((uintptr_t)p & ~(uintptr_t)3);
+  uint32_t t[17];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = ap[i];
+  t[16] = mis ? ap[16] : 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(__builtin_amdgcn_alignbyte(t[i + 1], t[i], mis));
 }
 
 __global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
@@ -327,8 +392,7 @@ __global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ t
   sha256_init(s);
   for (uint64_t blk = 0; blk < (len >> 6); ++blk) {
     uint32_t w[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = load_be32(p + blk * 64 + i * 4);
+    load_block_be(p + blk * 64, w);
     sha256_compress(s, w);
   }
 #pragma unroll
@@ -342,9 +406,8 @@ __device__ __constant__ const uint8_t SHA256_DI[19] = {0x30, 0x31, 0x30, 0x0d, 0
 struct TailSrc {
   const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
   const uint8_t* body; uint32_t pre_len;      // first 6+hl bytes of the signature body
-  uint64_t total_len;                         // bytes hashed in all = len(signed) + pre_len + 6
 };
-__device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j, uint32_t rem_len) {
+__device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j) {
   if (j < t.tail_len) return t.tail[j];
   j -= t.tail_len;
   if (j < t.pre_len) return t.body[j];
@@ -354,10 +417,7 @@ __device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j, uint
     if (j == 1) return 0xFF;
     return (t.pre_len >> (8 * (5 - j))) & 0xFF;
   }
-  j -= 6;
-  if (j == 0) return 0x80;
-  (void)rem_len;
-  return 0;
+  return (j == 6) ? 0x80 : 0;
 }
 
 // value of a big-endian byte string as radix-2^28 limb j
@@ -371,25 +431,23 @@ __device__ __forceinline__ uint32_t limb28(F byte_from_lsb, int j) {
   return (uint32_t)(v >> sh) & MONT_MASK;
 }
 
-__global__ void __launch_bounds__(256) k_digest_em(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
-                                                   const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid,
-                                                   SigRec* __restrict__ recs, uint32_t n_recs, KeyTableDev kt,
-                                                   uint32_t* __restrict__ x_limbs, uint32_t* __restrict__ em_limbs,
-                                                   uint32_t* __restrict__ rsa_list, uint32_t* __restrict__ rsa_count) {
+// Per signature: digest = H(signed || hash suffix) from the item's midstate; hash-tag check.
+__global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid,
+                                                SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][8]*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
-  SigRec rec = recs[ri];
+  const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_HASH) return;
-  const uint8_t* body = sig_blob + rec.body_off;
   uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
   TailSrc ts;
   ts.tail_len = (uint32_t)(tlen & 63);
   ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
-  ts.body = body;
+  ts.body = sig_blob + rec.body_off;
   ts.pre_len = 6u + rec.hashed_len;
-  ts.total_len = tlen + ts.pre_len + 6;
-  uint32_t rem = ts.tail_len + ts.pre_len + 6;     // message bytes still to hash
-  uint32_t nblk = (rem + 9 + 63) >> 6;
+  const uint32_t rem = ts.tail_len + ts.pre_len + 6;     // message bytes still to hash
+  const uint32_t nblk = (rem + 9 + 63) >> 6;
+  const uint64_t bits = (tlen + ts.pre_len + 6) * 8;
   uint32_t s[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = mid[(uint64_t)rec.item * 8 + i];
@@ -398,104 +456,72 @@ __global__ void __launch_bounds__(256) k_digest_em(const uint8_t* __restrict__ t
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       uint32_t j = blk * 64 + i * 4;
-      w[i] = (tail_byte(ts, j, rem) << 24) | (tail_byte(ts, j + 1, rem) << 16) | (tail_byte(ts, j + 2, rem) << 8) |
-             tail_byte(ts, j + 3, rem);
+      w[i] = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
     }
     if (blk == nblk - 1) {
-      uint64_t bits = ts.total_len * 8;
       w[14] = (uint32_t)(bits >> 32);
       w[15] = (uint32_t)bits;
     }
     sha256_compress(s, w);
   }
-  // PublicKey.VerifySignature order of checks: CanSign, hash tag, algorithm match, then the math
-  uint32_t k = (uint32_t)rec.key_slot;
-  uint8_t kflags = kt.flags[k];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) digests[(uint64_t)ri * 8 + i] = s[i];
+  // PublicKey.VerifySignature: hash tag first, then whatever k_parse_body determined
   uint8_t st;
-  if (!(kflags & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;
-  else if ((uint8_t)(s[0] >> 24) != rec.hash_tag[0] || (uint8_t)(s[0] >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
-  else if (kt.pk_algo[k] != rec.pk_algo) st = ST_ALGO_MISMATCH;
-  else if (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) {
-    uint32_t kbytes = (kt.mod_bits[k] + 7) >> 3;
-    const uint32_t hlen = 32, plen = 19, tl = hlen + plen;
-    // value of the signature MPI
-    uint32_t nb = (rec.mpi_bits[0] + 7u) >> 3;
-    const uint8_t* mp = body + rec.mpi_off[0];
-    uint32_t lead = 0;
-    while (lead < nb && mp[lead] == 0) ++lead;
-    uint32_t vbytes = nb - lead;
-    if (kbytes < tl + 11) st = ST_BAD_SIG;                 // rsa.VerifyPKCS1v15: k < tLen+11
-    else if (kt.mod_bits[k] > 2048) st = ST_UNSUPPORTED;   // TODO(next): 3072/4096-bit instantiations
-    else if (vbytes > 266) st = ST_BAD_SIG;                // value >= R: fenced, never a valid s
-    else {
-      auto sig_b = [&](uint32_t i) -> uint32_t { return i < nb ? mp[nb - 1 - i] : 0u; };
-      auto em_b = [&](uint32_t i) -> uint32_t {
-        if (i < hlen) return (s[7 - (i >> 2)] >> (8 * (i & 3))) & 0xFF;
-        if (i < tl) return SHA256_DI[plen - 1 - (i - hlen)];
-        if (i == tl) return 0;
-        if (i < kbytes - 2) return 0xFF;
-        if (i == kbytes - 2) return 1;
-        return 0;
-      };
-      uint32_t* xo = x_limbs + (uint64_t)ri * MONT_N;
-      uint32_t* eo = em_limbs + (uint64_t)ri * MONT_N;
-      for (int j = 0; j < MONT_N; ++j) {
-        xo[j] = limb28(sig_b, j);
-        eo[j] = limb28(em_b, j);
-      }
-      rec.pad = (vbytes > kbytes) ? 1u : 0u;   // bit0: signature value may be >= 2^(8k): no x-shortcut
-      st = ST_PENDING_RSA;
-      uint32_t slot = atomicAdd(rsa_count, 1u);
-      rsa_list[slot] = ri;
-    }
-  } else {
-    st = ST_UNSUPPORTED;   // DSA / ECDSA: DSA lands in k_dsa (next milestone)
-  }
-  rec.status = st;
+  if ((uint8_t)(s[0] >> 24) != rec.hash_tag[0] || (uint8_t)(s[0] >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
+  else st = (rec.after_tag == AFTER_TAG_PUBKEY) ? (uint8_t)ST_PENDING_RSA : rec.after_tag;
   recs[ri].status = st;
-  recs[ri].pad = rec.pad;
 }
 
 // ------------------------------------------------------------------------------------------------
-// RSA verify: 4 lanes per signature
+// RSA: 4 lanes per signature
 // ------------------------------------------------------------------------------------------------
 constexpr int RSA_BLOCK = 256;
 constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
 
 enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
 
-__global__ void __launch_bounds__(RSA_BLOCK) k_rsa_verify(SigRec* __restrict__ recs, const uint32_t* __restrict__ rsa_list,
-                                                          const uint32_t* __restrict__ rsa_count, KeyTableDev kt,
-                                                          const uint32_t* __restrict__ x_limbs,
-                                                          const uint32_t* __restrict__ em_limbs,
+// r = s^e mod n (+ possibly n) for every queued signature; canonical radix-2^28 limbs to r_limbs.
+__global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
+                                                          const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count,
+                                                          KeyTableDev kt, uint32_t* __restrict__ r_limbs,
                                                           uint32_t* __restrict__ xr_scratch) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  __shared__ uint32_t x_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
-  const uint32_t count = *rsa_count;
+  const uint32_t count = *pk_count;
   if (blockIdx.x * QUADS_PER_BLOCK >= count) return;   // whole block idle
   const uint32_t quad = threadIdx.x >> 2;
   const int qlane = threadIdx.x & 3;
   const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
   const bool active = gq < count;
-  const uint32_t ri = rsa_list[active ? gq : (count - 1)];
+  const uint32_t pi = active ? gq : (count - 1);
+  const uint32_t ri = pk_list[pi];
   const SigRec rec = recs[ri];
   const uint32_t key = (uint32_t)rec.key_slot;
   uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;     // this lane's slice of the quad's operand
   const uint32_t* a_rd = a_sh + quad * MONT_N;
+  uint32_t* x_lds = x_sh + quad * MONT_N + qlane * L;
 
   uint32_t n[L], b[L], y[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
   const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_N + qlane * L;
-  const uint32_t* xp = x_limbs + (uint64_t)ri * MONT_N + qlane * L;
-  uint32_t* xrp = xr_scratch + (uint64_t)ri * MONT_N + qlane * L;
+  uint32_t* xrp = xr_scratch + (uint64_t)pi * MONT_N + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) n[k] = np[k];
+  // signature value: big-endian MPI bytes -> this lane's 19 limbs
+  {
+    const uint32_t nb = (rec.mpi_bits[0] + 7u) >> 3;
+    const uint8_t* mp = sig_blob + rec.body_off + rec.mpi_off[0];
+    auto sig_b = [&](uint32_t i) -> uint32_t { return i < nb ? mp[nb - 1 - i] : 0u; };
+#pragma unroll
+    for (int k = 0; k < L; ++k) x_lds[k] = limb28(sig_b, qlane * L + k);
+  }
   const uint32_t n0inv = kt.n0inv[key];
   const uint32_t e = kt.rsa_e[key];
   // x-shortcut: the last multiplication of an odd exponent uses plain x instead of xR, which also
   // leaves the Montgomery domain.  Only when x < 2^(8k) so that the result stays below n(1+2^-79).
-  const uint32_t cls = (e << 1) | (((e & 1u) && e > 1u && !(rec.pad & 1u)) ? 1u : 0u);
-  bool ok_final = false;
+  const uint32_t cls = (e << 1) | (((e & 1u) && e > 1u && !(rec.flags & 1u)) ? 1u : 0u);
 
   // Exponent schedules are wave-uniform per (e, shortcut) class; a wave whose 16 signatures use
   // different public exponents runs the schedule once per class (all real keys use 65537).
@@ -512,7 +538,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_verify(SigRec* __restrict__ r
       // ---- operands of this step
       if (kind == OP_TO_MONT) {
 #pragma unroll
-        for (int k = 0; k < L; ++k) { b[k] = rp[k]; a_lds[k] = xp[k]; }
+        for (int k = 0; k < L; ++k) { b[k] = rp[k]; a_lds[k] = x_lds[k]; }
       } else {
 #pragma unroll
         for (int k = 0; k < L; ++k) b[k] = y[k];
@@ -524,7 +550,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_verify(SigRec* __restrict__ r
           for (int k = 0; k < L; ++k) a_lds[k] = xrp[k];
         } else if (kind == OP_MULP) {
 #pragma unroll
-          for (int k = 0; k < L; ++k) a_lds[k] = xp[k];
+          for (int k = 0; k < L; ++k) a_lds[k] = x_lds[k];
         } else {
 #pragma unroll
           for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
@@ -543,30 +569,68 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_verify(SigRec* __restrict__ r
       --bitpos;
       kind = (bitpos >= 0) ? OP_SQR : OP_MUL1;
     }
-    // y = s^e mod n (+ possibly n): canonicalise and compare with EM, then with EM + n
     canonicalize(y, qlane);
-    const uint32_t* ep = em_limbs + (uint64_t)ri * MONT_N + qlane * L;
-    uint32_t em[L];
-    uint32_t diff = 0;
+    if (live && active) {
+      uint32_t* out = r_limbs + (uint64_t)pi * MONT_N + qlane * L;
 #pragma unroll
-    for (int k = 0; k < L; ++k) { em[k] = ep[k]; diff |= em[k] ^ y[k]; }
-    diff = quad_or(diff);
-    bool ok = (diff == 0);
-    if (__any(!ok)) {
-      uint32_t diff2 = 0;
-#pragma unroll
-      for (int k = 0; k < L; ++k) em[k] += n[k];
-      canonicalize(em, qlane);
-#pragma unroll
-      for (int k = 0; k < L; ++k) diff2 |= em[k] ^ y[k];
-      diff2 = quad_or(diff2);
-      ok = ok || (diff2 == 0);
+      for (int k = 0; k < L; ++k) out[k] = (e_u == 0) ? ((qlane == 0 && k == 0) ? 1u : 0u) : y[k];   // x^0 = 1
     }
-    if (e_u == 0) ok = false;   // x^0 = 1 is never a PKCS#1 encoding
-    if (live) ok_final = ok;
     todo &= ~__builtin_amdgcn_ballot_w64(live);
   }
-  if (active && qlane == 0) recs[ri].status = ok_final ? ST_OK : ST_BAD_SIG;
+}
+
+// EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); 4 lanes per signature.
+__global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, const uint32_t* __restrict__ pk_list,
+                                                     const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                     const uint32_t* __restrict__ r_limbs, const uint32_t* __restrict__ digests) {
+  constexpr int L = MONT_L;
+  const uint32_t count = *pk_count;
+  const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int qlane = threadIdx.x & 3;
+  if ((blockIdx.x * blockDim.x) >> 2 >= count) return;
+  const bool active = gq < count;
+  const uint32_t pi = active ? gq : (count - 1);
+  const uint32_t ri = pk_list[pi];
+  const SigRec rec = recs[ri];
+  const bool pending = rec.status == ST_PENDING_RSA;   // hash tag matched
+  const uint32_t key = (uint32_t)rec.key_slot;
+  const uint32_t kbytes = (kt.mod_bits[key] + 7) >> 3;
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = digests[(uint64_t)ri * 8 + i];
+  const uint32_t hlen = 32, plen = 19, tl = hlen + plen;
+  auto em_b = [&](uint32_t i) -> uint32_t {
+    if (i < hlen) {
+      uint32_t w = d[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) w = ((i >> 2) == (uint32_t)(7 - q)) ? d[q] : w;
+      return (w >> (8 * (i & 3))) & 0xFF;
+    }
+    if (i < tl) return SHA256_DI[plen - 1 - (i - hlen)];
+    if (i == tl) return 0;
+    if (i < kbytes - 2) return 0xFF;
+    if (i == kbytes - 2) return 1;
+    return 0;
+  };
+  uint32_t em[L], r[L];
+  const uint32_t* rp = r_limbs + (uint64_t)pi * MONT_N + qlane * L;
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < L; ++k) { em[k] = limb28(em_b, qlane * L + k); r[k] = rp[k]; diff |= em[k] ^ r[k]; }
+  diff = quad_or(diff);
+  bool ok = (diff == 0);
+  if (__any(!ok)) {
+    const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
+    uint32_t diff2 = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) em[k] += np[k];
+    canonicalize(em, qlane);
+#pragma unroll
+    for (int k = 0; k < L; ++k) diff2 |= em[k] ^ r[k];
+    diff2 = quad_or(diff2);
+    ok = ok || (diff2 == 0);
+  }
+  if (active && pending && qlane == 0) recs[ri].status = ok ? ST_OK : ST_BAD_SIG;
 }
 
 // ------------------------------------------------------------------------------------------------

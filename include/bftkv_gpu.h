@@ -149,7 +149,8 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, ui
                      const uint8_t* exps, uint32_t exp_len, uint8_t* out);
 
 /* ---- timing of the last *_dev verify call (HIP events on the context's stream) ---------------- */
-/* ms[0] total, ms[1] parse, ms[2] hash, ms[3] rsa, ms[4] tally */
+/* ms[0] whole call, ms[1] walk+parse, ms[2] hash stream (midstates+digests, overlaps the modexp),
+ * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream) */
 int bftkv_gpu_last_timing(bftkv_gpu_ctx* ctx, float ms[8]);
 void* bftkv_gpu_stream(bftkv_gpu_ctx* ctx);   /* hipStream_t of the context */
 

@@ -15,7 +15,7 @@
  * CheckDetachedSignature, PublicKey.VerifySignature; Go crypto/rsa.VerifyPKCS1v15, crypto/dsa.Verify).
  */
 #include <openssl/bn.h>
-#include <openssl/evp.h>
+#include <openssl/sha.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -28,6 +28,7 @@ typedef struct {
   uint64_t key_id, entity_id;
   int pk_algo, usable_sign;
   BIGNUM *n, *e;          /* RSA */
+  BN_MONT_CTX* mont;      /* precomputed once per key (OpenSSL would otherwise rebuild it per call) */
   BIGNUM *p, *q, *g, *y;  /* DSA */
 } okey;
 
@@ -50,7 +51,7 @@ void oracle_free(void* h) {
   oracle* o = (oracle*)h;
   if (!o) return;
   for (int i = 0; i < o->n_keys; ++i) {
-    BN_free(o->keys[i].n); BN_free(o->keys[i].e); BN_free(o->keys[i].p);
+    BN_free(o->keys[i].n); BN_free(o->keys[i].e); BN_free(o->keys[i].p); BN_MONT_CTX_free(o->keys[i].mont);
     BN_free(o->keys[i].q); BN_free(o->keys[i].g); BN_free(o->keys[i].y);
   }
   free(o->keys);
@@ -72,6 +73,12 @@ void oracle_add_key(void* h, uint64_t key_id, uint64_t entity_id, int pk_algo, i
     k->g = BN_bin2bn(g, glen, NULL); k->y = BN_bin2bn(y, ylen, NULL);
   } else {
     k->n = BN_bin2bn(a, alen, NULL); k->e = BN_bin2bn(b, blen, NULL);
+    if (BN_is_odd(k->n)) {
+      BN_CTX* ctx = BN_CTX_new();
+      k->mont = BN_MONT_CTX_new();
+      BN_MONT_CTX_set(k->mont, k->n, ctx);
+      BN_CTX_free(ctx);
+    }
   }
 }
 
@@ -189,15 +196,43 @@ static int parse_body(const uint8_t* b, int n, psig* s, int depth) {
   return 1;
 }
 
-static const EVP_MD* md_for(int hash_id) {
+/* Low-level SHA contexts (no EVP): EVP_MD objects are reference-counted with atomics on ONE shared
+ * cache line, which serialises hundreds of worker threads. */
+typedef struct {
+  int id;
+  union { SHA_CTX s1; SHA256_CTX s256; SHA512_CTX s512; } u;
+} hctx;
+static int h_init(hctx* h, int hash_id) {
+  h->id = hash_id;
   switch (hash_id) {   /* md5 / ripemd160: fenced as unavailable */
-    case 2: return EVP_sha1();
-    case 8: return EVP_sha256();
-    case 9: return EVP_sha384();
-    case 10: return EVP_sha512();
-    case 11: return EVP_sha224();
-    default: return NULL;
+    case 2: SHA1_Init(&h->u.s1); return 1;
+    case 8: SHA256_Init(&h->u.s256); return 1;
+    case 9: SHA384_Init(&h->u.s512); return 1;
+    case 10: SHA512_Init(&h->u.s512); return 1;
+    case 11: SHA224_Init(&h->u.s256); return 1;
+    default: return 0;
   }
+}
+static void h_update(hctx* h, const void* p, size_t n) {
+  switch (h->id) {
+    case 2: SHA1_Update(&h->u.s1, p, n); break;
+    case 8: SHA256_Update(&h->u.s256, p, n); break;
+    case 9: SHA384_Update(&h->u.s512, p, n); break;
+    case 10: SHA512_Update(&h->u.s512, p, n); break;
+    case 11: SHA224_Update(&h->u.s256, p, n); break;
+  }
+}
+/* digest of a COPY of the running hash (the running hash keeps accumulating, B.3) */
+static unsigned h_peek(const hctx* h, uint8_t* out) {
+  hctx c = *h;
+  switch (c.id) {
+    case 2: SHA1_Final(out, &c.u.s1); return 20;
+    case 8: SHA256_Final(out, &c.u.s256); return 32;
+    case 9: SHA384_Final(out, &c.u.s512); return 48;
+    case 10: SHA512_Final(out, &c.u.s512); return 64;
+    case 11: SHA224_Final(out, &c.u.s256); return 28;
+  }
+  return 0;
 }
 
 static const uint8_t PFX_SHA1[] = {0x30, 0x21, 0x30, 0x09, 0x06, 0x05, 0x2b, 0x0e, 0x03, 0x02, 0x1a, 0x05, 0x00, 0x04, 0x14};
@@ -230,7 +265,7 @@ static int rsa_verify(const okey* k, int hash_id, const uint8_t* digest, int dle
   BIGNUM* m = BN_CTX_get(ctx);
   BN_bin2bn(sig, slen, c);
   if (BN_is_odd(k->n) && BN_cmp(c, k->n) < 0) {
-    if (!BN_mod_exp(m, c, k->e, k->n, ctx)) goto done;
+    if (!BN_mod_exp_mont(m, c, k->e, k->n, ctx, k->mont)) goto done;
   } else {
     /* math/big.Exp reduces the base and accepts any modulus */
     BIGNUM* cr = BN_CTX_get(ctx);
@@ -287,8 +322,7 @@ static int known_tag(int tag) { return tag < 32 && ((0x00066BFEu >> tag) & 1u); 
  * Returns the call's status; *signer = entity id on ST_OK; *pos advanced; per-packet statuses
  * appended to trace (if non-NULL). */
 static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sd, uint64_t end, uint64_t* pos,
-                          uint64_t* signer, uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, EVP_MD_CTX* mdctx,
-                          uint64_t* n_pk_ops) {
+                          uint64_t* signer, uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, uint64_t* n_pk_ops) {
 #define TRACE(st) do { if (trace && *ntrace < cap) trace[(*ntrace)++] = (uint8_t)(st); } while (0)
   for (;;) {
     uint64_t p = *pos;
@@ -333,11 +367,10 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
     int found = 0;
     for (int i = 0; i < o->n_keys; ++i) if (o->keys[i].key_id == s.issuer && o->keys[i].usable_sign) { found = 1; break; }
     if (!found) { TRACE(ST_UNKNOWN_ISSUER); continue; }
-    const EVP_MD* md = md_for(s.hash_id);
-    if (!md || s.sig_type != 0) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
+    hctx hc;
+    if (s.sig_type != 0 || !h_init(&hc, s.hash_id)) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
     /* the reference hashes the WHOLE payload again for every signature packet */
-    EVP_DigestInit_ex(mdctx, md, NULL);
-    EVP_DigestUpdate(mdctx, tbs, tbs_len);
+    h_update(&hc, tbs, tbs_len);
     int st = ST_BAD_SIG;
     for (int i = 0; i < o->n_keys; ++i) {
       const okey* k = &o->keys[i];
@@ -345,13 +378,10 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
       /* VerifySignature appends the suffix to the shared hash on every candidate */
       if (k->pk_algo == 2 || k->pk_algo == 16) { st = ST_KEY_CANNOT_SIGN; continue; }   /* checked before the hash is touched */
       uint8_t trailer[6] = {4, 0xFF, 0, 0, (uint8_t)(s.prefix_len >> 8), (uint8_t)s.prefix_len};
-      EVP_DigestUpdate(mdctx, s.prefix, s.prefix_len);
-      EVP_DigestUpdate(mdctx, trailer, 6);
-      EVP_MD_CTX* cp = EVP_MD_CTX_new();
-      EVP_MD_CTX_copy_ex(cp, mdctx);
-      uint8_t dg[64]; unsigned dl = 0;
-      EVP_DigestFinal_ex(cp, dg, &dl);
-      EVP_MD_CTX_free(cp);
+      h_update(&hc, s.prefix, s.prefix_len);
+      h_update(&hc, trailer, 6);
+      uint8_t dg[64];
+      unsigned dl = h_peek(&hc, dg);
       if (dg[0] != s.tag[0] || dg[1] != s.tag[1]) { st = ST_HASH_TAG; continue; }
       if (k->pk_algo != s.pk_algo) { st = ST_ALGO_MISMATCH; continue; }
       if (n_pk_ops) ++*n_pk_ops;
@@ -372,13 +402,13 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
 
 /* PGPCollectiveSignature.Verify for one item (crypto_pgp.go:485-500) */
 static int collective_one(const oracle* o, const uint8_t* tbs, uint64_t tl, const uint8_t* sd, uint64_t sl, uint32_t* nver,
-                          uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, EVP_MD_CTX* mdctx, uint64_t* ops) {
+                          uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, uint64_t* ops) {
   uint64_t pos = 0;
   uint64_t verified[4096];
   int nv = 0;
   while (pos < sl) {
     uint64_t signer = 0;
-    int st = check_detached(o, tbs, tl, sd, sl, &pos, &signer, trace, ntrace, cap, ctx, mdctx, ops);
+    int st = check_detached(o, tbs, tl, sd, sl, &pos, &signer, trace, ntrace, cap, ctx, ops);
     if (st == ST_OK) {
       if (nv < 4096) verified[nv++] = signer;
       if (is_sufficient(o, verified, nv)) { *nver = (uint32_t)nv; return 0; }
@@ -391,11 +421,9 @@ static int collective_one(const oracle* o, const uint8_t* tbs, uint64_t tl, cons
 int oracle_trace_item(void* h, const uint8_t* tbs, uint64_t tl, const uint8_t* sd, uint64_t sl, uint8_t* trace, int cap,
                       uint32_t* nver, int* err) {
   BN_CTX* ctx = BN_CTX_new();
-  EVP_MD_CTX* md = EVP_MD_CTX_new();
   int nt = 0;
   uint64_t ops = 0;
-  *err = collective_one((oracle*)h, tbs, tl, sd, sl, nver, trace, &nt, cap, ctx, md, &ops);
-  EVP_MD_CTX_free(md);
+  *err = collective_one((oracle*)h, tbs, tl, sd, sl, nver, trace, &nt, cap, ctx, &ops);
   BN_CTX_free(ctx);
   return nt;
 }
@@ -411,16 +439,14 @@ typedef struct {
 static void* worker(void* arg) {
   job* j = (job*)arg;
   BN_CTX* ctx = BN_CTX_new();
-  EVP_MD_CTX* md = EVP_MD_CTX_new();
   for (uint32_t i = j->lo; i < j->hi; ++i) {
     int nt = 0;
     uint32_t nv = 0;
     int e = collective_one(j->o, j->tbs + j->tbs_off[i], j->tbs_off[i + 1] - j->tbs_off[i], j->ss + j->ss_off[i],
-                           j->ss_off[i + 1] - j->ss_off[i], &nv, NULL, &nt, 0, ctx, md, &j->ops);
+                           j->ss_off[i + 1] - j->ss_off[i], &nv, NULL, &nt, 0, ctx, &j->ops);
     if (j->err) j->err[i] = (uint8_t)e;
     if (j->nver) j->nver[i] = nv;
   }
-  EVP_MD_CTX_free(md);
   BN_CTX_free(ctx);
   return NULL;
 }
