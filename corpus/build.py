@@ -259,6 +259,8 @@ class WriteCorpus:
     ss_off: np.ndarray            # uint64 [n_items+1]
     n_sigs: int                   # total signature packets
     mutation: np.ndarray          # uint8 [n_items]
+    expected_valid: Optional[np.ndarray] = None   # int32 [n_items]: packets that must verify (duplicates counted)
+    sig_count: Optional[np.ndarray] = None        # int32 [n_items]: packets in ss.Data
     requests: Optional[List[bytes]] = None   # full <x,v,t,sig,ss> packets (small corpora only)
 
     def tbss(self, i: int) -> bytes:
@@ -316,6 +318,7 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
     digests: List[bytes] = []
     flip: List[int] = []          # 1 => corrupt one MPI byte after signing; 2 => corrupt hash tag
     per_item_counts = np.zeros(n_items, dtype=np.int64)
+    expected_valid = np.zeros(n_items, dtype=np.int32)
 
     for i in range(n_items):
         x = b"key%08d" % i
@@ -360,6 +363,7 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
             digests.append(h.digest())
             flip.append(fl)
         per_item_counts[i] = len(order)
+        expected_valid[i] = sum(1 for kidx, fl in zip(order, flips) if kidx >= 0 and fl == 0)
 
     total = len(sig_item)
     # ---- sign: RSA in one batch, DSA and outsiders one by one
@@ -409,4 +413,5 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
     reqs = None
     if keep_requests:
         reqs = [tbss_parts[i] + sigpkt(ss_parts[i], None) for i in range(n_items)]
-    return WriteCorpus(cluster, n_items, tb, to, sb, so, total, mutation, reqs)
+    return WriteCorpus(cluster, n_items, tb, to, sb, so, total, mutation, expected_valid=expected_valid,
+                       sig_count=per_item_counts.astype(np.int32), requests=reqs)

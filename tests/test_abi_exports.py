@@ -1,0 +1,49 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bftkv_gpu.h declares (no compute calls:
+there is no GPU here), and the product path fails loudly instead of falling back to the CPU."""
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+from bftkv_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    ge.build()
+    return _native.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bftkv_gpu.h")).read()
+    declared = set(re.findall(r"\b(bftkv_gpu_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_native.EXPORTS)
+
+
+def test_error_strings_are_the_reference_singletons(lib):
+    # crypto/crypto.go:19-20; these strings travel in the X-error header (transport/http/http.go:145)
+    assert lib.bftkv_gpu_error_string(1) == b"crypto: invalid signature"
+    assert lib.bftkv_gpu_error_string(2) == b"crypto: insufficient number of signatures"
+    assert lib.bftkv_gpu_error_string(0) == b""
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_native.NativeError):
+        _native.Context(0)
+
+
+def test_product_package_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bftkv_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f

@@ -58,3 +58,208 @@ def test_collective_verify_matches_oracle(gpu_ctx, n, items):
     assert set(np.unique(err)) <= {0, 2}
     assert (err == 0).any() and (err == 2).any()
     gpu_ctx.quorum_destroy(qh)
+
+
+def _ring_and_ctx(gpu_ctx, cl, include_client=False):
+    kr = H.oracle_keyring(cl, include_client=include_client)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    return kr
+
+
+def _cat(parts):
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    return np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)[:int(off[-1])].copy(), off
+
+
+def test_signature_verify_and_with_certificate(gpu_ctx):
+    """PGPSignature.Verify / VerifyWithCertificate (crypto_pgp.go:319-344)."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(4)
+    kr = _ring_and_ctx(gpu_ctx, cl, include_client=True)
+    client_ent = pgp.read_entities(cl.client.entity)[0]
+    rng = np.random.default_rng(3)
+    tbs_l, sig_l, cert_l = [], [], []
+    for i in range(40):
+        tbs = cb.serialize_tbs(b"key%04d" % i, rng.bytes(int(rng.integers(0, 200))), i)
+        good = cb.detach_sign(cl.client, tbs)
+        other = cb.detach_sign(cl.replicas[i % 4], tbs)
+        outsider = cb.detach_sign(cl.outsiders[0], tbs)
+        variants = [good, good + other, b"", other, outsider + good, good + outsider, good[:-1] + bytes([good[-1] ^ 1]),
+                    good + b"\x00", b"\xd4\x01\x00" + good, good + b"\xd4\x01\x00", b"\xfe\x01\x00" + good, good + b"\xfe\x01\x00"]
+        sig = variants[i % len(variants)]
+        if i % 5 == 4:
+            tbs = tbs + b"x"      # signed bytes differ
+        tbs_l.append(tbs); sig_l.append(sig); cert_l.append(cl.client.key_id)
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(sig_l)
+    err = gpu_ctx.signature_verify(tb, to, sb, so)
+    errc = gpu_ctx.signature_verify(tb, to, sb, so, cert_key_id=np.array(cert_l, dtype=np.uint64))
+    n_ok = 0
+    for i in range(40):
+        sp = SignaturePacket(1, 0, False, sig_l[i] or None, None)
+        want = col.signature_verify(kr, tbs_l[i], sp)
+        wantc = col.signature_verify_with_certificate(tbs_l[i], sp, client_ent)
+        assert (err[i] == 0) == (want is None), (i, err[i], want)
+        assert (errc[i] == 0) == (wantc is None), (i, errc[i], wantc)
+        assert err[i] in (0, 1) and errc[i] in (0, 1)
+        n_ok += want is None
+    assert 5 < n_ok < 35
+
+
+def test_signers_parse_only(gpu_ctx):
+    """PGPSignature.Signers / PGPCollectiveSignature.Signers (crypto_pgp.go:373-390, 517-519)."""
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(10)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    c = cb.make_write_corpus(cl, 30, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.3, cb.MUT_DUP_SIGNER: 0.2})
+    parts = [c.ss_data(i) for i in range(30)]
+    parts[3] = b""
+    parts[4] = parts[4][:300] + b"\x00garbage" + parts[4][300:]      # bad tag byte ends the walk
+    parts[5] = b"\xd4\x02\x01\x02" + parts[5]                          # unknown packet type is skipped
+    parts[6] = parts[6][:287 + 100]                                    # truncated second packet
+    sb, so = _cat(parts)
+    ids, off = gpu_ctx.signers(sb, so)
+    for i in range(30):
+        want = col.signers(kr, SignaturePacket(1, 0, False, parts[i] or None, None))
+        got = [int(x) for x in ids[int(off[i]):int(off[i + 1])]]
+        assert got == want, i
+
+
+def test_quorum_tally_over_id_lists(gpu_ctx):
+    """wotq.IsQuorum / IsThreshold / IsSufficient / Reject over node lists (wotqs.go:144-185)."""
+    from oracle import wotqs as W
+    rng = np.random.default_rng(11)
+    quorums = [
+        W.WotQ([W.new_qc(list(range(1, 5)), 4, W.AUTH, 0)]),
+        W.WotQ([W.new_qc(list(range(1, 11)), 10, W.AUTH, 0), W.new_qc(list(range(20, 27)), 0, W.READ, 0)]),
+        W.WotQ([W.new_qc(list(range(1, 65)), 64, W.AUTH | W.CERT, 0)]),
+        W.WotQ([W.QC(list(range(30, 36)), 0, 0, 0, 0), W.new_qc(list(range(1, 8)), 0, W.READ, 0)]),
+        W.WotQ([]),
+    ]
+    for q in quorums:
+        qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+        lists = [[]] + [list(rng.integers(0, 70, size=int(rng.integers(0, 90)))) for _ in range(60)]
+        lists += [list(range(1, k)) for k in (3, 4, 5, 8, 11, 23, 44, 65)] + [[1] * 50, [1, 1, 2, 2, 3, 3]]
+        flat = np.array([x for l in lists for x in l], dtype=np.uint64)
+        off = np.zeros(len(lists) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(l) for l in lists])
+        v = gpu_ctx.quorum_tally(qh, flat, off)
+        for l, got in zip(lists, v):
+            want = (1 if q.is_quorum(l) else 0) | (2 if q.is_threshold(l) else 0) | (4 if q.is_sufficient(l) else 0) | (8 if q.reject(l) else 0)
+            assert got == want, (l, got, want)
+        gpu_ctx.quorum_destroy(qh)
+
+
+def test_malformed_and_edge_streams(gpu_ctx):
+    """Ragged / empty / malformed inputs: statuses and verdicts follow the oracle packet by packet."""
+    cl = cb.make_cluster(4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    rng = np.random.default_rng(5)
+    tbs_l, ss_l = [], []
+    pub = cl.replicas[0].entity[:280]                                   # a well-formed public-key packet (tag 6)
+    for i in range(64):
+        ln = [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 200, 1000][i % 14]   # SHA-256 padding boundaries
+        tbs = rng.bytes(ln)
+        sigs = [cb.detach_sign(r, tbs) for r in cl.replicas]
+        k = i % 16
+        if k == 0: data = b""
+        elif k == 1: data = b"".join(sigs)
+        elif k == 2: data = sigs[0] + pub + sigs[1] + sigs[2]                         # non-signature packet in between
+        elif k == 3: data = sigs[0] + b"\xd4\x03abc" + sigs[1] + sigs[2]              # unknown packet type
+        elif k == 4: data = sigs[0] + sigs[1] + sigs[2][:100]                          # truncated
+        elif k == 5: data = b"\x00\x01\x02" + b"".join(sigs[:3])                       # bytes without the tag MSB
+        elif k == 6: data = rng.bytes(300)                                             # noise
+        elif k == 7: data = sigs[0] + sigs[1] + b"\x89"                                # lone header byte
+        elif k == 8:
+            b = bytearray(sigs[0]); b[3] = 3; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]      # version 3 body
+        elif k == 9:
+            b = bytearray(sigs[0]); b[6] = 99; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]     # unknown hash id
+        elif k == 10:
+            b = bytearray(sigs[0]); b[5] = 22; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]     # unknown pk algo
+        elif k == 11:
+            b = bytearray(sigs[0]); b[9] = 0x83; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]   # subpacket type changed: no creation time
+        elif k == 12:
+            b = bytearray(sigs[0]); b[4] = 1; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]      # text signature type
+        elif k == 13: data = sigs[0] * 3                                                # duplicates count
+        elif k == 14: data = b"".join(cb.detach_sign(r, tbs + b"!") for r in cl.replicas)   # all over other bytes
+        else: data = sigs[3] + sigs[2] + sigs[1]
+        tbs_l.append(tbs); ss_l.append(data)
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    for i in range(64):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
+        assert (err[i] == 0) == (r.err is None), (i, i % 16, r.statuses, list(st[st_item == i]))
+        assert nver[i] == len(r.verified), (i, i % 16)
+        got = list(st[st_item == i])
+        assert got[:len(r.statuses)] == r.statuses, (i, i % 16, got, r.statuses)
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_golden_gpg_vectors_on_gpu(gpu_ctx):
+    """The committed GnuPG fixtures (tests/golden/gpg_vectors.json) through the HIP path."""
+    import json
+    import os
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
+    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B")):
+        ring = pgp.read_entities(bytes.fromhex(vec[ring_key]))
+        kr = col.Keyring(keyring=ring)
+        gpu_ctx.keyring_set(H.abi_keys(kr))
+        tbs_l = [bytes.fromhex(v["payload"]) for v in vec[group]]
+        sig_l = [bytes.fromhex(v["sig"]) for v in vec[group]]
+        tb, to = _cat(tbs_l)
+        sb, so = _cat(sig_l)
+        err = gpu_ctx.signature_verify(tb, to, sb, so)
+        checked = 0
+        for v, e, t, s in zip(vec[group], err, tbs_l, sig_l):
+            want = col.signature_verify(kr, t, SignaturePacket(1, 0, False, s, None))
+            assert (e == 0) == (want is None), v
+            if want is None or not v["gpg_good"]:
+                assert (e == 0) == v["gpg_good"]
+            checked += 1
+        assert checked == len(vec[group])
+
+
+def test_full_size_properties_cfg2(gpu_ctx):
+    """BASELINE configs[1] shape (64 replicas, suff 43) at 1,500 writes / ~80k signatures, signed on the GPU:
+    verdicts follow from how the corpus was built -- no oracle in the loop."""
+    cl = cb.make_cluster(64)
+    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+    signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
+    c = cb.make_write_corpus(cl, 1500, batch_signer=signer, seed=77,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.05, cb.MUT_UNKNOWN_ISSUER: 0.05, cb.MUT_DUP_SIGNER: 0.05,
+                                             cb.MUT_ONE_SHORT: 0.05, cb.MUT_BAD_TAG: 0.05})
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    err, nver, verdict = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    suff = cl.suff
+    want_ok = c.expected_valid >= suff
+    assert ((err == 0) == want_ok).all()
+    assert (nver == np.where(want_ok, suff, c.expected_valid)).all()
+    assert ((verdict & 4) != 0).tolist() == want_ok.tolist()
+    st, st_item = gpu_ctx.last_statuses()
+    assert len(st) == c.n_sigs and (np.bincount(st_item, minlength=c.n_items) == c.sig_count).all()
+    assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+    # idempotence: same inputs, same outputs
+    err2, nver2, verdict2 = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    assert (err2 == err).all() and (nver2 == nver).all() and (verdict2 == verdict).all()
+    # order independence of the verdict (counts are monotone): reverse every item's packet order
+    rev = [b"".join(reversed([c.ss_data(i)[j:j + 287] for j in range(0, len(c.ss_data(i)), 287)])) for i in range(200)]
+    sb, so = _cat(rev)
+    err3, _, _ = gpu_ctx.collective_verify(qh, c.tbss_blob[:int(c.tbss_off[200])], c.tbss_off[:201], sb, so)
+    assert (err3 == err[:200]).all()
+    gpu_ctx.quorum_destroy(qh)

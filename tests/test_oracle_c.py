@@ -1,0 +1,63 @@
+"""CPU: the C restatement (oracle/c/oracle.c, the cpu_baseline 'port') agrees with the Python oracle packet by
+packet, and the collective-signature semantics hold on mutated corpora."""
+import numpy as np
+import pytest
+
+from corpus import build as cb
+from oracle import collective as col
+from oracle.cbind import COracle
+from oracle.packet import SignaturePacket
+from tests import helpers as H
+
+RATES = {cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_BAD_TAG: 0.1}
+
+
+@pytest.mark.parametrize("n,dsa,items", [(4, 0.0, 40), (10, 0.3, 30)])
+def test_c_oracle_matches_python_oracle(n, dsa, items):
+    cl = cb.make_cluster(n, dsa_fraction=dsa)
+    c = cb.make_write_corpus(cl, items, mutation_rates=RATES)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    err, nver, ops = co.collective_verify(c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off, 2)
+    for i in range(items):
+        r = H.oracle_collective(kr, q, c, i)
+        tr, nv, e = co.trace_item(c.tbss(i), c.ss_data(i))
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified) == nv and tr == r.statuses, i
+    assert ops > 0 and (err == 0).any() and (err == 2).any()
+
+
+def test_collective_semantics_on_mutations():
+    cl = cb.make_cluster(4)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    c = cb.make_write_corpus(cl, 60, mutation_rates=RATES)
+    for i in range(c.n_items):
+        ss = SignaturePacket(1, 0, False, c.ss_data(i), None)
+        r = col.collective_verify(kr, c.tbss(i), ss, q)
+        m = int(c.mutation[i])
+        if m == cb.MUT_ONE_SHORT:
+            assert r.err == col.ErrInsufficientNumberOfSignatures and not ss.Completed
+        if m in (cb.MUT_NONE, cb.MUT_UNKNOWN_ISSUER, cb.MUT_DUP_SIGNER):
+            assert r.err is None and ss.Completed                 # Verify mutates ss.Completed (crypto_pgp.go:494)
+        if r.err is None:
+            assert len(r.verified) == cl.suff                     # early exit at the first sufficient prefix
+        # Combine counts CLAIMED issuers only (crypto_pgp.go:506-515)
+        acc = SignaturePacket()
+        assert col.collective_combine(kr, acc, ss, q) == q.is_sufficient(col.signers(kr, ss))
+        assert acc.Type == 1 and acc.Data == ss.Data
+    # duplicate signer packets satisfy IsSufficient
+    one = cb.make_write_corpus(cl, 1, mutation_rates={})
+    first = one.ss_data(0)[:287]
+    ss = SignaturePacket(1, 0, False, first * 3, None)
+    assert col.collective_verify(kr, one.tbss(0), ss, q).err is None
+
+
+def test_max_timestamped_value():
+    q = H.clique_quorum(cb.make_cluster(4))   # threshold 3 under AUTH
+    ids = q.qcs[0].nodes
+    assert col.max_timestamped_value([(ids[0], 5, b"v"), (ids[1], 5, b"v"), (ids[2], 5, b"v")], q) == (b"v", 5)
+    assert col.max_timestamped_value([(ids[0], 5, b"v"), (ids[1], 5, b"v"), (ids[2], 4, b"v")], q) is None
+    # only the LARGEST t is considered
+    assert col.max_timestamped_value([(ids[0], 4, b"a"), (ids[1], 4, b"a"), (ids[2], 4, b"a"), (ids[3], 9, b"b")], q) is None
+    assert col.max_timestamped_value([], q) is None
