@@ -56,15 +56,16 @@ struct bftkv_gpu_ctx {
   // key table
   uint64_t keyring_gen = 0;
   uint32_t n_keys = 0, n_entities = 0;
+  bool have_dsa_keys = false;
   std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
   std::vector<uint32_t> h_key_entity;
-  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0;
+  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab;
   KeyTableDev kt{};
 
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, cert_ent, mid, recs, digests, r, xr, pk_list, pk_count, ids_tmp;
+  DevBuf counts, base, total, item_flags, cert_ent, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
@@ -190,7 +191,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
   HIPCHK(c, c->item_flags.ensure(n_items + 16));
-  HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * (size_t)n_items + 16));
+  HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
+  HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
+  HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
   HIPCHK(c, c->pk_count.ensure(16));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
@@ -204,28 +207,34 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                      c->total.as<uint32_t>());
   uint32_t total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 4, s));
+  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 16, s));
+  HIPCHK(c, hipMemsetAsync(c->hash_mask.p, 0, sizeof(uint32_t) * (size_t)n_items, s));
   HIPCHK(c, hipStreamSynchronize(s));
   c->last_total = total;
   c->last_items = n_items;
   const size_t tr = total ? total : 1;
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
-  HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 8 * tr));
+  HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
   HIPCHK(c, c->r.ensure(sizeof(uint32_t) * MONT_N * tr));
   HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * MONT_N * tr));
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
+  HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>());
   if (total) {
     hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, c->recs.as<SigRec>(), total, c->kt,
-                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>());
+                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
+                       c->hash_mask.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   // hash stream: digests need the parsed records
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
   if (total) {
+    // other hashes: a no-op grid unless some signature asked for them
+    hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
+                       c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
     hipLaunchKernelGGL(k_digest, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                       c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[6], sh));
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
@@ -239,6 +248,25 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (total) {
     hipLaunchKernelGGL(k_rsa_compare, dim3((total * 4 + 255) / 256), dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
+  }
+  // DSA signatures (if any): the exponents u1, u2 depend on the digests, so this runs after the join.
+  // The count is read back only when the keyring holds a DSA key at all.
+  if (total && c->have_dsa_keys) {
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const uint32_t nd = cnt[1];
+    if (nd) {
+      HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * 16 * (size_t)nd));
+      HIPCHK(c, c->dsa_v.ensure(sizeof(uint32_t) * MONT_N * (size_t)nd));
+      hipLaunchKernelGGL(k_dsa_prep, dim3((nd + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>(), c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
+      hipLaunchKernelGGL(k_dsa_modexp, dim3((nd + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>(),
+                         c->dsa_v.as<uint32_t>());
+      hipLaunchKernelGGL(k_dsa_finish, dim3((nd + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>(), c->kt, c->dsa_v.as<uint32_t>());
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipGetLastError());
@@ -273,9 +301,9 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
-  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0,
-                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->recs, &c->digests, &c->r, &c->xr,
-                    &c->pk_list, &c->pk_count, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab,
+                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
+                    &c->pk_list, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
@@ -309,7 +337,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<uint64_t> key_id;
-  std::vector<uint32_t> entity, bits, e32, nl, r2, n0;
+  std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
   std::vector<uint8_t> algo, flags;
   std::vector<uint64_t> entity_ids;
   std::vector<std::string> material;
@@ -359,6 +387,37 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
         nbits = 0xFFFFFFFFu;   // even / zero modulus: no Montgomery form (never a real key)
       }
     }
+    size_t oq = qw.size(), ot = dtab.size();
+    qw.resize(oq + 8, 0);
+    dtab.resize(ot + 3 * MONT_N, 0);
+    uint32_t qb = 0;
+    if (k.pk_algo == PK_DSA) {
+      // n = p, e = q.  Montgomery domain mod p; g, y, g*y in Montgomery form for Shamir's trick.
+      qb = (uint32_t)hostbn::bit_length(k.e, k.e_len);
+      const int nwords = (28 * MONT_N + 31) / 32 + 1;
+      std::vector<uint32_t> p(nwords), g(nwords), y(nwords), gy(nwords), q(nwords);
+      hostbn::from_be(k.e, k.e_len, q.data(), nwords);
+      bool ok = nbits >= 2 && nbits <= 2048 && qb >= 32 && qb <= 256 && (q[0] & 1u) &&
+                hostbn::mont_setup(k.n, k.n_len, MONT_N, &nl[o], &r2[o], &n0i);
+      if (ok) {
+        hostbn::from_be(k.n, k.n_len, p.data(), nwords);
+        hostbn::from_be(k.g, k.g_len, g.data(), nwords);
+        hostbn::from_be(k.y, k.y_len, y.data(), nwords);
+        if (hostbn::bit_length(k.g, k.g_len) > 2048 || hostbn::bit_length(k.y, k.y_len) > 2048) ok = false;
+      }
+      if (ok) {
+        hostbn::reduce(g.data(), p.data(), nwords);
+        hostbn::reduce(y.data(), p.data(), nwords);
+        hostbn::mul_mod(g.data(), y.data(), p.data(), gy.data(), nwords);
+        hostbn::to_mont_limbs(g.data(), p.data(), nwords, MONT_N, &dtab[ot]);
+        hostbn::to_mont_limbs(y.data(), p.data(), nwords, MONT_N, &dtab[ot + MONT_N]);
+        hostbn::to_mont_limbs(gy.data(), p.data(), nwords, MONT_N, &dtab[ot + 2 * MONT_N]);
+        for (int j = 0; j < 8; ++j) qw[oq + j] = q[j];
+      } else {
+        nbits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 2048 bits): ST_UNSUPPORTED
+      }
+    }
+    qbits.push_back(qb);
     flags.push_back(fl);
     bits.push_back(nbits);
     e32.push_back(ev);
@@ -374,8 +433,13 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   if ((rc = upload(c, c->k_n, nl))) return rc;
   if ((rc = upload(c, c->k_r2, r2))) return rc;
   if ((rc = upload(c, c->k_n0, n0))) return rc;
+  if ((rc = upload(c, c->k_q, qw))) return rc;
+  if ((rc = upload(c, c->k_qbits, qbits))) return rc;
+  if ((rc = upload(c, c->k_dsatab, dtab))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->n_keys = (uint32_t)key_id.size();
+  c->have_dsa_keys = false;
+  for (uint8_t a : algo) if (a == PK_DSA) c->have_dsa_keys = true;
   c->n_entities = (uint32_t)entity_ids.size();
   c->h_key_id = key_id;
   c->h_entity_id = entity_ids;
@@ -390,6 +454,9 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   c->kt.n_limbs = c->k_n.as<uint32_t>();
   c->kt.r2_limbs = c->k_r2.as<uint32_t>();
   c->kt.n0inv = c->k_n0.as<uint32_t>();
+  c->kt.q_words = c->k_q.as<uint32_t>();
+  c->kt.q_bits = c->k_qbits.as<uint32_t>();
+  c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
   ++c->keyring_gen;
   return 0;
 }
@@ -563,12 +630,12 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   if (!c || !counters) return BFTKV_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  uint32_t rsa = 0;
-  if (c->pk_count.p) HIPCHK(c, hipMemcpy(&rsa, c->pk_count.p, 4, hipMemcpyDeviceToHost));
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  if (c->pk_count.p) HIPCHK(c, hipMemcpy(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost));
   counters[0] = c->last_total;
-  counters[1] = rsa;
+  counters[1] = (uint64_t)cnt[0] + cnt[1];
   counters[2] = c->last_items;
-  counters[3] = 0;
+  counters[3] = cnt[1];
   return 0;
 }
 

@@ -60,6 +60,10 @@ struct KeyTableDev {
   const uint32_t* n_limbs;    // [n_keys][76] modulus (RSA n / DSA p), radix 2^28
   const uint32_t* r2_limbs;   // [n_keys][76] R^2 mod n
   const uint32_t* n0inv;      // [n_keys] -n^-1 mod 2^28
+  // DSA keys only (zero otherwise)
+  const uint32_t* q_words;    // [n_keys][8] subgroup order q, little-endian 32-bit words
+  const uint32_t* q_bits;     // [n_keys]
+  const uint32_t* dsa_tab;    // [n_keys][3][76] g*R, y*R, g*y*R mod p (Montgomery form) for Shamir's trick
 };
 
 constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;

@@ -86,5 +86,40 @@ inline bool mont_setup(const uint8_t* n_be, uint32_t n_len, int nlimbs, uint32_t
   return true;
 }
 
+// a = (a + b) mod m for a, b < m
+inline void add_mod(uint32_t* a, const uint32_t* b, const uint32_t* m, int n) {
+  uint64_t c = 0;
+  for (int i = 0; i < n; ++i) { c += (uint64_t)a[i] + b[i]; a[i] = (uint32_t)c; c >>= 32; }
+  if (c || cmp(a, m, n) >= 0) sub(a, m, n);
+}
+// r = a * b mod m (double-and-add), a, b < m
+inline void mul_mod(const uint32_t* a, const uint32_t* b, const uint32_t* m, uint32_t* r, int n) {
+  std::vector<uint32_t> acc(n, 0);
+  for (int i = 32 * n - 1; i >= 0; --i) {
+    dbl_mod(acc.data(), m, n);
+    if ((b[i >> 5] >> (i & 31)) & 1u) add_mod(acc.data(), a, m, n);
+  }
+  memcpy(r, acc.data(), sizeof(uint32_t) * n);
+}
+// a mod m by shift-subtract (a arbitrary, n words)
+inline void reduce(uint32_t* a, const uint32_t* m, int n) {
+  std::vector<uint32_t> r(n, 0);
+  for (int i = 32 * n - 1; i >= 0; --i) {
+    dbl_mod(r.data(), m, n);
+    if ((a[i >> 5] >> (i & 31)) & 1u) {
+      uint64_t c = 1;
+      for (int k = 0; k < n && c; ++k) { c += r[k]; r[k] = (uint32_t)c; c >>= 32; }
+      if (cmp(r.data(), m, n) >= 0) sub(r.data(), m, n);
+    }
+  }
+  memcpy(a, r.data(), sizeof(uint32_t) * n);
+}
+// out_limbs = x * 2^(28*nlimbs) mod m (Montgomery form of x), x given big-endian
+inline void to_mont_limbs(const uint32_t* x_words, const uint32_t* m, int nwords, int nlimbs, uint32_t* out_limbs) {
+  std::vector<uint32_t> t(x_words, x_words + nwords);
+  for (int i = 0; i < 28 * nlimbs; ++i) dbl_mod(t.data(), m, nwords);
+  to_limbs28(t.data(), nwords, out_limbs, nlimbs);
+}
+
 }  // namespace hostbn
 }  // namespace bftkv

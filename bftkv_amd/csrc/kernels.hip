@@ -22,7 +22,8 @@
 
 #include "device_types.h"
 #include "mont28.h"
-#include "sha256.h"
+#include "u256.h"
+#include "hashes.h"
 
 namespace bftkv {
 
@@ -238,16 +239,11 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   else if (item_flags) item_flags[item] = trailing_skip ? 1 : 0;
 }
 
-// hash parameters by OpenPGP hash id (digest length, DigestInfo prefix length)
-__device__ __forceinline__ bool hash_supported(uint32_t hash_id, uint32_t& hlen, uint32_t& plen) {
-  if (hash_id == HASH_SHA256) { hlen = 32; plen = 19; return true; }
-  return false;   // TODO(next): SHA-1/224/384/512 (needed for certification signatures)
-}
-
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
 __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs, uint32_t n_recs,
                                                     KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
-                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count) {
+                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count /*[0] RSA, [1] DSA*/,
+                                                    uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   SigRec rec = recs[ri];
@@ -273,14 +269,16 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
         }
       }
       rec.key_slot = slot;
-      uint32_t hlen = 0, plen = 0;
+      const HashInfo hi = hash_info(rec.hash_id);
+      const uint32_t hlen = hi.dlen, plen = hi.plen;
       if (slot < 0) st = ST_UNKNOWN_ISSUER;
       else if (rec.sig_type != 0x00) st = ST_HASH_UNSUPPORTED;            // hashForSignature: binary only (text: fenced)
-      else if (!hash_supported(rec.hash_id, hlen, plen)) st = ST_HASH_UNSUPPORTED;
+      else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {
         // everything below is only reached when the hash tag matches (k_digest decides)
         st = ST_PENDING_HASH;
+        if (rec.hash_id != HASH_SHA256) atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot));
         if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
         else if (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) {
           const uint32_t mod_bits = kt.mod_bits[slot];
@@ -299,7 +297,14 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
             rec.pk_idx = atomicAdd(pk_count, 1u);
             pk_list[rec.pk_idx] = ri;
           }
-        } else rec.after_tag = ST_UNSUPPORTED;   // DSA: k_dsa (next milestone); ECDSA out of scope
+        } else if (rec.pk_algo == PK_DSA) {
+          if (kt.mod_bits[slot] == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;   // fenced key shape
+          else {
+            rec.after_tag = AFTER_TAG_PUBKEY;
+            rec.pk_idx = atomicAdd(pk_count + 1, 1u);
+            dsa_list[rec.pk_idx] = ri;
+          }
+        } else rec.after_tag = ST_UNSUPPORTED;   // ECDSA: out of scope
       }
     }
   }
@@ -399,9 +404,45 @@ __global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ t
   for (int i = 0; i < 8; ++i) mid[(uint64_t)item * 8 + i] = s[i];
 }
 
-// DigestInfo prefix of SHA-256 (Go crypto/rsa hashPrefixes; reference copy crypto/threshold/rsa/rsa.go:349)
-__device__ __constant__ const uint8_t SHA256_DI[19] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01,
-                                                       0x65, 0x03, 0x04, 0x02, 0x01, 0x05, 0x00, 0x04, 0x20};
+// Midstates of the other hashes, only for the items whose signatures ask for them
+// (item_hash_mask bits: 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384).  Thread per (algorithm, item).
+__global__ void __launch_bounds__(64) k_hash_mid_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                       uint32_t n_items, const uint32_t* __restrict__ item_hash_mask,
+                                                       uint32_t* __restrict__ mid32 /*[3][n][8]*/, uint64_t* __restrict__ mid64 /*[2][n][8]*/) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t which = blockIdx.y;   // 0 SHA-224, 1 SHA-1, 2 SHA-512, 3 SHA-384
+  if (item >= n_items) return;
+  if (!((item_hash_mask[item] >> (which + 1)) & 1u)) return;
+  const uint8_t* p = tbs_blob + tbs_off[item];
+  const uint64_t len = tbs_off[item + 1] - tbs_off[item];
+  if (which < 2) {
+    uint32_t s[8];
+    if (which == 0) sha224_init(s); else sha1_init(s);
+    for (uint64_t blk = 0; blk < (len >> 6); ++blk) {
+      uint32_t w[16];
+      load_block_be(p + blk * 64, w);
+      if (which == 0) sha256_compress(s, w); else sha1_compress(s, w);
+    }
+    uint32_t* o = mid32 + ((uint64_t)(which + 1) * n_items + item) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = s[i];
+  } else {
+    uint64_t s[8];
+    if (which == 2) sha512_init(s); else sha384_init(s);
+    for (uint64_t blk = 0; blk < (len >> 7); ++blk) {
+      uint32_t lo[16], hi[16];
+      load_block_be(p + blk * 128, lo);
+      load_block_be(p + blk * 128 + 64, hi);
+      uint64_t w[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { w[i] = ((uint64_t)lo[2 * i] << 32) | lo[2 * i + 1]; w[8 + i] = ((uint64_t)hi[2 * i] << 32) | hi[2 * i + 1]; }
+      sha512_compress(s, w);
+    }
+    uint64_t* o = mid64 + ((uint64_t)(which - 2) * n_items + item) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = s[i];
+  }
+}
 
 struct TailSrc {
   const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
@@ -417,7 +458,7 @@ __device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j) {
     if (j == 1) return 0xFF;
     return (t.pre_len >> (8 * (5 - j))) & 0xFF;
   }
-  return (j == 6) ? 0x80 : 0;
+  return (j == 6) ? 0x80 : 0;   // first byte after the message: the padding marker
 }
 
 // value of a big-endian byte string as radix-2^28 limb j
@@ -432,43 +473,72 @@ __device__ __forceinline__ uint32_t limb28(F byte_from_lsb, int j) {
 }
 
 // Per signature: digest = H(signed || hash suffix) from the item's midstate; hash-tag check.
+// digests: 64 bytes per record, the digest in its natural (big-endian) byte order.
 __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
-                                                const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid,
-                                                SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][8]*/) {
+                                                const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
+                                                const uint64_t* __restrict__ mid64, uint32_t n_items,
+                                                SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_HASH) return;
-  uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
+  const HashInfo hi = hash_info(rec.hash_id);
+  const uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
+  const uint32_t bmask = (hi.family == 64) ? 127u : 63u;
   TailSrc ts;
-  ts.tail_len = (uint32_t)(tlen & 63);
+  ts.tail_len = (uint32_t)(tlen & bmask);
   ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
   ts.body = sig_blob + rec.body_off;
   ts.pre_len = 6u + rec.hashed_len;
   const uint32_t rem = ts.tail_len + ts.pre_len + 6;     // message bytes still to hash
-  const uint32_t nblk = (rem + 9 + 63) >> 6;
   const uint64_t bits = (tlen + ts.pre_len + 6) * 8;
-  uint32_t s[8];
+  uint32_t* dg = digests + (uint64_t)ri * 16;
+  uint32_t tag_hi;
+  if (hi.family == 32) {
+    const uint32_t nblk = (rem + 9 + 63) >> 6;
+    uint32_t s[8];
+    const uint32_t* m = mid32 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s[i] = mid[(uint64_t)rec.item * 8 + i];
-  for (uint32_t blk = 0; blk < nblk; ++blk) {
-    uint32_t w[16];
+    for (int i = 0; i < 8; ++i) s[i] = m[i];
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+      uint32_t w[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      uint32_t j = blk * 64 + i * 4;
-      w[i] = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
+      for (int i = 0; i < 16; ++i) {
+        uint32_t j = blk * 64 + i * 4;
+        w[i] = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
+      }
+      if (blk == nblk - 1) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
+      if (hi.slot == 2) sha1_compress(s, w); else sha256_compress(s, w);
     }
-    if (blk == nblk - 1) {
-      w[14] = (uint32_t)(bits >> 32);
-      w[15] = (uint32_t)bits;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dg[i] = __builtin_bswap32(s[i]);
+    tag_hi = s[0];
+  } else {
+    const uint32_t nblk = (rem + 17 + 127) >> 7;
+    uint64_t s[8];
+    const uint64_t* m = mid64 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = m[i];
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+      uint64_t w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        uint32_t j = blk * 128 + i * 8;
+        uint64_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v = (v << 8) | tail_byte(ts, j + t);
+        w[i] = v;
+      }
+      if (blk == nblk - 1) { w[14] = 0; w[15] = bits; }
+      sha512_compress(s, w);
     }
-    sha256_compress(s, w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dg[2 * i] = __builtin_bswap32((uint32_t)(s[i] >> 32)); dg[2 * i + 1] = __builtin_bswap32((uint32_t)s[i]); }
+    tag_hi = (uint32_t)(s[0] >> 32);
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) digests[(uint64_t)ri * 8 + i] = s[i];
   // PublicKey.VerifySignature: hash tag first, then whatever k_parse_body determined
   uint8_t st;
-  if ((uint8_t)(s[0] >> 24) != rec.hash_tag[0] || (uint8_t)(s[0] >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
+  if ((uint8_t)(tag_hi >> 24) != rec.hash_tag[0] || (uint8_t)(tag_hi >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
   else st = (rec.after_tag == AFTER_TAG_PUBKEY) ? (uint8_t)ST_PENDING_RSA : rec.after_tag;
   recs[ri].status = st;
 }
@@ -595,18 +665,12 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   const bool pending = rec.status == ST_PENDING_RSA;   // hash tag matched
   const uint32_t key = (uint32_t)rec.key_slot;
   const uint32_t kbytes = (kt.mod_bits[key] + 7) >> 3;
-  uint32_t d[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) d[i] = digests[(uint64_t)ri * 8 + i];
-  const uint32_t hlen = 32, plen = 19, tl = hlen + plen;
+  const HashInfo hi = hash_info(rec.hash_id);
+  const uint32_t hlen = hi.dlen, plen = hi.plen, tl = hlen + plen;
+  const uint8_t* dgb = (const uint8_t*)(digests + (uint64_t)ri * 16);
   auto em_b = [&](uint32_t i) -> uint32_t {
-    if (i < hlen) {
-      uint32_t w = d[7];
-#pragma unroll
-      for (int q = 0; q < 7; ++q) w = ((i >> 2) == (uint32_t)(7 - q)) ? d[q] : w;
-      return (w >> (8 * (i & 3))) & 0xFF;
-    }
-    if (i < tl) return SHA256_DI[plen - 1 - (i - hlen)];
+    if (i < hlen) return dgb[hlen - 1 - i];
+    if (i < tl) return digestinfo_byte(rec.hash_id, plen - 1 - (i - hlen));
     if (i == tl) return 0;
     if (i < kbytes - 2) return 0xFF;
     if (i == kbytes - 2) return 1;
@@ -631,6 +695,136 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
     ok = ok || (diff2 == 0);
   }
   if (active && pending && qlane == 0) recs[ri].status = ok ? ST_OK : ST_BAD_SIG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DSA (Go crypto/dsa.Verify): mod-q side per thread, g^u1 * y^u2 mod p per quad
+// ------------------------------------------------------------------------------------------------
+// Per DSA signature, after its digest is known: range checks, w = s^-1 mod q, u1 = z*w, u2 = r*w.
+__global__ void __launch_bounds__(64) k_dsa_prep(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs,
+                                                 const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
+                                                 KeyTableDev kt, const uint32_t* __restrict__ digests,
+                                                 uint32_t* __restrict__ dsa_u /*[n][16]*/) {
+  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+  if (di >= pk_count[1]) return;
+  const uint32_t ri = dsa_list[di];
+  const SigRec rec = recs[ri];
+  if (rec.status != ST_PENDING_RSA) return;   // hash tag mismatch etc.: already final
+  const uint32_t key = (uint32_t)rec.key_slot;
+  U256 q, r, s_, w;
+  for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
+  const uint32_t qbits = kt.q_bits[key];
+  const uint8_t* body = sig_blob + rec.body_off;
+  bool ok = u256_from_be(body + rec.mpi_off[0], (rec.mpi_bits[0] + 7u) >> 3, r);
+  ok = u256_from_be(body + rec.mpi_off[1], (rec.mpi_bits[1] + 7u) >> 3, s_) && ok;
+  ok = ok && !u256_is_zero(r) && u256_cmp(r, q) < 0 && !u256_is_zero(s_) && u256_cmp(s_, q) < 0;   // 0 < r, s < q
+  ok = ok && (qbits & 7u) == 0;
+  ok = ok && u256_modinv_odd(s_, q, w);
+  if (!ok) { recs[ri].status = ST_BAD_SIG; return; }
+  // z = leftmost min(len(digest), bytes(q)) digest bytes (openpgp truncates, then dsa.Verify again)
+  const HashInfo hi = hash_info(rec.hash_id);
+  const uint32_t zlen = min(hi.dlen, qbits >> 3);
+  U256 z;
+  u256_from_be((const uint8_t*)(digests + (uint64_t)ri * 16), zlen, z);
+  while (u256_cmp(z, q) >= 0) u256_sub(z, q);        // z < 2^bits(q) < 2q: at most one round
+  const U256 u1 = u256_mulmod(w, z, q);
+  const U256 u2 = u256_mulmod(w, r, q);
+  uint32_t* o = dsa_u + (uint64_t)di * 16;
+  for (int i = 0; i < 8; ++i) { o[i] = u1.w[i]; o[8 + i] = u2.w[i]; }
+}
+
+// v = g^u1 * y^u2 mod p by Shamir's trick over the per-key table {gR, yR, gyR}: 256 squarings and
+// 256 table multiplications selected per quad (square-and-always-multiply keeps the wave uniform).
+__global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(const SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
+                                                          const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                          const uint32_t* __restrict__ dsa_u, uint32_t* __restrict__ v_limbs) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  constexpr int L = MONT_L;
+  const uint32_t count = pk_count[1];
+  if (blockIdx.x * QUADS_PER_BLOCK >= count) return;
+  const uint32_t quad = threadIdx.x >> 2;
+  const int qlane = threadIdx.x & 3;
+  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const bool active = gq < count;
+  const uint32_t di = active ? gq : (count - 1);
+  const uint32_t ri = dsa_list[di];
+  const SigRec rec = recs[ri];
+  const uint32_t key = (uint32_t)rec.key_slot;
+  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
+  const uint32_t* a_rd = a_sh + quad * MONT_N;
+  uint32_t n[L], b[L], y[L], t[L];
+  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
+  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_N + qlane * L;
+  const uint32_t* tab = kt.dsa_tab + (uint64_t)key * 3 * MONT_N + qlane * L;
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = np[k]; b[k] = rp[k]; a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; }
+  const uint32_t n0inv = kt.n0inv[key];
+  const uint32_t* up = dsa_u + (uint64_t)di * 16;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  mont_mul(y, a_rd, b, n, n0inv, qlane);     // y = R mod p (Montgomery one)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int bit = 255; bit >= 0; --bit) {
+    const uint32_t sel = ((up[bit >> 5] >> (bit & 31)) & 1u) | (((up[8 + (bit >> 5)] >> (bit & 31)) & 1u) << 1);
+    // square
+#pragma unroll
+    for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    mont_mul(y, a_rd, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (__any(sel != 0)) {
+      const uint32_t* tp = tab + (sel ? (sel - 1) : 0) * MONT_N;
+#pragma unroll
+      for (int k = 0; k < L; ++k) { a_lds[k] = tp[k]; b[k] = y[k]; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      mont_mul(t, a_rd, b, n, n0inv, qlane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (sel) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) y[k] = t[k];
+      }
+    }
+  }
+  // leave the Montgomery domain; the result is <= p and equals p only for 0
+#pragma unroll
+  for (int k = 0; k < L; ++k) { a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; b[k] = y[k]; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  mont_mul(t, a_rd, b, n, n0inv, qlane);
+  canonicalize(t, qlane);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < L; ++k) diff |= t[k] ^ n[k];
+  diff = quad_or(diff);
+  if (active) {
+    uint32_t* o = v_limbs + (uint64_t)di * MONT_N + qlane * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) o[k] = (diff == 0) ? 0u : t[k];
+  }
+}
+
+// (v mod q) == r
+__global__ void __launch_bounds__(64) k_dsa_finish(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs,
+                                                   const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
+                                                   KeyTableDev kt, const uint32_t* __restrict__ v_limbs) {
+  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+  if (di >= pk_count[1]) return;
+  const uint32_t ri = dsa_list[di];
+  const SigRec rec = recs[ri];
+  if (rec.status != ST_PENDING_RSA) return;
+  const uint32_t key = (uint32_t)rec.key_slot;
+  U256 q, r, acc = u256_zero();
+  for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
+  u256_from_be(sig_blob + rec.body_off + rec.mpi_off[0], (rec.mpi_bits[0] + 7u) >> 3, r);
+  const uint32_t* v = v_limbs + (uint64_t)di * MONT_N;
+  for (int j = MONT_N - 1; j >= 0; --j) {
+    for (int k = 0; k < MONT_W; ++k) {
+      uint32_t c = u256_shl1(acc);
+      if (c || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
+    }
+    U256 l = u256_zero();
+    l.w[0] = v[j];             // < 2^28 <= q (q has at least 32 bits, bftkv_gpu_keyring_set)
+    u256_addmod(acc, l, q);
+  }
+  recs[ri].status = (u256_cmp(acc, r) == 0) ? ST_OK : ST_BAD_SIG;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,104 @@
+// 256-bit unsigned arithmetic for the mod-q side of DSA verification (one thread per signature):
+// modular inverse by binary extended GCD (exact for ANY odd modulus, like math/big.ModInverse --
+// no primality assumption), modular multiplication by double-and-add, Horner reduction of a
+// 2128-bit radix-2^28 number.  Off the critical path: ~2 % of a DSA verification's work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bftkv {
+
+struct U256 { uint32_t w[8]; };
+
+__device__ __forceinline__ U256 u256_zero() { U256 r; for (int i = 0; i < 8; ++i) r.w[i] = 0; return r; }
+__device__ __forceinline__ bool u256_is_zero(const U256& a) { uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= a.w[i]; return o == 0; }
+__device__ __forceinline__ bool u256_is_one(const U256& a) { uint32_t o = a.w[0] ^ 1u; for (int i = 1; i < 8; ++i) o |= a.w[i]; return o == 0; }
+__device__ __forceinline__ int u256_cmp(const U256& a, const U256& b) {
+  int r = 0;
+  for (int i = 0; i < 8; ++i) { if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; }
+  return r;   // the most significant differing word wins (loop runs LSW -> MSW)
+}
+__device__ __forceinline__ uint32_t u256_add(U256& a, const U256& b) {
+  uint64_t c = 0;
+  for (int i = 0; i < 8; ++i) { c += (uint64_t)a.w[i] + b.w[i]; a.w[i] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)c;
+}
+__device__ __forceinline__ uint32_t u256_sub(U256& a, const U256& b) {
+  uint64_t br = 0;
+  for (int i = 0; i < 8; ++i) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; }
+  return (uint32_t)br;
+}
+__device__ __forceinline__ void u256_shr1(U256& a, uint32_t top) {
+  for (int i = 0; i < 7; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 31);
+  a.w[7] = (a.w[7] >> 1) | (top << 31);
+}
+__device__ __forceinline__ uint32_t u256_shl1(U256& a) {
+  uint32_t c = a.w[7] >> 31;
+  for (int i = 7; i > 0; --i) a.w[i] = (a.w[i] << 1) | (a.w[i - 1] >> 31);
+  a.w[0] <<= 1;
+  return c;
+}
+__device__ __forceinline__ int u256_bits(const U256& a) {
+  int b = 0;
+  for (int i = 0; i < 8; ++i) if (a.w[i]) b = 32 * i + (32 - __builtin_clz(a.w[i]));
+  return b;
+}
+// big-endian bytes -> U256; false when the value does not fit in 256 bits
+__device__ __forceinline__ bool u256_from_be(const uint8_t* p, uint32_t len, U256& out) {
+  out = u256_zero();
+  bool fits = true;
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t k = len - 1 - i;   // byte index from the LSB
+    uint32_t b = p[i];
+    if (k < 32) out.w[k >> 2] |= b << (8 * (k & 3));
+    else if (b) fits = false;
+  }
+  return fits;
+}
+// (a + b) mod q for a, b < q
+__device__ __forceinline__ void u256_addmod(U256& a, const U256& b, const U256& q) {
+  uint32_t c = u256_add(a, b);
+  if (c || u256_cmp(a, q) >= 0) u256_sub(a, q);
+}
+// a * b mod q, a < q (b arbitrary 256-bit)
+__device__ __forceinline__ U256 u256_mulmod(const U256& a, const U256& b, const U256& q) {
+  U256 r = u256_zero();
+  for (int i = 255; i >= 0; --i) {
+    uint32_t c = u256_shl1(r);
+    if (c || u256_cmp(r, q) >= 0) u256_sub(r, q);
+    if ((b.w[i >> 5] >> (i & 31)) & 1u) u256_addmod(r, a, q);
+  }
+  return r;
+}
+// s^-1 mod q for odd q > 1 and 0 < s < q; false when gcd(s, q) != 1 (math/big.ModInverse returns nil)
+__device__ __forceinline__ bool u256_modinv_odd(const U256& s, const U256& q, U256& out) {
+  U256 u = s, v = q, x1 = u256_zero(), x2 = u256_zero();
+  x1.w[0] = 1;
+  for (int guard = 0; guard < 1024; ++guard) {
+    if (u256_is_one(u)) { out = x1; return true; }
+    if (u256_is_one(v)) { out = x2; return true; }
+    if (u256_is_zero(u) || u256_is_zero(v)) return false;
+    while (!(u.w[0] & 1u)) {
+      u256_shr1(u, 0);
+      uint32_t c = 0;
+      if (x1.w[0] & 1u) c = u256_add(x1, q);
+      u256_shr1(x1, c);
+    }
+    while (!(v.w[0] & 1u)) {
+      u256_shr1(v, 0);
+      uint32_t c = 0;
+      if (x2.w[0] & 1u) c = u256_add(x2, q);
+      u256_shr1(x2, c);
+    }
+    if (u256_cmp(u, v) >= 0) {
+      u256_sub(u, v);
+      if (u256_sub(x1, x2)) u256_add(x1, q);
+    } else {
+      u256_sub(v, u);
+      if (u256_sub(x2, x1)) u256_add(x2, q);
+    }
+  }
+  return false;
+}
+
+}  // namespace bftkv

@@ -183,7 +183,7 @@ def test_malformed_and_edge_streams(gpu_ctx):
         elif k == 10:
             b = bytearray(sigs[0]); b[5] = 22; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]     # unknown pk algo
         elif k == 11:
-            b = bytearray(sigs[0]); b[9] = 0x83; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]   # subpacket type changed: no creation time
+            b = bytearray(sigs[0]); b[10] = 0x83; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]  # creation time -> critical expiry: no creation time
         elif k == 12:
             b = bytearray(sigs[0]); b[4] = 1; data = bytes(b) + sigs[1] + sigs[2] + sigs[3]      # text signature type
         elif k == 13: data = sigs[0] * 3                                                # duplicates count
