@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--items", type=int, default=10000, help="signed writes per GPU per step")
     ap.add_argument("--replicas", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus-cache", default="", help="path prefix of an .npz cache of the generated corpus (profiling reruns)")
     args = ap.parse_args()
 
     import torch
@@ -57,14 +58,25 @@ def main():
     cl = cb.make_cluster(n)
 
     # ---- synthetic signed writes; RSA signatures made on this GPU (generic modexp kernel)
-    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
-    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+    signers = cl.replicas + [cl.client]   # key index len(replicas) = the client (corpus/build.py BatchSigner)
+    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in signers])
+    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in signers])
 
     def gpu_signer(em, key_index):
         return ctx.modexp(em, key_index.astype(np.uint32), mods, exps)
 
     t0 = time.time()
-    corpus = cb.make_write_corpus(cl, args.items, seed=cb.MASTER_SEED + rank, batch_signer=gpu_signer, with_client_sig=True)
+    cache = None
+    if args.corpus_cache:
+        cache = "%s.n%d.i%d.r%d.npz" % (args.corpus_cache, n, args.items, rank)
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        corpus = cb.WriteCorpus(cl, args.items, z["tb"], z["to"], z["sb"], z["so"], int(z["n_sigs"]), z["mut"])
+    else:
+        corpus = cb.make_write_corpus(cl, args.items, seed=cb.MASTER_SEED + rank, batch_signer=gpu_signer, with_client_sig=True)
+        if cache:
+            np.savez(cache, tb=corpus.tbss_blob, to=corpus.tbss_off, sb=corpus.ss_blob, so=corpus.ss_off,
+                     n_sigs=corpus.n_sigs, mut=corpus.mutation)
     t_corpus = time.time() - t0
 
     # keyring + quorum through the C ABI (clique of all replicas, AUTH rule: wotqs.go:36-70)
@@ -135,6 +147,7 @@ def main():
         rsa_avg_s = float(np.mean(rsa_ms)) * 1e-3
         alg_bytes = int(corpus.tbss_off[-1]) + corpus.n_sigs * RSA_BYTES + (args.items + 7) // 8
         achieved = alg_bytes / rsa_avg_s / 1e9
+        traffic, traffic_src = measured_traffic("k_rsa_modexp") if args.items == 10000 and n == 64 else (None, None)
         out = {
             "metric": "pgp_rsa2048_signature_verifies_per_sec",
             "value": verifies_per_s,
@@ -158,7 +171,8 @@ def main():
             "pubkey_ops_per_step_per_gpu": int(counters["pubkey_ops"]),
             "kernel_ms": {"pipeline_total": float(np.mean(tot_ms)), "k_rsa_modexp": float(np.mean(rsa_ms)), "last_call": tm},
             "roofline": {"bound": "hbm", "kernel": "k_rsa_modexp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"},
             "int_mac": {"achieved": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s, "peak": INT_MAC_PEAK,
                         "frac": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s / INT_MAC_PEAK,
@@ -172,6 +186,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json,
+    made by tools/profile_bench.sh + tools/summarize_profile.py: separate rocprofv3 --pmc passes over this
+    same command, gfx950 FETCH_SIZE correction applied).  None when no summary is present."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        best = p
+    if not best:
+        return None, None
+    with open(best) as f:
+        d = json.load(f)
+    k = d["kernels"].get("bftkv::" + kernel)
+    return (k["hbm_bytes_corrected"] if k else None), os.path.relpath(best, ROOT)
 
 
 def effective_cores():

@@ -271,14 +271,16 @@ class WriteCorpus:
 
 
 BatchSigner = Callable[[np.ndarray, np.ndarray], np.ndarray]
-"""(em[n,256] uint8 big-endian, key_index[n] int32 into cluster.replicas) -> sig[n,256] uint8."""
+"""(em[n,256] uint8 big-endian, key_index[n] int32 into cluster.replicas; index len(replicas) = the client)
+-> sig[n,256] uint8."""
 
 
 def python_batch_signer(cluster: Cluster) -> BatchSigner:
     def sign(em: np.ndarray, key_index: np.ndarray) -> np.ndarray:
         out = np.empty_like(em)
         for i in range(em.shape[0]):
-            kp = cluster.replicas[int(key_index[i])]
+            ki = int(key_index[i])
+            kp = cluster.replicas[ki] if ki < len(cluster.replicas) else cluster.client
             s = kp.rsa_private(int.from_bytes(em[i].tobytes(), "big"))
             out[i] = np.frombuffer(s.to_bytes(em.shape[1], "big"), dtype=np.uint8)
         return out
@@ -320,14 +322,29 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
     per_item_counts = np.zeros(n_items, dtype=np.int64)
     expected_valid = np.zeros(n_items, dtype=np.int32)
 
+    signer = batch_signer or python_batch_signer(cluster)
+    # client signatures over tbs = Serialize(x,v,t) (client.go:127-131), signed in one batch
+    tbs_list = []
     for i in range(n_items):
         x = b"key%08d" % i
         v = nprng.bytes(value_len)
-        t = 1 + i
-        tbs = serialize_tbs(x, v, t)
+        tbs_list.append(serialize_tbs(x, v, 1 + i))
+    csigs: List[Optional[bytes]] = [None] * n_items
+    if with_client_sig:
+        cprefix = sig_prefix(0x00, cluster.client.algo, _hashed_area(cluster.client.key_id))
+        csuffix = hash_suffix(cprefix)
+        cdig = [hashlib.sha256(t + csuffix).digest() for t in tbs_list]
+        cem = np.zeros((n_items, 256), dtype=np.uint8)
+        for i in range(n_items):
+            cem[i] = np.frombuffer(emsa(cdig[i], 256).to_bytes(256, "big"), dtype=np.uint8)
+        csv = signer(cem, np.full(n_items, len(cluster.replicas), dtype=np.int32))
+        for i in range(n_items):
+            csigs[i] = make_sig_packet(cluster.client, cprefix, cdig[i], sig_value=int.from_bytes(csv[i].tobytes(), "big"))
+
+    for i in range(n_items):
+        tbs = tbs_list[i]
         if with_client_sig:
-            csig = detach_sign(cluster.client, tbs)
-            tbss = tbs + sigpkt(csig, client_cert)
+            tbss = tbs + sigpkt(csigs[i], client_cert)
         else:
             tbss = tbs + sigpkt(None, None)
         tbss_parts.append(tbss)
@@ -374,7 +391,6 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
         for r, j in enumerate(rsa_rows):
             em[r] = np.frombuffer(emsa(digests[j], 256).to_bytes(256, "big"), dtype=np.uint8)
         kidx = np.array([sig_key[j] for j in rsa_rows], dtype=np.int32)
-        signer = batch_signer or python_batch_signer(cluster)
         sv = signer(em, kidx)
         for r, j in enumerate(rsa_rows):
             kp = cluster.replicas[sig_key[j]]

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the small summaries kept under profiles/."""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main(tag, rnd):
+    src = os.path.join("gpurun_out", "prof_" + tag)
+    dst = "profiles"
+    # 1. kernel stats (rocprofv3 --kernel-trace --stats)
+    rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+    with open(os.path.join(dst, "%s_kernel_stats.csv" % rnd), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                              r["Percentage"], r["MinNs"], r["MaxNs"]))
+    avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+    # 2. HBM counters, one pass each
+    def agg(path, counter):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in d.items()}
+    fetch = agg(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+    write = agg(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+    sq = collections.defaultdict(dict)
+    p = os.path.join(src, "pmc_sq", "s_counter_collection.csv")
+    if os.path.exists(p):
+        tmp = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(p)):
+            tmp[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k in tmp:
+            sq[k] = {c: sum(v) / len(v) for c, v in tmp[k].items()}
+    out = {"source": "rocprofv3 separate --pmc passes over `python bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced "
+                         "reads -> doubled; WRITE_SIZE taken as is (uncalibrated); both are KiB per dispatch",
+           "workload": json.load(open(os.path.join(src, "bench_plain.json")))["config"], "kernels": {}}
+    with open(os.path.join(dst, "%s_pmc_hbm.csv" % rnd), "w") as f:
+        f.write("Kernel,AvgDurationNs,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,HBM_bytes_corrected\n")
+        for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
+            if not k.startswith("bftkv::"):
+                continue
+            b = int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024)
+            f.write('"%s",%.0f,%.1f,%.1f,%d\n' % (k, avg_ns.get(k, 0), fetch.get(k, 0), write.get(k, 0), b))
+            out["kernels"][k] = {"avg_ns": avg_ns.get(k, 0), "fetch_kib_raw": fetch.get(k, 0), "write_kib_raw": write.get(k, 0),
+                                 "hbm_bytes_corrected": b, "sq": sq.get(k, {})}
+    with open(os.path.join(dst, "%s_pmc_summary.json" % rnd), "w") as f:
+        json.dump(out, f, indent=1)
+    for n in ("bench_plain.json", "bench_trace.json"):
+        with open(os.path.join(src, n)) as g, open(os.path.join(dst, "%s_%s" % (rnd, n)), "w") as f:
+            f.write(g.read())
+    print("wrote profiles/%s_*" % rnd)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
