@@ -58,9 +58,7 @@ def main():
     cl = cb.make_cluster(n)
 
     # ---- synthetic signed writes; RSA signatures made on this GPU (generic modexp kernel)
-    signers = cl.replicas + [cl.client]   # key index len(replicas) = the client (corpus/build.py BatchSigner)
-    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in signers])
-    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in signers])
+    mods, exps = cb.signer_tables(cl)   # replicas in order, then the client (corpus/build.py BatchSigner)
 
     def gpu_signer(em, key_index):
         return ctx.modexp(em, key_index.astype(np.uint32), mods, exps)

@@ -59,6 +59,7 @@ struct bftkv_gpu_ctx {
   bool have_dsa_keys = false;
   std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
   std::vector<uint32_t> h_key_entity;
+  std::vector<uint8_t> h_key_flags;
   DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab;
   KeyTableDev kt{};
 
@@ -75,6 +76,15 @@ struct bftkv_gpu_ctx {
 };
 
 namespace {
+
+// live contexts: lets long-lived host objects (bftkv_quorum) notice that their context is gone
+std::mutex g_live_mu;
+std::vector<bftkv_gpu_ctx*> g_live;
+bool ctx_is_live(bftkv_gpu_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  for (auto* p : g_live) if (p == c) return true;
+  return false;
+}
 
 int fail(bftkv_gpu_ctx* c, int rc, const char* what, hipError_t e = hipSuccess) {
   char buf[512];
@@ -292,12 +302,17 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   c->device = device_ordinal;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
   *out = c;
   return BFTKV_OK;
 }
 
 void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (size_t i = 0; i < g_live.size(); ++i) if (g_live[i] == c) { g_live.erase(g_live.begin() + i); break; }
+  }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
@@ -444,6 +459,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   c->h_key_id = key_id;
   c->h_entity_id = entity_ids;
   c->h_key_entity = entity;
+  c->h_key_flags = flags;
   c->kt.n_keys = c->n_keys;
   c->kt.key_id = c->k_id.as<uint64_t>();
   c->kt.entity = c->k_entity.as<uint32_t>();
@@ -764,3 +780,5 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 }
 
 }  // extern "C"
+
+#include "host_capi.inc"

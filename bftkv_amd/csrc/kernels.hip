@@ -36,18 +36,18 @@ struct ParsedPacket {
   SigRec rec;
 };
 
-__device__ __forceinline__ bool known_tag(uint32_t tag) {
+__host__ __device__ __forceinline__ bool known_tag(uint32_t tag) {
   // packet types packet.Read constructs; anything else is an UnknownPacketTypeError that
   // Reader.Next skips
   return tag < 32 && ((0x00066BFEu >> tag) & 1u);  // {1..9,11,13,14,17,18}
 }
 
 // subpacket area walk; returns false on structural/unsupported error
-__device__ bool parse_subpackets(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
-                                 bool& have_issuer, uint64_t& issuer, int depth);
+__host__ __device__ bool parse_subpackets(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
+                                          bool& have_issuer, uint64_t& issuer, int depth);
 
-__device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
-                               uint64_t& issuer, int depth) {
+__host__ __device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
+                                        uint64_t& issuer, int depth) {
   if (blen < 1) return false;
   if (body[0] != 4) return false;  // v3 handled by the caller, others unsupported
   if (blen < 6) return false;
@@ -92,8 +92,8 @@ __device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, 
   return true;
 }
 
-__device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
-                                 bool& have_issuer, uint64_t& issuer, int depth) {
+__host__ __device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
+                                          bool& have_issuer, uint64_t& issuer, int depth) {
   uint32_t p = 0;
   while (p < len) {
     uint32_t b = a[p], ln;
@@ -162,7 +162,7 @@ struct WalkStep {
   uint8_t status;      // ST_PENDING_PARSE for signature packets, final otherwise
 };
 
-__device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
+__host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
   WalkStep r;
   r.event = true;
   r.status = ST_PARSE_ERROR;

@@ -1,0 +1,374 @@
+"""Python face of the host-side mirror (include/bftkv_host.h): the reference's names over the C++
+implementation inside libbftkv_gpu.so.  No oracle import; the packet / graph / quorum parts need no GPU.
+
+  packet.Serialize / Parse / TBS / TBSS          packet/packet.go
+  Graph.AddNodes / SetSelfNodes / Revoke / GetCliques / GetReachableNodes    node/graph/graph.go
+  wotqs.New(g).ChooseQuorum(rw) -> Quorum.IsQuorum / IsThreshold / IsSufficient / Reject / GetThreshold
+  Client.collect_signatures, Client.max_timestamped_value, Server.write_verify   protocol/{client,server}.go
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native
+from ._native import QC as _QC
+
+READ, WRITE, AUTH, CERT, PEER = 0x01, 0x02, 0x04, 0x08, 0x10   # quorum/quorum.go:10-16
+
+
+class _SigPkt(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("version", C.c_uint32), ("completed", C.c_uint8),
+                ("data", C.c_void_p), ("data_len", C.c_uint64), ("cert", C.c_void_p), ("cert_len", C.c_uint64)]
+
+
+class _Parsed(C.Structure):
+    _fields_ = [("x_off", C.c_uint64), ("x_len", C.c_uint64), ("v_off", C.c_uint64), ("v_len", C.c_uint64), ("t", C.c_uint64),
+                ("has_sig", C.c_int), ("has_ss", C.c_int), ("sig", _SigPkt), ("ss", _SigPkt),
+                ("auth_off", C.c_uint64), ("auth_len", C.c_uint64)]
+
+
+class _Reply(C.Structure):
+    _fields_ = [("peer_id", C.c_uint64), ("err", C.c_int32), ("data", C.c_void_p), ("data_len", C.c_uint64)]
+
+
+HOST_EXPORTS = [
+    "bftkv_host_packet_serialize", "bftkv_host_packet_parse", "bftkv_host_packet_tbs", "bftkv_host_packet_tbss",
+    "bftkv_host_graph_new", "bftkv_host_graph_free", "bftkv_host_graph_add_node", "bftkv_host_graph_set_self",
+    "bftkv_host_graph_revoke", "bftkv_host_graph_reachable", "bftkv_host_graph_cliques", "bftkv_host_choose_quorum",
+    "bftkv_host_quorum_from_qcs", "bftkv_host_quorum_free", "bftkv_host_quorum_n_qcs", "bftkv_host_quorum_qc",
+    "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
+    "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
+    "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value",
+]
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    lib = _native.load_library()
+    if not _ready:
+        vp = C.c_void_p
+        lib.bftkv_host_graph_new.restype = vp
+        lib.bftkv_host_choose_quorum.restype = vp
+        lib.bftkv_host_choose_quorum.argtypes = [vp, C.c_int]
+        lib.bftkv_host_quorum_from_qcs.restype = vp
+        lib.bftkv_host_quorum_from_qcs.argtypes = [C.POINTER(_QC), C.c_uint32]
+        lib.bftkv_host_graph_free.argtypes = [vp]
+        lib.bftkv_host_graph_free.restype = None
+        lib.bftkv_host_quorum_free.argtypes = [vp]
+        lib.bftkv_host_quorum_free.restype = None
+        lib.bftkv_host_graph_add_node.argtypes = [vp, C.c_uint64, vp, C.c_uint32]
+        lib.bftkv_host_graph_set_self.argtypes = [vp, C.c_uint64]
+        lib.bftkv_host_graph_revoke.argtypes = [vp, C.c_uint64]
+        lib.bftkv_host_graph_reachable.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.bftkv_host_graph_cliques.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.bftkv_host_quorum_n_qcs.argtypes = [vp]
+        lib.bftkv_host_quorum_n_qcs.restype = C.c_uint32
+        lib.bftkv_host_quorum_qc.argtypes = [vp, C.c_uint32, C.POINTER(_QC)]
+        for n in ("is_quorum", "is_threshold", "is_sufficient", "reject"):
+            getattr(lib, "bftkv_host_quorum_" + n).argtypes = [vp, vp, C.c_uint32]
+        lib.bftkv_host_quorum_get_threshold.argtypes = [vp]
+        lib.bftkv_host_quorum_gpu_handle.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        lib.bftkv_host_packet_serialize.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64,
+                                                    C.POINTER(_SigPkt), C.POINTER(_SigPkt), C.c_char_p, C.c_uint64,
+                                                    vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.bftkv_host_packet_parse.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(_Parsed)]
+        lib.bftkv_host_packet_tbs.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.bftkv_host_packet_tbss.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.bftkv_host_collect_signatures.argtypes = [vp, vp, C.c_uint32, vp, vp, C.POINTER(_Reply), vp, vp, C.c_uint64, vp, vp, vp]
+        lib.bftkv_host_server_write_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        lib.bftkv_host_max_timestamped_value.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        _ready = True
+    return lib
+
+
+class MalformedPacket(ValueError):
+    pass
+
+
+@dataclass
+class SignaturePacket:   # packet/packet.go:25-31
+    Type: int = 0
+    Version: int = 0
+    Completed: bool = False
+    Data: Optional[bytes] = None
+    Cert: Optional[bytes] = None
+
+
+def _c_sig(s: Optional[SignaturePacket], keep: list):
+    if s is None:
+        return None
+    c = _SigPkt()
+    c.type, c.version, c.completed = s.Type, s.Version, 1 if s.Completed else 0
+    for name in ("data", "cert"):
+        b = getattr(s, name.capitalize()) or b""
+        buf = C.create_string_buffer(b, len(b)) if b else None
+        keep.append(buf)
+        setattr(c, name, C.cast(buf, C.c_void_p) if buf is not None else None)
+        setattr(c, name + "_len", len(b))
+    return C.pointer(c)
+
+
+class packet:
+    """packet/packet.go"""
+
+    @staticmethod
+    def Serialize(*args) -> bytes:
+        lib = _lib()
+        n = len(args)
+        a = list(args) + [None] * (6 - n)
+        keep: list = []
+        x, v, t = a[0] or b"", a[1] or b"", a[2] or 0
+        auth = a[5] or b""
+        out_len = C.c_uint64(0)
+        cap = 64 + len(x) + len(v) + len(auth) + sum(len(getattr(s, f) or b"") for s in (a[3], a[4]) if s for f in ("Data", "Cert")) + 64
+        buf = C.create_string_buffer(cap)
+        rc = lib.bftkv_host_packet_serialize(n, x, len(x), v, len(v), t, _c_sig(a[3], keep), _c_sig(a[4], keep), auth, len(auth),
+                                             C.cast(buf, C.c_void_p), cap, C.byref(out_len))
+        if rc:
+            raise ValueError("Serialize failed: %d" % rc)
+        return buf.raw[:out_len.value]
+
+    @staticmethod
+    def Parse(pkt: bytes):
+        p = _Parsed()
+        if _lib().bftkv_host_packet_parse(pkt, len(pkt), C.byref(p)):
+            raise MalformedPacket("Parse")
+
+        def sl(off, ln):
+            return pkt[off:off + ln] if ln else None
+
+        def sg(has, s):
+            if not has:
+                return None
+            data = C.string_at(s.data, s.data_len) if s.data_len else None
+            cert = C.string_at(s.cert, s.cert_len) if s.cert_len else None
+            return SignaturePacket(s.type, s.version, bool(s.completed), data, cert)
+        return sl(p.x_off, p.x_len), sl(p.v_off, p.v_len), p.t, sg(p.has_sig, p.sig), sg(p.has_ss, p.ss), sl(p.auth_off, p.auth_len)
+
+    @staticmethod
+    def TBS(pkt: bytes) -> bytes:
+        n = C.c_uint64(0)
+        if _lib().bftkv_host_packet_tbs(pkt, len(pkt), C.byref(n)):
+            raise MalformedPacket("TBS")
+        return pkt[:n.value]
+
+    @staticmethod
+    def TBSS(pkt: bytes) -> bytes:
+        n = C.c_uint64(0)
+        if _lib().bftkv_host_packet_tbss(pkt, len(pkt), C.byref(n)):
+            raise MalformedPacket("TBSS")
+        return pkt[:n.value]
+
+
+class Quorum:
+    """quorum.Quorum (quorum/quorum.go:18-25) backed by wotq (quorum/wotqs/wotqs.go:24-26)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("no quorum")
+        self.h = C.c_void_p(handle)
+
+    def __del__(self):
+        try:
+            _lib().bftkv_host_quorum_free(self.h)
+        except Exception:
+            pass
+
+    @classmethod
+    def from_qcs(cls, qcs):
+        arr = (_QC * max(1, len(qcs)))()
+        keep = []
+        for i, (f, mn, thr, suff, nodes) in enumerate(qcs):
+            ids = np.ascontiguousarray(np.array(list(nodes), dtype=np.uint64))
+            keep.append(ids)
+            arr[i].f, arr[i].min, arr[i].threshold, arr[i].suff = f, mn, thr, suff
+            arr[i].node_ids = ids.ctypes.data if len(ids) else None
+            arr[i].n_nodes = len(ids)
+        return cls(_lib().bftkv_host_quorum_from_qcs(arr, len(qcs)))
+
+    def qcs(self) -> List[Tuple[int, int, int, int, List[int]]]:
+        out = []
+        for i in range(_lib().bftkv_host_quorum_n_qcs(self.h)):
+            q = _QC()
+            _lib().bftkv_host_quorum_qc(self.h, i, C.byref(q))
+            ids = list(np.ctypeslib.as_array((C.c_uint64 * q.n_nodes).from_address(q.node_ids))) if q.n_nodes else []
+            out.append((q.f, q.min, q.threshold, q.suff, [int(x) for x in ids]))
+        return out
+
+    def _pred(self, name, nodes) -> bool:
+        ids = np.ascontiguousarray(np.array(list(nodes), dtype=np.uint64))
+        return bool(getattr(_lib(), "bftkv_host_quorum_" + name)(self.h, ids.ctypes.data if len(ids) else None, len(ids)))
+
+    def Nodes(self) -> List[int]:
+        return [n for q in self.qcs() for n in q[4]]
+
+    def IsQuorum(self, nodes) -> bool:
+        return self._pred("is_quorum", nodes)
+
+    def IsThreshold(self, nodes) -> bool:
+        return self._pred("is_threshold", nodes)
+
+    def IsSufficient(self, nodes) -> bool:
+        return self._pred("is_sufficient", nodes)
+
+    def Reject(self, nodes) -> bool:
+        return self._pred("reject", nodes)
+
+    def GetThreshold(self) -> int:
+        return _lib().bftkv_host_quorum_get_threshold(self.h)
+
+
+class Graph:
+    """node/graph/graph.go"""
+
+    def __init__(self):
+        self.h = C.c_void_p(_lib().bftkv_host_graph_new())
+
+    def __del__(self):
+        try:
+            _lib().bftkv_host_graph_free(self.h)
+        except Exception:
+            pass
+
+    def AddNodes(self, nodes):
+        """nodes: iterable of (id, [ids of the keys that certified it])."""
+        for i, signers in nodes:
+            s = np.ascontiguousarray(np.array(list(signers), dtype=np.uint64))
+            _lib().bftkv_host_graph_add_node(self.h, i, s.ctypes.data if len(s) else None, len(s))
+
+    def SetSelfNodes(self, ids):
+        for i in ids:
+            _lib().bftkv_host_graph_set_self(self.h, i)
+
+    def Revoke(self, i: int):
+        _lib().bftkv_host_graph_revoke(self.h, i)
+
+    def GetReachableNodes(self, sid: int, distance: int) -> List[int]:
+        n = C.c_uint32(0)
+        _lib().bftkv_host_graph_reachable(self.h, sid, distance, None, 0, C.byref(n))
+        out = np.zeros(max(1, n.value), dtype=np.uint64)
+        _lib().bftkv_host_graph_reachable(self.h, sid, distance, out.ctypes.data, len(out), C.byref(n))
+        return [int(x) for x in out[:n.value]]
+
+    def GetCliques(self, sid: int, distance: int):
+        ids = np.zeros(1 << 16, dtype=np.uint64)
+        sizes = np.zeros(256, dtype=np.uint32)
+        weights = np.zeros(256, dtype=np.int32)
+        n = C.c_uint32(0)
+        rc = _lib().bftkv_host_graph_cliques(self.h, sid, distance, ids.ctypes.data, len(ids), sizes.ctypes.data, weights.ctypes.data,
+                                             len(sizes), C.byref(n))
+        if rc:
+            raise RuntimeError("GetCliques: %d" % rc)
+        out, k = [], 0
+        for i in range(n.value):
+            out.append(([int(x) for x in ids[k:k + sizes[i]]], int(weights[i])))
+            k += int(sizes[i])
+        return out
+
+
+class wotqs:
+    """quorum/wotqs/wotqs.go"""
+
+    def __init__(self, g: Graph):
+        self.g = g
+
+    @classmethod
+    def New(cls, g: Graph):
+        return cls(g)
+
+    def ChooseQuorum(self, rw: int) -> Quorum:
+        return Quorum(_lib().bftkv_host_choose_quorum(self.g.h, rw))
+
+
+@dataclass
+class Reply:   # transport.MulticastResponse (transport/transport.go:30-34)
+    Peer: int
+    Data: Optional[bytes] = None
+    Err: int = 0
+
+
+def _cat(parts: Sequence[bytes]):
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)[:int(off[-1])].copy()
+    if blob.size == 0:
+        blob = np.zeros(1, dtype=np.uint8)
+    return blob, off
+
+
+class Client:
+    """The vote-collecting half of protocol.Client (protocol/client.go) over a GPU context."""
+
+    def __init__(self, ctx: _native.Context):
+        self.ctx = ctx
+
+    def collect_signatures(self, qa: Quorum, tbss_list: Sequence[bytes], replies: Sequence[Sequence[Reply]]):
+        """client.go:139-169 for a batch of writes.  Returns (ss_data[w], consumed[w], err[w])."""
+        n = len(tbss_list)
+        tb, to = _cat(tbss_list)
+        flat = [r for rs in replies for r in rs]
+        arr = (_Reply * max(1, len(flat)))()
+        keep = []
+        for i, r in enumerate(flat):
+            arr[i].peer_id, arr[i].err = r.Peer, r.Err
+            b = r.Data or b""
+            buf = C.create_string_buffer(b, len(b)) if b else None
+            keep.append(buf)
+            arr[i].data = C.cast(buf, C.c_void_p) if buf is not None else None
+            arr[i].data_len = len(b)
+        roff = np.zeros(n + 1, dtype=np.uint64)
+        roff[1:] = np.cumsum([len(rs) for rs in replies], dtype=np.uint64)
+        cap = sum(len(r.Data or b"") for r in flat) + 16
+        ss = np.zeros(cap, dtype=np.uint8)
+        ss_off = np.zeros(n + 1, dtype=np.uint64)
+        consumed = np.zeros(n, dtype=np.uint32)
+        err = np.zeros(n, dtype=np.uint8)
+        rc = _lib().bftkv_host_collect_signatures(self.ctx.h, qa.h, n, tb.ctypes.data, to.ctypes.data, arr, roff.ctypes.data,
+                                                  ss.ctypes.data, cap, ss_off.ctypes.data, consumed.ctypes.data, err.ctypes.data)
+        if rc:
+            raise _native.NativeError("collect_signatures failed: %d" % rc)
+        data = [ss[int(ss_off[i]):int(ss_off[i + 1])].tobytes() for i in range(n)]
+        return data, consumed, err
+
+    @staticmethod
+    def max_timestamped_value(q: Quorum, reads: Sequence[Sequence[Tuple[int, int, bytes]]]):
+        """client.go:181-205 for a batch of variables; per read the winning (value, t) or None."""
+        flat = [r for rs in reads for r in rs]
+        peers = np.ascontiguousarray(np.array([r[0] for r in flat], dtype=np.uint64))
+        ts = np.ascontiguousarray(np.array([r[1] for r in flat], dtype=np.uint64))
+        vb, vo = _cat([r[2] or b"" for r in flat])
+        roff = np.zeros(len(reads) + 1, dtype=np.uint64)
+        roff[1:] = np.cumsum([len(rs) for rs in reads], dtype=np.uint64)
+        out = np.zeros(max(1, len(reads)), dtype=np.int64)
+        p = lambda a: a.ctypes.data if a.size else None
+        rc = _lib().bftkv_host_max_timestamped_value(q.h, len(reads), p(peers), p(ts), vb.ctypes.data, vo.ctypes.data, roff.ctypes.data,
+                                                     out.ctypes.data)
+        if rc:
+            raise RuntimeError("max_timestamped_value: %d" % rc)
+        res = []
+        for i, rs in enumerate(reads):
+            res.append(None if out[i] < 0 else (rs[int(out[i])][2] or b"", rs[int(out[i])][1]))
+        return res
+
+
+class Server:
+    """The verification site of protocol.Server.write (protocol/server.go:286-302) over a GPU context."""
+
+    ErrMalformedRequest = 0xFF
+
+    def __init__(self, ctx: _native.Context):
+        self.ctx = ctx
+
+    def write_verify(self, q: Quorum, requests: Sequence[bytes]) -> np.ndarray:
+        rb, ro = _cat(requests)
+        err = np.zeros(len(requests), dtype=np.uint8)
+        rc = _lib().bftkv_host_server_write_verify(self.ctx.h, q.h, len(requests), rb.ctypes.data, ro.ctypes.data, err.ctypes.data)
+        if rc:
+            raise _native.NativeError("server_write_verify failed: %d" % rc)
+        return err

@@ -275,6 +275,15 @@ BatchSigner = Callable[[np.ndarray, np.ndarray], np.ndarray]
 -> sig[n,256] uint8."""
 
 
+def signer_tables(cluster: Cluster):
+    """(moduli[n+1,256], private exponents[n+1,256]) big-endian uint8 for a modexp-based BatchSigner: rows are the
+    replicas in order, then the client (RSA keys only; DSA replicas get a dummy odd modulus and are never indexed)."""
+    ks = cluster.replicas + [cluster.client]
+    mods = np.stack([np.frombuffer((k.n if k.algo == PK_RSA else 3).to_bytes(256, "big"), dtype=np.uint8) for k in ks])
+    exps = np.stack([np.frombuffer((k.d if k.algo == PK_RSA else 1).to_bytes(256, "big"), dtype=np.uint8) for k in ks])
+    return mods, exps
+
+
 def python_batch_signer(cluster: Cluster) -> BatchSigner:
     def sign(em: np.ndarray, key_index: np.ndarray) -> np.ndarray:
         out = np.empty_like(em)

@@ -1,0 +1,131 @@
+/*
+ * bftkv_host.h -- host-side mirror (C++ inside libbftkv_gpu.so, flat C ABI here) of the reference
+ * code that sits directly on either side of the GPU path.  The reference is compiled Go and no Go
+ * toolchain exists in the build image, so these are the pieces the cgo shim would otherwise keep in
+ * Go; they exist so that the whole path -- request bytes in, reference error identity out -- can be
+ * driven and parity-tested end to end through one library.
+ *
+ *   packet framing            packet/packet.go:35-115, 142-248
+ *   trust graph + cliques     node/graph/graph.go:46-140, 279-393, 420-438
+ *   quorum system             quorum/wotqs/wotqs.go:36-193
+ *   vote collector            protocol/client.go:28-50, 125-205; protocol/server.go:286-302
+ *
+ * All functions return 0 on success, a negative BFTKV_E_* otherwise (bftkv_gpu.h).
+ */
+#ifndef BFTKV_HOST_H
+#define BFTKV_HOST_H
+
+#include <stdint.h>
+
+#include "bftkv_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- packet (packet/packet.go) ------------------------------------------------------------- */
+typedef struct {
+  uint8_t type;          /* SignaturePacket.Type: 0 nil, 1 PGP (packet.go:13-19) */
+  uint32_t version;
+  uint8_t completed;
+  const uint8_t* data; uint64_t data_len;
+  const uint8_t* cert; uint64_t cert_len;
+} bftkv_sigpkt;
+
+/* Serialize(x, v, t, sig, ss, auth) with the first n_fields arguments present (1..6), packet.go:35-60.
+ * A NULL sig/ss with the field present is written as the nil signature (22 zero bytes). */
+int bftkv_host_packet_serialize(int n_fields, const uint8_t* x, uint64_t x_len, const uint8_t* v, uint64_t v_len, uint64_t t,
+                                const bftkv_sigpkt* sig, const bftkv_sigpkt* ss, const uint8_t* auth, uint64_t auth_len,
+                                uint8_t* out, uint64_t cap, uint64_t* out_len);
+
+typedef struct {
+  uint64_t x_off, x_len, v_off, v_len, t;
+  int has_sig, has_ss;                 /* 0: absent or Type==0 (nil), packet.go:231-233 */
+  bftkv_sigpkt sig, ss;                /* pointers into the parsed buffer */
+  uint64_t auth_off, auth_len;
+} bftkv_parsed;
+/* Parse, packet.go:62-115: trailing fields may be absent (io.EOF => nil); a short read inside a
+ * field is BFTKV_E_INVALID. */
+int bftkv_host_packet_parse(const uint8_t* pkt, uint64_t len, bftkv_parsed* out);
+/* TBS / TBSS return prefix LENGTHS of pkt (packet.go:156-190). */
+int bftkv_host_packet_tbs(const uint8_t* pkt, uint64_t len, uint64_t* tbs_len);
+int bftkv_host_packet_tbss(const uint8_t* pkt, uint64_t len, uint64_t* tbss_len);
+
+/* ---- trust graph (node/graph/graph.go) + quorum system (quorum/wotqs/wotqs.go) ---------------- */
+typedef struct bftkv_graph bftkv_graph;
+typedef struct bftkv_quorum bftkv_quorum;
+
+#define BFTKV_Q_READ 0x01   /* quorum/quorum.go:10-16 */
+#define BFTKV_Q_WRITE 0x02
+#define BFTKV_Q_AUTH 0x04
+#define BFTKV_Q_CERT 0x08
+#define BFTKV_Q_PEER 0x10
+
+bftkv_graph* bftkv_host_graph_new(void);
+void bftkv_host_graph_free(bftkv_graph* g);
+/* AddNodes for one node: vertex id with the ids of the keys that certified it (graph.go:46-75). */
+int bftkv_host_graph_add_node(bftkv_graph* g, uint64_t id, const uint64_t* signer_ids, uint32_t n_signers);
+int bftkv_host_graph_set_self(bftkv_graph* g, uint64_t id);               /* SetSelfNodes, graph.go:77-88 */
+int bftkv_host_graph_revoke(bftkv_graph* g, uint64_t id);                 /* Revoke, graph.go:131-140 */
+/* GetReachableNodes (graph.go:279-295); ids_out may be NULL to query the count. */
+int bftkv_host_graph_reachable(bftkv_graph* g, uint64_t sid, int distance, uint64_t* ids_out, uint32_t cap, uint32_t* n_out);
+/* GetCliques (graph.go:297-320): concatenated member ids, per-clique sizes and weights. */
+int bftkv_host_graph_cliques(bftkv_graph* g, uint64_t sid, int distance, uint64_t* ids_out, uint32_t ids_cap,
+                             uint32_t* sizes_out, int32_t* weights_out, uint32_t cliques_cap, uint32_t* n_cliques_out);
+
+/* wot.ChooseQuorum(rw) (wotqs.go:117-127) from the graph's self vertex. */
+bftkv_quorum* bftkv_host_choose_quorum(bftkv_graph* g, int rw);
+/* A quorum from explicit cliques (tests, replay tools). */
+bftkv_quorum* bftkv_host_quorum_from_qcs(const bftkv_gpu_qc* qcs, uint32_t n_qcs);
+void bftkv_host_quorum_free(bftkv_quorum* q);
+uint32_t bftkv_host_quorum_n_qcs(const bftkv_quorum* q);
+int bftkv_host_quorum_qc(const bftkv_quorum* q, uint32_t i, bftkv_gpu_qc* out);   /* node_ids point into q */
+/* Quorum interface (quorum/quorum.go:18-25, wotqs.go:132-193) on the host, one list at a time. */
+int bftkv_host_quorum_is_quorum(const bftkv_quorum* q, const uint64_t* ids, uint32_t n);
+int bftkv_host_quorum_is_threshold(const bftkv_quorum* q, const uint64_t* ids, uint32_t n);
+int bftkv_host_quorum_is_sufficient(const bftkv_quorum* q, const uint64_t* ids, uint32_t n);
+int bftkv_host_quorum_reject(const bftkv_quorum* q, const uint64_t* ids, uint32_t n);
+int bftkv_host_quorum_get_threshold(const bftkv_quorum* q);
+/* Registers the quorum with a GPU context (bftkv_gpu_quorum_create) once and returns the handle. */
+int bftkv_host_quorum_gpu_handle(bftkv_quorum* q, bftkv_gpu_ctx* ctx, int* handle_out);
+
+/* ---- vote collector (protocol/client.go, protocol/server.go) ---------------------------------- */
+/* One Multicast reply as the callback sees it (transport/transport.go:129-136). */
+typedef struct {
+  uint64_t peer_id;
+  int32_t err;                          /* 0: Data valid; != 0: res.Err (an index into err_strings of the caller) */
+  const uint8_t* data; uint64_t data_len;
+} bftkv_reply;
+
+/* Client.collectSignatures fold + final verification (client.go:139-169), for a batch of writes.
+ * For write w the replies are replies[reply_off[w] .. reply_off[w+1]) in arrival order; each reply's
+ * data is a serialized SignaturePacket (packet.ParseSignature).  The fold appends with Combine
+ * (crypto_pgp.go:506-515) and stops at the first reply after which Combine returns true or Reject(failure)
+ * holds; then CollectiveSignature.Verify(tbss, ss, qa) runs for ALL writes in one GPU batch.
+ *   ss_out / ss_off_out   collected ss.Data per write (cap bytes)
+ *   consumed_out[w]       replies folded before the callback stopped the multicast
+ *   err_out[w]            BFTKV_ERR_NONE / BFTKV_ERR_INSUFFICIENT_SIGNATURES (majorityError is the caller's) */
+int bftkv_host_collect_signatures(bftkv_gpu_ctx* ctx, bftkv_quorum* qa, uint32_t n_writes,
+                                  const uint8_t* tbss_blob, const uint64_t* tbss_off,
+                                  const bftkv_reply* replies, const uint64_t* reply_off,
+                                  uint8_t* ss_out, uint64_t ss_cap, uint64_t* ss_off_out,
+                                  uint32_t* consumed_out, uint8_t* err_out);
+
+/* Server.write's verification site for a batch of requests <x,v,t,sig,ss> (server.go:286-302):
+ * packet.Parse, TBSS, CollectiveSignature.Verify(tbss, ss, q).  err_out[i]: BFTKV_ERR_NONE,
+ * BFTKV_ERR_INSUFFICIENT_SIGNATURES, or 0xFF for a malformed request / missing ss
+ * (bftkv.ErrMalformedRequest, server.go:288-294). */
+int bftkv_host_server_write_verify(bftkv_gpu_ctx* ctx, bftkv_quorum* q, uint32_t n_requests,
+                                   const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
+
+/* Client.Read tally (client.go:181-205) for a batch of variables: replies (peer, t, value) in arrival
+ * order; value_idx_out[r] = index of the reply whose value wins at the maximum timestamp, or -1 for
+ * errInProgress. */
+int bftkv_host_max_timestamped_value(const bftkv_quorum* q, uint32_t n_reads, const uint64_t* peer_ids, const uint64_t* ts,
+                                     const uint8_t* value_blob, const uint64_t* value_off, const uint64_t* reply_off,
+                                     int64_t* value_idx_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFTKV_HOST_H */

@@ -236,8 +236,7 @@ def test_full_size_properties_cfg2(gpu_ctx):
     """BASELINE configs[1] shape (64 replicas, suff 43) at 1,500 writes / ~80k signatures, signed on the GPU:
     verdicts follow from how the corpus was built -- no oracle in the loop."""
     cl = cb.make_cluster(64)
-    mods = np.stack([np.frombuffer(r.n.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
-    exps = np.stack([np.frombuffer(r.d.to_bytes(256, "big"), dtype=np.uint8) for r in cl.replicas])
+    mods, exps = cb.signer_tables(cl)
     signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
     c = cb.make_write_corpus(cl, 1500, batch_signer=signer, seed=77,
                              mutation_rates={cb.MUT_BAD_MPI: 0.05, cb.MUT_UNKNOWN_ISSUER: 0.05, cb.MUT_DUP_SIGNER: 0.05,

@@ -1,0 +1,142 @@
+"""-m gpu: the vote collector and the server-side verification site (protocol/client.go:125-170,
+protocol/server.go:286-302) through the host mirror + GPU, against the oracle.  Scenarios follow the reference's
+own protocol tests (protocol/rw_test.go, mal_test.go: honest quorum, failing peers, colluding signers)."""
+import numpy as np
+import pytest
+
+from corpus import build as cb
+from oracle import collective as col
+from oracle import packet as opk
+from oracle import wotqs as W
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _world(n):
+    """Cluster + the client's view of the trust graph (scripts/setup.sh shape), in oracle and host form."""
+    from bftkv_amd import host
+    cl = cb.make_cluster(n)
+    members = [r.key_id for r in cl.replicas]
+    # clique; the client trusts (certifies) the members that did NOT certify it, as scripts/setup.sh:33-43 does --
+    # otherwise client + certifiers would form a second clique
+    nodes = [(m, [x for x in members if x != m] + ([] if m in cl.client.certifiers else [cl.client.key_id])) for m in members]
+    nodes.append((cl.client.key_id, cl.client.certifiers))                                   # quorum certificate
+    og, hg = W.Graph(), host.Graph()
+    og.add_nodes(nodes)
+    hg.AddNodes(nodes)
+    return cl, og, hg, host
+
+
+def _oracle_collect(kr, qa, tbss, replies):
+    ss = opk.SignaturePacket()
+    failure, consumed = [], 0
+    for r in replies:
+        consumed += 1
+        stop, failed = False, r.Err != 0
+        if not failed and r.Data:
+            try:
+                s = opk.parse_signature(r.Data)
+            except opk.PacketError:
+                s = None
+            if s is None:
+                failed = True
+            else:
+                stop = col.collective_combine(kr, ss, s, qa)
+        if failed:
+            failure.append(r.Peer)
+            stop = qa.reject(failure)
+        if stop:
+            break
+    res = col.collective_verify(kr, tbss, ss, qa)
+    return ss.Data or b"", consumed, res.err
+
+
+@pytest.mark.parametrize("n", [4, 10])
+def test_collect_signatures_scenarios(gpu_ctx, n):
+    cl, og, hg, host = _world(n)
+    og.set_self([cl.client.key_id])
+    hg.SetSelfNodes([cl.client.key_id])
+    oqa = W.Wot(og).choose_quorum(W.AUTH | W.PEER)            # collectSignatures (client.go:141)
+    hqa = host.wotqs.New(hg).ChooseQuorum(host.AUTH | host.PEER)
+    assert hqa.qcs() == [(q.f, q.min, q.threshold, q.suff, q.nodes) for q in oqa.qcs] and len(oqa.qcs) == 1 and oqa.qcs[0].suff > 0
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    rng = np.random.default_rng(n)
+    f, suff = oqa.qcs[0].f, oqa.qcs[0].suff
+    tbss_l, replies_l = [], []
+    for w in range(36):
+        tbs = cb.serialize_tbs(b"key%03d" % w, rng.bytes(32), w + 1)
+        tbss = tbs + cb.sigpkt(cb.detach_sign(cl.client, tbs), cl.client.entity)
+        other = tbs[:-1] + bytes([tbs[-1] ^ 1])                 # a conflicting <x,v,t'> colluders would sign
+        order = [int(i) for i in rng.permutation(n)]
+        reps = []
+        scenario = w % 9
+        for pos, i in enumerate(order):
+            r = cl.replicas[i]
+            good = opk.serialize_signature(opk.SignaturePacket(1, 0, False, cb.detach_sign(r, tbss), r.entity))
+            rep = host.Reply(Peer=r.key_id, Data=good)
+            if scenario == 1 and pos < f:                       # f peers fail: still enough
+                rep = host.Reply(Peer=r.key_id, Err=1)
+            elif scenario == 2 and pos <= f:                    # f+1 failures up front: Reject stops the multicast
+                rep = host.Reply(Peer=r.key_id, Err=1)
+            elif scenario == 3 and pos % 2 == 0:                # colluders sign a conflicting value (mal_test.go)
+                bad = cb.detach_sign(r, other + tbss[len(tbs):])
+                rep = host.Reply(Peer=r.key_id, Data=opk.serialize_signature(opk.SignaturePacket(1, 0, False, bad, r.entity)))
+            elif scenario == 4 and pos == 1:                    # garbage instead of a signature packet
+                rep = host.Reply(Peer=r.key_id, Data=rng.bytes(9))
+            elif scenario == 5 and pos == 0:                    # empty reply body: no error, nothing combined
+                rep = host.Reply(Peer=r.key_id, Data=None)
+            elif scenario == 6 and pos == 2:                    # a different SignaturePacket.Type is refused by Combine
+                rep = host.Reply(Peer=r.key_id, Data=opk.serialize_signature(opk.SignaturePacket(2, 0, False, cb.detach_sign(r, tbss), None)))
+            elif scenario == 7:                                 # every reply is the same peer's signature
+                r0 = cl.replicas[order[0]]
+                rep = host.Reply(Peer=r0.key_id, Data=opk.serialize_signature(opk.SignaturePacket(1, 0, False, cb.detach_sign(r0, tbss), None)))
+            elif scenario == 8 and pos >= 1:                    # nobody else answers
+                break
+            reps.append(rep)
+        tbss_l.append(tbss)
+        replies_l.append(reps)
+    data, consumed, err = host.Client(gpu_ctx).collect_signatures(hqa, tbss_l, replies_l)
+    oks = 0
+    for w in range(len(tbss_l)):
+        wd, wc, we = _oracle_collect(kr, oqa, tbss_l[w], replies_l[w])
+        assert data[w] == wd and consumed[w] == wc, (w, w % 9, consumed[w], wc)
+        assert (err[w] == 0) == (we is None), (w, w % 9, err[w], we)
+        oks += we is None
+    assert 0 < oks < len(tbss_l)
+    # honest rounds stop after exactly `suff` replies; duplicates of one signer also reach sufficiency
+    assert consumed[0] == suff and err[0] == 0 and err[7] == 0 and err[2] == 2 and err[8] == 2
+
+
+def test_server_write_verify(gpu_ctx):
+    cl, og, hg, host = _world(10)
+    me = cl.replicas[3].key_id
+    og.set_self([me])
+    hg.SetSelfNodes([me])
+    oq = W.Wot(og).choose_quorum(W.AUTH)                        # Server.write (server.go:300)
+    hq = host.wotqs.New(hg).ChooseQuorum(host.AUTH)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    c = cb.make_write_corpus(cl, 40, keep_requests=True,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.15, cb.MUT_ONE_SHORT: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1})
+    reqs = list(c.requests)
+    reqs[5] = reqs[5][:len(reqs[5]) - 7]                         # short read inside ss
+    reqs[6] = opk.serialize(b"k", b"v", 3)                       # no sig, no ss  -> malformed request
+    x, v, t, sig, ss, _ = opk.parse(reqs[7])
+    reqs[7] = opk.serialize(x, v, t, sig)                        # ss absent
+    reqs[8] = opk.serialize(x, v, t, None, ss)                   # nil sig
+    reqs[9] = b""
+    err = host.Server(gpu_ctx).write_verify(hq, reqs)
+    for i, r in enumerate(reqs):
+        try:
+            x, v, t, sig, ss, _ = opk.parse(r)
+            want = 0xFF if (sig is None or ss is None) else None
+        except opk.PacketError:
+            want = 0xFF
+        if want is None:
+            res = col.collective_verify(kr, opk.tbss(r), ss, oq)
+            want = 0 if res.err is None else 2
+        assert err[i] == want, (i, err[i], want)
+    assert set(err) == {0, 2, 0xFF}
+    assert host.packet.TBSS(reqs[0]) == c.tbss(0)

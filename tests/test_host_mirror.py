@@ -1,0 +1,148 @@
+"""CPU: the host-side C++ mirror (include/bftkv_host.h: packet framing, trust graph, wotqs quorum system, read
+tally) against the oracle restatement -- no GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import collective as col
+from oracle import packet as opk
+from oracle import wotqs as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    ge.build()
+    from bftkv_amd import host
+    host._lib()
+    return host
+
+
+def test_host_header_symbols_exported(H):
+    from bftkv_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "bftkv_host.h")).read()
+    declared = set(re.findall(r"\b(bftkv_host_[a-z_0-9]+)\s*\(", hdr))
+    lib = _native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(H.HOST_EXPORTS)
+
+
+def _rand_sig(rng, H, O):
+    if rng.random() < 0.2:
+        return None, None
+    kw = dict(Type=int(rng.integers(1, 3)), Version=int(rng.integers(0, 5)), Completed=bool(rng.integers(0, 2)),
+              Data=rng.bytes(int(rng.integers(0, 40))) or None, Cert=rng.bytes(int(rng.integers(0, 40))) or None)
+    return H.SignaturePacket(**kw), O.SignaturePacket(**kw)
+
+
+def test_packet_matches_oracle_on_random_packets(H):
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        nf = int(rng.integers(1, 7))
+        x, v, t = rng.bytes(int(rng.integers(0, 20))), rng.bytes(int(rng.integers(0, 50))), int(rng.integers(0, 2 ** 63))
+        hs, os_ = _rand_sig(rng, H, opk)
+        hss, oss = _rand_sig(rng, H, opk)
+        auth = rng.bytes(int(rng.integers(0, 10)))
+        hargs = [x, v, t, hs, hss, auth][:nf]
+        oargs = [x, v, t, os_, oss, auth][:nf]
+        pkt = H.packet.Serialize(*hargs)
+        assert pkt == opk.serialize(*oargs)
+        for cut in {len(pkt)} | {int(c) for c in rng.integers(0, len(pkt) + 1, size=4)}:
+            p = pkt[:cut]
+            try:
+                want = opk.parse(p)
+            except opk.PacketError:
+                with pytest.raises(H.MalformedPacket):
+                    H.packet.Parse(p)
+                continue
+            got = H.packet.Parse(p)
+            assert got[:3] == want[:3] and got[5] == want[5]
+            for g, w in zip(got[3:5], want[3:5]):
+                assert (g is None) == (w is None)
+                if g is not None:
+                    assert (g.Type, g.Version, g.Completed, g.Data, g.Cert) == (w.Type, w.Version, w.Completed, w.Data, w.Cert)
+            for name in ("tbs", "tbss"):
+                try:
+                    w = getattr(opk, name)(p)
+                except opk.PacketError:
+                    with pytest.raises(H.MalformedPacket):
+                        getattr(H.packet, name.upper())(p)
+                else:
+                    assert getattr(H.packet, name.upper())(p) == w
+
+
+def _random_world(rng):
+    """Disjoint complete cliques + peripheral nodes certified by / certifying clique members."""
+    nodes, next_id = [], 1
+    cliques = []
+    for _ in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(2, 12))
+        ids = list(range(next_id, next_id + k))
+        next_id += k
+        cliques.append(ids)
+    spec = {}
+    for ids in cliques:
+        for i in ids:
+            spec[i] = [j for j in ids if j != i]
+    for _ in range(int(rng.integers(0, 10))):
+        i = next_id
+        next_id += 1
+        members = [m for ids in cliques for m in ids]
+        signers = [int(x) for x in rng.choice(members, size=int(rng.integers(0, min(6, len(members)) + 1)), replace=False)]
+        spec[i] = signers
+        for tgt in rng.choice(members, size=int(rng.integers(0, 4)), replace=False):   # the periphery trusts some members
+            spec[int(tgt)] = spec[int(tgt)] + [i]
+    order = list(spec.keys())
+    rng.shuffle(order)
+    return [(i, spec[i]) for i in order], cliques
+
+
+def test_graph_and_choose_quorum_match_oracle(H):
+    rng = np.random.default_rng(2)
+    flags = [W.AUTH, W.AUTH | W.PEER, W.AUTH | W.CERT, W.READ, W.WRITE, W.READ | W.AUTH, W.READ | W.WRITE, W.CERT]
+    for trial in range(120):
+        nodes, cliques = _random_world(rng)
+        og, hg = W.Graph(), H.Graph()
+        og.add_nodes(nodes)
+        hg.AddNodes(nodes)
+        self_id = int(rng.choice([i for i, _ in nodes]))
+        og.set_self([self_id])
+        hg.SetSelfNodes([self_id])
+        if trial % 5 == 4:
+            victim = int(rng.choice([i for i, _ in nodes if i != self_id]))
+            og.revoke(victim)
+            hg.Revoke(victim)
+        for d in (0, 1, 2, -1):
+            assert hg.GetReachableNodes(self_id, d) == og.get_reachable_nodes(self_id, d)
+            assert hg.GetCliques(self_id, d) == [(c.nodes, c.weight) for c in og.get_cliques(self_id, d)]
+        for rw in flags:
+            oq = W.Wot(og).choose_quorum(rw)
+            hq = H.wotqs.New(hg).ChooseQuorum(rw)
+            assert hq.qcs() == [(q.f, q.min, q.threshold, q.suff, q.nodes) for q in oq.qcs], (trial, rw)
+            assert hq.GetThreshold() == oq.get_threshold() and hq.Nodes() == oq.nodes()
+            universe = [i for i, _ in nodes] + [9999]
+            for _ in range(6):
+                l = [int(x) for x in rng.choice(universe, size=int(rng.integers(0, 25)))]
+                assert hq.IsQuorum(l) == oq.is_quorum(l) and hq.IsThreshold(l) == oq.is_threshold(l)
+                assert hq.IsSufficient(l) == oq.is_sufficient(l) and hq.Reject(l) == oq.reject(l)
+
+
+def test_max_timestamped_value_matches_oracle(H):
+    rng = np.random.default_rng(3)
+    ids = list(range(1, 8))
+    oq = W.WotQ([W.new_qc(ids, 0, W.READ, 0)])            # threshold f+1 = 3
+    hq = H.Quorum.from_qcs([(q.f, q.min, q.threshold, q.suff, q.nodes) for q in oq.qcs])
+    reads = []
+    for _ in range(200):
+        k = int(rng.integers(0, 9))
+        reads.append([(int(rng.choice(ids + [99])), int(rng.integers(1, 4)), bytes([int(rng.integers(0, 3))]) * int(rng.integers(0, 3)))
+                      for _ in range(k)])
+    got = H.Client.max_timestamped_value(hq, reads)
+    for r, g in zip(reads, got):
+        assert g == col.max_timestamped_value(r, oq)
+    assert any(g is not None for g in got) and any(g is None for g in got)
