@@ -37,7 +37,7 @@ EXPORTS = [
     "bftkv_gpu_collective_verify", "bftkv_gpu_collective_verify_dev", "bftkv_gpu_sync",
     "bftkv_gpu_signature_verify", "bftkv_gpu_last_statuses", "bftkv_gpu_last_counters",
     "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
-    "bftkv_gpu_stream",
+    "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
 ]
 
 _lib = None
@@ -72,6 +72,9 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_quorum_tally.argtypes = [vp, C.c_int, u32, u64p, u64p, u8p]
     lib.bftkv_gpu_modexp.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u32, u8p]
     lib.bftkv_gpu_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.bftkv_gpu_modmul_product.argtypes = [vp, u32, u32, u8p, u32, vp, u32, u8p, u8p]
+    lib.bftkv_gpu_lagrange_combine.argtypes = [vp, u32, u32, vp, u8p, u32, vp, u32, u8p, u8p, u8p]
+    lib.bftkv_gpu_dsa_calculate_r.argtypes = [vp, u32, u32, vp, u8p, u32, u8p, u32, vp, u32, u8p, u8p, u8p, u8p]
     lib.bftkv_gpu_stream.argtypes = [vp]
     lib.bftkv_gpu_stream.restype = vp
     for name in EXPORTS:
@@ -220,6 +223,45 @@ class Context:
         self._check(self.lib.bftkv_gpu_quorum_tally(self.h, quorum, n, _ptr(ids), _ptr(list_off), _ptr(v)), "quorum_tally")
         return v
 
+    # ---- threshold share combine (config 5); numbers are Python ints at this level
+    def modmul_product(self, factors, moduli, mod_idx, nbytes: int = 256):
+        """factors: [n_ops][k] ints; returns [n_ops] ints = prod mod moduli[mod_idx[op]] (rsa.go:318-329)."""
+        n, k = len(factors), len(factors[0])
+        f = _ints_to_be([x for row in factors for x in row], nbytes)
+        m = _ints_to_be(moduli, nbytes)
+        mi = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros((n, nbytes), dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_modmul_product(self.h, n, k, _ptr(f), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out)), "modmul_product")
+        return [int.from_bytes(out[i].tobytes(), "big") for i in range(n)]
+
+    def lagrange_combine(self, xs, ys, moduli, mod_idx, nbytes: int = 256):
+        """xs: [n_ops][k] small ints, ys: [n_ops][k] ints -> ([n_ops] ints, status[n_ops]) (sss.go:69-107)."""
+        n, k = len(xs), len(xs[0])
+        x = np.ascontiguousarray(np.array(xs, dtype=np.int32))
+        y = _ints_to_be([v for row in ys for v in row], nbytes)
+        m = _ints_to_be(moduli, nbytes)
+        mi = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros((n, nbytes), dtype=np.uint8)
+        st = np.zeros(n + 8, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_lagrange_combine(self.h, n, k, _ptr(x), _ptr(y), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out),
+                                                        _ptr(st)), "lagrange_combine")
+        return [int.from_bytes(out[i].tobytes(), "big") for i in range(n)], st[:n]
+
+    def dsa_calculate_r(self, xs, ri, vi, groups, group_idx, pbytes: int = 256, qbytes: int = 32):
+        """CalculateR (dsa.go:33-52): xs/ri/vi [n_ops][k]; groups: list of (p, q) -> ([n_ops] ints, status)."""
+        n, k = len(xs), len(xs[0])
+        x = np.ascontiguousarray(np.array(xs, dtype=np.int32))
+        r = _ints_to_be([v for row in ri for v in row], pbytes)
+        v = _ints_to_be([v for row in vi for v in row], qbytes)
+        p = _ints_to_be([g[0] for g in groups], pbytes)
+        q = _ints_to_be([g[1] for g in groups], qbytes)
+        gi = np.ascontiguousarray(group_idx, dtype=np.uint32)
+        out = np.zeros((n, qbytes), dtype=np.uint8)
+        st = np.zeros(n + 8, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_dsa_calculate_r(self.h, n, k, _ptr(x), _ptr(r), pbytes, _ptr(v), qbytes, _ptr(gi), len(groups), _ptr(p),
+                                                       _ptr(q), _ptr(out), _ptr(st)), "dsa_calculate_r")
+        return [int.from_bytes(out[i].tobytes(), "big") for i in range(n)], st[:n]
+
     def modexp(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
         """base [n, nbytes] u8 BE; mods [m, nbytes]; exps [m, exp_len] -> [n, nbytes]."""
         base, mods, exps = _u8(base), _u8(mods), _u8(exps)
@@ -228,6 +270,10 @@ class Context:
         self._check(self.lib.bftkv_gpu_modexp(self.h, base.shape[0], _ptr(base), base.shape[1], _ptr(mod_idx), mods.shape[0],
                                               _ptr(mods), _ptr(exps), exps.shape[1], _ptr(out)), "modexp")
         return out
+
+
+def _ints_to_be(vals, nbytes: int) -> np.ndarray:
+    return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "big") for v in vals), dtype=np.uint8).reshape(len(vals), nbytes).copy()
 
 
 def _u8(a) -> np.ndarray:

@@ -13,6 +13,7 @@
 
 #include "host_bignum.h"
 #include "kernels.hip"
+#include "threshold_kernels.hip"
 
 using namespace bftkv;
 
@@ -781,4 +782,5 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 }  // extern "C"
 
+#include "threshold_capi.inc"
 #include "host_capi.inc"

@@ -1,0 +1,317 @@
+// Share-combine kernels of the threshold-signature path (BASELINE config 5), gfx950.
+//   k_modmul_product     S = prod psig_i mod N            calculateSignature, crypto/threshold/rsa/rsa.go:318-329
+//   k_lagrange_inv       (prod_{m!=j}(x_m - x_j))^-1 mod m, exact for any modulus coprime to it
+//   k_lagrange_terms     lambda_j = a_j * inv_j mod m  and  sum_j lambda_j * y_j mod m
+//                                                         sss.Lagrange / calculateSecret (crypto/sss/sss.go:69-107),
+//                                                         calculateS (crypto/threshold/dsa/dsa_core.go:389-403)
+//   k_multiexp           prod_j base_j ^ e_j mod p          CalculateR (crypto/threshold/dsa/dsa.go:33-52)
+//   k_u256_inv_modq, k_limbs_mod_q                          the mod-q tail of CalculateR
+// All big-number work reuses the quad Montgomery multiplier of mont28.h (4 lanes per operation).
+#pragma once
+// (kernels.hip is included before this file by capi.hip)
+
+namespace bftkv {
+
+struct ModTab {               // per distinct modulus, built on the host (hostbn::mont_setup)
+  const uint32_t* n_limbs;    // [n_mods][76]
+  const uint32_t* r2_limbs;   // [n_mods][76]
+  const uint32_t* n0inv;      // [n_mods]
+};
+
+#define QUAD_SETUP()                                                        \
+  constexpr int L = MONT_L;                                                 \
+  const uint32_t quad = threadIdx.x >> 2;                                   \
+  const int qlane = threadIdx.x & 3;                                        \
+  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;                  \
+  const bool active = gq < n_ops;                                           \
+  const uint32_t op = active ? gq : (n_ops - 1);                            \
+  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;                       \
+  const uint32_t* a_rd = a_sh + quad * MONT_N;
+
+#define MONT(out, bexpr)                                                    \
+  do {                                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                  \
+    mont_mul(out, a_rd, bexpr, n, n0inv, qlane);                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                  \
+  } while (0)
+
+__device__ __forceinline__ void store_mod_result(uint32_t* dst, uint32_t (&t)[MONT_L], const uint32_t (&n)[MONT_L], int qlane) {
+  // t <= n after mont(., 1) + canonicalize; t == n only for 0
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < MONT_L; ++k) diff |= t[k] ^ n[k];
+  diff = quad_or(diff);
+#pragma unroll
+  for (int k = 0; k < MONT_L; ++k) dst[k] = (diff == 0) ? 0u : t[k];
+}
+
+// ---- RSA combine: product of k factors mod N ---------------------------------------------------------
+__global__ void __launch_bounds__(RSA_BLOCK) k_modmul_product(uint32_t n_ops, uint32_t k_factors, const uint32_t* __restrict__ f_limbs /*[n_ops][k][76]*/,
+                                                              const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ out_limbs) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], acc[L], t[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  const uint32_t n0inv = mt.n0inv[mi];
+  for (uint32_t j = 0; j < k_factors; ++j) {
+    const uint32_t* fp = f_limbs + ((uint64_t)op * k_factors + j) * MONT_N + qlane * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = fp[k];
+    MONT(t, r2);                                   // f_j * R
+    if (j == 0) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) acc[k] = t[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+      MONT(t, acc);                                // acc * f_j (Montgomery form)
+#pragma unroll
+      for (int k = 0; k < L; ++k) acc[k] = t[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(t, acc);
+  canonicalize(t, qlane);
+  if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
+}
+
+// ---- Lagrange: small-integer side ------------------------------------------------------------------
+// Per (op, share j): a = prod_{m != j} x_m, b = prod_{m != j} (x_m - x_j) (exact, |.| < 2^31 required),
+// inv = (b mod m)^-1 mod m computed WITHOUT big-number inversion: with t = m^-1 mod |b|,
+// |b|^-1 mod m = (1 + ((|b| - t) mod |b|) * m) / |b| exactly -- valid for any m coprime to b.
+// status: 0 ok, 1 no inverse / duplicate x, 2 magnitude overflow (fenced: DESIGN.md)
+__device__ __forceinline__ int64_t egcd_inv64(int64_t a, int64_t m) {   // a^-1 mod m, or -1
+  int64_t r0 = m, r1 = a % m, s0 = 0, s1 = 1;
+  while (r1 != 0) {
+    int64_t qq = r0 / r1;
+    int64_t t = r0 - qq * r1; r0 = r1; r1 = t;
+    t = s0 - qq * s1; s0 = s1; s1 = t;
+  }
+  if (r0 != 1) return -1;
+  return s0 < 0 ? s0 + m : s0;
+}
+
+__global__ void __launch_bounds__(64) k_lagrange_inv(uint32_t n_ops, uint32_t k_shares, const int32_t* __restrict__ xs /*[n_ops][k]*/,
+                                                     const uint32_t* __restrict__ mod_idx, ModTab mt,
+                                                     uint32_t* __restrict__ inv_limbs /*[n_ops][k][76]*/, uint32_t* __restrict__ a_out /*[n_ops][k]*/,
+                                                     uint8_t* __restrict__ status /*[n_ops]*/) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_ops * k_shares) return;
+  const uint32_t op = t / k_shares, j = t % k_shares;
+  const int32_t* x = xs + (uint64_t)op * k_shares;
+  const uint32_t* m = mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N;
+  uint32_t* out = inv_limbs + (uint64_t)t * MONT_N;
+  int64_t a = 1, b = 1;
+  bool overflow = false;
+  for (uint32_t i = 0; i < k_shares; ++i) {
+    if (x[i] == x[j]) continue;                            // sss.Lagrange skips every res == x (sss.go:99-101)
+    a *= x[i];
+    b *= (int64_t)x[i] - x[j];
+    if (a >= (1ll << 31) || a <= -(1ll << 31) || b >= (1ll << 31) || b <= -(1ll << 31)) overflow = true;
+  }
+  uint8_t st = 0;
+  if (overflow || a < 0) st = 2;
+  const int64_t ab = b < 0 ? -b : b;
+  if (!st && ab == 0) st = 1;
+  int64_t tinv = 0;
+  if (!st && ab > 1) {
+    uint64_t r = 0;
+    for (int i = MONT_N - 1; i >= 0; --i) r = ((r << MONT_W) | m[i]) % (uint64_t)ab;   // m mod |b|
+    tinv = egcd_inv64((int64_t)r, ab);
+    if (tinv < 0) st = 1;
+  }
+  if (st) { atomicOr((unsigned int*)(status + (op & ~3u)), (unsigned int)st << (8 * (op & 3))); for (int i = 0; i < MONT_N; ++i) out[i] = 0; a_out[t] = 0; return; }
+  if (ab == 1) {
+    for (int i = 0; i < MONT_N; ++i) out[i] = (i == 0) ? 1u : 0u;
+  } else {
+    const uint64_t kk = (uint64_t)((ab - tinv) % ab);
+    // prod = 1 + kk * m   (78 limbs), then exact division by |b| from the top
+    uint64_t carry = 1;
+    uint32_t prod[MONT_N + 2];
+    for (int i = 0; i < MONT_N; ++i) { uint64_t v = (uint64_t)m[i] * kk + carry; prod[i] = (uint32_t)v & MONT_MASK; carry = v >> MONT_W; }
+    prod[MONT_N] = (uint32_t)carry & MONT_MASK;
+    prod[MONT_N + 1] = (uint32_t)(carry >> MONT_W);
+    uint64_t rem = 0;
+    for (int i = MONT_N + 1; i >= 0; --i) {
+      uint64_t cur = (rem << MONT_W) | prod[i];
+      uint64_t qd = cur / (uint64_t)ab;
+      rem = cur % (uint64_t)ab;
+      if (i < MONT_N) out[i] = (uint32_t)qd;
+    }
+  }
+  if (b < 0) {   // (-|b|)^-1 = m - |b|^-1
+    int64_t borrow = 0;
+    for (int i = 0; i < MONT_N; ++i) {
+      int64_t v = (int64_t)m[i] - out[i] - borrow;
+      borrow = v < 0;
+      out[i] = (uint32_t)(v + (borrow << MONT_W)) & MONT_MASK;
+    }
+  }
+  a_out[t] = (uint32_t)a;
+}
+
+// Per op (quad): lambda_j = a_j * inv_j mod m (optionally written out), S = sum_j lambda_j * y_j mod m.
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ inv_limbs,
+                                                              const uint32_t* __restrict__ a_in, const uint32_t* __restrict__ y_limbs /*[n_ops][k][76] or null*/,
+                                                              const uint32_t* __restrict__ mod_idx, ModTab mt,
+                                                              uint32_t* __restrict__ lambda_out /*[n_ops][k][76] or null*/,
+                                                              uint32_t* __restrict__ sum_out /*[n_ops][76] or null*/) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], acc[L], t[L], u[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; acc[k] = 0; }
+  const uint32_t n0inv = mt.n0inv[mi];
+  for (uint32_t j = 0; j < k_shares; ++j) {
+    const uint64_t sj = (uint64_t)op * k_shares + j;
+    const uint32_t* ip = inv_limbs + sj * MONT_N + qlane * L;
+    const uint32_t av = a_in[sj];
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = ip[k];
+    MONT(t, r2);                                                     // inv * R
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0) ? (k == 0 ? (av & MONT_MASK) : (k == 1 ? (av >> MONT_W) : 0u)) : 0u;
+    MONT(u, t);                                                      // lambda = a * inv (plain, < 2m)
+    if (lambda_out) {
+      // canonical value below m: one more round trip through the Montgomery domain
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = u[k];
+      MONT(t, r2);
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+      uint32_t c[L];
+      MONT(c, t);
+      canonicalize(c, qlane);
+      if (active) store_mod_result(lambda_out + sj * MONT_N + qlane * L, c, n, qlane);
+    }
+    if (sum_out) {
+      const uint32_t* yp = y_limbs + sj * MONT_N + qlane * L;
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = u[k];
+      MONT(t, r2);                                                   // lambda * R
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = yp[k];
+      MONT(u, t);                                                    // lambda * y (plain, < 2m)
+#pragma unroll
+      for (int k = 0; k < L; ++k) acc[k] += u[k];
+      canonicalize(acc, qlane);
+    }
+  }
+  if (sum_out) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = acc[k];
+    MONT(t, r2);
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+    MONT(u, t);
+    canonicalize(u, qlane);
+    if (active) store_mod_result(sum_out + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
+  }
+}
+
+// r = prod_j base_j ^ e_j mod p, e_j up to 256 bits (little-endian words taken from 76-limb numbers' low part)
+__global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
+                                                        const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
+                                                        const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][76]*/,
+                                                        uint32_t* __restrict__ out_limbs) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], y[L], t[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  const uint32_t n0inv = mt.n0inv[mi];
+  // bases into the Montgomery domain (global scratch, re-read 256 times: L2 resident)
+  for (uint32_t j = 0; j < k_bases; ++j) {
+    const uint64_t sj = (uint64_t)op * k_bases + j;
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = base_limbs[sj * MONT_N + qlane * L + k];
+    MONT(t, r2);
+#pragma unroll
+    for (int k = 0; k < L; ++k) scratch[sj * MONT_N + qlane * L + k] = t[k];
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(y, r2);                                                       // Montgomery one
+  for (int bit = 279; bit >= 0; --bit) {                             // 10 limbs = 280 bits cover any 256-bit exponent
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = y[k];
+    MONT(t, y);
+#pragma unroll
+    for (int k = 0; k < L; ++k) y[k] = t[k];
+    for (uint32_t j = 0; j < k_bases; ++j) {
+      const uint64_t sj = (uint64_t)op * k_bases + j;
+      const bool b = (exp_limbs[sj * MONT_N + bit / MONT_W] >> (bit % MONT_W)) & 1u;
+      if (!__any(b)) continue;
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = scratch[sj * MONT_N + qlane * L + k];
+      MONT(t, y);
+      if (b) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) y[k] = t[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(t, y);
+  canonicalize(t, qlane);
+  if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
+}
+
+// thread per op: out = in^-1 mod q (numbers as 76-limb radix-2^28, q <= 256 bits, odd); status |= 1 when no inverse
+__device__ __forceinline__ U256 u256_from_limbs(const uint32_t* l) {
+  U256 r = u256_zero();
+  for (int j = 0; j < 10; ++j) {
+    const uint32_t bit = 28u * j;
+    const uint64_t v = (uint64_t)l[j] << (bit & 31);
+    if ((bit >> 5) < 8) r.w[bit >> 5] |= (uint32_t)v;
+    if ((bit >> 5) + 1 < 8) r.w[(bit >> 5) + 1] |= (uint32_t)(v >> 32);
+  }
+  return r;
+}
+__device__ __forceinline__ void u256_to_limbs(const U256& a, uint32_t* l) {
+  for (int j = 0; j < MONT_N; ++j) {
+    const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
+    uint64_t v = 0;
+    if (wi < 8) v = a.w[wi];
+    if (wi + 1 < 8) v |= (uint64_t)a.w[wi + 1] << 32;
+    l[j] = (wi < 8) ? ((uint32_t)(v >> sh) & MONT_MASK) : 0u;
+  }
+}
+__global__ void __launch_bounds__(64) k_u256_inv_modq(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,
+                                                      ModTab mt, uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status) {
+  const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
+  if (op >= n_ops) return;
+  const U256 q = u256_from_limbs(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N);
+  const U256 v = u256_from_limbs(in_limbs + (uint64_t)op * MONT_N);
+  U256 w = u256_zero();
+  if (u256_is_zero(v) || !u256_modinv_odd(v, q, w)) { atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3))); w = u256_zero(); }
+  u256_to_limbs(w, out_limbs + (uint64_t)op * MONT_N);
+}
+// thread per op: out = in mod q  (in: 76 limbs, q <= 256 bits)
+__global__ void __launch_bounds__(64) k_limbs_mod_q(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,
+                                                    ModTab mt, uint32_t* __restrict__ out_limbs) {
+  const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
+  if (op >= n_ops) return;
+  const U256 q = u256_from_limbs(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N);
+  const uint32_t* v = in_limbs + (uint64_t)op * MONT_N;
+  U256 acc = u256_zero();
+  for (int j = MONT_N - 1; j >= 0; --j) {
+    for (int k = 0; k < MONT_W; ++k) {
+      uint32_t c = u256_shl1(acc);
+      if (c || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
+    }
+    U256 l = u256_zero();
+    l.w[0] = v[j];
+    while (u256_cmp(l, q) >= 0) u256_sub(l, q);
+    u256_addmod(acc, l, q);
+  }
+  u256_to_limbs(acc, out_limbs + (uint64_t)op * MONT_N);
+}
+
+}  // namespace bftkv

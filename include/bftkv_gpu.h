@@ -148,6 +148,25 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, ui
                      const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
                      const uint8_t* exps, uint32_t exp_len, uint8_t* out);
 
+/* ---- threshold-signature share combine (BASELINE config 5) ------------------------------------ */
+/* Numbers are big-endian, nbytes each (<= 256); moduli must be odd; mod_idx[op] selects the modulus.
+ * status_out[op] (where present): 0 ok, 1 no modular inverse, 2 Lagrange integers beyond 2^31 (fenced). */
+
+/* S = prod_j factors[op][j] mod N -- calculateSignature (crypto/threshold/rsa/rsa.go:318-329). */
+int bftkv_gpu_modmul_product(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const uint8_t* factors, uint32_t nbytes,
+                             const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods, uint8_t* out);
+/* S = sum_j Lagrange(x_j; xs) * y_j mod m -- SSSProcess.calculateSecret (crypto/sss/sss.go:69-107) and
+ * calculateS (crypto/threshold/dsa/dsa_core.go:389-403).  xs: [n_ops][k] int32, ys: [n_ops][k][nbytes]. */
+int bftkv_gpu_lagrange_combine(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const int32_t* xs, const uint8_t* ys,
+                               uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
+                               uint8_t* out, uint8_t* status_out);
+/* r = (prod_j Ri_j^l_j mod p)^((sum_j Vi_j*l_j)^-1 mod q) mod p mod q, l_j = Lagrange(x_j; xs) mod q --
+ * dsaGroupOperations.CalculateR (crypto/threshold/dsa/dsa.go:33-52).  ri: [n_ops][k][pbytes],
+ * vi: [n_ops][k][qbytes], groups: p[n_groups][pbytes], q[n_groups][qbytes] (q <= 256 bits); r_out: [n_ops][qbytes]. */
+int bftkv_gpu_dsa_calculate_r(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const int32_t* xs, const uint8_t* ri, uint32_t pbytes,
+                              const uint8_t* vi, uint32_t qbytes, const uint32_t* group_idx, uint32_t n_groups,
+                              const uint8_t* p, const uint8_t* q, uint8_t* r_out, uint8_t* status_out);
+
 /* ---- timing of the last *_dev verify call (HIP events on the context's stream) ---------------- */
 /* ms[0] whole call, ms[1] walk+parse, ms[2] hash stream (midstates+digests, overlaps the modexp),
  * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream) */
