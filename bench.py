@@ -91,9 +91,7 @@ def main():
     d_err = torch.zeros(args.items, dtype=torch.uint8, device=dev)
     d_nver = torch.zeros(args.items, dtype=torch.int32, device=dev)
     d_verdict = torch.zeros(args.items, dtype=torch.uint8, device=dev)
-    nbits = (args.items + 7) // 8
-    d_bits_all = torch.zeros(world * nbits, dtype=torch.uint8, device=dev) if world > 1 else None
-    weights = (2 ** torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
+    from bftkv_amd import dist as D
     torch.cuda.synchronize()
 
     def step():
@@ -103,11 +101,8 @@ def main():
         if world > 1:
             # per-write verdict bitmap (1 bit per write), all-gathered over RCCL/xGMI so that every
             # rank holds every verdict -- as every replica of the reference reaches every decision
-            ok = (d_err == 0).to(torch.uint8)
-            pad = torch.zeros(nbits * 8, dtype=torch.uint8, device=dev)
-            pad[:args.items] = ok
-            bits = (pad.view(nbits, 8) * weights).sum(dim=1).to(torch.uint8)
-            dist.all_gather_into_tensor(d_bits_all, bits)
+            return D.allgather_verdicts(d_err == 0, args.items * world)
+        return None
 
     for _ in range(args.warmup):
         step()

@@ -38,6 +38,7 @@ EXPORTS = [
     "bftkv_gpu_signature_verify", "bftkv_gpu_last_statuses", "bftkv_gpu_last_counters",
     "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
+    "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts",
 ]
 
 _lib = None
@@ -76,6 +77,9 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_lagrange_combine.argtypes = [vp, u32, u32, vp, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_dsa_calculate_r.argtypes = [vp, u32, u32, vp, u8p, u32, u8p, u32, vp, u32, u8p, u8p, u8p, u8p]
     lib.bftkv_gpu_stream.argtypes = [vp]
+    lib.bftkv_gpu_comm_unique_id.argtypes = [u8p]
+    lib.bftkv_gpu_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
+    lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
     for name in EXPORTS:
         if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream"):
@@ -222,6 +226,21 @@ class Context:
         v = np.zeros(n, dtype=np.uint8)
         self._check(self.lib.bftkv_gpu_quorum_tally(self.h, quorum, n, _ptr(ids), _ptr(list_off), _ptr(v)), "quorum_tally")
         return v
+
+    # ---- multi-GPU exchange step (RCCL)
+    @staticmethod
+    def comm_unique_id() -> np.ndarray:
+        uid = np.zeros(128, dtype=np.uint8)
+        rc = load_library().bftkv_gpu_comm_unique_id(_ptr(uid))
+        if rc:
+            raise NativeError("bftkv_gpu_comm_unique_id failed (%d): librccl not loadable" % rc)
+        return uid
+
+    def comm_init(self, n_ranks: int, rank: int, uid: np.ndarray):
+        self._check(self.lib.bftkv_gpu_comm_init(self.h, n_ranks, rank, _ptr(np.ascontiguousarray(uid, dtype=np.uint8))), "comm_init")
+
+    def allgather_verdicts(self, local_ptr: int, nbytes: int, out_ptr: int):
+        self._check(self.lib.bftkv_gpu_allgather_verdicts(self.h, local_ptr, nbytes, out_ptr), "allgather_verdicts")
 
     # ---- threshold share combine (config 5); numbers are Python ints at this level
     def modmul_product(self, factors, moduli, mod_idx, nbytes: int = 256):

@@ -74,7 +74,11 @@ struct bftkv_gpu_ctx {
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
   hipEvent_t ev[8] = {};   // 0 start, 1 parsed, 2 modexp done, 3 compare done, 4 end, 5 hash start, 6 hash done
   bool have_timing = false;
+  void* rccl_comm = nullptr;   // ncclComm_t
+  int n_ranks = 1, rank = 0;
 };
+
+void rccl_release(bftkv_gpu_ctx* c);
 
 namespace {
 
@@ -323,6 +327,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
+  rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->stream_h);
@@ -782,5 +787,6 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 }  // extern "C"
 
+#include "rccl_capi.inc"
 #include "threshold_capi.inc"
 #include "host_capi.inc"

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing of the verifier: shard-by-write partitioning and the one exchange step of the path,
+the all-gather of per-write verdict bitmaps.  One process per GPU; ``torch.distributed``
+backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  No data-path collective besides this.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank: the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def max_shard(n_items: int, world: int) -> int:
+    return (n_items + world - 1) // world
+
+
+def pack_verdicts(ok: torch.Tensor, n_slots: int) -> torch.Tensor:
+    """ok: bool/uint8 [n_local] (1 = CollectiveSignature.Verify returned nil) -> uint8 bitmap of
+    ceil(n_slots/8) bytes, bit i of byte i//8 = item i (LSB first), zero padded to n_slots."""
+    nbytes = (n_slots + 7) // 8
+    pad = torch.zeros(nbytes * 8, dtype=torch.uint8, device=ok.device)
+    pad[:ok.numel()] = ok.to(torch.uint8)
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=ok.device)
+    return (pad.view(nbytes, 8).to(torch.int32) * weights).sum(dim=1).to(torch.uint8)
+
+
+def unpack_verdicts(bits: torch.Tensor, n_slots: int) -> torch.Tensor:
+    shifts = torch.arange(8, dtype=torch.int32, device=bits.device)
+    return ((bits.to(torch.int32).unsqueeze(1) >> shifts) & 1).reshape(-1)[:n_slots].to(torch.uint8)
+
+
+def allgather_verdicts(local_ok: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+    """Every rank contributes the verdicts of its shard (shard_range) and receives the verdict of EVERY write,
+    in global write order -- as every replica of the reference independently reaches every decision.
+    Traffic: ceil(max_shard/8) bytes per rank (cfg 4: 1M writes over 8 GPUs = 15.6 KB per rank)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    slots = max_shard(n_items, world)
+    bits = pack_verdicts(local_ok, slots)
+    if world == 1:
+        return unpack_verdicts(bits, n_items)
+    gathered = torch.empty(world * bits.numel(), dtype=torch.uint8, device=bits.device)
+    dist.all_gather_into_tensor(gathered, bits, group=group)
+    out = torch.empty(n_items, dtype=torch.uint8, device=bits.device)
+    for r in range(world):
+        lo, hi = shard_range(n_items, r, world)
+        out[lo:hi] = unpack_verdicts(gathered[r * bits.numel():(r + 1) * bits.numel()], slots)[:hi - lo]
+    return out

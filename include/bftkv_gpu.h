@@ -148,6 +148,14 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, ui
                      const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
                      const uint8_t* exps, uint32_t exp_len, uint8_t* out);
 
+/* ---- multi-GPU: all-gather of verdict bitmaps over RCCL ----------------------------- */
+/* One context per GPU/process.  uid: 128 opaque bytes from bftkv_gpu_comm_unique_id on rank 0, distributed by
+ * the caller (the Go shim: over its own transport).  librccl.so.1 is dlopen'ed on first use. */
+int bftkv_gpu_comm_unique_id(uint8_t uid_out[128]);
+int bftkv_gpu_comm_init(bftkv_gpu_ctx* ctx, int n_ranks, int rank, const uint8_t uid[128]);
+/* local_bits: nbytes DEVICE bytes of this rank; all_bits_out: n_ranks*nbytes DEVICE bytes, rank-major. */
+int bftkv_gpu_allgather_verdicts(bftkv_gpu_ctx* ctx, const uint8_t* local_bits, uint64_t nbytes, uint8_t* all_bits_out);
+
 /* ---- threshold-signature share combine (BASELINE config 5) ------------------------------------ */
 /* Numbers are big-endian, nbytes each (<= 256); moduli must be odd; mod_idx[op] selects the modulus.
  * status_out[op] (where present): 0 ok, 1 no modular inverse, 2 Lagrange integers beyond 2^31 (fenced). */

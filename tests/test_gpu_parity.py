@@ -262,3 +262,20 @@ def test_full_size_properties_cfg2(gpu_ctx):
     err3, _, _ = gpu_ctx.collective_verify(qh, c.tbss_blob[:int(c.tbss_off[200])], c.tbss_off[:201], sb, so)
     assert (err3 == err[:200]).all()
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_rccl_allgather_entry_points_single_rank(gpu_ctx):
+    """bftkv_gpu_comm_* / bftkv_gpu_allgather_verdicts: librccl loads, a 1-rank communicator gathers by copying.
+    (The box has one GPU; the N>1 exchange is covered by tests/test_dist_gloo.py and bench.py --gpus N.)"""
+    import torch
+    from bftkv_amd import Context
+    from bftkv_amd import dist as D
+    uid = Context.comm_unique_id()
+    assert uid.any()
+    gpu_ctx.comm_init(1, 0, uid)
+    ok = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 1], dtype=torch.uint8, device="cuda")
+    bits = D.pack_verdicts(ok, 11)
+    out = torch.zeros_like(bits)
+    gpu_ctx.allgather_verdicts(bits.data_ptr(), bits.numel(), out.data_ptr())
+    assert torch.equal(D.unpack_verdicts(out, 11), ok)
+    assert torch.equal(D.allgather_verdicts(ok, 11), ok)
