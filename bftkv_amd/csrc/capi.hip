@@ -67,7 +67,7 @@ struct bftkv_gpu_ctx {
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, cert_ent, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
+  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
@@ -206,6 +206,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
   HIPCHK(c, c->item_flags.ensure(n_items + 16));
+  HIPCHK(c, c->walk_scratch.ensure(sizeof(WalkEnt) * WALK_CAP * (size_t)n_items + 16));
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
@@ -217,7 +218,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   const uint32_t nb = (n_items + 63) / 64;
   hipLaunchKernelGGL(k_walk<false>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     (const uint32_t*)nullptr, (SigRec*)nullptr, (uint8_t*)nullptr);
+                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>());
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>());
   uint32_t total = 0;
@@ -234,10 +235,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * MONT_N * tr));
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
+  // sequential fill only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>());
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), (uint8_t*)nullptr, (WalkEnt*)nullptr);
   if (total) {
-    hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, c->recs.as<SigRec>(), total, c->kt,
+    hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, d_ss_off, c->base.as<uint32_t>(),
+                       c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
                        d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
                        c->hash_mask.as<uint32_t>());
   }
@@ -248,7 +251,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     // other hashes: a no-op grid unless some signature asked for them
     hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
                        c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
-    hipLaunchKernelGGL(k_digest, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+    hipLaunchKernelGGL(k_digest<false>, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+    hipLaunchKernelGGL(k_digest<true>, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                        c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[6], sh));
@@ -322,7 +327,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab,
-                    &c->counts, &c->base, &c->total, &c->item_flags, &c->cert_ent, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
+                    &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();

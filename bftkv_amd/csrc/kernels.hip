@@ -208,14 +208,23 @@ __host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint
   return r;
 }
 
+// Per-item scratch of the counting pass: the first WALK_CAP packet events of an item as
+// (offset of the body relative to the item's stream, body length, status), so that the fill pass is a
+// parallel thread-per-packet expansion instead of a second sequential walk.  Items with more events
+// (n = 256 cliques carry 171) fall back to the sequential k_walk<true>.
+constexpr uint32_t WALK_CAP = 96;
+struct WalkEnt { uint32_t body_rel; uint32_t body_len_status; };   // len in the low 24 bits, status in the high 8
+
 template <bool FILL>
 __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                              uint32_t n_items, uint32_t* __restrict__ counts,
                                              const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
-                                             uint8_t* __restrict__ item_flags) {
+                                             uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch) {
   uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
+  if (FILL && counts[item] <= WALK_CAP) return;     // expanded in parallel by k_parse_body
   uint64_t pos = sig_off[item], end = sig_off[item + 1];
+  const uint64_t pos0 = pos;
   uint32_t n = 0;
   uint32_t base = FILL ? rec_base[item] : 0;
   bool trailing_skip = false;   // silently skipped packet(s) after the last event
@@ -224,6 +233,14 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     pos = w.next;
     if (!w.event) { trailing_skip = true; continue; }
     trailing_skip = false;
+    if (!FILL && n < WALK_CAP && w.body_len < (1u << 24) && w.body_off - pos0 < (1ull << 32)) {
+      WalkEnt e;
+      e.body_rel = (uint32_t)(w.body_off - pos0);
+      e.body_len_status = w.body_len | ((uint32_t)w.status << 24);
+      scratch[(uint64_t)item * WALK_CAP + n] = e;
+    } else if (!FILL && n < WALK_CAP) {
+      n = WALK_CAP;      // does not fit the scratch encoding: force the sequential fill for this item
+    }
     if (FILL) {
       SigRec rec;
       rec.body_off = w.body_off; rec.body_len = w.body_len; rec.item = item; rec.key_slot = -1;
@@ -235,19 +252,39 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     }
     ++n;
   }
-  if (!FILL) counts[item] = n;
-  else if (item_flags) item_flags[item] = trailing_skip ? 1 : 0;
+  if (!FILL) { counts[item] = n; item_flags[item] = trailing_skip ? 1 : 0; }
 }
 
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
-__global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs, uint32_t n_recs,
+__global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
+                                                    const uint32_t* __restrict__ rec_base, const uint32_t* __restrict__ counts,
+                                                    uint32_t n_items, const WalkEnt* __restrict__ scratch,
+                                                    SigRec* __restrict__ recs, uint32_t n_recs,
                                                     KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
                                                     uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count /*[0] RSA, [1] DSA*/,
                                                     uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
-  SigRec rec = recs[ri];
-  if (rec.status != ST_PENDING_PARSE) return;
+  // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
+  uint32_t lo = 0, hi = n_items;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (rec_base[mid] <= ri) lo = mid; else hi = mid;
+  }
+  const uint32_t item = lo;
+  SigRec rec;
+  if (counts[item] <= WALK_CAP) {
+    const WalkEnt e = scratch[(uint64_t)item * WALK_CAP + (ri - rec_base[item])];
+    rec.body_off = sig_off[item] + e.body_rel; rec.body_len = e.body_len_status & 0xFFFFFFu; rec.item = item; rec.key_slot = -1;
+    rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
+    rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
+    rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = (uint8_t)(e.body_len_status >> 24);
+    rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
+    if (rec.status != ST_PENDING_PARSE) { recs[ri] = rec; return; }
+  } else {
+    rec = recs[ri];                                  // written by the sequential k_walk<true>
+    if (rec.status != ST_PENDING_PARSE) return;
+  }
   const uint8_t* body = sig_blob + rec.body_off;
   uint8_t st;
   if (rec.body_len >= 1 && body[0] < 4) st = ST_UNSUPPORTED;   // SignatureV3: fenced
@@ -474,6 +511,7 @@ __device__ __forceinline__ uint32_t limb28(F byte_from_lsb, int j) {
 
 // Per signature: digest = H(signed || hash suffix) from the item's midstate; hash-tag check.
 // digests: 64 bytes per record, the digest in its natural (big-endian) byte order.
+template <bool OTHERS>   // false: SHA-256 only (the path's default, light on registers); true: every other hash
 __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                 const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                 const uint64_t* __restrict__ mid64, uint32_t n_items,
@@ -482,9 +520,10 @@ __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_HASH) return;
-  const HashInfo hi = hash_info(rec.hash_id);
+  if ((rec.hash_id != HASH_SHA256) != OTHERS) return;
+  const HashInfo hi = OTHERS ? hash_info(rec.hash_id) : HashInfo{32, 0, 32, 19};
   const uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
-  const uint32_t bmask = (hi.family == 64) ? 127u : 63u;
+  const uint32_t bmask = (OTHERS && hi.family == 64) ? 127u : 63u;
   TailSrc ts;
   ts.tail_len = (uint32_t)(tlen & bmask);
   ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
@@ -494,7 +533,7 @@ __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_
   const uint64_t bits = (tlen + ts.pre_len + 6) * 8;
   uint32_t* dg = digests + (uint64_t)ri * 16;
   uint32_t tag_hi;
-  if (hi.family == 32) {
+  if (!OTHERS || hi.family == 32) {
     const uint32_t nblk = (rem + 9 + 63) >> 6;
     uint32_t s[8];
     const uint32_t* m = mid32 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
@@ -508,12 +547,12 @@ __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_
         w[i] = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
       }
       if (blk == nblk - 1) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
-      if (hi.slot == 2) sha1_compress(s, w); else sha256_compress(s, w);
+      if (OTHERS && hi.slot == 2) sha1_compress(s, w); else sha256_compress(s, w);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) dg[i] = __builtin_bswap32(s[i]);
     tag_hi = s[0];
-  } else {
+  } else if (OTHERS) {
     const uint32_t nblk = (rem + 17 + 127) >> 7;
     uint64_t s[8];
     const uint64_t* m = mid64 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
@@ -535,6 +574,8 @@ __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dg[2 * i] = __builtin_bswap32((uint32_t)(s[i] >> 32)); dg[2 * i + 1] = __builtin_bswap32((uint32_t)s[i]); }
     tag_hi = (uint32_t)(s[0] >> 32);
+  } else {
+    tag_hi = 0;
   }
   // PublicKey.VerifySignature: hash tag first, then whatever k_parse_body determined
   uint8_t st;

@@ -279,3 +279,52 @@ def test_rccl_allgather_entry_points_single_rank(gpu_ctx):
     gpu_ctx.allgather_verdicts(bits.data_ptr(), bits.numel(), out.data_ptr())
     assert torch.equal(D.unpack_verdicts(out, 11), ok)
     assert torch.equal(D.allgather_verdicts(ok, 11), ok)
+
+
+def test_cfg4_shape_256_replicas(gpu_ctx):
+    """BASELINE configs[3] shape: 256-replica clique (f=85, suff=171), 171..256 packets per write -- exercises the
+    sequential-walk fallback (more than WALK_CAP packet events per item); verdicts vs construction and vs the oracle."""
+    cl = cb.make_cluster(256)
+    mods, exps = cb.signer_tables(cl)
+    signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
+    c = cb.make_write_corpus(cl, 24, batch_signer=signer, seed=4,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.2})
+    assert cl.suff == 171 and c.sig_count.min() >= 171
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    err, nver, verdict = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    want_ok = c.expected_valid >= cl.suff
+    assert ((err == 0) == want_ok).all() and (nver == np.where(want_ok, cl.suff, c.expected_valid)).all()
+    assert want_ok.any() and (~want_ok).any()
+    st, st_item = gpu_ctx.last_statuses()
+    for i in (0, 5, 11, 23):
+        r = H.oracle_collective(kr, q, c, i)
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
+        assert list(st[st_item == i][:len(r.statuses)]) == r.statuses
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx):
+    """BASELINE configs[2] shape: 64 replicas, half RSA-2048 / half DSA-2048-256, collective signatures over reads."""
+    cl = cb.make_cluster(64, dsa_fraction=0.5)
+    assert sum(r.algo == cb.PK_DSA for r in cl.replicas) == 32
+    mods, exps = cb.signer_tables(cl)
+    signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
+    c = cb.make_write_corpus(cl, 40, batch_signer=signer, seed=9,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.15, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.2})
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    err, nver, verdict = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    want_ok = c.expected_valid >= cl.suff
+    assert ((err == 0) == want_ok).all() and (nver == np.where(want_ok, cl.suff, c.expected_valid)).all()
+    st, st_item = gpu_ctx.last_statuses()
+    assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+    cnt = gpu_ctx.last_counters()
+    assert cnt["pubkey_ops"] >= 0.9 * c.n_sigs
+    for i in (0, 7, 19, 39):
+        r = H.oracle_collective(kr, q, c, i)
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
+        assert list(st[st_item == i][:len(r.statuses)]) == r.statuses
+    gpu_ctx.quorum_destroy(qh)
