@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -32,6 +33,18 @@ struct DevBuf {
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   template <typename T> T* as() const { return (T*)p; }
+};
+
+struct KeyEntry {
+  uint64_t key_id = 0, entity_id = 0;
+  uint8_t algo = 0, flags = 0;
+  uint32_t bits = 0, e = 0, n0 = 0, qbits = 0;
+  std::vector<uint32_t> nl, r2, qw, dtab;
+  std::string material;
+  bool cert_only = false;
+  int cert_group = -1;          // certificates: entries of one certificate share a group
+  uint32_t entity_index = 0;   // filled by upload_key_table
+  std::string cert_digest;     // certificates: identity of the certificate bytes
 };
 
 struct QuorumHost {
@@ -61,6 +74,8 @@ struct bftkv_gpu_ctx {
   std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
   std::vector<uint32_t> h_key_entity;
   std::vector<uint8_t> h_key_flags;
+  std::vector<KeyEntry> ring, certs;   // processed rows: node keyring, then certificate-only entities
+  uint32_t n_ring_entities = 0;
   DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab;
   KeyTableDev kt{};
 
@@ -293,6 +308,126 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   return 0;
 }
 
+// One processed key-table row (host copy, so that certificate entities can be appended later).
+int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, KeyEntry* out) {
+  KeyEntry& e = *out;
+  e.key_id = k.key_id; e.entity_id = k.entity_id; e.algo = k.pk_algo; e.cert_only = cert_only;
+  e.material.clear();
+  e.material.push_back((char)k.pk_algo);
+  e.material.push_back((char)k.usable_sign);
+  auto app = [&](const uint8_t* p, uint32_t l) {
+    uint32_t z = 0;
+    while (z < l && p[z] == 0) ++z;
+    if (l > z) e.material.append((const char*)p + z, l - z);
+    e.material.push_back('|');
+  };
+  app(k.n, k.n_len); app(k.e, k.e_len); app(k.g, k.g_len); app(k.y, k.y_len);
+  e.flags = 0;
+  if (k.usable_sign) e.flags |= KEYF_USABLE_SIGN;
+  if (k.pk_algo != PK_RSA_ENCRYPT_ONLY && k.pk_algo != PK_ELGAMAL) e.flags |= KEYF_CAN_SIGN;   // PublicKey.CanSign
+  if (k.key_id == k.entity_id) e.flags |= KEYF_PRIMARY;
+  if (cert_only) e.flags |= KEYF_CERT_ONLY;
+  e.bits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
+  e.e = 0; e.n0 = 0; e.qbits = 0;
+  e.nl.assign(MONT_N, 0); e.r2.assign(MONT_N, 0); e.qw.assign(8, 0); e.dtab.assign(3 * MONT_N, 0);
+  if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
+    if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
+    for (uint32_t j = 0; j < k.e_len; ++j) e.e = (e.e << 8) | k.e[j];
+    if (e.bits > 2048) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
+    else if (!hostbn::mont_setup(k.n, k.n_len, MONT_N, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
+  } else if (k.pk_algo == PK_DSA) {
+    // n = p, e = q.  Montgomery domain mod p; g, y, g*y in Montgomery form for Shamir's trick.
+    e.qbits = (uint32_t)hostbn::bit_length(k.e, k.e_len);
+    const int nwords = (28 * MONT_N + 31) / 32 + 1;
+    std::vector<uint32_t> p(nwords), g(nwords), y(nwords), gy(nwords), q(nwords);
+    hostbn::from_be(k.e, k.e_len, q.data(), nwords);
+    bool ok = e.bits >= 2 && e.bits <= 2048 && e.qbits >= 32 && e.qbits <= 256 && (q[0] & 1u) &&
+              hostbn::mont_setup(k.n, k.n_len, MONT_N, e.nl.data(), e.r2.data(), &e.n0);
+    if (ok && (hostbn::bit_length(k.g, k.g_len) > 2048 || hostbn::bit_length(k.y, k.y_len) > 2048)) ok = false;
+    if (ok) {
+      hostbn::from_be(k.n, k.n_len, p.data(), nwords);
+      hostbn::from_be(k.g, k.g_len, g.data(), nwords);
+      hostbn::from_be(k.y, k.y_len, y.data(), nwords);
+      hostbn::reduce(g.data(), p.data(), nwords);
+      hostbn::reduce(y.data(), p.data(), nwords);
+      hostbn::mul_mod(g.data(), y.data(), p.data(), gy.data(), nwords);
+      hostbn::to_mont_limbs(g.data(), p.data(), nwords, MONT_N, &e.dtab[0]);
+      hostbn::to_mont_limbs(y.data(), p.data(), nwords, MONT_N, &e.dtab[MONT_N]);
+      hostbn::to_mont_limbs(gy.data(), p.data(), nwords, MONT_N, &e.dtab[2 * MONT_N]);
+      for (int j = 0; j < 8; ++j) e.qw[j] = q[j];
+    } else {
+      e.bits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 2048 bits): ST_UNSUPPORTED
+    }
+  }
+  return 0;
+}
+
+// Builds and uploads the device key table from c->ring (the node keyring, in getKeyring() order) followed by
+// c->certs (entities that only exist inside request certificates, reachable through VerifyWithCertificate).
+int upload_key_table(bftkv_gpu_ctx* c) {
+  std::vector<uint64_t> key_id, entity_ids;
+  std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
+  std::vector<uint8_t> algo, flags;
+  auto add = [&](const KeyEntry& e, bool own_entity) {
+    uint32_t ent = 0;
+    if (own_entity) { ent = (uint32_t)entity_ids.size(); entity_ids.push_back(e.entity_id); }
+    else {
+      for (; ent < entity_ids.size(); ++ent) if (entity_ids[ent] == e.entity_id) break;
+      if (ent == entity_ids.size()) entity_ids.push_back(e.entity_id);
+    }
+    key_id.push_back(e.key_id); entity.push_back(ent); algo.push_back(e.algo); flags.push_back(e.flags);
+    bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
+    nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
+    qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
+    return ent;
+  };
+  for (auto& e : c->ring) add(e, false);
+  c->n_ring_entities = (uint32_t)entity_ids.size();
+  // certificate entities: one entity index per distinct certificate (cert_group), never merged with the keyring's
+  int last_group = -1;
+  uint32_t group_ent = 0;
+  for (auto& e : c->certs) {
+    if (e.cert_group != last_group) { group_ent = add(e, true); last_group = e.cert_group; }
+    else {
+      key_id.push_back(e.key_id); entity.push_back(group_ent); algo.push_back(e.algo); flags.push_back(e.flags);
+      bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
+      nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
+      qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
+    }
+    const_cast<KeyEntry&>(e).entity_index = group_ent;
+  }
+  int rc;
+  if ((rc = upload(c, c->k_id, key_id)) || (rc = upload(c, c->k_entity, entity)) || (rc = upload(c, c->k_algo, algo)) ||
+      (rc = upload(c, c->k_flags, flags)) || (rc = upload(c, c->k_bits, bits)) || (rc = upload(c, c->k_e, e32)) ||
+      (rc = upload(c, c->k_n, nl)) || (rc = upload(c, c->k_r2, r2)) || (rc = upload(c, c->k_n0, n0)) ||
+      (rc = upload(c, c->k_q, qw)) || (rc = upload(c, c->k_qbits, qbits)) || (rc = upload(c, c->k_dsatab, dtab)))
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_keys = (uint32_t)key_id.size();
+  c->have_dsa_keys = false;
+  for (uint8_t a : algo) if (a == PK_DSA) c->have_dsa_keys = true;
+  c->n_entities = (uint32_t)entity_ids.size();
+  c->h_key_id = key_id;
+  c->h_entity_id = entity_ids;
+  c->h_key_entity = entity;
+  c->h_key_flags = flags;
+  c->kt.n_keys = c->n_keys;
+  c->kt.key_id = c->k_id.as<uint64_t>();
+  c->kt.entity = c->k_entity.as<uint32_t>();
+  c->kt.pk_algo = c->k_algo.as<uint8_t>();
+  c->kt.flags = c->k_flags.as<uint8_t>();
+  c->kt.mod_bits = c->k_bits.as<uint32_t>();
+  c->kt.rsa_e = c->k_e.as<uint32_t>();
+  c->kt.n_limbs = c->k_n.as<uint32_t>();
+  c->kt.r2_limbs = c->k_r2.as<uint32_t>();
+  c->kt.n0inv = c->k_n0.as<uint32_t>();
+  c->kt.q_words = c->k_q.as<uint32_t>();
+  c->kt.q_bits = c->k_qbits.as<uint32_t>();
+  c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
+  ++c->keyring_gen;
+  return 0;
+}
+
 int check_quorum(bftkv_gpu_ctx* c, int quorum) {
   if (quorum < 0 || (size_t)quorum >= c->quorums.size() || !c->quorums[quorum].live) return fail(c, BFTKV_E_INVALID, "bad quorum handle");
   return 0;
@@ -362,130 +497,23 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   if (!c || (!keys && n_keys)) return BFTKV_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<uint64_t> key_id;
-  std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
-  std::vector<uint8_t> algo, flags;
-  std::vector<uint64_t> entity_ids;
-  std::vector<std::string> material;
+  std::vector<KeyEntry> ring;
   for (uint32_t i = 0; i < n_keys; ++i) {
-    const bftkv_gpu_pubkey& k = keys[i];
-    std::string mat;
-    mat.push_back((char)k.pk_algo);
-    mat.push_back((char)k.usable_sign);
-    auto app = [&](const uint8_t* p, uint32_t l) {
-      uint32_t z = 0;
-      while (z < l && p[z] == 0) ++z;
-      mat.append((const char*)p + z, l - z);
-      mat.push_back('|');
-    };
-    app(k.n, k.n_len); app(k.e, k.e_len); app(k.g, k.g_len); app(k.y, k.y_len);
+    KeyEntry e;
+    int rc = make_key_entry(c, keys[i], false, &e);
+    if (rc) return rc;
     bool dup = false;
-    for (size_t j = 0; j < key_id.size(); ++j) {
-      if (key_id[j] == k.key_id) {
-        if (material[j] == mat) { dup = true; break; }
+    for (auto& o : ring) {
+      if (o.key_id == e.key_id) {
+        if (o.material == e.material) { dup = true; break; }
         return fail(c, BFTKV_E_UNSUPPORTED, "two different keys share one 64-bit key id");
       }
     }
-    if (dup) continue;
-    uint32_t ent = 0;
-    for (; ent < entity_ids.size(); ++ent) if (entity_ids[ent] == k.entity_id) break;
-    if (ent == entity_ids.size()) entity_ids.push_back(k.entity_id);
-    key_id.push_back(k.key_id);
-    material.push_back(mat);
-    entity.push_back(ent);
-    algo.push_back(k.pk_algo);
-    uint8_t fl = 0;
-    if (k.usable_sign) fl |= KEYF_USABLE_SIGN;
-    if (k.pk_algo != PK_RSA_ENCRYPT_ONLY && k.pk_algo != PK_ELGAMAL) fl |= KEYF_CAN_SIGN;   // PublicKey.CanSign
-    if (k.key_id == k.entity_id) fl |= KEYF_PRIMARY;
-    uint32_t nbits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
-    uint32_t ev = 0;
-    size_t o = nl.size();
-    nl.resize(o + MONT_N, 0); r2.resize(o + MONT_N, 0);
-    uint32_t n0i = 0;
-    if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
-      int ebits = hostbn::bit_length(k.e, k.e_len);
-      if (ebits > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
-      for (uint32_t j = 0; j < k.e_len; ++j) ev = (ev << 8) | k.e[j];
-      if (nbits > 2048) {
-        nbits = 0xFFFFFFFFu;   // k_digest_em reports ST_UNSUPPORTED for this key
-      } else if (!hostbn::mont_setup(k.n, k.n_len, MONT_N, &nl[o], &r2[o], &n0i)) {
-        nbits = 0xFFFFFFFFu;   // even / zero modulus: no Montgomery form (never a real key)
-      }
-    }
-    size_t oq = qw.size(), ot = dtab.size();
-    qw.resize(oq + 8, 0);
-    dtab.resize(ot + 3 * MONT_N, 0);
-    uint32_t qb = 0;
-    if (k.pk_algo == PK_DSA) {
-      // n = p, e = q.  Montgomery domain mod p; g, y, g*y in Montgomery form for Shamir's trick.
-      qb = (uint32_t)hostbn::bit_length(k.e, k.e_len);
-      const int nwords = (28 * MONT_N + 31) / 32 + 1;
-      std::vector<uint32_t> p(nwords), g(nwords), y(nwords), gy(nwords), q(nwords);
-      hostbn::from_be(k.e, k.e_len, q.data(), nwords);
-      bool ok = nbits >= 2 && nbits <= 2048 && qb >= 32 && qb <= 256 && (q[0] & 1u) &&
-                hostbn::mont_setup(k.n, k.n_len, MONT_N, &nl[o], &r2[o], &n0i);
-      if (ok) {
-        hostbn::from_be(k.n, k.n_len, p.data(), nwords);
-        hostbn::from_be(k.g, k.g_len, g.data(), nwords);
-        hostbn::from_be(k.y, k.y_len, y.data(), nwords);
-        if (hostbn::bit_length(k.g, k.g_len) > 2048 || hostbn::bit_length(k.y, k.y_len) > 2048) ok = false;
-      }
-      if (ok) {
-        hostbn::reduce(g.data(), p.data(), nwords);
-        hostbn::reduce(y.data(), p.data(), nwords);
-        hostbn::mul_mod(g.data(), y.data(), p.data(), gy.data(), nwords);
-        hostbn::to_mont_limbs(g.data(), p.data(), nwords, MONT_N, &dtab[ot]);
-        hostbn::to_mont_limbs(y.data(), p.data(), nwords, MONT_N, &dtab[ot + MONT_N]);
-        hostbn::to_mont_limbs(gy.data(), p.data(), nwords, MONT_N, &dtab[ot + 2 * MONT_N]);
-        for (int j = 0; j < 8; ++j) qw[oq + j] = q[j];
-      } else {
-        nbits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 2048 bits): ST_UNSUPPORTED
-      }
-    }
-    qbits.push_back(qb);
-    flags.push_back(fl);
-    bits.push_back(nbits);
-    e32.push_back(ev);
-    n0.push_back(n0i);
+    if (!dup) ring.push_back(std::move(e));
   }
-  int rc;
-  if ((rc = upload(c, c->k_id, key_id))) return rc;
-  if ((rc = upload(c, c->k_entity, entity))) return rc;
-  if ((rc = upload(c, c->k_algo, algo))) return rc;
-  if ((rc = upload(c, c->k_flags, flags))) return rc;
-  if ((rc = upload(c, c->k_bits, bits))) return rc;
-  if ((rc = upload(c, c->k_e, e32))) return rc;
-  if ((rc = upload(c, c->k_n, nl))) return rc;
-  if ((rc = upload(c, c->k_r2, r2))) return rc;
-  if ((rc = upload(c, c->k_n0, n0))) return rc;
-  if ((rc = upload(c, c->k_q, qw))) return rc;
-  if ((rc = upload(c, c->k_qbits, qbits))) return rc;
-  if ((rc = upload(c, c->k_dsatab, dtab))) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->n_keys = (uint32_t)key_id.size();
-  c->have_dsa_keys = false;
-  for (uint8_t a : algo) if (a == PK_DSA) c->have_dsa_keys = true;
-  c->n_entities = (uint32_t)entity_ids.size();
-  c->h_key_id = key_id;
-  c->h_entity_id = entity_ids;
-  c->h_key_entity = entity;
-  c->h_key_flags = flags;
-  c->kt.n_keys = c->n_keys;
-  c->kt.key_id = c->k_id.as<uint64_t>();
-  c->kt.entity = c->k_entity.as<uint32_t>();
-  c->kt.pk_algo = c->k_algo.as<uint8_t>();
-  c->kt.flags = c->k_flags.as<uint8_t>();
-  c->kt.mod_bits = c->k_bits.as<uint32_t>();
-  c->kt.rsa_e = c->k_e.as<uint32_t>();
-  c->kt.n_limbs = c->k_n.as<uint32_t>();
-  c->kt.r2_limbs = c->k_r2.as<uint32_t>();
-  c->kt.n0inv = c->k_n0.as<uint32_t>();
-  c->kt.q_words = c->k_q.as<uint32_t>();
-  c->kt.q_bits = c->k_qbits.as<uint32_t>();
-  c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
-  ++c->keyring_gen;
-  return 0;
+  c->ring = std::move(ring);
+  c->certs.clear();
+  return upload_key_table(c);
 }
 
 int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t n_qcs, int* out) {
@@ -594,10 +622,10 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   return 0;
 }
 
-int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
-                               const uint8_t* sig, const uint64_t* sig_off, const uint64_t* cert_key_id, uint8_t* err_out) {
-  if (!c || (n_items && (!tbs_off || !sig_off || !err_out))) return BFTKV_E_INVALID;
-  if (n_items == 0) return 0;
+// Signature.Verify over a batch with the keyring of item i restricted to entity index ent[i] (0xFFFFFFFF: the node
+// keyring).  Shared by bftkv_gpu_signature_verify and the Server.sign site of the host mirror.
+int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
+                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t tl = tbs_off[n_items], sl = sig_off[n_items];
@@ -611,16 +639,9 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t
   HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, sig_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
   const uint32_t* d_cert = nullptr;
-  std::vector<uint32_t> ce;
-  if (cert_key_id) {
-    ce.resize(n_items);
-    for (uint32_t i = 0; i < n_items; ++i) {
-      uint32_t e = 0xFFFFFFFEu;   // an entity that is not in the table: nothing matches
-      for (uint32_t k = 0; k < c->n_entities; ++k) if (c->h_entity_id[k] == cert_key_id[i]) { e = k; break; }
-      ce[i] = e;
-    }
-    int rc = upload(c, c->cert_ent, ce);
-    if (rc) return rc;
+  if (ent) {
+    HIPCHK(c, c->cert_ent.ensure(sizeof(uint32_t) * n_items));
+    HIPCHK(c, hipMemcpyAsync(c->cert_ent.p, ent, sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
     d_cert = c->cert_ent.as<uint32_t>();
   }
   int rc = run_pipeline(c, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
@@ -634,6 +655,23 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t
   HIPCHK(c, hipGetLastError());
   c->have_timing = true;
   return 0;
+}
+
+int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                               const uint8_t* sig, const uint64_t* sig_off, const uint64_t* cert_key_id, uint8_t* err_out) {
+  if (!c || (n_items && (!tbs_off || !sig_off || !err_out))) return BFTKV_E_INVALID;
+  if (n_items == 0) return 0;
+  std::vector<uint32_t> ce;
+  if (cert_key_id) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    ce.resize(n_items);
+    for (uint32_t i = 0; i < n_items; ++i) {
+      uint32_t e = 0xFFFFFFFEu;   // an entity that is not in the table: nothing matches
+      for (uint32_t k = 0; k < c->n_entities; ++k) if (c->h_entity_id[k] == cert_key_id[i]) { e = k; break; }
+      ce[i] = e;
+    }
+  }
+  return signature_verify_entities(c, n_items, tbs, tbs_off, sig, sig_off, cert_key_id ? ce.data() : nullptr, err_out);
 }
 
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint32_t cap, uint32_t* n_out) {
@@ -792,6 +830,8 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 }  // extern "C"
 
+extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
+                                         const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out);
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"
 #include "host_capi.inc"

@@ -67,6 +67,9 @@ struct KeyTableDev {
 };
 
 constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;
+// key only exists inside a request's certificate: invisible to keyring lookups, reachable when the lookup is
+// restricted to its entity (PGPSignature.VerifyWithCertificate, crypto_pgp.go:332-344)
+constexpr uint8_t KEYF_CERT_ONLY = 8;
 
 // Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.
 constexpr int MAX_QC = 8;

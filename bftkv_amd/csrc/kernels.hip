@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
       int32_t slot = -1;
       for (uint32_t k = 0; k < kt.n_keys; ++k) {
-        if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) && (only_ent == 0xFFFFFFFFu || kt.entity[k] == only_ent)) {
+        if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) &&
+            (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
           slot = (int32_t)k;
           break;
         }
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
     if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, 0)) break;   // parse error => Next returns err
     if (!have_issuer) break;                              // nil dereference in the reference: fenced
     for (uint32_t k = 0; k < kt.n_keys; ++k) {
-      if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY)) {
+      if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY) && !(kt.flags[k] & KEYF_CERT_ONLY)) {
         if (FILL) ids_out[base + n] = issuer;
         ++n;
         break;

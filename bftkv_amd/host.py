@@ -42,7 +42,9 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_from_qcs", "bftkv_host_quorum_free", "bftkv_host_quorum_n_qcs", "bftkv_host_quorum_qc",
     "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
-    "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value",
+    "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
+    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
+    "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode",
 ]
 
 _ready = False
@@ -83,6 +85,18 @@ def _lib():
         lib.bftkv_host_collect_signatures.argtypes = [vp, vp, C.c_uint32, vp, vp, C.POINTER(_Reply), vp, vp, C.c_uint64, vp, vp, vp]
         lib.bftkv_host_server_write_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_max_timestamped_value.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        lib.bftkv_host_vote_fold.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
+        lib.bftkv_host_certs_parse.restype = vp
+        lib.bftkv_host_certs_parse.argtypes = [C.c_char_p, C.c_uint64]
+        lib.bftkv_host_certs_free.argtypes = [vp]
+        lib.bftkv_host_certs_free.restype = None
+        lib.bftkv_host_certs_n_entities.argtypes = [vp]
+        lib.bftkv_host_certs_n_entities.restype = C.c_uint32
+        lib.bftkv_host_certs_entity.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32)]
+        lib.bftkv_host_certs_key.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(_native.PubKey)]
+        lib.bftkv_host_server_sign_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        lib.bftkv_host_equivocation_signers.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.bftkv_host_emsa_encode.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_uint32]
         _ready = True
     return lib
 
@@ -302,6 +316,42 @@ def _cat(parts: Sequence[bytes]):
     return blob, off
 
 
+class Certificate:
+    """PGPCertificate.Parse / Signers reduced to what the path reads (crypto_pgp.go:236-272, 80-88)."""
+
+    @staticmethod
+    def Parse(cert: bytes):
+        """-> list of entities: dict(id, keys=[dict(key_id, pk_algo, usable_sign, n, e, g, y)], certifiers=[ids])."""
+        lib = _lib()
+        h = C.c_void_p(lib.bftkv_host_certs_parse(cert, len(cert)))
+        out = []
+        try:
+            for e in range(lib.bftkv_host_certs_n_entities(h)):
+                eid, nk, cp, nc = C.c_uint64(0), C.c_uint32(0), C.c_void_p(), C.c_uint32(0)
+                lib.bftkv_host_certs_entity(h, e, C.byref(eid), C.byref(nk), C.byref(cp), C.byref(nc))
+                certifiers = [int(x) for x in (C.c_uint64 * nc.value).from_address(cp.value)] if nc.value else []
+                keys = []
+                for k in range(nk.value):
+                    pk = _native.PubKey()
+                    lib.bftkv_host_certs_key(h, e, k, C.byref(pk))
+                    g = lambda p, l: C.string_at(p, l) if l else b""
+                    keys.append({"key_id": pk.key_id, "entity_id": pk.entity_id, "pk_algo": pk.pk_algo, "usable_sign": bool(pk.usable_sign),
+                                 "n": g(pk.n, pk.n_len), "e": g(pk.e, pk.e_len), "g": g(pk.g, pk.g_len), "y": g(pk.y, pk.y_len)})
+                out.append({"id": eid.value, "keys": keys, "certifiers": certifiers})
+        finally:
+            lib.bftkv_host_certs_free(h)
+        return out
+
+
+def emsa_encode(hash_id: int, digest: bytes, n_bits: int) -> bytes:
+    """emsaEncode (crypto/threshold/rsa/rsa.go:356-378)."""
+    emlen = (n_bits + 7) // 8
+    buf = C.create_string_buffer(emlen)
+    if _lib().bftkv_host_emsa_encode(hash_id, digest, len(digest), n_bits, C.cast(buf, C.c_void_p), emlen):
+        raise ValueError("crypto: invalid input")
+    return buf.raw
+
+
 class Client:
     """The vote-collecting half of protocol.Client (protocol/client.go) over a GPU context."""
 
@@ -337,6 +387,35 @@ class Client:
         return data, consumed, err
 
     @staticmethod
+    def vote_fold(q: Quorum, rounds: Sequence[Sequence[Tuple[int, bool]]]):
+        """client.go:67-86 / 108-123 for a batch of Multicast rounds of (peer, accepted) replies.
+        Returns (consumed[i], is_threshold[i])."""
+        flat = [r for rs in rounds for r in rs]
+        peers = np.ascontiguousarray(np.array([r[0] for r in flat], dtype=np.uint64))
+        ok = np.ascontiguousarray(np.array([1 if r[1] else 0 for r in flat], dtype=np.uint8))
+        roff = np.zeros(len(rounds) + 1, dtype=np.uint64)
+        roff[1:] = np.cumsum([len(rs) for rs in rounds], dtype=np.uint64)
+        consumed = np.zeros(max(1, len(rounds)), dtype=np.uint32)
+        thr = np.zeros(max(1, len(rounds)), dtype=np.uint8)
+        p = lambda a: a.ctypes.data if a.size else None
+        rc = _lib().bftkv_host_vote_fold(q.h, len(rounds), p(peers), p(ok), roff.ctypes.data, consumed.ctypes.data, thr.ctypes.data)
+        if rc:
+            raise RuntimeError("vote_fold: %d" % rc)
+        return consumed[:len(rounds)], thr[:len(rounds)].astype(bool)
+
+    def equivocation_signers(self, values: Sequence[Tuple[int, bytes]]) -> List[int]:
+        """client.go:304-353 for one (variable, t): values = (value group, ss.Data) per stored reply."""
+        grp = np.ascontiguousarray(np.array([v[0] for v in values], dtype=np.uint32))
+        sb, so = _cat([v[1] or b"" for v in values])
+        out = np.zeros(4096, dtype=np.uint64)
+        n = C.c_uint32(0)
+        rc = _lib().bftkv_host_equivocation_signers(self.ctx.h, len(values), grp.ctypes.data, sb.ctypes.data, so.ctypes.data, out.ctypes.data,
+                                                    len(out), C.byref(n))
+        if rc:
+            raise _native.NativeError("equivocation_signers failed: %d" % rc)
+        return [int(x) for x in out[:n.value]]
+
+    @staticmethod
     def max_timestamped_value(q: Quorum, reads: Sequence[Sequence[Tuple[int, int, bytes]]]):
         """client.go:181-205 for a batch of variables; per read the winning (value, t) or None."""
         flat = [r for rs in reads for r in rs]
@@ -361,6 +440,17 @@ class Server:
     """The verification site of protocol.Server.write (protocol/server.go:286-302) over a GPU context."""
 
     ErrMalformedRequest = 0xFF
+    ErrCertificateNotFound = 0xFE
+    ErrInvalidQuorumCertificate = 0xFD
+
+    def sign_verify(self, q_cert: Quorum, requests: Sequence[bytes]) -> np.ndarray:
+        """server.go:189-214 for a batch of Sign requests."""
+        rb, ro = _cat(requests)
+        err = np.zeros(len(requests), dtype=np.uint8)
+        rc = _lib().bftkv_host_server_sign_verify(self.ctx.h, q_cert.h, len(requests), rb.ctypes.data, ro.ctypes.data, err.ctypes.data)
+        if rc:
+            raise _native.NativeError("server_sign_verify failed: %d" % rc)
+        return err
 
     def __init__(self, ctx: _native.Context):
         self.ctx = ctx

@@ -118,6 +118,44 @@ int bftkv_host_collect_signatures(bftkv_gpu_ctx* ctx, bftkv_quorum* qa, uint32_t
 int bftkv_host_server_write_verify(bftkv_gpu_ctx* ctx, bftkv_quorum* q, uint32_t n_requests,
                                    const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
 
+/* Votes of a Multicast round folded the way Client.Write does it (client.go:67-86, 108-123): an accepted reply
+ * appends the peer to `actives` and stops when IsThreshold(actives); a failed one appends to `failure` and stops
+ * when Reject(failure).  ok[r] != 0: accepted.  consumed_out[i]: replies folded before the callback stopped the
+ * multicast; threshold_out[i]: the final IsThreshold(actives) the caller tests. */
+int bftkv_host_vote_fold(const bftkv_quorum* q, uint32_t n_rounds, const uint64_t* peer_ids, const uint8_t* ok,
+                         const uint64_t* reply_off, uint32_t* consumed_out, uint8_t* threshold_out);
+
+/* Certificates carried in SignaturePacket.Cert: PGPCertificate.Parse / PGPSignature.Issuer
+ * (crypto_pgp.go:236-249, 392-405) reduced to what the path reads -- key material, the self-signature's key
+ * flags (KeysByIdUsage) and the issuer ids of third-party certifications (PGPCertificateInstance.Signers,
+ * crypto_pgp.go:80-88).  Self-signature VERIFICATION (done by openpgp.ReadEntity) is SURVEY.md 8(f)-1, not here. */
+typedef struct bftkv_certs bftkv_certs;
+bftkv_certs* bftkv_host_certs_parse(const uint8_t* cert, uint64_t len);
+void bftkv_host_certs_free(bftkv_certs* c);
+uint32_t bftkv_host_certs_n_entities(const bftkv_certs* c);
+/* entity e: primary key id, number of keys (primary + subkeys), certifier ids (in packet order) */
+int bftkv_host_certs_entity(const bftkv_certs* c, uint32_t e, uint64_t* id_out, uint32_t* n_keys_out,
+                            const uint64_t** certifiers_out, uint32_t* n_certifiers_out);
+int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu_pubkey* out);   /* pointers into c */
+
+/* Server.sign's verification site for a batch of requests (server.go:189-214): packet.Parse; Issuer(sig) = first
+ * entity of sig.Cert; VerifyWithCertificate(TBS(req), sig, issuer) on the GPU; then
+ * ChooseQuorum(AUTH|CERT).IsThreshold(Certificate.Signers(issuer)) with the certifier ids looked up in the
+ * node keyring (crypto_pgp.go:263-272).  err_out: 0 ok, BFTKV_ERR_INVALID_SIGNATURE,
+ * 0xFF malformed request / nil sig, 0xFE crypto.ErrCertificateNotFound, 0xFD bftkv.ErrInvalidQuorumCertificate. */
+int bftkv_host_server_sign_verify(bftkv_gpu_ctx* ctx, const bftkv_quorum* q_cert, uint32_t n_requests,
+                                  const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
+
+/* Equivocation tally of Client.revoke (client.go:304-353) for one variable: values[v] of replies at the same
+ * timestamp t != 0, value group g[v]; ids_out: the signer ids (sorted) that appear, by PARSE ONLY
+ * (CollectiveSignature.Signers), under two different value groups. */
+int bftkv_host_equivocation_signers(bftkv_gpu_ctx* ctx, uint32_t n_values, const uint32_t* group, const uint8_t* ss_blob,
+                                    const uint64_t* ss_off, uint64_t* ids_out, uint32_t cap, uint32_t* n_out);
+
+/* emsaEncode (crypto/threshold/rsa/rsa.go:356-378): 00 01 FF.. 00 prefix digest, emlen = ceil(bits(N)/8);
+ * hash_id is the OpenPGP hash id (2, 8, 9, 10, 11).  BFTKV_E_INVALID when padlen < 3 (crypto.ErrInvalidInput). */
+int bftkv_host_emsa_encode(int hash_id, const uint8_t* digest, uint32_t digest_len, uint32_t n_bits, uint8_t* em_out, uint32_t cap);
+
 /* Client.Read tally (client.go:181-205) for a batch of variables: replies (peer, t, value) in arrival
  * order; value_idx_out[r] = index of the reply whose value wins at the maximum timestamp, or -1 for
  * errInProgress. */

@@ -140,3 +140,87 @@ def test_server_write_verify(gpu_ctx):
         assert err[i] == want, (i, err[i], want)
     assert set(err) == {0, 2, 0xFF}
     assert host.packet.TBSS(reqs[0]) == c.tbss(0)
+
+
+def test_server_sign_verify(gpu_ctx):
+    """Server.sign's checks (server.go:189-214): VerifyWithCertificate with the issuer taken from the request's own
+    certificate, then IsThreshold over the certificate's certifiers under ChooseQuorum(AUTH|CERT)."""
+    from oracle import openpgp as pgp
+    cl, og, hg, host = _world(10)
+    me = cl.replicas[2].key_id
+    og.set_self([me])
+    hg.SetSelfNodes([me])
+    oq = W.Wot(og).choose_quorum(W.AUTH | W.CERT)
+    hq = host.wotqs.New(hg).ChooseQuorum(host.AUTH | host.CERT)
+    assert oq.qcs[0].threshold == 4
+    kr = H.oracle_keyring(cl)                                   # the server's keyring does NOT hold the client
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    rng = np.random.default_rng(12)
+    # a second client certified by too few members, and an outsider nobody certified
+    weak = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 80)[79], "u02 <u02@bftkv.example>")
+    from corpus.keys import DRBG
+    cb.build_entity(weak, [r for r in cl.replicas if r.algo == cb.PK_RSA][:3], DRBG("weak"))
+    reqs, certs = [], []
+    for i in range(24):
+        signer = [cl.client, weak, cl.outsiders[0]][i % 3]
+        x, v, t = b"key%03d" % i, rng.bytes(20), i + 1
+        tbs = cb.serialize_tbs(x, v, t)
+        sigdata = cb.detach_sign(signer, tbs)
+        cert = signer.entity
+        k = i % 8
+        if k == 3: sigdata = cb.detach_sign(signer, tbs + b"x")                       # signature over other bytes
+        if k == 4: cert = cl.replicas[0].entity                                        # certificate of somebody else
+        if k == 5: cert = None                                                         # no certificate
+        if k == 6: sigdata = sigdata + cb.detach_sign(cl.replicas[1], tbs)             # second packet by a key outside the certificate
+        reqs.append(opk.serialize(x, v, t, opk.SignaturePacket(1, 0, False, sigdata, cert)))
+        certs.append(cert)
+    reqs.append(opk.serialize(b"k", b"v", 9))                                          # no signature
+    reqs.append(reqs[0][:-3])
+    err = host.Server(gpu_ctx).sign_verify(hq, reqs)
+    seen = set()
+    for i, r in enumerate(reqs):
+        try:
+            x, v, t, sig, ss, _ = opk.parse(r)
+            want = 0xFF if sig is None else None
+        except opk.PacketError:
+            want = 0xFF
+        if want is None:
+            ents = pgp.read_entities(sig.Cert or b"")
+            if not ents:
+                want = 0xFE
+            elif col.signature_verify_with_certificate(opk.tbs(r), sig, ents[0]) is not None:
+                want = 1
+            else:
+                nodes = [c for c in ents[0].certifiers if kr.get_cert_by_id(c) is not None]
+                want = 0 if oq.is_threshold(nodes) else 0xFD
+        assert err[i] == want, (i, err[i], want)
+        seen.add(int(want))
+    assert seen == {0, 1, 0xFD, 0xFE, 0xFF}
+    # the node keyring is unaffected by certificate entities: collective verification still sees 10 replicas only
+    c = cb.make_write_corpus(cl, 6, mutation_rates={})
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    e2, _, _ = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    assert (e2 == 0).all()
+    client_sig = cb.detach_sign(cl.client, b"abc")
+    assert gpu_ctx.signature_verify(np.frombuffer(b"abc", dtype=np.uint8), np.array([0, 3], dtype=np.uint64),
+                                    np.frombuffer(client_sig, dtype=np.uint8), np.array([0, len(client_sig)], dtype=np.uint64))[0] == 1
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_equivocation_signers(gpu_ctx):
+    """Client.revoke's tally (client.go:304-353): signers common to two different values at one timestamp."""
+    cl, og, hg, host = _world(10)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    tb_a, tb_b = b"value-a", b"value-b"
+    sa = [cb.detach_sign(r, tb_a) for r in cl.replicas]
+    sb = [cb.detach_sign(r, tb_b) for r in cl.replicas]
+    values = [(0, b"".join(sa[:7])), (0, b"".join(sa[2:8])), (1, b"".join(sb[5:10])), (1, b"".join(sb[6:9]) + cb.detach_sign(cl.outsiders[0], tb_b)),
+              (2, b"")]
+    got = host.Client(gpu_ctx).equivocation_signers(values)
+    by_group = {}
+    for g, data in values:
+        by_group.setdefault(g, set()).update(col.signers(kr, opk.SignaturePacket(1, 0, False, data or None, None)))
+    want = sorted(i for i in set().union(*by_group.values()) if sum(i in s for s in by_group.values()) >= 2)
+    assert got == want == sorted(r.key_id for r in cl.replicas[5:8])

@@ -146,3 +146,69 @@ def test_max_timestamped_value_matches_oracle(H):
     for r, g in zip(reads, got):
         assert g == col.max_timestamped_value(r, oq)
     assert any(g is not None for g in got) and any(g is None for g in got)
+
+
+def test_certificate_parse_matches_oracle(H):
+    import json
+    from corpus import build as cb
+    from oracle import openpgp as pgp
+    cl = cb.make_cluster(10, dsa_fraction=0.3)
+    blobs = [cl.client.entity, b"".join(r.entity for r in cl.replicas[:4]), cl.replicas[5].entity + cl.client.entity]
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "gpg_vectors.json")))
+    blobs.append(bytes.fromhex(vec["A_pubring"]))            # gpg-made entities: subkeys, SHA-512 self-signatures
+    blobs.append(cl.client.entity[:-40])                     # truncated last packet
+    blobs.append(b"")
+    for blob in blobs:
+        want = pgp.read_entities(blob)
+        got = H.Certificate.Parse(blob)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g["id"] == w.id and g["certifiers"] == w.certifiers
+            wkeys = [(w.primary, w.flags_valid, w.flag_sign, w.self_sig_revoked)] + [(k, fv, fs, False) for k, fv, fs in w.subkeys]
+            assert len(g["keys"]) == len(wkeys)
+            for gk, (wk, fv, fs, rr) in zip(g["keys"], wkeys):
+                assert gk["key_id"] == wk.key_id and gk["pk_algo"] == wk.pk_algo
+                assert gk["usable_sign"] == (not (w.revoked or rr) and not (fv and not fs))
+                if wk.pk_algo == 17:
+                    assert [int.from_bytes(gk[x], "big") for x in "negy"] == [wk.p, wk.q, wk.g, wk.y]
+                else:
+                    assert int.from_bytes(gk["n"], "big") == wk.n and int.from_bytes(gk["e"], "big") == wk.e
+    assert H.Certificate.Parse(cl.client.entity)[0]["certifiers"] == cl.client.certifiers
+
+
+def test_vote_fold_matches_reference_fold(H):
+    rng = np.random.default_rng(4)
+    oq = W.WotQ([W.new_qc(list(range(1, 11)), 10, W.READ | W.AUTH, 0), W.new_qc(list(range(20, 26)), 0, W.READ, 0)])
+    hq = H.Quorum.from_qcs([(q.f, q.min, q.threshold, q.suff, q.nodes) for q in oq.qcs])
+    rounds = [[(int(p), bool(rng.random() < 0.7)) for p in rng.permutation(list(range(1, 11)) + list(range(20, 26)))[:int(rng.integers(0, 17))]]
+              for _ in range(100)]
+    consumed, thr = H.Client.vote_fold(hq, rounds)
+    for rs, c, t in zip(rounds, consumed, thr):
+        actives, failure, n = [], [], 0
+        for peer, ok in rs:                      # client.go:67-86
+            n += 1
+            if ok:
+                actives.append(peer)
+                stop = oq.is_threshold(actives)
+            else:
+                failure.append(peer)
+                stop = oq.reject(failure)
+            if stop:
+                break
+        assert (c, bool(t)) == (n, oq.is_threshold(actives))
+    assert thr.any() and not thr.all()
+
+
+def test_emsa_encode_matches_oracle_and_kat(H):
+    import hashlib
+    import json
+    from oracle import threshold as T
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "threshold_kat.json")))
+    n = int(kat["rsa"]["n"], 16)
+    for hid, name in ((2, "sha1"), (8, "sha256"), (9, "sha384"), (10, "sha512"), (11, "sha224")):
+        d = hashlib.new(name, b"tbs").digest()
+        assert int.from_bytes(H.emsa_encode(hid, d, n.bit_length()), "big") == T.emsa_encode(name, d, n)
+    with pytest.raises(ValueError):
+        H.emsa_encode(10, b"x" * 64, 600)        # padlen < 3 => crypto.ErrInvalidInput
+    em = H.emsa_encode(8, hashlib.sha256(kat["rsa"]["tbs"].encode()).digest(), n.bit_length())
+    assert pow(int(kat["rsa"]["sha256_pkcs1v15_sig"], 16), kat["rsa"]["e"], n) == int.from_bytes(em, "big")
