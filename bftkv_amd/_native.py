@@ -38,7 +38,7 @@ EXPORTS = [
     "bftkv_gpu_signature_verify", "bftkv_gpu_last_statuses", "bftkv_gpu_last_counters",
     "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
-    "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts",
+    "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
 ]
 
 _lib = None
@@ -77,6 +77,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_lagrange_combine.argtypes = [vp, u32, u32, vp, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_dsa_calculate_r.argtypes = [vp, u32, u32, vp, u8p, u32, u8p, u32, vp, u32, u8p, u8p, u8p, u8p]
     lib.bftkv_gpu_stream.argtypes = [vp]
+    lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
+    lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_comm_unique_id.argtypes = [u8p]
     lib.bftkv_gpu_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
@@ -280,6 +282,26 @@ class Context:
         self._check(self.lib.bftkv_gpu_dsa_calculate_r(self.h, n, k, _ptr(x), _ptr(r), pbytes, _ptr(v), qbytes, _ptr(gi), len(groups), _ptr(p),
                                                        _ptr(q), _ptr(out), _ptr(st)), "dsa_calculate_r")
         return [int.from_bytes(out[i].tobytes(), "big") for i in range(n)], st[:n]
+
+    def sss_distribute(self, polys, n_shares: int, moduli, mod_idx, nbytes: int = 256):
+        """polys: [n_polys][k] ints (polys[p][0] = secret) -> [n_polys][n_shares] ints (sss.go:23-47)."""
+        n, k = len(polys), len(polys[0])
+        cf = _ints_to_be([c for row in polys for c in row], nbytes)
+        m = _ints_to_be(moduli, nbytes)
+        mi = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros((n * n_shares, nbytes), dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_sss_distribute(self.h, n, n_shares, k, _ptr(cf), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out)),
+                    "sss_distribute")
+        return [[int.from_bytes(out[p * n_shares + x].tobytes(), "big") for x in range(n_shares)] for p in range(n)]
+
+    def modinv(self, values, moduli, mod_idx, nbytes: int = 256):
+        v = _ints_to_be(values, nbytes)
+        m = _ints_to_be(moduli, nbytes)
+        mi = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros((len(values), nbytes), dtype=np.uint8)
+        st = np.zeros(len(values) + 8, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_modinv(self.h, len(values), _ptr(v), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out), _ptr(st)), "modinv")
+        return [int.from_bytes(out[i].tobytes(), "big") for i in range(len(values))], st[:len(values)]
 
     def modexp(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
         """base [n, nbytes] u8 BE; mods [m, nbytes]; exps [m, exp_len] -> [n, nbytes]."""

@@ -315,3 +315,97 @@ __global__ void __launch_bounds__(64) k_limbs_mod_q(uint32_t n_ops, const uint32
 }
 
 }  // namespace bftkv
+
+namespace bftkv {
+
+// ---- sss.Distribute (crypto/sss/sss.go:23-47): f(x) = sum_j poly_j x^j mod m for x = 1..n ------------------------
+// quad per (op, x); Horner over the Montgomery multiplier, the small x as a one-limb operand.
+__global__ void __launch_bounds__(RSA_BLOCK) k_sss_distribute(uint32_t n_ops_total /* = n_polys * n_shares */, uint32_t n_shares, uint32_t k_coeffs,
+                                                              const uint32_t* __restrict__ poly_limbs /*[n_polys][k][76]*/,
+                                                              const uint32_t* __restrict__ mod_idx /*[n_polys]*/, ModTab mt,
+                                                              uint32_t* __restrict__ out_limbs /*[n_polys][n_shares][76]*/) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  const uint32_t n_ops = n_ops_total;
+  QUAD_SETUP();
+  const uint32_t poly = op / n_shares, x = op % n_shares + 1;
+  const uint32_t mi = mod_idx[poly];
+  uint32_t n[L], r2[L], acc[L], t[L], u[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  const uint32_t n0inv = mt.n0inv[mi];
+  const uint32_t* pp = poly_limbs + (uint64_t)poly * k_coeffs * MONT_N + qlane * L;
+#pragma unroll
+  for (int k = 0; k < L; ++k) acc[k] = pp[(uint64_t)(k_coeffs - 1) * MONT_N + k];
+  for (int j = (int)k_coeffs - 2; j >= 0; --j) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = acc[k];
+    MONT(t, r2);                                                     // acc * R
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? x : 0u;
+    MONT(u, t);                                                      // acc * x  (< 2m)
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = u[k] + pp[(uint64_t)j * MONT_N + k];
+    canonicalize(acc, qlane);                                        // < 3m < R
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = acc[k];
+  MONT(t, r2);
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(u, t);
+  canonicalize(u, qlane);
+  if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
+}
+
+// ---- modular inverse of up to 2048-bit numbers, odd modulus, by binary extended GCD (thread per op) -------------
+// big.Int.ModInverse inside rsaContext.Sign for negative key fragments (crypto/threshold/rsa/rsa.go:164-167).
+constexpr int INV_W = 68;   // 32-bit words: 2176 bits, headroom for x + n
+struct BigW { uint32_t w[INV_W]; };
+__device__ __forceinline__ bool bw_is_zero(const BigW& a) { uint32_t o = 0; for (int i = 0; i < INV_W; ++i) o |= a.w[i]; return o == 0; }
+__device__ __forceinline__ bool bw_is_one(const BigW& a) { uint32_t o = a.w[0] ^ 1u; for (int i = 1; i < INV_W; ++i) o |= a.w[i]; return o == 0; }
+__device__ __forceinline__ int bw_cmp(const BigW& a, const BigW& b) { int r = 0; for (int i = 0; i < INV_W; ++i) if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; return r; }
+__device__ __forceinline__ void bw_add(BigW& a, const BigW& b) { uint64_t c = 0; for (int i = 0; i < INV_W; ++i) { c += (uint64_t)a.w[i] + b.w[i]; a.w[i] = (uint32_t)c; c >>= 32; } }
+__device__ __forceinline__ uint32_t bw_sub(BigW& a, const BigW& b) { uint64_t br = 0; for (int i = 0; i < INV_W; ++i) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; } return (uint32_t)br; }
+__device__ __forceinline__ void bw_shr1(BigW& a) { for (int i = 0; i < INV_W - 1; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 31); a.w[INV_W - 1] >>= 1; }
+
+__global__ void __launch_bounds__(64) k_modinv(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx, ModTab mt,
+                                               uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status) {
+  const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
+  if (op >= n_ops) return;
+  auto load = [](const uint32_t* l, BigW& o) {
+    for (int i = 0; i < INV_W; ++i) o.w[i] = 0;
+    for (int j = 0; j < MONT_N; ++j) {
+      const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
+      const uint64_t v = (uint64_t)l[j] << sh;
+      o.w[wi] |= (uint32_t)v;
+      if (wi + 1 < INV_W) o.w[wi + 1] |= (uint32_t)(v >> 32);
+    }
+  };
+  BigW u, v, x1, x2, q;
+  load(in_limbs + (uint64_t)op * MONT_N, u);
+  load(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N, q);
+  v = q;
+  while (bw_cmp(u, q) >= 0) bw_sub(u, q);            // ModInverse reduces its argument first (at most a few rounds for < R)
+  for (int i = 0; i < INV_W; ++i) { x1.w[i] = 0; x2.w[i] = 0; }
+  x1.w[0] = 1;
+  bool ok = false, done = false;
+  for (int guard = 0; guard < 2 * 2176 + 8 && !done; ++guard) {
+    if (bw_is_one(u)) { ok = true; done = true; break; }
+    if (bw_is_one(v)) { x1 = x2; ok = true; done = true; break; }
+    if (bw_is_zero(u) || bw_is_zero(v)) { done = true; break; }
+    while (!(u.w[0] & 1u)) { bw_shr1(u); if (x1.w[0] & 1u) bw_add(x1, q); bw_shr1(x1); }
+    while (!(v.w[0] & 1u)) { bw_shr1(v); if (x2.w[0] & 1u) bw_add(x2, q); bw_shr1(x2); }
+    if (bw_cmp(u, v) >= 0) { bw_sub(u, v); if (bw_sub(x1, x2)) bw_add(x1, q); }
+    else { bw_sub(v, u); if (bw_sub(x2, x1)) bw_add(x2, q); }
+  }
+  if (!ok) atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3)));
+  uint32_t* o = out_limbs + (uint64_t)op * MONT_N;
+  for (int j = 0; j < MONT_N; ++j) {
+    const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
+    uint64_t w = x1.w[wi];
+    if (wi + 1 < INV_W) w |= (uint64_t)x1.w[wi + 1] << 32;
+    o[j] = ok ? ((uint32_t)(w >> sh) & MONT_MASK) : 0u;
+  }
+}
+
+}  // namespace bftkv

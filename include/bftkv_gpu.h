@@ -175,6 +175,15 @@ int bftkv_gpu_dsa_calculate_r(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, co
                               const uint8_t* vi, uint32_t qbytes, const uint32_t* group_idx, uint32_t n_groups,
                               const uint8_t* p, const uint8_t* q, uint8_t* r_out, uint8_t* status_out);
 
+/* shares[poly][x-1] = sum_j coeffs[poly][j] * x^j mod m for x = 1..n_shares -- sss.Distribute (crypto/sss/sss.go:23-47)
+ * with the random coefficients supplied by the caller (coeffs[poly][0] is the secret). */
+int bftkv_gpu_sss_distribute(bftkv_gpu_ctx* ctx, uint32_t n_polys, uint32_t n_shares, uint32_t k, const uint8_t* coeffs, uint32_t nbytes,
+                             const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods, uint8_t* shares_out);
+/* out[op] = values[op]^-1 mod m (any odd m, exact binary extended GCD; status 1: no inverse) -- the ModInverse of
+ * rsaContext.Sign for negative key fragments (crypto/threshold/rsa/rsa.go:164-167). */
+int bftkv_gpu_modinv(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods,
+                     const uint8_t* mods, uint8_t* out, uint8_t* status_out);
+
 /* ---- timing of the last *_dev verify call (HIP events on the context's stream) ---------------- */
 /* ms[0] whole call, ms[1] walk+parse, ms[2] hash stream (midstates+digests, overlaps the modexp),
  * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream) */

@@ -91,3 +91,55 @@ def test_dsa_calculate_r(gpu_ctx):
         assert want[-1] == pow(g, pow(kk, -1, q), p) % q
     got, st = gpu_ctx.dsa_calculate_r(xs, ri, vi, [(p, q)], [0] * len(xs))
     assert list(st) == [0] * len(xs) and got == want
+
+
+def test_sss_distribute_and_round_trip(gpu_ctx):
+    """sss.Distribute on the GPU == the restatement; Distribute -> (drop shares) -> calculateSecret recovers the secret."""
+    s = KAT["sss"]
+    m = int(s["pb"], 16)
+    q = int(KAT["dsa_group"]["q"], 16)
+    rng = np.random.default_rng(10)
+    polys, mi, moduli = [], [], [m, q, 1237]
+    for trial in range(9):
+        mod_i = trial % 3
+        mod = moduli[mod_i]
+        polys.append([int.from_bytes(rng.bytes(260), "big") % mod for _ in range(7)])
+        mi.append(mod_i)
+    polys[0][0] = int.from_bytes(s["secret"].encode(), "big")
+    polys.append(KAT["auth_sss_example"]["poly"] + [0, 0, 0]); mi.append(2)
+    shares = gpu_ctx.sss_distribute(polys, 10, moduli, mi)
+    for p, sh, i in zip(polys, shares, mi):
+        assert sh == [y for _, y in T.distribute(p[0], 10, 7, moduli[i], p[1:])]
+    xs = [[int(x) + 1 for x in rng.choice(10, size=7, replace=False)] for _ in polys]
+    ys = [[sh[x - 1] for x in xr] for sh, xr in zip(shares, xs)]
+    got, st = gpu_ctx.lagrange_combine(xs, ys, moduli, mi)
+    assert list(st) == [0] * len(polys) and got == [p[0] for p in polys]
+    assert got[0].to_bytes(6, "big") == b"secret"
+
+
+def test_partial_sign_with_negative_fragments(gpu_ctx):
+    """rsaContext.Sign per fragment (rsa.go:161-171): m^|d_i| mod N by the modexp kernel, inverted on the GPU when the
+    fragment is negative; the product of all fragments' partial signatures is the PKCS#1 signature (TestCombine)."""
+    r = KAT["rsa"]
+    n, d = int(r["n"], 16), int(r["d"], 16)
+    rng = np.random.default_rng(11)
+    m = T.emsa_encode("sha256", hashlib.sha256(r["tbs"].encode()).digest(), n)
+    di = T.split_key(d, 10, [int.from_bytes(rng.bytes(513), "big") % (1 << (2 * d.bit_length())) for _ in range(9)])
+    nb = 520
+    base = np.frombuffer(b"".join(m.to_bytes(256, "big") for _ in di), dtype=np.uint8).reshape(len(di), 256).copy()
+    exps = np.frombuffer(b"".join(abs(x).to_bytes(nb, "big") for x in di), dtype=np.uint8).reshape(len(di), nb).copy()
+    mods = np.frombuffer(b"".join(n.to_bytes(256, "big") for _ in di), dtype=np.uint8).reshape(len(di), 256).copy()
+    out = gpu_ctx.modexp(base, np.arange(len(di), dtype=np.uint32), mods, exps)
+    ci = [int.from_bytes(out[i].tobytes(), "big") for i in range(len(di))]
+    neg = [i for i, x in enumerate(di) if x < 0]
+    assert neg
+    inv, st = gpu_ctx.modinv([ci[i] for i in neg], [n], [0] * len(neg))
+    assert list(st) == [0] * len(neg)
+    for i, v in zip(neg, inv):
+        ci[i] = v
+    assert ci == [T.partial_sign(m, x, n) for x in di]
+    assert T.i2os(gpu_ctx.modmul_product([ci], [n], [0])[0], 256).hex() == r["sha256_pkcs1v15_sig"]
+    # no inverse: a multiple of a factor of N; zero
+    p = int(r["p"], 16)
+    vals, st = gpu_ctx.modinv([p, 0, 3 * p, 5, n + 7], [n], [0] * 5)
+    assert list(st) == [1, 1, 1, 0, 0] and vals[3] == pow(5, -1, n) and vals[4] == pow(7, -1, n)
