@@ -76,13 +76,14 @@ struct bftkv_gpu_ctx {
   std::vector<uint8_t> h_key_flags;
   std::vector<KeyEntry> ring, certs;   // processed rows: node keyring, then certificate-only entities
   uint32_t n_ring_entities = 0;
+  std::map<std::string, bool> cert_valid;   // certificate bytes -> openpgp.ReadEntity would accept it
   DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab;
   KeyTableDev kt{};
 
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
+  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
@@ -94,6 +95,8 @@ struct bftkv_gpu_ctx {
 };
 
 void rccl_release(bftkv_gpu_ctx* c);
+extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
+                                         const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class = nullptr);
 
 namespace {
 
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 // the parse): SHA-256 midstates -> per-signature digests; joined before the compare.  Leaves SigRec
 // statuses final.
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
-                 const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent) {
+                 const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr) {
   hipStream_t s = c->stream, sh = c->stream_h;
   if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
@@ -257,7 +260,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, d_ss_off, c->base.as<uint32_t>(),
                        c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
                        d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
-                       c->hash_mask.as<uint32_t>());
+                       c->hash_mask.as<uint32_t>(), d_sig_class);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   // hash stream: digests need the parsed records
@@ -462,7 +465,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab,
-                    &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
+                    &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
@@ -513,6 +516,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   }
   c->ring = std::move(ring);
   c->certs.clear();
+  c->cert_valid.clear();
   return upload_key_table(c);
 }
 
@@ -625,7 +629,7 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
 // Signature.Verify over a batch with the keyring of item i restricted to entity index ent[i] (0xFFFFFFFF: the node
 // keyring).  Shared by bftkv_gpu_signature_verify and the Server.sign site of the host mirror.
 int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
-                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out) {
+                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t tl = tbs_off[n_items], sl = sig_off[n_items];
@@ -644,8 +648,14 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
     HIPCHK(c, hipMemcpyAsync(c->cert_ent.p, ent, sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
     d_cert = c->cert_ent.as<uint32_t>();
   }
+  const uint8_t* d_cls = nullptr;
+  if (sig_class) {
+    HIPCHK(c, c->sig_class.ensure(n_items + 16));
+    HIPCHK(c, hipMemcpyAsync(c->sig_class.p, sig_class, n_items, hipMemcpyHostToDevice, c->stream));
+    d_cls = c->sig_class.as<uint8_t>();
+  }
   int rc = run_pipeline(c, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
-                        c->in_ss_off.as<uint64_t>(), d_cert);
+                        c->in_ss_off.as<uint64_t>(), d_cert, d_cls);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sigverify_fold, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(),
                      c->base.as<uint32_t>(), c->counts.as<uint32_t>(), c->item_flags.as<uint8_t>(), n_items, c->o_err.as<uint8_t>());
@@ -830,8 +840,6 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 }  // extern "C"
 
-extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
-                                         const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out);
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"
 #include "host_capi.inc"

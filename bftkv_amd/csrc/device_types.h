@@ -70,6 +70,9 @@ constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;
 // key only exists inside a request's certificate: invisible to keyring lookups, reachable when the lookup is
 // restricted to its entity (PGPSignature.VerifyWithCertificate, crypto_pgp.go:332-344)
 constexpr uint8_t KEYF_CERT_ONLY = 8;
+// certificate key whose self-signature forbids data signatures (key flags without Sign): it still verifies the
+// certificate's own self-signatures / bindings (sig_class != 0) but never a detached signature
+constexpr uint8_t KEYF_CERT_CHECK_ONLY = 16;
 
 // Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.
 constexpr int MAX_QC = 8;

@@ -255,6 +255,13 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   if (!FILL) { counts[item] = n; item_flags[item] = trailing_skip ? 1 : 0; }
 }
 
+__device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
+  if (cls == 0) return sig_type == 0x00;
+  if (cls == 1) return sig_type >= 0x10 && sig_type <= 0x13;
+  if (cls == 2) return sig_type == 0x18;
+  return false;
+}
+
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
 __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                                     const uint32_t* __restrict__ rec_base, const uint32_t* __restrict__ counts,
@@ -262,7 +269,8 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
                                                     SigRec* __restrict__ recs, uint32_t n_recs,
                                                     KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
                                                     uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count /*[0] RSA, [1] DSA*/,
-                                                    uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask) {
+                                                    uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask,
+                                                    const uint8_t* __restrict__ sig_class /*per item or null*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
@@ -299,8 +307,10 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       // KeysByIdUsage(issuer, KeyFlagSign): first usable key with that id (ids are unique in the
       // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
       int32_t slot = -1;
+      const uint32_t cls = sig_class ? sig_class[rec.item] : 0;
       for (uint32_t k = 0; k < kt.n_keys; ++k) {
-        if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_USABLE_SIGN) &&
+        const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
+        if (kt.key_id[k] == issuer && usable &&
             (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
           slot = (int32_t)k;
           break;
@@ -310,7 +320,10 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       const HashInfo hi = hash_info(rec.hash_id);
       const uint32_t hlen = hi.dlen, plen = hi.plen;
       if (slot < 0) st = ST_UNKNOWN_ISSUER;
-      else if (rec.sig_type != 0x00) st = ST_HASH_UNSUPPORTED;            // hashForSignature: binary only (text: fenced)
+      // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
+      // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
+      // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
+      else if (!sig_class_ok(cls, rec.sig_type)) st = ST_HASH_UNSUPPORTED;
       else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {

@@ -44,7 +44,8 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
-    "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode",
+    "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
+    "bftkv_host_quorum_cert_verify",
 ]
 
 _ready = False
@@ -96,6 +97,8 @@ def _lib():
         lib.bftkv_host_certs_key.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(_native.PubKey)]
         lib.bftkv_host_server_sign_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_equivocation_signers.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.bftkv_host_certs_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.bftkv_host_quorum_cert_verify.argtypes = [vp, vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.bftkv_host_emsa_encode.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_uint32]
         _ready = True
     return lib
@@ -341,6 +344,27 @@ class Certificate:
         finally:
             lib.bftkv_host_certs_free(h)
         return out
+
+
+def certs_verify(ctx: _native.Context, cert: bytes) -> List[bool]:
+    """Which entities of a certificate blob openpgp.ReadEntity would accept (self-signatures, subkey bindings)."""
+    valid = np.zeros(64, dtype=np.uint8)
+    n = C.c_uint32(0)
+    rc = _lib().bftkv_host_certs_verify(ctx.h, cert, len(cert), valid.ctypes.data, len(valid), C.byref(n))
+    if rc:
+        raise _native.NativeError("certs_verify failed: %d" % rc)
+    return [bool(v) for v in valid[:n.value]]
+
+
+def quorum_cert_verify(ctx: _native.Context, q: "Quorum", cert: bytes):
+    """CheckQuorumCert of the paper: (IsThreshold over VERIFIED certifiers, their ids)."""
+    ok = np.zeros(4, dtype=np.uint8)
+    ids = np.zeros(1024, dtype=np.uint64)
+    n = C.c_uint32(0)
+    rc = _lib().bftkv_host_quorum_cert_verify(ctx.h, q.h, cert, len(cert), ok.ctypes.data, ids.ctypes.data, len(ids), C.byref(n))
+    if rc:
+        raise _native.NativeError("quorum_cert_verify failed: %d" % rc)
+    return bool(ok[0]), [int(x) for x in ids[:n.value]]
 
 
 def emsa_encode(hash_id: int, digest: bytes, n_bits: int) -> bytes:

@@ -159,12 +159,23 @@ def certify(signer: KeyPair, signee: KeyPair, uid: bytes, sig_type: int, rng: Op
     return make_sig_packet(signer, prefix, digest, rng)
 
 
-def build_entity(kp: KeyPair, certifiers: Sequence[KeyPair], rng: DRBG) -> None:
+def bind_subkey(primary: KeyPair, sub: KeyPair, rng: Optional[DRBG] = None) -> bytes:
+    """Public-subkey packet (tag 14) + subkey binding signature (0x18, key flags = encrypt) by the primary key."""
+    prefix = sig_prefix(0x18, primary.algo, _hashed_area(primary.key_id, b"\x02\x1b\x0c"))
+    signed = (b"\x99" + struct.pack(">H", len(primary.pub_body)) + primary.pub_body +
+              b"\x99" + struct.pack(">H", len(sub.pub_body)) + sub.pub_body)
+    digest = hashlib.sha256(signed + hash_suffix(prefix)).digest()
+    return _hdr(14, len(sub.pub_body)) + sub.pub_body + make_sig_packet(primary, prefix, digest, rng)
+
+
+def build_entity(kp: KeyPair, certifiers: Sequence[KeyPair], rng: DRBG, subkey: Optional[KeyPair] = None) -> None:
     uid = kp.name.encode()
     out = _hdr(6, len(kp.pub_body)) + kp.pub_body + _hdr(13, len(uid)) + uid
     out += certify(kp, kp, uid, 0x13, rng)
     for c in certifiers:
         out += certify(c, kp, uid, 0x10, rng)
+    if subkey is not None:
+        out += bind_subkey(kp, subkey, rng)
     kp.entity = out
     kp.certifiers = [c.key_id for c in certifiers]
 

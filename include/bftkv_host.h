@@ -138,10 +138,24 @@ int bftkv_host_certs_entity(const bftkv_certs* c, uint32_t e, uint64_t* id_out, 
                             const uint64_t** certifiers_out, uint32_t* n_certifiers_out);
 int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu_pubkey* out);   /* pointers into c */
 
+/* What openpgp.ReadEntity verifies while reading, on the GPU: every user-id self-signature
+ * (classes 0x10 / 0x13 issued by the primary key, over 0x99 len key || 0xB4 len uid) and every subkey binding
+ * (0x18, over 0x99 len key || 0x99 len subkey) with the entity's own primary key.  valid_out[e] = 1 iff the entity
+ * has a signing-capable primary key, at least one validly self-signed identity, no invalid self-signature and a valid
+ * binding for every subkey.  (The embedded cross-signature of signing subkeys is not checked: fenced.) */
+int bftkv_host_certs_verify(bftkv_gpu_ctx* ctx, const uint8_t* cert, uint64_t len, uint8_t* valid_out, uint32_t cap, uint32_t* n_out);
+
+/* CheckQuorumCert as the paper states it (docs/tex/algo.tex:68-83; the code only counts certifier key ids,
+ * server.go:211-214): the third-party certifications on the FIRST entity of `cert` that verify under a key of the node
+ * keyring; ok_out = q.IsThreshold(verified certifiers). */
+int bftkv_host_quorum_cert_verify(bftkv_gpu_ctx* ctx, const bftkv_quorum* q, const uint8_t* cert, uint64_t len, uint8_t* ok_out,
+                                  uint64_t* verified_ids_out, uint32_t cap, uint32_t* n_out);
+
 /* Server.sign's verification site for a batch of requests (server.go:189-214): packet.Parse; Issuer(sig) = first
  * entity of sig.Cert; VerifyWithCertificate(TBS(req), sig, issuer) on the GPU; then
  * ChooseQuorum(AUTH|CERT).IsThreshold(Certificate.Signers(issuer)) with the certifier ids looked up in the
- * node keyring (crypto_pgp.go:263-272).  err_out: 0 ok, BFTKV_ERR_INVALID_SIGNATURE,
+ * node keyring (crypto_pgp.go:263-272).  An issuer entity that ReadEntity would refuse (bftkv_host_certs_verify) is
+ * no issuer at all.  err_out: 0 ok, BFTKV_ERR_INVALID_SIGNATURE,
  * 0xFF malformed request / nil sig, 0xFE crypto.ErrCertificateNotFound, 0xFD bftkv.ErrInvalidQuorumCertificate. */
 int bftkv_host_server_sign_verify(bftkv_gpu_ctx* ctx, const bftkv_quorum* q_cert, uint32_t n_requests,
                                   const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);

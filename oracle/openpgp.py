@@ -601,7 +601,7 @@ def read_entities(blob: bytes) -> List[Entity]:
                 if s.sig_type == 0x18 and cur.subkeys:
                     k, _, _ = cur.subkeys[-1]
                     cur.subkeys[-1] = (k, s.flags_valid, s.flag_sign)
-            elif s.sig_type in (0x10, 0x11, 0x12, 0x13):
+            elif s.sig_type in (0x10, 0x11, 0x12, 0x13) and cur.name:   # only signatures that follow a user id attach
                 if s.issuer == cur.primary.key_id:
                     if not cur._have_self:
                         cur.flags_valid, cur.flag_sign, cur.flag_certify = s.flags_valid, s.flag_sign, s.flag_certify
@@ -613,3 +613,86 @@ def read_entities(blob: bytes) -> List[Entity]:
                 cur.revoked = True
         cur.serialized = blob[cur._start:pos]
     return ents
+
+
+# ------------------------------------------------------------------------------------------------
+# What openpgp.ReadEntity VERIFIES while reading (B.6): user-id self-signatures and subkey bindings
+# (SURVEY.md 8(f)-1); third-party certifications are only collected -- verifying them is what the
+# paper's CheckQuorumCert asks for (docs/tex/algo.tex:68-83).
+# ------------------------------------------------------------------------------------------------
+def _verify_with_key(key: PublicKey, signed: bytes, sig: Signature) -> bool:
+    name = HASH_BY_ID.get(sig.hash_id)
+    if name in (None, "md5", "ripemd160"):
+        return False
+    h = hashlib.new(name)
+    h.update(signed)
+    h.update(sig.hash_suffix)
+    return verify_signature(key, sig.hash_id, h.digest(), sig) == ST_OK
+
+
+def entity_checks(blob: bytes):
+    """Per entity of a certificate blob: (entity_valid, [verified third-party certifier ids are computed by the caller]).
+    Returns a list of dicts: primary, valid (ReadEntity would accept it), third_party = [(issuer, signed_data, Signature)]."""
+    out = []
+    pos = 0
+    cur = None
+    key_hdr = last_uid = last_sub = b""
+    in_sub = False
+    while pos < len(blob):
+        try:
+            pkt = next_packet(blob, pos)
+        except (EOFError, _Truncated, StructuralError, UnsupportedError):
+            break
+        pos = pkt.end
+        if pkt.tag == 6:
+            try:
+                pk = parse_public_key_body(pkt.body)
+            except Exception:
+                break
+            cur = {"primary": pk, "valid": pk.can_sign(), "uids_ok": 0, "third_party": [], "subkeys": 0, "bound": 0}
+            out.append(cur)
+            key_hdr = b"\x99" + struct.pack(">H", len(pkt.body)) + pkt.body
+            last_uid, in_sub = b"", False
+        elif cur is None:
+            continue
+        elif pkt.tag == 13:
+            last_uid = b"\xb4" + struct.pack(">I", len(pkt.body)) + pkt.body
+            in_sub = False
+        elif pkt.tag == 14:
+            last_sub = b"\x99" + struct.pack(">H", len(pkt.body)) + pkt.body
+            in_sub = True
+            cur["subkeys"] += 1
+        elif pkt.tag == 2:
+            try:
+                s = parse_signature_body(pkt.body)
+            except Exception:
+                continue
+            if in_sub:
+                if s.sig_type == 0x18:
+                    cur["bound"] += 1
+                    if not _verify_with_key(cur["primary"], key_hdr + last_sub, s):
+                        cur["valid"] = False          # "subkey signature invalid"
+            elif s.sig_type in (0x10, 0x11, 0x12, 0x13) and last_uid:
+                if s.issuer == cur["primary"].key_id:
+                    if s.sig_type in (0x10, 0x13):
+                        if _verify_with_key(cur["primary"], key_hdr + last_uid, s):
+                            cur["uids_ok"] += 1
+                        else:
+                            cur["valid"] = False      # "user ID self-signature invalid"
+                elif s.issuer is not None:
+                    cur["third_party"].append((s.issuer, key_hdr + last_uid, s))
+    for e in out:
+        if e["uids_ok"] == 0 or e["bound"] < e["subkeys"]:
+            e["valid"] = False                        # no self-signed identity / subkey without binding signature
+    return out
+
+
+def verified_certifiers(blob_entity: dict, keyring: List[Entity]) -> List[int]:
+    """CheckQuorumCert: ids of keyring members whose certification over (key, uid) verifies."""
+    ids = []
+    for issuer, signed, sig in blob_entity["third_party"]:
+        for ent, key in keys_by_id_usage_sign(keyring, issuer):
+            if _verify_with_key(key, signed, sig):
+                ids.append(ent.id)
+                break
+    return ids

@@ -224,3 +224,54 @@ def test_equivocation_signers(gpu_ctx):
         by_group.setdefault(g, set()).update(col.signers(kr, opk.SignaturePacket(1, 0, False, data or None, None)))
     want = sorted(i for i in set().union(*by_group.values()) if sum(i in s for s in by_group.values()) >= 2)
     assert got == want == sorted(r.key_id for r in cl.replicas[5:8])
+
+
+def test_entity_verification_and_quorum_certificate(gpu_ctx):
+    """what openpgp.ReadEntity verifies (uid self-signatures, subkey bindings) and the paper's
+    CheckQuorumCert (certifications verified, not just counted), on the GPU, against the oracle and GnuPG's verdict."""
+    import json
+    import os
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp
+    cl, og, hg, host = _world(10)
+    me = cl.replicas[1].key_id
+    og.set_self([me]); hg.SetSelfNodes([me])
+    oq = W.Wot(og).choose_quorum(W.AUTH | W.CERT)
+    hq = host.wotqs.New(hg).ChooseQuorum(host.AUTH | host.CERT)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    # an entity with an (encryption) subkey
+    sub_owner = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 82)[80], "s01 <s01@bftkv.example>")
+    sub = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 82)[81], "")
+    cb.build_entity(sub_owner, [], DRBG("sub"), subkey=sub)
+
+    def flip(blob, marker_from_end):
+        b = bytearray(blob); b[len(b) - marker_from_end] ^= 0x20; return bytes(b)
+    client = cl.client.entity
+    selfsig_end = client.index(b"\xc2", client.index(cl.client.name.encode()))    # first signature packet after the uid = self-signature
+    bad_self = bytearray(client); bad_self[selfsig_end + 200] ^= 1; bad_self = bytes(bad_self)
+    bad_cert = flip(client, 30)                                                     # last certification corrupted
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
+    gpg_ring = bytes.fromhex(vec["A_pubring"])                                      # entities gpg itself made (SHA-512 self-signatures)
+    blobs = {"client": client, "bad_self": bad_self, "bad_cert": bad_cert, "replicas": b"".join(r.entity for r in cl.replicas[:3]),
+             "subkey": sub_owner.entity, "bad_binding": flip(sub_owner.entity, 25), "gpg": gpg_ring, "empty": b""}
+    for name, blob in blobs.items():
+        want = [e["valid"] for e in pgp.entity_checks(blob)]
+        got = host.certs_verify(gpu_ctx, blob)
+        assert got == want, (name, got, want)
+    assert host.certs_verify(gpu_ctx, client) == [True] and host.certs_verify(gpu_ctx, bad_self) == [False]
+    assert host.certs_verify(gpu_ctx, sub_owner.entity) == [True] and host.certs_verify(gpu_ctx, blobs["bad_binding"]) == [False]
+    assert host.certs_verify(gpu_ctx, gpg_ring) == [True, True]
+    # CheckQuorumCert: the code path counts ids (4 of 4 => threshold), the paper's check verifies them
+    for blob, n_ok in ((client, 4), (bad_cert, 3)):
+        ent = pgp.entity_checks(blob)[0]
+        want_ids = pgp.verified_certifiers(ent, kr.get_keyring())
+        ok, ids = host.quorum_cert_verify(gpu_ctx, hq, blob)
+        assert ids == want_ids and len(ids) == n_ok and ok == oq.is_threshold(want_ids)
+    assert host.quorum_cert_verify(gpu_ctx, hq, client)[0] and not host.quorum_cert_verify(gpu_ctx, hq, bad_cert)[0]
+    # Server.sign: a request whose certificate has a forged self-signature has no issuer
+    tbs = cb.serialize_tbs(b"k", b"v", 1)
+    sig = cb.detach_sign(cl.client, tbs)
+    reqs = [opk.serialize(b"k", b"v", 1, opk.SignaturePacket(1, 0, False, sig, c)) for c in (client, bad_self, bad_cert)]
+    err = host.Server(gpu_ctx).sign_verify(hq, reqs)
+    assert list(err) == [0, 0xFE, 0]      # bad_cert still passes the CODE's check: its certifier ids are only counted
