@@ -6,4 +6,4 @@ Package contents (only what the path needs):
   crypto_gpu.py    host-side mirror of crypto.Signature / crypto.CollectiveSignature
                    (crypto/crypto.go:50-71) over the C ABI
 """
-from ._native import Context, NativeError, load_library, LIB_PATH  # noqa: F401
+from ._native import Batcher, Context, NativeError, load_library, LIB_PATH  # noqa: F401

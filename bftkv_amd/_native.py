@@ -39,6 +39,8 @@ EXPORTS = [
     "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
+    "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats",
 ]
 
 _lib = None
@@ -77,6 +79,13 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_lagrange_combine.argtypes = [vp, u32, u32, vp, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_dsa_calculate_r.argtypes = [vp, u32, u32, vp, u8p, u32, u8p, u32, vp, u32, u8p, u8p, u8p, u8p]
     lib.bftkv_gpu_stream.argtypes = [vp]
+    lib.bftkv_gpu_batcher_create.argtypes = [vp, u32, u32]
+    lib.bftkv_gpu_batcher_create.restype = vp
+    lib.bftkv_gpu_batcher_destroy.argtypes = [vp]
+    lib.bftkv_gpu_batcher_destroy.restype = None
+    lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
+    lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p]
+    lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
     lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_comm_unique_id.argtypes = [u8p]
@@ -84,7 +93,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
     for name in EXPORTS:
-        if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream"):
+        if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream",
+                        "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -311,6 +321,42 @@ class Context:
         self._check(self.lib.bftkv_gpu_modexp(self.h, base.shape[0], _ptr(base), base.shape[1], _ptr(mod_idx), mods.shape[0],
                                               _ptr(mods), _ptr(exps), exps.shape[1], _ptr(out)), "modexp")
         return out
+
+
+class Batcher:
+    """bftkv_gpu_batcher: blocking one-message calls from many threads, aggregated into device batches."""
+
+    def __init__(self, ctx: Context, max_items: int = 256, max_wait_us: int = 200):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.h = C.c_void_p(self.lib.bftkv_gpu_batcher_create(ctx.h, max_items, max_wait_us))
+        if not self.h:
+            raise NativeError("bftkv_gpu_batcher_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.bftkv_gpu_batcher_destroy(self.h)
+            self.h = None
+
+    def collective_verify(self, quorum: int, tbs: bytes, ss: bytes) -> int:
+        err = np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_collective_verify(self.h, quorum, tbs, len(tbs), ss, len(ss), _ptr(err))
+        if rc:
+            raise NativeError("batcher collective_verify failed: %d" % rc)
+        return int(err[0])
+
+    def signature_verify(self, tbs: bytes, sig: bytes, cert_key_id: Optional[int] = None) -> int:
+        err = np.zeros(1, dtype=np.uint8)
+        ck = None if cert_key_id is None else np.array([cert_key_id], dtype=np.uint64)
+        rc = self.lib.bftkv_gpu_batcher_signature_verify(self.h, tbs, len(tbs), sig, len(sig), _ptr(ck), _ptr(err))
+        if rc:
+            raise NativeError("batcher signature_verify failed: %d" % rc)
+        return int(err[0])
+
+    def stats(self):
+        st = (C.c_uint64 * 4)()
+        self.lib.bftkv_gpu_batcher_stats(self.h, st)
+        return {"calls": st[0], "batches": st[1], "max_batch": st[2]}
 
 
 def _ints_to_be(vals, nbytes: int) -> np.ndarray:

@@ -8,7 +8,10 @@
 
 #include <algorithm>
 #include <map>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -269,9 +272,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     // other hashes: a no-op grid unless some signature asked for them
     hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
                        c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
-    hipLaunchKernelGGL(k_digest<false>, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+    hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                        c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
-    hipLaunchKernelGGL(k_digest<true>, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+    hipLaunchKernelGGL(k_digest_other, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                        c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[6], sh));
@@ -842,4 +845,5 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"
+#include "batcher_capi.inc"
 #include "host_capi.inc"

@@ -526,10 +526,10 @@ __device__ __forceinline__ uint32_t limb28(F byte_from_lsb, int j) {
 // Per signature: digest = H(signed || hash suffix) from the item's midstate; hash-tag check.
 // digests: 64 bytes per record, the digest in its natural (big-endian) byte order.
 template <bool OTHERS>   // false: SHA-256 only (the path's default, light on registers); true: every other hash
-__global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
-                                                const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
-                                                const uint64_t* __restrict__ mid64, uint32_t n_items,
-                                                SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/) {
+__device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                            const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
+                                            const uint64_t* __restrict__ mid64, uint32_t n_items,
+                                            SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
@@ -596,6 +596,22 @@ __global__ void __launch_bounds__(256) k_digest(const uint8_t* __restrict__ tbs_
   if ((uint8_t)(tag_hi >> 24) != rec.hash_tag[0] || (uint8_t)(tag_hi >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
   else st = (rec.after_tag == AFTER_TAG_PUBKEY) ? (uint8_t)ST_PENDING_RSA : rec.after_tag;
   recs[ri].status = st;
+}
+
+__global__ void __launch_bounds__(256) k_digest_sha256(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                       const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
+                                                       const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
+                                                       uint32_t n_recs, uint32_t* __restrict__ digests) {
+  digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests);
+}
+// Every other hash.  Capped at 128 VGPRs (4 waves/SIMD): on the default workload this kernel is a grid of
+// immediate exits that runs BESIDE k_rsa_modexp (2 x 190 VGPRs per SIMD) -- with its natural 198 VGPRs it could
+// not be co-scheduled and would hold the hash stream (and with it the compare) until the modexp drained.
+__global__ void __launch_bounds__(256, 4) k_digest_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                         const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
+                                                         const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
+                                                         uint32_t n_recs, uint32_t* __restrict__ digests) {
+  digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests);
 }
 
 // ------------------------------------------------------------------------------------------------

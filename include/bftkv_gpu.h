@@ -123,6 +123,23 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
                                const uint8_t* sig_blob, const uint64_t* sig_off,
                                const uint64_t* cert_key_id, uint8_t* err_out);
 
+/* ---- micro-batching of concurrent single calls ---------------------------------------------------- */
+/* The reference verifies ONE message per call, concurrently from one goroutine per HTTP request
+ * (transport/http/http.go:85,143 -> protocol/server.go:562-620).  A batcher turns such calls into device batches:
+ * each call blocks until its batch -- closed after max_items calls or max_wait_us microseconds, whichever comes
+ * first -- has been verified.  Thread-safe; buffers are only read for the duration of the call. */
+typedef struct bftkv_gpu_batcher bftkv_gpu_batcher;
+bftkv_gpu_batcher* bftkv_gpu_batcher_create(bftkv_gpu_ctx* ctx, uint32_t max_items, uint32_t max_wait_us);
+void bftkv_gpu_batcher_destroy(bftkv_gpu_batcher* b);
+/* CollectiveSignature.Verify(tbs, ss, q) (crypto_pgp.go:485-500): *err_out = BFTKV_ERR_NONE / _INSUFFICIENT_SIGNATURES */
+int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const uint8_t* tbs, uint64_t tbs_len,
+                                        const uint8_t* ss, uint64_t ss_len, uint8_t* err_out);
+/* Signature.Verify / VerifyWithCertificate (crypto_pgp.go:319-344); cert_key_id NULL = node keyring */
+int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sig,
+                                       uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out);
+/* stats[0] calls served, stats[1] device batches launched, stats[2] largest batch */
+int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
+
 /* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* ctx, uint8_t* status_out, uint32_t* item_out, uint32_t cap, uint32_t* n_out);
 /* counters of the last verify call: [0] packets parsed, [1] public-key operations performed */

@@ -275,3 +275,39 @@ def test_entity_verification_and_quorum_certificate(gpu_ctx):
     reqs = [opk.serialize(b"k", b"v", 1, opk.SignaturePacket(1, 0, False, sig, c)) for c in (client, bad_self, bad_cert)]
     err = host.Server(gpu_ctx).sign_verify(hq, reqs)
     assert list(err) == [0, 0xFE, 0]      # bad_cert still passes the CODE's check: its certifier ids are only counted
+
+
+def test_micro_batcher_concurrent_single_calls(gpu_ctx):
+    """One CollectiveSignature.Verify per call from many threads (the reference's goroutine-per-request shape,
+    transport/http/http.go:85,143) -> device batches; every caller gets the oracle's answer."""
+    import threading
+    from bftkv_amd import Batcher
+    cl = cb.make_cluster(4)
+    kr = H.oracle_keyring(cl, include_client=True)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    c = cb.make_write_corpus(cl, 96, mutation_rates={cb.MUT_ONE_SHORT: 0.3, cb.MUT_BAD_MPI: 0.2})
+    want = [0 if H.oracle_collective(kr, q, c, i).err is None else 2 for i in range(c.n_items)]
+    b = Batcher(gpu_ctx, max_items=32, max_wait_us=20000)
+    got = [None] * c.n_items
+    sig_got = [None] * 16
+
+    def worker(i):
+        got[i] = b.collective_verify(qh, c.tbss(i), c.ss_data(i))
+
+    def sig_worker(i):
+        tbs = b"msg%d" % i
+        s = cb.detach_sign(cl.client, tbs if i % 2 == 0 else tbs + b"!")
+        sig_got[i] = b.signature_verify(tbs, s, cert_key_id=cl.client.key_id if i % 4 < 2 else None)
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(c.n_items)] + [threading.Thread(target=sig_worker, args=(i,)) for i in range(16)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    st = b.stats()
+    b.close()
+    assert got == want and 0 < sum(g == 0 for g in got) < len(got)
+    assert sig_got == [0 if i % 2 == 0 else 1 for i in range(16)]
+    assert st["calls"] == c.n_items + 16 and st["batches"] < st["calls"] / 2 and st["max_batch"] > 4
+    gpu_ctx.quorum_destroy(qh)
