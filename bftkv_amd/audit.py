@@ -1,0 +1,99 @@
+"""Re-verify a stored bftkv database on the GPU.
+
+The reference's plain storage keeps every accepted write as a file ``hex(x).t`` holding the request bytes
+``<x,v,t,sig,ss>`` exactly as Server.write received them (storage/plain/plain.go:48-90, protocol/server.go:348).
+``audit_plain_db`` walks such a directory, rebuilds the verifier's inputs from a public key ring
+(``pubring.gpg`` as cmd/bftkv/main.go:70-71 loads it) and runs the verification site of Server.write
+(server.go:286-302) over all stored writes in device batches.  Product path only: host mirror + C ABI + HIP kernels.
+
+CLI:  python -m bftkv_amd.audit --db DIR --pubring FILE --self KEYID_HEX
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+from . import host
+from ._native import Context
+
+
+@dataclass
+class AuditRecord:
+    path: str
+    variable: bytes
+    t: int
+    status: str        # "ok" | "insufficient" | "malformed" | "name-mismatch"
+
+
+def load_ring(ctx: Context, pubring: bytes):
+    """Certificate.ParseStream + Keyring.Register + graph.AddNodes (cmd/bftkv/main.go:70-98) for a key ring blob.
+    Returns the trust graph (vertices = entities, edges = certifications) after uploading the key table."""
+    ents = host.Certificate.Parse(pubring)
+    keys = [k for e in ents for k in e["keys"]]
+    ctx.keyring_set(keys)
+    g = host.Graph()
+    g.AddNodes([(e["id"], e["certifiers"]) for e in ents])
+    return g, ents
+
+
+def read_plain_db(db_dir: str) -> List[Tuple[str, bytes, int, bytes]]:
+    """(path, variable, t, stored bytes) of every ``hex(x).t`` file (storage/plain/plain.go:48-61)."""
+    out = []
+    for name in sorted(os.listdir(db_dir)):
+        stem, dot, tstr = name.rpartition(".")
+        if not dot or not tstr.isdigit():
+            continue
+        try:
+            variable = bytes.fromhex(stem)
+        except ValueError:
+            continue
+        path = os.path.join(db_dir, name)
+        with open(path, "rb") as f:
+            out.append((path, variable, int(tstr), f.read()))
+    return out
+
+
+def audit_plain_db(ctx: Context, db_dir: str, pubring: bytes, self_id: int, batch: int = 4096) -> List[AuditRecord]:
+    g, _ = load_ring(ctx, pubring)
+    g.SetSelfNodes([self_id])
+    q = host.wotqs.New(g).ChooseQuorum(host.AUTH)          # Server.write (server.go:300)
+    server = host.Server(ctx)
+    files = read_plain_db(db_dir)
+    records: List[AuditRecord] = []
+    for lo in range(0, len(files), batch):
+        chunk = files[lo:lo + batch]
+        err = server.write_verify(q, [c[3] for c in chunk])
+        for (path, variable, t, blob), e in zip(chunk, err):
+            status = {0: "ok", 2: "insufficient"}.get(int(e), "malformed")
+            if status != "malformed":
+                x, _, pt, _, _, _ = host.packet.Parse(blob)
+                if (x or b"") != variable or pt != t:
+                    status = "name-mismatch"
+            records.append(AuditRecord(path, variable, t, status))
+    return records
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--db", required=True)
+    ap.add_argument("--pubring", required=True)
+    ap.add_argument("--self", dest="self_id", required=True, help="key id (hex) of the auditing node's own certificate")
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args()
+    ctx = Context(args.device)
+    with open(args.pubring, "rb") as f:
+        ring = f.read()
+    recs = audit_plain_db(ctx, args.db, ring, int(args.self_id, 16))
+    counts: Dict[str, int] = {}
+    for r in recs:
+        counts[r.status] = counts.get(r.status, 0) + 1
+        if r.status != "ok":
+            print("%-14s %s" % (r.status, r.path))
+    print("audited %d stored writes: %s" % (len(recs), ", ".join("%s=%d" % kv for kv in sorted(counts.items()))))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -311,3 +311,36 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
     assert sig_got == [0 if i % 2 == 0 else 1 for i in range(16)]
     assert st["calls"] == c.n_items + 16 and st["batches"] < st["calls"] / 2 and st["max_batch"] > 4
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_audit_plain_storage_db(gpu_ctx, tmp_path):
+    """a storage/plain directory of accepted writes (files hex(x).t = request bytes) re-verified on the GPU."""
+    import os
+    from bftkv_amd import audit
+    from corpus.keys import DRBG
+    cl = cb.make_cluster(10)
+    members = [r.key_id for r in cl.replicas]
+    # pubring.gpg as the daemon loads it: clique members cross-certify (scripts/clique.sh), so the ring carries the graph
+    rng = DRBG("ring")
+    for r in cl.replicas:
+        cb.build_entity(r, [o for o in cl.replicas if o is not r], rng)
+    pubring = b"".join(r.entity for r in cl.replicas) + cl.client.entity
+    c = cb.make_write_corpus(cl, 30, keep_requests=True, mutation_rates={cb.MUT_ONE_SHORT: 0.2, cb.MUT_BAD_MPI: 0.2})
+    db = tmp_path / "db"
+    db.mkdir()
+    want = {}
+    for i, req in enumerate(c.requests):
+        x, v, t, sig, ss, _ = opk.parse(req)
+        name = "%s.%d" % (x.hex(), t)
+        blob = req
+        status = "ok" if c.expected_valid[i] >= cl.suff else "insufficient"
+        if i == 3:
+            blob, status = req[:len(req) // 2], "malformed"
+        if i == 4:
+            name, status = "%s.%d" % (x.hex(), t + 1000), ("name-mismatch" if status == "ok" else status)
+        (db / name).write_bytes(blob)
+        want[name] = status
+    (db / "README").write_text("not a record")
+    recs = audit.audit_plain_db(gpu_ctx, str(db), pubring, members[2])
+    got = {os.path.basename(r.path): r.status for r in recs}
+    assert got == want and set(want.values()) >= {"ok", "insufficient", "malformed"}
