@@ -193,7 +193,7 @@ def measured_traffic(kernel):
         return None, None
     with open(best) as f:
         d = json.load(f)
-    k = d["kernels"].get("bftkv::" + kernel)
+    k = d["kernels"].get("bftkv::" + kernel) or d["kernels"].get("bftkv::" + kernel + "<19>")
     return (k["hbm_bytes_corrected"] if k else None), os.path.relpath(best, ROOT)
 
 

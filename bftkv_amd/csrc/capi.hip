@@ -73,7 +73,7 @@ struct bftkv_gpu_ctx {
   // key table
   uint64_t keyring_gen = 0;
   uint32_t n_keys = 0, n_entities = 0;
-  bool have_dsa_keys = false;
+  bool have_dsa_keys = false, have_rsa3072 = false, have_rsa4096 = false;
   std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
   std::vector<uint32_t> h_key_entity;
   std::vector<uint8_t> h_key_flags;
@@ -86,7 +86,7 @@ struct bftkv_gpu_ctx {
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
+  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
@@ -253,8 +253,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
   HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
   HIPCHK(c, c->r.ensure(sizeof(uint32_t) * MONT_N * tr));
-  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? 4 * MONT_L3072 : MONT_N) * tr));
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
+  HIPCHK(c, c->pk_list3072.ensure(c->have_rsa3072 ? sizeof(uint32_t) * tr : 16));
+  HIPCHK(c, c->pk_list4096.ensure(c->have_rsa4096 ? sizeof(uint32_t) * tr : 16));
+  if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * 4 * MONT_L3072 * tr));
+  if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * 4 * MONT_L4096 * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   // sequential fill only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
@@ -262,7 +266,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (total) {
     hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, d_ss_off, c->base.as<uint32_t>(),
                        c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
-                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
+                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_list3072.as<uint32_t>(), c->pk_list4096.as<uint32_t>(),
+                       c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
                        c->hash_mask.as<uint32_t>(), d_sig_class);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -280,15 +285,29 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, hipEventRecord(c->ev[6], sh));
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
   if (total) {
-    hipLaunchKernelGGL(k_rsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s, d_ss,
-                       c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(),
-                       c->xr.as<uint32_t>());
+    const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
+    hipLaunchKernelGGL(k_rsa_modexp<MONT_L>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+                       c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>());
+    // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
+    if (c->have_rsa3072)
+      hipLaunchKernelGGL(k_rsa_modexp<MONT_L3072>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>());
+    if (c->have_rsa4096)
+      hipLaunchKernelGGL(k_rsa_modexp<MONT_L4096>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
   if (total) {
-    hipLaunchKernelGGL(k_rsa_compare, dim3((total * 4 + 255) / 256), dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    const dim3 cg((total * 4 + 255) / 256);
+    hipLaunchKernelGGL(k_rsa_compare<MONT_L>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
+    if (c->have_rsa3072)
+      hipLaunchKernelGGL(k_rsa_compare<MONT_L3072>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->digests.as<uint32_t>());
+    if (c->have_rsa4096)
+      hipLaunchKernelGGL(k_rsa_compare<MONT_L4096>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
   }
   // DSA signatures (if any): the exponents u1, u2 depend on the digests, so this runs after the join.
   // The count is read back only when the keyring holds a DSA key at all.
@@ -335,12 +354,14 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
   if (cert_only) e.flags |= KEYF_CERT_ONLY;
   e.bits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
   e.e = 0; e.n0 = 0; e.qbits = 0;
-  e.nl.assign(MONT_N, 0); e.r2.assign(MONT_N, 0); e.qw.assign(8, 0); e.dtab.assign(3 * MONT_N, 0);
+  e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(3 * MONT_N, 0);
   if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
     if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
     for (uint32_t j = 0; j < k.e_len; ++j) e.e = (e.e << 8) | k.e[j];
-    if (e.bits > 2048) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
-    else if (!hostbn::mont_setup(k.n, k.n_len, MONT_N, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
+    // size class: limbs per number 76 / 112 / 148 for moduli up to 2048 / 3072 / 4096 bits (R = 2^(28 N) > 4n)
+    const int nlimbs = e.bits <= 2048 ? MONT_N : (e.bits <= 3072 ? MONT_TPI * MONT_L3072 : MONT_TPI * MONT_L4096);
+    if (e.bits > 4096) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
+    else if (!hostbn::mont_setup(k.n, k.n_len, nlimbs, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
   } else if (k.pk_algo == PK_DSA) {
     // n = p, e = q.  Montgomery domain mod p; g, y, g*y in Montgomery form for Shamir's trick.
     e.qbits = (uint32_t)hostbn::bit_length(k.e, k.e_len);
@@ -410,8 +431,13 @@ int upload_key_table(bftkv_gpu_ctx* c) {
     return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->n_keys = (uint32_t)key_id.size();
-  c->have_dsa_keys = false;
-  for (uint8_t a : algo) if (a == PK_DSA) c->have_dsa_keys = true;
+  c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = false;
+  for (size_t i = 0; i < algo.size(); ++i) {
+    if (algo[i] == PK_DSA) c->have_dsa_keys = true;
+    if ((algo[i] == PK_RSA || algo[i] == PK_RSA_SIGN_ONLY) && bits[i] != 0xFFFFFFFFu) {
+      if (bits[i] > 3072) c->have_rsa4096 = true; else if (bits[i] > 2048) c->have_rsa3072 = true;
+    }
+  }
   c->n_entities = (uint32_t)entity_ids.size();
   c->h_key_id = key_id;
   c->h_entity_id = entity_ids;
@@ -469,7 +495,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream_h);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
-                    &c->pk_list, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
@@ -711,7 +737,7 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   uint32_t cnt[4] = {0, 0, 0, 0};
   if (c->pk_count.p) HIPCHK(c, hipMemcpy(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost));
   counters[0] = c->last_total;
-  counters[1] = (uint64_t)cnt[0] + cnt[1];
+  counters[1] = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
   counters[2] = c->last_items;
   counters[3] = cnt[1];
   return 0;

@@ -255,6 +255,19 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   if (!FILL) { counts[item] = n; item_flags[item] = trailing_skip ? 1 : 0; }
 }
 
+// Wave-aggregated slot allocation: ONE atomic per wave and counter instead of one per lane (534k single-address
+// atomics cost 6 ms; the compiler only aggregates by itself when the address is provably wave-uniform).
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want) {
+  const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+  if (m == 0) return 0;
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi((uint32_t)(~0ull >> 32), __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int leader = __builtin_ctzll(m);
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+}
+
 __device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
   if (cls == 0) return sig_type == 0x00;
   if (cls == 1) return sig_type >= 0x10 && sig_type <= 0x13;
@@ -268,7 +281,8 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
                                                     uint32_t n_items, const WalkEnt* __restrict__ scratch,
                                                     SigRec* __restrict__ recs, uint32_t n_recs,
                                                     KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
-                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_count /*[0] RSA, [1] DSA*/,
+                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_list3072, uint32_t* __restrict__ pk_list4096,
+                                                    uint32_t* __restrict__ pk_count /*[0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096*/,
                                                     uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask,
                                                     const uint8_t* __restrict__ sig_class /*per item or null*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +309,7 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
   }
   const uint8_t* body = sig_blob + rec.body_off;
   uint8_t st;
+  int q_kind = -1;             // public-key work list this record joins (decided below, queued at the end)
   if (rec.body_len >= 1 && body[0] < 4) st = ST_UNSUPPORTED;   // SignatureV3: fenced
   else {
     bool have_issuer = false;
@@ -339,25 +354,33 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
           uint32_t lead = 0;
           while (lead < nb && mp[lead] == 0) ++lead;
           const uint32_t vbytes = nb - lead;
-          if (mod_bits == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;          // > 2048 bits or no Montgomery form
+          // size class of the modulus: 0 <= 2048 bits (76 limbs), 1 <= 3072 (112), 2 <= 4096 (148)
+          const uint32_t cls_sz = mod_bits <= 2048 ? 0u : (mod_bits <= 3072 ? 1u : 2u);
+          const uint32_t cap_bytes = (cls_sz == 0 ? MONT_N : cls_sz == 1 ? 4 * MONT_L3072 : 4 * MONT_L4096) * MONT_W / 8;
+          if (mod_bits == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;          // > 4096 bits or no Montgomery form
           else if (kbytes < hlen + plen + 11) rec.after_tag = ST_BAD_SIG;       // rsa.VerifyPKCS1v15: k < tLen+11
-          else if (vbytes > 266) rec.after_tag = ST_BAD_SIG;                    // value >= R: fenced
+          else if (vbytes > cap_bytes) rec.after_tag = ST_BAD_SIG;              // value >= R: fenced
           else {
             rec.after_tag = AFTER_TAG_PUBKEY;
             rec.flags = (vbytes > kbytes) ? 1 : 0;
-            rec.pk_idx = atomicAdd(pk_count, 1u);
-            pk_list[rec.pk_idx] = ri;
+            q_kind = cls_sz == 0 ? 0 : (int)cls_sz + 1;                         // [0] <=2048, [1] DSA, [2] <=3072, [3] <=4096
           }
         } else if (rec.pk_algo == PK_DSA) {
           if (kt.mod_bits[slot] == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;   // fenced key shape
           else {
             rec.after_tag = AFTER_TAG_PUBKEY;
-            rec.pk_idx = atomicAdd(pk_count + 1, 1u);
-            dsa_list[rec.pk_idx] = ri;
+            q_kind = 1;
           }
         } else rec.after_tag = ST_UNSUPPORTED;   // ECDSA: out of scope
       }
     }
+  }
+  // queue the public-key work: one atomic per wave and list
+  uint32_t* const lists[4] = {pk_list, dsa_list, pk_list3072, pk_list4096};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t idx = wave_alloc(pk_count + k, q_kind == k);
+    if (q_kind == k) { rec.pk_idx = idx; lists[k][idx] = ri; }
   }
   rec.status = st;
   recs[ri] = rec;
@@ -623,14 +646,15 @@ constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
 enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
 
 // r = s^e mod n (+ possibly n) for every queued signature; canonical radix-2^28 limbs to r_limbs.
+template <int L>   // limbs per lane: 19 (<= 2048-bit moduli), 28 (<= 3072), 37 (<= 4096)
 __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
-                                                          const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count,
+                                                          const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
                                                           KeyTableDev kt, uint32_t* __restrict__ r_limbs,
                                                           uint32_t* __restrict__ xr_scratch) {
-  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
-  __shared__ uint32_t x_sh[QUADS_PER_BLOCK * MONT_N];
-  constexpr int L = MONT_L;
-  const uint32_t count = *pk_count;
+  constexpr int NL = MONT_TPI * L;
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * NL];
+  __shared__ uint32_t x_sh[QUADS_PER_BLOCK * NL];
+  const uint32_t count = *pk_count_ptr;
   if (blockIdx.x * QUADS_PER_BLOCK >= count) return;   // whole block idle
   const uint32_t quad = threadIdx.x >> 2;
   const int qlane = threadIdx.x & 3;
@@ -640,14 +664,14 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
   const uint32_t ri = pk_list[pi];
   const SigRec rec = recs[ri];
   const uint32_t key = (uint32_t)rec.key_slot;
-  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;     // this lane's slice of the quad's operand
-  const uint32_t* a_rd = a_sh + quad * MONT_N;
-  uint32_t* x_lds = x_sh + quad * MONT_N + qlane * L;
+  uint32_t* a_lds = a_sh + quad * NL + qlane * L;     // this lane's slice of the quad's operand
+  const uint32_t* a_rd = a_sh + quad * NL;
+  uint32_t* x_lds = x_sh + quad * NL + qlane * L;
 
   uint32_t n[L], b[L], y[L];
-  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
-  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_N + qlane * L;
-  uint32_t* xrp = xr_scratch + (uint64_t)pi * MONT_N + qlane * L;
+  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  uint32_t* xrp = xr_scratch + (uint64_t)pi * NL + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) n[k] = np[k];
   // signature value: big-endian MPI bytes -> this lane's 19 limbs
@@ -712,7 +736,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
     }
     canonicalize(y, qlane);
     if (live && active) {
-      uint32_t* out = r_limbs + (uint64_t)pi * MONT_N + qlane * L;
+      uint32_t* out = r_limbs + (uint64_t)pi * NL + qlane * L;
 #pragma unroll
       for (int k = 0; k < L; ++k) out[k] = (e_u == 0) ? ((qlane == 0 && k == 0) ? 1u : 0u) : y[k];   // x^0 = 1
     }
@@ -721,11 +745,12 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
 }
 
 // EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); 4 lanes per signature.
+template <int L>
 __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, const uint32_t* __restrict__ pk_list,
-                                                     const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                     const uint32_t* __restrict__ pk_count_ptr, KeyTableDev kt,
                                                      const uint32_t* __restrict__ r_limbs, const uint32_t* __restrict__ digests) {
-  constexpr int L = MONT_L;
-  const uint32_t count = *pk_count;
+  constexpr int NL = MONT_TPI * L;
+  const uint32_t count = *pk_count_ptr;
   const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const int qlane = threadIdx.x & 3;
   if ((blockIdx.x * blockDim.x) >> 2 >= count) return;
@@ -748,14 +773,14 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
     return 0;
   };
   uint32_t em[L], r[L];
-  const uint32_t* rp = r_limbs + (uint64_t)pi * MONT_N + qlane * L;
+  const uint32_t* rp = r_limbs + (uint64_t)pi * NL + qlane * L;
   uint32_t diff = 0;
 #pragma unroll
   for (int k = 0; k < L; ++k) { em[k] = limb28(em_b, qlane * L + k); r[k] = rp[k]; diff |= em[k] ^ r[k]; }
   diff = quad_or(diff);
   bool ok = (diff == 0);
   if (__any(!ok)) {
-    const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
+    const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
     uint32_t diff2 = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) em[k] += np[k];
@@ -824,8 +849,8 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(const SigRec* __restri
   uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
   const uint32_t* a_rd = a_sh + quad * MONT_N;
   uint32_t n[L], b[L], y[L], t[L];
-  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_N + qlane * L;
-  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_N + qlane * L;
+  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
   const uint32_t* tab = kt.dsa_tab + (uint64_t)key * 3 * MONT_N + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = np[k]; b[k] = rp[k]; a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; }

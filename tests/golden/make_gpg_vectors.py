@@ -62,6 +62,31 @@ def main():
                     bad = gpg(home, "--verify", os.path.join(home, "sg"), os.path.join(home, "pl"), ok=None).returncode == 0
                     vectors["A"].append({"signer": uid, "digest": digest, "payload": pl.hex(), "sig": sig.hex(),
                                          "gpg_good": good, "gpg_tampered_good": bad})
+        # ---- C: larger RSA moduli (gpg 2.2's default is rsa3072), same checks as A
+        home3 = tempfile.mkdtemp(prefix="gnupg")
+        os.chmod(home3, 0o700)
+        try:
+            vectors["C"] = []
+            for algo, uid in (("rsa3072", "a03 (http://localhost:5703) <a03@gpg.example>"), ("rsa4096", "a04 (http://localhost:5704) <a04@gpg.example>")):
+                gpg(home3, "--passphrase", "", "--faked-system-time", "20200101T000000", "--quick-gen-key", uid, algo, "sign,cert", "never")
+            vectors["C_pubring"] = gpg(home3, "--export").stdout.hex()
+            for uid in ("a03@gpg.example", "a04@gpg.example"):
+                for digest in ("SHA256", "SHA512"):
+                    for pl in payloads[:4]:
+                        sig = gpg(home3, "--faked-system-time", "20200102T000000", "--digest-algo", digest, "-u", uid, "--detach-sign", "-o", "-", inp=pl).stdout
+                        with open(os.path.join(home3, "pl"), "wb") as f:
+                            f.write(pl)
+                        with open(os.path.join(home3, "sg"), "wb") as f:
+                            f.write(sig)
+                        good = gpg(home3, "--verify", os.path.join(home3, "sg"), os.path.join(home3, "pl"), ok=None).returncode == 0
+                        with open(os.path.join(home3, "pl"), "wb") as f:
+                            f.write(pl + b"!")
+                        bad = gpg(home3, "--verify", os.path.join(home3, "sg"), os.path.join(home3, "pl"), ok=None).returncode == 0
+                        vectors["C"].append({"signer": uid, "digest": digest, "payload": pl.hex(), "sig": sig.hex(), "gpg_good": good,
+                                             "gpg_tampered_good": bad})
+        finally:
+            subprocess.run(["gpgconf", "--homedir", home3, "--kill", "gpg-agent"], stderr=subprocess.DEVNULL)
+            shutil.rmtree(home3, ignore_errors=True)
         # ---- B: generator keys + Go-shaped signatures, judged by gpg
         cl = cb.make_cluster(4, dsa_fraction=0.5, n_outsiders=1)
         home2 = tempfile.mkdtemp(prefix="gnupg")
@@ -98,8 +123,8 @@ def main():
     with open(out, "w") as f:
         json.dump(vectors, f)
     na = sum(v["gpg_good"] for v in vectors["A"]); nb = sum(v["gpg_good"] for v in vectors["B"])
-    print("wrote %s: A %d vectors (%d good), B %d vectors (%d good), import rc %s" %
-          (out, len(vectors["A"]), na, len(vectors["B"]), nb, vectors["B_import_rc"]))
+    print("wrote %s: A %d vectors (%d good), B %d vectors (%d good), C %d vectors, import rc %s" %
+          (out, len(vectors["A"]), na, len(vectors["B"]), nb, len(vectors["C"]), vectors["B_import_rc"]))
 
 
 if __name__ == "__main__":

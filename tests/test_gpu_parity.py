@@ -213,7 +213,7 @@ def test_golden_gpg_vectors_on_gpu(gpu_ctx):
     from oracle import openpgp as pgp
     from oracle.packet import SignaturePacket
     vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
-    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B")):
+    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B"), ("C_pubring", "C")):   # C: rsa3072 / rsa4096
         ring = pgp.read_entities(bytes.fromhex(vec[ring_key]))
         kr = col.Keyring(keyring=ring)
         gpu_ctx.keyring_set(H.abi_keys(kr))
@@ -222,6 +222,16 @@ def test_golden_gpg_vectors_on_gpu(gpu_ctx):
         tb, to = _cat(tbs_l)
         sb, so = _cat(sig_l)
         err = gpu_ctx.signature_verify(tb, to, sb, so)
+        if group == "C":   # tampered payloads and a flipped signature bit as well
+            tbs_l = tbs_l + [t + b"!" for t in tbs_l] + tbs_l
+            sig_l = sig_l + sig_l + [s[:-5] + bytes([s[-5] ^ 4]) + s[-4:] for s in sig_l]
+            tb, to = _cat(tbs_l)
+            sb, so = _cat(sig_l)
+            err = gpu_ctx.signature_verify(tb, to, sb, so)
+            for e, t, s in zip(err, tbs_l, sig_l):
+                assert (e == 0) == (col.signature_verify(kr, t, SignaturePacket(1, 0, False, s, None)) is None)
+            assert (err[:16] == 0).all() and (err[16:] == 1).all()
+            continue
         checked = 0
         for v, e, t, s in zip(vec[group], err, tbs_l, sig_l):
             want = col.signature_verify(kr, t, SignaturePacket(1, 0, False, s, None))
