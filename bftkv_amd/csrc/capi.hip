@@ -460,6 +460,13 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   return 0;
 }
 
+// offsets must start at 0 and be non-decreasing: they become device-side read ranges
+int check_offsets(bftkv_gpu_ctx* c, const uint64_t* off, uint32_t n, const char* what) {
+  if (off[0] != 0) return fail(c, BFTKV_E_INVALID, what);
+  for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return fail(c, BFTKV_E_INVALID, what);
+  return 0;
+}
+
 int check_quorum(bftkv_gpu_ctx* c, int quorum) {
   if (quorum < 0 || (size_t)quorum >= c->quorums.size() || !c->quorums[quorum].live) return fail(c, BFTKV_E_INVALID, "bad quorum handle");
   return 0;
@@ -630,6 +637,9 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   {
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
+    int rco;
+    if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
+      return rco;
     const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
     HIPCHK(c, c->in_tbs.ensure(tl + 64));
     HIPCHK(c, c->in_ss.ensure(sl + 64));
@@ -661,6 +671,9 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
                               const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  int rco;
+  if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, sig_off, n_items, "sig_off not monotone from 0")))
+    return rco;
   const uint64_t tl = tbs_off[n_items], sl = sig_off[n_items];
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
   HIPCHK(c, c->in_ss.ensure(sl + 64));
@@ -768,6 +781,7 @@ int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* c, int quorum, uint32_t n_lists, const
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
   QuorumHost& q = c->quorums[quorum];
+  if ((rc = check_offsets(c, list_off, n_lists, "list_off not monotone from 0"))) return rc;
   const uint64_t n_ids = list_off[n_lists];
   HIPCHK(c, c->in_ss.ensure(sizeof(uint64_t) * (n_ids + 1)));
   HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_lists + 1)));
@@ -795,6 +809,7 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   ids_off_out[0] = 0;
   if (n_items == 0) return 0;
   hipStream_t s = c->stream;
+  { int rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0"); if (rco) return rco; }
   const uint64_t sl = ss_off[n_items];
   HIPCHK(c, c->in_ss.ensure(sl + 64));
   HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));

@@ -338,3 +338,36 @@ def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx):
         assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
         assert list(st[st_item == i][:len(r.statuses)]) == r.statuses
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_bad_arguments_and_reentrancy(gpu_ctx):
+    """Infrastructure errors are return codes (never verdicts); one context may be called from several threads."""
+    import threading
+    from bftkv_amd import NativeError
+    cl = cb.make_cluster(4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    c = cb.make_write_corpus(cl, 40, mutation_rates={cb.MUT_ONE_SHORT: 0.3})
+    bad = c.ss_off.copy(); bad[3], bad[4] = bad[4], bad[3]
+    with pytest.raises(NativeError):
+        gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, bad)
+    with pytest.raises(NativeError):
+        gpu_ctx.collective_verify(qh + 99, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    with pytest.raises(NativeError):
+        gpu_ctx.quorum_create([(1, 4, 3, 3, [1, 2, 3, 4])] * 9)          # more cliques than MAX_QC
+    want, _, _ = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    res = [None] * 6
+
+    def worker(k):
+        res[k] = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)[0]
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert all((r == want).all() for r in res) and (want == 0).any() and (want == 2).any()
+    # zero items is a no-op
+    e, nv, vd = gpu_ctx.collective_verify(qh, np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(e) == 0
+    gpu_ctx.quorum_destroy(qh)
