@@ -371,3 +371,127 @@ def test_bad_arguments_and_reentrancy(gpu_ctx):
     e, nv, vd = gpu_ctx.collective_verify(qh, np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert len(e) == 0
     gpu_ctx.quorum_destroy(qh)
+
+
+def _rsa_key_with_e(e, idx):
+    """A seeded RSA-2048 key pair with public exponent e (generic exponent ladder on the GPU)."""
+    from corpus.keys import DRBG, gen_prime
+    rng = DRBG("rsa-e", e, idx)
+    while True:
+        p, q = gen_prime(1024, rng), gen_prime(1024, rng)
+        phi = (p - 1) * (q - 1)
+        if p != q and (p * q).bit_length() == 2048 and np.gcd(e, phi % e if phi % e else e) == 1 and phi % e != 0:
+            break
+    kp = cb.make_keypair(cb.PK_RSA, {"p": p, "q": q, "e": e}, "e%d-%d <k@bftkv.example>" % (e, idx))
+    cb.build_entity(kp, [], rng)
+    return kp
+
+
+def test_public_exponents_and_value_ranges(gpu_ctx):
+    """Exponent ladder classes in one wave (e = 3, 17, 257, 65537), signature values >= n (Go <= 1.13 has no s < n
+    check: s + n verifies when it fits the MPI), MPIs with leading zero bytes / non-canonical bit counts."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    keys = [_rsa_key_with_e(e, i) for i, e in enumerate((3, 17, 257, 65537, 3))]
+    ents = [pgp.read_entities(k.entity)[0] for k in keys]
+    kr = col.Keyring(keyring=ents)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    rng = np.random.default_rng(21)
+    tbs_l, sig_l = [], []
+    for i in range(60):
+        kp = keys[i % len(keys)]
+        tbs = rng.bytes(int(rng.integers(0, 300)))
+        pkt = bytearray(cb.detach_sign(kp, tbs))
+        hdr = 3
+        mpi_at = hdr + 6 + 16 + 2 + 2            # body prefix (22) + unhashed len + tag
+        s = int.from_bytes(pkt[mpi_at + 2:], "big")
+        variant = i % 6
+        if variant == 1:                          # s + n still fits 256 bytes for about half the keys
+            if s + kp.n < 1 << 2048:
+                pkt[mpi_at + 2:] = (s + kp.n).to_bytes(256, "big")
+        elif variant == 2:                        # 257-byte MPI with a leading zero byte: same value
+            body = bytes(pkt[hdr:mpi_at]) + (2056).to_bytes(2, "big") + b"\x00" + s.to_bytes(256, "big")
+            pkt = bytearray(cb._hdr(2, len(body)) + body)
+        elif variant == 3:                        # value >= 2^(8k): s + n*2^8-ish does not verify, but takes the no-shortcut path
+            big = s + kp.n * 3
+            body = bytes(pkt[hdr:mpi_at]) + (big.bit_length()).to_bytes(2, "big") + big.to_bytes((big.bit_length() + 7) // 8, "big")
+            pkt = bytearray(cb._hdr(2, len(body)) + body)
+        elif variant == 4:                        # canonical bit count instead of Go's 8*len
+            pkt[mpi_at:mpi_at + 2] = s.bit_length().to_bytes(2, "big")
+            pkt[mpi_at + 2:] = s.to_bytes((s.bit_length() + 7) // 8, "big")
+            body = bytes(pkt[hdr:])
+            pkt = bytearray(cb._hdr(2, len(body)) + body)
+        elif variant == 5:
+            pkt[-1] ^= 1
+        tbs_l.append(tbs)
+        sig_l.append(bytes(pkt))
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(sig_l)
+    err = gpu_ctx.signature_verify(tb, to, sb, so)
+    n_ok = 0
+    for i, (t, s_) in enumerate(zip(tbs_l, sig_l)):
+        want = col.signature_verify(kr, t, SignaturePacket(1, 0, False, s_, None))
+        assert (err[i] == 0) == (want is None), (i, i % 6, keys[i % 5].e, err[i], want)
+        n_ok += want is None
+    assert 30 < n_ok < 60
+
+
+def test_hashed_area_variants(gpu_ctx):
+    """Signature.parse corner cases on signatures we can sign ourselves: extra / unknown / critical
+    subpackets, two-octet and five-octet subpacket lengths, issuer only in the unhashed area, two issuer subpackets,
+    creation time missing from the hashed area, embedded signatures."""
+    import hashlib
+    import struct
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    kp, other = cl.replicas[0], cl.replicas[1]
+    ct = b"\x05\x02" + struct.pack(">I", cb.CREATION_TIME)
+    iss = lambda k: b"\x09\x10" + struct.pack(">Q", k.key_id)
+    notation = lambda n: bytes([192 + ((n + 1 - 192) >> 8), (n + 1 - 192) & 0xFF, 20]) + b"n" * n if n + 1 >= 192 else bytes([n + 1, 20]) + b"n" * n
+    inner = cb.detach_sign(other, b"inner")[3:]          # an embedded signature body
+    cases = {
+        "plain": (ct + iss(kp), b""),
+        "notation": (ct + notation(30) + iss(kp), b""),
+        "two-octet-len": (ct + notation(300) + iss(kp), b""),
+        "five-octet-len": (ct + b"\xff" + struct.pack(">I", 41) + bytes([20]) + b"x" * 40 + iss(kp), b""),
+        "unknown-critical": (ct + b"\x02\xe5\x01" + iss(kp), b""),
+        "unknown-noncritical": (ct + b"\x02\x65\x01" + iss(kp), b""),
+        "issuer-unhashed": (ct, iss(kp)),
+        "issuer-twice": (ct + iss(other) + iss(kp), b""),
+        "issuer-twice-rev": (ct + iss(kp) + iss(other), b""),
+        "no-issuer": (ct, b""),
+        "ctime-unhashed-only": (iss(kp), ct),
+        "bad-ctime-len": (b"\x04\x02\x00\x00\x01" + iss(kp), b""),
+        "zero-len-subpacket": (ct + b"\x00" + iss(kp), b""),
+        "embedded-sig": (ct + bytes([len(inner) + 1, 32]) + inner + iss(kp), b"") if len(inner) + 1 < 192 else (ct + iss(kp), b""),
+        "embedded-garbage": (ct + b"\x05\x20abcd" + iss(kp), b""),
+        "key-flags+expiry": (ct + b"\x02\x1b\x03" + b"\x05\x03\x00\x00\x10\x00" + b"\x05\x09\x00\x00\x20\x00" + iss(kp), b""),
+        "truncated-subpacket": (ct + b"\x30\x14abc", b""),
+    }
+    tbs = b"payload of the hashed-area test"
+    tbs_l, sig_l, names = [], [], []
+    for name, (hashed, unhashed) in cases.items():
+        prefix = cb.sig_prefix(0x00, kp.algo, hashed)
+        digest = hashlib.sha256(tbs + cb.hash_suffix(prefix)).digest()
+        s = kp.rsa_private(cb.emsa(digest, 256))
+        body = prefix + struct.pack(">H", len(unhashed)) + unhashed + digest[:2] + cb.go_mpi_bytes(s.to_bytes(256, "big"))
+        names.append(name); tbs_l.append(tbs); sig_l.append(cb._hdr(2, len(body)) + body)
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(sig_l)
+    err = gpu_ctx.signature_verify(tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    outcome = {}
+    for i, name in enumerate(names):
+        sp = SignaturePacket(1, 0, False, sig_l[i], None)
+        tr = []
+        want = col.signature_verify(kr, tbs, sp, trace=tr)
+        assert (err[i] == 0) == (want is None), (name, err[i], want)
+        assert list(st[st_item == i]) == tr, (name, list(st[st_item == i]), tr)
+        outcome[name] = want is None
+    assert outcome["plain"] and outcome["notation"] and outcome["two-octet-len"] and outcome["five-octet-len"] and outcome["issuer-unhashed"]
+    assert outcome["issuer-twice"] and not outcome["issuer-twice-rev"] and outcome["unknown-noncritical"] and outcome["key-flags+expiry"]
+    assert not outcome["unknown-critical"] and not outcome["no-issuer"] and not outcome["ctime-unhashed-only"] and not outcome["embedded-garbage"]
