@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_error_string.argtypes = [C.c_int]
     lib.bftkv_gpu_error_string.restype = C.c_char_p
     lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
+    lib.bftkv_gpu_set_dsa_window_bits.argtypes = [vp, u32]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p]
@@ -154,6 +155,10 @@ class Context:
                 setattr(arr[i], name, C.cast(cb, C.c_void_p) if cb is not None else None)
                 setattr(arr[i], name + "_len", len(b))
         self._check(self.lib.bftkv_gpu_keyring_set(self.h, arr, len(keys)), "keyring_set")
+
+    def set_dsa_window_bits(self, bits: int) -> None:
+        """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""
+        self._check(self.lib.bftkv_gpu_set_dsa_window_bits(self.h, bits), "set_dsa_window_bits")
 
     # ---- quorum
     def quorum_create(self, qcs) -> int:

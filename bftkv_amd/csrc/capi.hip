@@ -42,7 +42,7 @@ struct KeyEntry {
   uint64_t key_id = 0, entity_id = 0;
   uint8_t algo = 0, flags = 0;
   uint32_t bits = 0, e = 0, n0 = 0, qbits = 0;
-  std::vector<uint32_t> nl, r2, qw, dtab;
+  std::vector<uint32_t> nl, r2, qw, dtab, qpow;
   std::string material;
   bool cert_only = false;
   int cert_group = -1;          // certificates: entries of one certificate share a group
@@ -67,6 +67,7 @@ struct bftkv_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // main stream: walk, parse, modexp, compare, tally
   hipStream_t stream_h = nullptr;    // hashing stream: runs beside the modexp
+  hipStream_t stream_d = nullptr;    // DSA inverses (s^-1 mod q): latency-bound, runs beside both
   std::mutex mu;
   std::string err;
 
@@ -80,13 +81,17 @@ struct bftkv_gpu_ctx {
   std::vector<KeyEntry> ring, certs;   // processed rows: node keyring, then certificate-only entities
   uint32_t n_ring_entities = 0;
   std::map<std::string, bool> cert_valid;   // certificate bytes -> openpgp.ReadEntity would accept it
-  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab;
+  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab, k_dsaslot;
+  // fixed-base DSA tables: built once per distinct key material, kept across key-table uploads
+  DevBuf dsa_comb;
+  uint32_t dsa_wbits = 8, dsa_wbits_pinned = 0;
+  std::map<std::string, uint32_t> dsa_comb_slot;   // key material -> slot in dsa_comb
   KeyTableDev kt{};
 
   std::vector<QuorumHost> quorums;
 
   // per-call arena
-  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, dsa_v, ids_tmp;
+  DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
@@ -260,6 +265,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * 4 * MONT_L3072 * tr));
   if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * 4 * MONT_L4096 * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
+  if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
   // sequential fill only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      c->base.as<uint32_t>(), c->recs.as<SigRec>(), (uint8_t*)nullptr, (WalkEnt*)nullptr);
@@ -271,6 +277,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                        c->hash_mask.as<uint32_t>(), d_sig_class);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
+  if (total && c->have_dsa_keys) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream_d, c->ev[1], 0));
+    hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, c->stream_d, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                       c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>());
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream_d));
+  }
   // hash stream: digests need the parsed records
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
   if (total) {
@@ -309,24 +321,15 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       hipLaunchKernelGGL(k_rsa_compare<MONT_L4096>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
   }
-  // DSA signatures (if any): the exponents u1, u2 depend on the digests, so this runs after the join.
-  // The count is read back only when the keyring holds a DSA key at all.
+  // DSA signatures (if any): u1 depends on the digest, so the table multiplications run after the join; the
+  // inverses were started on their own stream right after the parse.  Grids cover every signature and exit on
+  // the device-side count, so no host read-back sits between the kernels.
   if (total && c->have_dsa_keys) {
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const uint32_t nd = cnt[1];
-    if (nd) {
-      HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * 16 * (size_t)nd));
-      HIPCHK(c, c->dsa_v.ensure(sizeof(uint32_t) * MONT_N * (size_t)nd));
-      hipLaunchKernelGGL(k_dsa_prep, dim3((nd + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>(), c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
-      hipLaunchKernelGGL(k_dsa_modexp, dim3((nd + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
-                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>(),
-                         c->dsa_v.as<uint32_t>());
-      hipLaunchKernelGGL(k_dsa_finish, dim3((nd + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>(), c->kt, c->dsa_v.as<uint32_t>());
-    }
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev[7], 0));
+    hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                       c->pk_count.as<uint32_t>(), c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
+    hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                       c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipGetLastError());
@@ -354,7 +357,7 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
   if (cert_only) e.flags |= KEYF_CERT_ONLY;
   e.bits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
   e.e = 0; e.n0 = 0; e.qbits = 0;
-  e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(3 * MONT_N, 0);
+  e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(2 * MONT_N, 0); e.qpow.clear();
   if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
     if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
     for (uint32_t j = 0; j < k.e_len; ++j) e.e = (e.e << 8) | k.e[j];
@@ -363,10 +366,10 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
     if (e.bits > 4096) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
     else if (!hostbn::mont_setup(k.n, k.n_len, nlimbs, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
   } else if (k.pk_algo == PK_DSA) {
-    // n = p, e = q.  Montgomery domain mod p; g, y, g*y in Montgomery form for Shamir's trick.
+    // n = p, e = q.  Montgomery domain mod p; g and y in Montgomery form seed the fixed-base tables.
     e.qbits = (uint32_t)hostbn::bit_length(k.e, k.e_len);
     const int nwords = (28 * MONT_N + 31) / 32 + 1;
-    std::vector<uint32_t> p(nwords), g(nwords), y(nwords), gy(nwords), q(nwords);
+    std::vector<uint32_t> p(nwords), g(nwords), y(nwords), q(nwords);
     hostbn::from_be(k.e, k.e_len, q.data(), nwords);
     bool ok = e.bits >= 2 && e.bits <= 2048 && e.qbits >= 32 && e.qbits <= 256 && (q[0] & 1u) &&
               hostbn::mont_setup(k.n, k.n_len, MONT_N, e.nl.data(), e.r2.data(), &e.n0);
@@ -377,15 +380,88 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
       hostbn::from_be(k.y, k.y_len, y.data(), nwords);
       hostbn::reduce(g.data(), p.data(), nwords);
       hostbn::reduce(y.data(), p.data(), nwords);
-      hostbn::mul_mod(g.data(), y.data(), p.data(), gy.data(), nwords);
       hostbn::to_mont_limbs(g.data(), p.data(), nwords, MONT_N, &e.dtab[0]);
       hostbn::to_mont_limbs(y.data(), p.data(), nwords, MONT_N, &e.dtab[MONT_N]);
-      hostbn::to_mont_limbs(gy.data(), p.data(), nwords, MONT_N, &e.dtab[2 * MONT_N]);
       for (int j = 0; j < 8; ++j) e.qw[j] = q[j];
+      // 2^(28 j) mod q, j = 0 .. 75, as radix-2^28 limbs (k_dsa_modexp folds v mod p to v mod q with them)
+      e.qpow.assign(DSA_QTAIL_WORDS, 0);
+      uint32_t x[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0}, q9[9];
+      for (int j = 0; j < 9; ++j) q9[j] = j < 8 ? q[j] : 0;
+      for (int j = 0; j < MONT_N; ++j) {
+        hostbn::to_limbs28(x, 9, &e.qpow[(size_t)j * 10], 10);
+        for (int b = 0; b < MONT_W; ++b) hostbn::dbl_mod(x, q9, 9);
+      }
+      // mod-q Montgomery constants (u256_montmul): 2^512 mod q and -q^-1 mod 2^32
+      uint32_t r2q[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < 512; ++b) hostbn::dbl_mod(r2q, q9, 9);
+      for (int j = 0; j < 8; ++j) e.qpow[DSA_QPOW_WORDS + j] = r2q[j];
+      uint32_t inv = 1;
+      for (int it = 0; it < 5; ++it) inv *= 2u - q[0] * inv;     // Newton: q^-1 mod 2^32
+      e.qpow[DSA_QPOW_WORDS + 8] = 0u - inv;
     } else {
       e.bits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 2048 bits): ST_UNSUPPORTED
     }
   }
+  return 0;
+}
+
+// Fixed-base tables for the DSA rows of the table being uploaded.  A table depends only on (p, g, y), so it is
+// keyed by the row's key material and survives re-uploads (certificate batches re-upload the table per request).
+// Window width 8 while the slots fit 4096 keys (20 GB); a larger DSA population restarts the cache at width 4.
+int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, const std::vector<uint8_t>& algo,
+                    const std::vector<uint32_t>& bits) {
+  std::vector<uint32_t> slot(rows.size() ? rows.size() : 1, 0xFFFFFFFFu);
+  auto assign = [&](std::vector<uint32_t>& new_slots, std::vector<uint32_t>& new_rows) {
+    new_slots.clear(); new_rows.clear();
+    for (size_t i = 0; i < rows.size(); ++i) {
+      if (algo[i] != PK_DSA || bits[i] == 0xFFFFFFFFu) continue;
+      auto it = c->dsa_comb_slot.find(rows[i]->material);
+      if (it == c->dsa_comb_slot.end()) {
+        it = c->dsa_comb_slot.emplace(rows[i]->material, (uint32_t)c->dsa_comb_slot.size()).first;
+        new_slots.push_back(it->second); new_rows.push_back((uint32_t)i);
+      }
+      slot[i] = it->second;
+    }
+  };
+  std::vector<uint32_t> new_slots, new_rows;
+  assign(new_slots, new_rows);
+  const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
+  const uint32_t want_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : (c->dsa_comb_slot.size() > 4096 ? 4u : 8u);
+  bool restart = false;
+  if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256) {   // width change, or mostly stale: restart
+    restart = true;
+    c->dsa_comb_slot.clear();
+    c->dsa_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : (live > 4096 ? 4u : 8u);
+    assign(new_slots, new_rows);
+  }
+  int rc;
+  if ((rc = upload(c, c->k_dsaslot, slot))) return rc;
+  c->kt.dsa_slot = c->k_dsaslot.as<uint32_t>();
+  c->kt.dsa_wbits = c->dsa_wbits;
+  if (new_slots.empty()) return 0;
+  const size_t per_key = dsa_slot_stride(c->dsa_wbits) * sizeof(uint32_t);
+  const size_t need = per_key * c->dsa_comb_slot.size();
+  if (need > c->dsa_comb.cap) {           // grow, keeping the tables already built
+    DevBuf bigger;
+    HIPCHK(c, bigger.ensure(need + need / 2));
+    const size_t keep = restart ? 0 : per_key * (c->dsa_comb_slot.size() - new_slots.size());
+    if (keep && c->dsa_comb.p && keep <= c->dsa_comb.cap) HIPCHK(c, hipMemcpyAsync(bigger.p, c->dsa_comb.p, keep, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dsa_comb.release();
+    c->dsa_comb = bigger;
+  }
+  c->kt.dsa_comb = c->dsa_comb.as<uint32_t>();
+  for (size_t k = 0; k < new_slots.size(); ++k)      // the slot's 2^(28 j) mod q table (host-computed, 3 KB)
+    HIPCHK(c, hipMemcpyAsync((char*)c->dsa_comb.p + per_key * new_slots[k] + dsa_comb_limbs_per_key(c->dsa_wbits) * sizeof(uint32_t),
+                             rows[new_rows[k]]->qpow.data(), DSA_QTAIL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  DevBuf d_slots, d_rows;
+  if ((rc = upload(c, d_slots, new_slots)) || (rc = upload(c, d_rows, new_rows))) { d_slots.release(); d_rows.release(); return rc; }
+  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * (256u / c->dsa_wbits);
+  hipLaunchKernelGGL(k_dsa_build_comb, dim3((n_quads + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
+                     (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>());
+  hipError_t e = hipStreamSynchronize(c->stream);
+  d_slots.release(); d_rows.release();
+  if (e != hipSuccess) return fail(c, BFTKV_E_DEVICE, "k_dsa_build_comb", e);
   return 0;
 }
 
@@ -395,6 +471,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   std::vector<uint64_t> key_id, entity_ids;
   std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
   std::vector<uint8_t> algo, flags;
+  std::vector<const KeyEntry*> rows;
   auto add = [&](const KeyEntry& e, bool own_entity) {
     uint32_t ent = 0;
     if (own_entity) { ent = (uint32_t)entity_ids.size(); entity_ids.push_back(e.entity_id); }
@@ -406,6 +483,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
     bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
     nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
     qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
+    rows.push_back(&e);
     return ent;
   };
   for (auto& e : c->ring) add(e, false);
@@ -420,6 +498,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
       bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
       nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
       qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
+      rows.push_back(&e);
     }
     const_cast<KeyEntry&>(e).entity_index = group_ent;
   }
@@ -429,8 +508,13 @@ int upload_key_table(bftkv_gpu_ctx* c) {
       (rc = upload(c, c->k_n, nl)) || (rc = upload(c, c->k_r2, r2)) || (rc = upload(c, c->k_n0, n0)) ||
       (rc = upload(c, c->k_q, qw)) || (rc = upload(c, c->k_qbits, qbits)) || (rc = upload(c, c->k_dsatab, dtab)))
     return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->n_keys = (uint32_t)key_id.size();
+  c->kt.n_keys = c->n_keys;
+  c->kt.n_limbs = c->k_n.as<uint32_t>();
+  c->kt.n0inv = c->k_n0.as<uint32_t>();
+  c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
+  if ((rc = sync_dsa_tables(c, rows, algo, bits))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = false;
   for (size_t i = 0; i < algo.size(); ++i) {
     if (algo[i] == PK_DSA) c->have_dsa_keys = true;
@@ -456,6 +540,9 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->kt.q_words = c->k_q.as<uint32_t>();
   c->kt.q_bits = c->k_qbits.as<uint32_t>();
   c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
+  c->kt.dsa_slot = c->k_dsaslot.as<uint32_t>();
+  c->kt.dsa_comb = c->dsa_comb.as<uint32_t>();
+  c->kt.dsa_wbits = c->dsa_wbits;
   ++c->keyring_gen;
   return 0;
 }
@@ -485,7 +572,8 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   bftkv_gpu_ctx* c = new bftkv_gpu_ctx();
   c->device = device_ordinal;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
+      hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
   *out = c;
   return BFTKV_OK;
@@ -500,9 +588,10 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
-  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab,
+  (void)hipStreamSynchronize(c->stream_d);
+  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
-                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_v, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
@@ -510,6 +599,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->stream_h);
+  (void)hipStreamDestroy(c->stream_d);
   delete c;
 }
 
@@ -529,6 +619,13 @@ void* bftkv_gpu_stream(bftkv_gpu_ctx* c) { return c ? (void*)c->stream : nullptr
 int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
   if (!c) return BFTKV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
+  if (!c || (bits != 0 && bits != 4 && bits != 8)) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->dsa_wbits_pinned = bits;
   return 0;
 }
 

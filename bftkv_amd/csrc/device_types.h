@@ -63,8 +63,22 @@ struct KeyTableDev {
   // DSA keys only (zero otherwise)
   const uint32_t* q_words;    // [n_keys][8] subgroup order q, little-endian 32-bit words
   const uint32_t* q_bits;     // [n_keys]
-  const uint32_t* dsa_tab;    // [n_keys][3][76] g*R, y*R, g*y*R mod p (Montgomery form) for Shamir's trick
+  const uint32_t* dsa_tab;    // [n_keys][2][76] g*R, y*R mod p (Montgomery form): seeds of the fixed-base tables
+  // Fixed-base window tables, resident in HBM for as long as the key is known (k_dsa_build_comb):
+  //   dsa_comb[slot][base in {g, y}][window w][digit d-1][76] = base^(d * 2^(wbits*w)) * R mod p,  d = 1 .. 2^wbits - 1
+  // so g^u1 * y^u2 is at most 2 * 256/wbits table multiplications and no squarings.  The slot ends with
+  //   q_pow28[76][10] = 2^(28 j) mod q as radix-2^28 limbs, which folds v (mod p) down to v mod q.
+  const uint32_t* dsa_slot;   // [n_keys] table slot of a DSA key (0xFFFFFFFF otherwise)
+  const uint32_t* dsa_comb;
+  uint32_t dsa_wbits;         // 8 (4.96 MB per key) or 4 (0.58 MB per key, very large DSA keyrings)
 };
+constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits) {
+  return 2ull * (256u / wbits) * ((1u << wbits) - 1u) * 76u;
+}
+constexpr uint32_t DSA_QPOW_WORDS = 76 * 10;
+// ... followed by the mod-q Montgomery constants: 2^512 mod q (8 words), -q^-1 mod 2^32 (1 word), 3 words padding
+constexpr uint32_t DSA_QTAIL_WORDS = DSA_QPOW_WORDS + 12;
+constexpr uint64_t dsa_slot_stride(uint32_t wbits) { return dsa_comb_limbs_per_key(wbits) + DSA_QTAIL_WORDS; }
 
 constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;
 // key only exists inside a request's certificate: invisible to keyring lookups, reachable when the lookup is

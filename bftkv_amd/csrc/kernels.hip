@@ -796,44 +796,134 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
 // ------------------------------------------------------------------------------------------------
 // DSA (Go crypto/dsa.Verify): mod-q side per thread, g^u1 * y^u2 mod p per quad
 // ------------------------------------------------------------------------------------------------
-// Per DSA signature, after its digest is known: range checks, w = s^-1 mod q, u1 = z*w, u2 = r*w.
-__global__ void __launch_bounds__(64) k_dsa_prep(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs,
-                                                 const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
-                                                 KeyTableDev kt, const uint32_t* __restrict__ digests,
-                                                 uint32_t* __restrict__ dsa_u /*[n][16]*/) {
+// Per DSA signature, as soon as it is parsed (runs beside the RSA modexp and the hashing): range checks,
+// w = s^-1 mod q, u2 = r*w.  dsa_u row = { w (all zero: signature already refused), u2, r }.
+constexpr int DSA_U_WORDS = 24;
+__global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
+                                                const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
+                                                KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/) {
+  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+  if (di >= pk_count[1]) return;
+  const uint32_t ri = dsa_list[di];
+  const uint32_t key = (uint32_t)recs[ri].key_slot;      // parse-time fields only: the status byte is the hash stream's
+  const uint32_t body_off = recs[ri].body_off;
+  const uint32_t off0 = recs[ri].mpi_off[0], off1 = recs[ri].mpi_off[1], bits0 = recs[ri].mpi_bits[0], bits1 = recs[ri].mpi_bits[1];
+  U256 q, r, s_, w;
+  for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
+  const uint32_t qbits = kt.q_bits[key];
+  const uint8_t* body = sig_blob + body_off;
+  bool ok = u256_from_be(body + off0, (bits0 + 7u) >> 3, r);
+  ok = u256_from_be(body + off1, (bits1 + 7u) >> 3, s_) && ok;
+  ok = ok && !u256_is_zero(r) && u256_cmp(r, q) < 0 && !u256_is_zero(s_) && u256_cmp(s_, q) < 0;   // 0 < r, s < q
+  ok = ok && (qbits & 7u) == 0;
+  ok = ok && u256_modinv_odd(s_, q, w);
+  U256 u2 = u256_zero();
+  if (ok) {
+    const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+    U256 r2;
+    for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
+    u2 = u256_mulmod_mont(w, r, q, qc[8], r2);
+  } else w = u256_zero();
+  uint32_t* o = dsa_u + (uint64_t)di * DSA_U_WORDS;
+  for (int i = 0; i < 8; ++i) { o[i] = w.w[i]; o[8 + i] = u2.w[i]; o[16 + i] = r.w[i]; }
+}
+
+// After the digests: u1 = z*w mod q replaces w in the row; refused signatures get their final status here.
+__global__ void __launch_bounds__(64) k_dsa_mul(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
+                                                const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                const uint32_t* __restrict__ digests, uint32_t* __restrict__ dsa_u) {
   const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
   if (di >= pk_count[1]) return;
   const uint32_t ri = dsa_list[di];
   const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_RSA) return;   // hash tag mismatch etc.: already final
-  const uint32_t key = (uint32_t)rec.key_slot;
-  U256 q, r, s_, w;
-  for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
-  const uint32_t qbits = kt.q_bits[key];
-  const uint8_t* body = sig_blob + rec.body_off;
-  bool ok = u256_from_be(body + rec.mpi_off[0], (rec.mpi_bits[0] + 7u) >> 3, r);
-  ok = u256_from_be(body + rec.mpi_off[1], (rec.mpi_bits[1] + 7u) >> 3, s_) && ok;
-  ok = ok && !u256_is_zero(r) && u256_cmp(r, q) < 0 && !u256_is_zero(s_) && u256_cmp(s_, q) < 0;   // 0 < r, s < q
-  ok = ok && (qbits & 7u) == 0;
-  ok = ok && u256_modinv_odd(s_, q, w);
-  if (!ok) { recs[ri].status = ST_BAD_SIG; return; }
+  uint32_t* o = dsa_u + (uint64_t)di * DSA_U_WORDS;
+  U256 q, w;
+  for (int i = 0; i < 8; ++i) { q.w[i] = kt.q_words[(uint64_t)rec.key_slot * 8 + i]; w.w[i] = o[i]; }
+  if (u256_is_zero(w)) { recs[ri].status = ST_BAD_SIG; return; }
   // z = leftmost min(len(digest), bytes(q)) digest bytes (openpgp truncates, then dsa.Verify again)
   const HashInfo hi = hash_info(rec.hash_id);
-  const uint32_t zlen = min(hi.dlen, qbits >> 3);
+  const uint32_t zlen = min(hi.dlen, kt.q_bits[rec.key_slot] >> 3);
   U256 z;
   u256_from_be((const uint8_t*)(digests + (uint64_t)ri * 16), zlen, z);
   while (u256_cmp(z, q) >= 0) u256_sub(z, q);        // z < 2^bits(q) < 2q: at most one round
-  const U256 u1 = u256_mulmod(w, z, q);
-  const U256 u2 = u256_mulmod(w, r, q);
-  uint32_t* o = dsa_u + (uint64_t)di * 16;
-  for (int i = 0; i < 8; ++i) { o[i] = u1.w[i]; o[8 + i] = u2.w[i]; }
+  const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[rec.key_slot] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+  U256 r2;
+  for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
+  const U256 u1 = u256_mulmod_mont(w, z, q, qc[8], r2);
+  for (int i = 0; i < 8; ++i) o[i] = u1.w[i];
 }
 
-// v = g^u1 * y^u2 mod p by Shamir's trick over the per-key table {gR, yR, gyR}: 256 squarings and
-// 256 table multiplications selected per quad (square-and-always-multiply keeps the wave uniform).
-__global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(const SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
+// Fixed-base window tables for one DSA key (see KeyTableDev::dsa_comb).  One quad per (slot, base, window):
+// B = seed^(2^(wbits*w)) by repeated squaring, then the entries B, B^2, ... by repeated multiplication.
+// Runs once per new DSA key (bftkv_gpu_keyring_set / certificate upload), never on the verify path.
+__global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, const uint32_t* __restrict__ new_slots /*[n_new]*/,
+                                                              const uint32_t* __restrict__ slot_key /*[n_new] key table row*/,
+                                                              KeyTableDev kt, uint32_t* __restrict__ comb) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  constexpr int L = MONT_L;
+  const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
+  const uint32_t n_quads = n_new * 2u * nwin;
+  const uint32_t quad = threadIdx.x >> 2;
+  const int qlane = threadIdx.x & 3;
+  const uint32_t gq0 = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const bool active = gq0 < n_quads;
+  const uint32_t gq = active ? gq0 : (n_quads - 1);
+  const uint32_t which = gq / (2u * nwin), base = (gq / nwin) & 1u, w = gq % nwin;
+  const uint32_t key = slot_key[which];
+  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
+  const uint32_t* a_rd = a_sh + quad * MONT_N;
+  uint32_t n[L], b[L], y[L], t[L];
+  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  const uint32_t* sp = kt.dsa_tab + ((uint64_t)key * 2 + base) * MONT_N + qlane * L;
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = np[k]; y[k] = sp[k]; }
+  const uint32_t n0inv = kt.n0inv[key];
+  const uint32_t nsq = wbits * w;
+  for (uint32_t i = 0; i < wbits * (nwin - 1); ++i) {     // uniform trip count; quads past their own count keep y
+#pragma unroll
+    for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i < nsq) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) y[k] = t[k];
+    }
+  }
+  uint32_t* out = comb + (uint64_t)new_slots[which] * dsa_slot_stride(wbits) + ((uint64_t)(base * nwin + w) * nent) * MONT_N + qlane * L;
+#pragma unroll
+  for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }       // a = B for the whole chain
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (uint32_t d = 0; d < nent; ++d) {
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) out[(uint64_t)d * MONT_N + k] = b[k];
+    }
+    mont_mul(t, a_rd, b, n, n0inv, qlane);
+#pragma unroll
+    for (int k = 0; k < L; ++k) b[k] = t[k];
+  }
+}
+
+__device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  v += ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_QUAD_SWAP1, 0xF, 0xF, false) << 32) |
+       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, DPP_QUAD_SWAP1, 0xF, 0xF, false);
+  lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+  v += ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_QUAD_SWAP2, 0xF, 0xF, false) << 32) |
+       (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, DPP_QUAD_SWAP2, 0xF, 0xF, false);
+  return v;
+}
+
+// v = g^u1 * y^u2 mod p from the per-key fixed-base tables: one table multiplication per non-zero
+// window digit of u1 and u2 (<= 2 * 256/wbits), no squarings.  A table row is 304 B read straight from
+// HBM/MALL into the quad's LDS slot; a wave skips a (window, base) step when all 16 digits are zero.
+// The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each quad lane
+// folds its 19 limbs, the quad adds up, 35 shift-subtract steps finish), then (v mod q) == r.
+__global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
                                                           const uint32_t* __restrict__ pk_count, KeyTableDev kt,
-                                                          const uint32_t* __restrict__ dsa_u, uint32_t* __restrict__ v_limbs) {
+                                                          const uint32_t* __restrict__ dsa_u) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
   const uint32_t count = pk_count[1];
@@ -851,30 +941,29 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(const SigRec* __restri
   uint32_t n[L], b[L], y[L], t[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
   const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t* tab = kt.dsa_tab + (uint64_t)key * 3 * MONT_N + qlane * L;
+  const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
+  const uint32_t* slot_base = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(wbits);
+  const uint32_t* tab = slot_base + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = np[k]; b[k] = rp[k]; a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; }
   const uint32_t n0inv = kt.n0inv[key];
-  const uint32_t* up = dsa_u + (uint64_t)di * 16;
+  const uint32_t* up = dsa_u + (uint64_t)di * DSA_U_WORDS;
+  const bool live = active && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   mont_mul(y, a_rd, b, n, n0inv, qlane);     // y = R mod p (Montgomery one)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int bit = 255; bit >= 0; --bit) {
-    const uint32_t sel = ((up[bit >> 5] >> (bit & 31)) & 1u) | (((up[8 + (bit >> 5)] >> (bit & 31)) & 1u) << 1);
-    // square
-#pragma unroll
-    for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(y, a_rd, b, n, n0inv, qlane);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (__any(sel != 0)) {
-      const uint32_t* tp = tab + (sel ? (sel - 1) : 0) * MONT_N;
+  for (uint32_t step = 0; step < 2u * nwin; ++step) {
+    const uint32_t base = step & 1u, w = step >> 1;
+    const uint32_t bitpos = w * wbits;
+    const uint32_t d = live ? ((up[base * 8 + (bitpos >> 5)] >> (bitpos & 31)) & nent) : 0u;
+    if (__any(d != 0)) {
+      const uint32_t* tp = tab + ((uint64_t)(base * nwin + w) * nent + (d ? d - 1 : 0)) * MONT_N;
 #pragma unroll
       for (int k = 0; k < L; ++k) { a_lds[k] = tp[k]; b[k] = y[k]; }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       mont_mul(t, a_rd, b, n, n0inv, qlane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (sel) {
+      if (d) {
 #pragma unroll
         for (int k = 0; k < L; ++k) y[k] = t[k];
       }
@@ -889,38 +978,48 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(const SigRec* __restri
   uint32_t diff = 0;
 #pragma unroll
   for (int k = 0; k < L; ++k) diff |= t[k] ^ n[k];
-  diff = quad_or(diff);
-  if (active) {
-    uint32_t* o = v_limbs + (uint64_t)di * MONT_N + qlane * L;
+  diff = quad_or(diff);                      // 0: v == p, i.e. v = 0, and r > 0 can never match
+  // v mod q: sum_j v_j * (2^(28 j) mod q) over 10 radix-2^28 columns (76 terms of < 2^56 each)
+  uint64_t col[10];
 #pragma unroll
-    for (int k = 0; k < L; ++k) o[k] = (diff == 0) ? 0u : t[k];
+  for (int j = 0; j < 10; ++j) col[j] = 0;
+  const uint32_t* pw = slot_base + dsa_comb_limbs_per_key(wbits) + (qlane * L) * 10;
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) col[j] = mad64(t[k], pw[k * 10 + j], col[j]);
   }
-}
-
-// (v mod q) == r
-__global__ void __launch_bounds__(64) k_dsa_finish(const uint8_t* __restrict__ sig_blob, SigRec* __restrict__ recs,
-                                                   const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
-                                                   KeyTableDev kt, const uint32_t* __restrict__ v_limbs) {
-  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
-  if (di >= pk_count[1]) return;
-  const uint32_t ri = dsa_list[di];
-  const SigRec rec = recs[ri];
-  if (rec.status != ST_PENDING_RSA) return;
-  const uint32_t key = (uint32_t)rec.key_slot;
-  U256 q, r, acc = u256_zero();
-  for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
-  u256_from_be(sig_blob + rec.body_off + rec.mpi_off[0], (rec.mpi_bits[0] + 7u) >> 3, r);
-  const uint32_t* v = v_limbs + (uint64_t)di * MONT_N;
-  for (int j = MONT_N - 1; j >= 0; --j) {
-    for (int k = 0; k < MONT_W; ++k) {
-      uint32_t c = u256_shl1(acc);
-      if (c || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
-    }
-    U256 l = u256_zero();
-    l.w[0] = v[j];             // < 2^28 <= q (q has at least 32 bits, bftkv_gpu_keyring_set)
-    u256_addmod(acc, l, q);
+#pragma unroll
+  for (int j = 0; j < 10; ++j) col[j] = quad_sum64(col[j]);
+  // columns -> 32-bit words W (value < q * 2^34.3)
+  uint32_t W[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) W[i] = 0;
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const uint64_t sacc = (j < 10 ? col[j] : 0ull) + carry;
+    const uint32_t limb = (uint32_t)sacc & MONT_MASK;
+    carry = sacc >> MONT_W;
+    const int bit = MONT_W * j, wi = bit >> 5, sh = bit & 31;
+    W[wi] |= limb << sh;
+    if (sh > 4 && wi + 1 < 12) W[wi + 1] |= limb >> (32 - sh);
   }
-  recs[ri].status = (u256_cmp(acc, r) == 0) ? ST_OK : ST_BAD_SIG;
+  U256 q, rr, acc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { q.w[i] = kt.q_words[(uint64_t)key * 8 + i]; rr.w[i] = up[16 + i]; }
+  // acc = top part (value >> 35 < 2^bits(q) <= 2q), then 35 double-and-reduce steps for the low bits
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc.w[i] = (W[i + 1] >> 3) | (W[i + 2] << 29);
+  if (u256_cmp(acc, q) >= 0) u256_sub(acc, q);
+  const uint64_t low = ((uint64_t)(W[1] & 7u) << 32) | W[0];
+#pragma unroll 1
+  for (int bit = 34; bit >= 0; --bit) {
+    uint32_t cbit = u256_shl1(acc);
+    acc.w[0] |= (uint32_t)(low >> bit) & 1u;
+    if (cbit || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
+  }
+  if (live && qlane == 0) recs[ri].status = (diff != 0 && u256_cmp(acc, rr) == 0) ? ST_OK : ST_BAD_SIG;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // 256-bit unsigned arithmetic for the mod-q side of DSA verification (one thread per signature):
 // modular inverse by binary extended GCD (exact for ANY odd modulus, like math/big.ModInverse --
-// no primality assumption), modular multiplication by double-and-add, Horner reduction of a
+// no primality assumption), modular multiplication by 8-word Montgomery products (double-and-add kept as the reference form), Horner reduction of a
 // 2128-bit radix-2^28 number.  Off the critical path: ~2 % of a DSA verification's work.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -69,6 +69,33 @@ __device__ __forceinline__ U256 u256_mulmod(const U256& a, const U256& b, const 
     if ((b.w[i >> 5] >> (i & 31)) & 1u) u256_addmod(r, a, q);
   }
   return r;
+}
+// Montgomery product a*b*2^-256 mod q for odd q, a, b < q  (q0inv = -q^-1 mod 2^32); result < q
+__device__ __forceinline__ U256 u256_montmul(const U256& a, const U256& b, const U256& q, uint32_t q0inv) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c += (uint64_t)a.w[j] * b.w[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+    c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
+    const uint32_t m = t[0] * q0inv;
+    c = ((uint64_t)m * q.w[0] + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { c += (uint64_t)m * q.w[j] + t[j]; t[j - 1] = (uint32_t)c; c >>= 32; }
+    c += t[8]; t[7] = (uint32_t)c; t[8] = t[9] + (uint32_t)(c >> 32);
+  }
+  U256 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = t[i];
+  if (t[8] || u256_cmp(r, q) >= 0) u256_sub(r, q);
+  return r;
+}
+// a * b mod q for a, b < q through two Montgomery products (r2 = 2^512 mod q)
+__device__ __forceinline__ U256 u256_mulmod_mont(const U256& a, const U256& b, const U256& q, uint32_t q0inv, const U256& r2) {
+  return u256_montmul(u256_montmul(a, b, q, q0inv), r2, q, q0inv);
 }
 // s^-1 mod q for odd q > 1 and 0 < s < q; false when gcd(s, q) != 1 (math/big.ModInverse returns nil)
 __device__ __forceinline__ bool u256_modinv_odd(const U256& s, const U256& q, U256& out) {

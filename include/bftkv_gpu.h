@@ -87,6 +87,12 @@ typedef struct {
  * material under one id is BFTKV_E_UNSUPPORTED. */
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint32_t n_keys);
 
+/* DSA verification (Go crypto/dsa.Verify under packet.PublicKey.VerifySignature) multiplies from per-key
+ * fixed-base window tables kept in HBM: 8-bit windows cost 4.96 MB and <= 64 multiplications per signature,
+ * 4-bit windows 0.58 MB and <= 128.  The default is 8 up to 4096 DSA keys, 4 beyond; bits = 4 or 8 pins
+ * the width, 0 returns to the default.  Takes effect at the next bftkv_gpu_keyring_set. */
+int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t bits);
+
 /* ---- quorum: replaces wotq / qc (quorum/wotqs/wotqs.go:16-26) ------------------------------- */
 typedef struct {
   int32_t f, min, threshold, suff;       /* as computed by wot.newQC (wotqs.go:36-70) */

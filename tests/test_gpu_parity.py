@@ -340,6 +340,34 @@ def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx):
     gpu_ctx.quorum_destroy(qh)
 
 
+def test_dsa_fixed_base_tables_both_widths(gpu_ctx):
+    """DSA verifies from per-key window tables (k_dsa_build_comb): the 8-bit and 4-bit layouts give the oracle's statuses,
+    and re-uploading the keyring (tables cached by key material) changes nothing."""
+    cl = cb.make_cluster(12, dsa_fraction=1.0)
+    c = cb.make_write_corpus(cl, 48, seed=21, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.2})
+    q = H.clique_quorum(cl)
+    want = None
+    try:
+        for bits in (8, 4, 4, 0):
+            gpu_ctx.set_dsa_window_bits(bits)
+            kr = _ring_and_ctx(gpu_ctx, cl)
+            qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+            err, nver, _ = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+            st, st_item = gpu_ctx.last_statuses()
+            gpu_ctx.quorum_destroy(qh)
+            if want is None:
+                want = (err.copy(), nver.copy(), st.copy())
+                assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+                for i in range(0, c.n_items, 5):
+                    r = H.oracle_collective(kr, q, c, i)
+                    assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
+                    assert list(st[st_item == i][:len(r.statuses)]) == r.statuses
+            else:
+                assert (err == want[0]).all() and (nver == want[1]).all() and (st == want[2]).all()
+    finally:
+        gpu_ctx.set_dsa_window_bits(0)
+
+
 def test_bad_arguments_and_reentrancy(gpu_ctx):
     """Infrastructure errors are return codes (never verdicts); one context may be called from several threads."""
     import threading
