@@ -6,6 +6,7 @@
 
 #include <deque>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -136,6 +137,13 @@ struct Graph {
   std::unordered_map<uint64_t, Vertex> vertices;
   std::unordered_set<uint64_t> revoked;
   std::vector<uint64_t> self;
+  // Selector cache: the reference recomputes the clique search on every ChooseQuorum; here every
+  // mutation bumps `epoch` and GetCliques results are kept per (start, distance) until the epoch moves.
+  uint64_t epoch = 0;
+  bool caching = true;
+  struct CliqueCacheEntry { uint64_t epoch; std::vector<Clique> cs; };
+  std::map<std::pair<uint64_t, int>, CliqueCacheEntry> clique_cache;
+  uint64_t cache_hits = 0, cache_misses = 0;
 
   Vertex* find(uint64_t id) { auto it = vertices.find(id); return it == vertices.end() ? nullptr : &it->second; }
   Vertex& get_or_add(uint64_t id, bool instance) {
@@ -145,6 +153,7 @@ struct Graph {
     return it->second;
   }
   bool add_node(uint64_t id, const uint64_t* signers, uint32_t n) {   // AddNodes, graph.go:46-75
+    ++epoch;
     if (revoked.count(id)) return false;
     get_or_add(id, true);
     for (uint32_t i = 0; i < n; ++i) {
@@ -154,17 +163,19 @@ struct Graph {
     return true;
   }
   void set_self(uint64_t id) {                                          // SetSelfNodes, graph.go:77-88
+    ++epoch;
     Vertex* v = find(id);
     if (!v || !v->has_instance) add_node(id, nullptr, 0);
     self.push_back(id);
   }
   uint64_t self_id() const { return self.empty() ? 0 : self[0]; }
   void remove_node(uint64_t id) {                                       // RemoveNodes, graph.go:90-107
+    ++epoch;
     for (auto& kv : vertices) kv.second.del_edge(id);
     if (vertices.erase(id)) for (size_t i = 0; i < order.size(); ++i) if (order[i] == id) { order.erase(order.begin() + i); break; }
     for (size_t i = 0; i < self.size(); ++i) if (self[i] == id) { self.erase(self.begin() + i); break; }
   }
-  void revoke(uint64_t id) { if (find(id)) remove_node(id); revoked.insert(id); }   // Revoke, graph.go:131-140
+  void revoke(uint64_t id) { ++epoch; if (find(id)) remove_node(id); revoked.insert(id); }   // Revoke, graph.go:131-140
   std::vector<uint64_t> peers() {                                       // GetPeers, graph.go:117-125
     std::vector<uint64_t> r; uint64_t me = self_id();
     for (uint64_t id : order) { Vertex& v = vertices[id]; if (v.has_instance && id != me) r.push_back(id); }
@@ -205,6 +216,16 @@ struct Graph {
     for (Vertex* c : clique) out->nodes.push_back(c->id);
     return true;
   }
+  const std::vector<Clique>& cliques_cached(uint64_t sid, int distance) {
+    auto key = std::make_pair(sid, distance);
+    auto it = clique_cache.find(key);
+    if (caching && it != clique_cache.end() && it->second.epoch == epoch) { ++cache_hits; return it->second.cs; }
+    ++cache_misses;
+    CliqueCacheEntry& e = clique_cache[key];
+    e.cs = cliques(sid, distance);
+    e.epoch = epoch;
+    return e.cs;
+  }
   std::vector<Clique> cliques(uint64_t sid, int distance) {             // GetCliques, graph.go:297-320
     std::vector<Clique> cs;
     Vertex* s = find(sid);
@@ -231,7 +252,18 @@ struct Graph {
 // ---------------------------------------------------------------------------------------------
 // quorum/wotqs/wotqs.go
 // ---------------------------------------------------------------------------------------------
-struct QC { std::vector<uint64_t> nodes; int f = 0, min = 0, threshold = 0, suff = 0; };
+struct QC {
+  std::vector<uint64_t> nodes;
+  int f = 0, min = 0, threshold = 0, suff = 0;
+  // membership index: intersection() emits every element of s1 found in s2 -- duplicates in s1 count again
+  // (wotqs.go:195-206) -- so a tally is sum over s1 of member(id), O(|s1|) instead of O(|s1| * |s2|)
+  mutable std::unordered_set<uint64_t> member;
+  mutable bool indexed = false;
+  bool has(uint64_t id) const {
+    if (!indexed) { member.clear(); member.insert(nodes.begin(), nodes.end()); indexed = true; }
+    return member.count(id) != 0;
+  }
+};
 
 inline bool new_qc(const std::vector<uint64_t>& in, int weight, int rw, uint64_t self, QC* out) {   // newQC, wotqs.go:36-70
   out->nodes.clear();
@@ -248,16 +280,21 @@ inline bool new_qc(const std::vector<uint64_t>& in, int weight, int rw, uint64_t
   return true;
 }
 
-inline int intersection_count(const uint64_t* s1, uint32_t n1, const std::vector<uint64_t>& s2) {   // wotqs.go:195-206
+inline int intersection_count(const uint64_t* s1, uint32_t n1, const QC& qc) {   // wotqs.go:195-206
   int c = 0;
-  for (uint32_t i = 0; i < n1; ++i) for (uint64_t b : s2) if (s1[i] == b) { ++c; break; }
+  for (uint32_t i = 0; i < n1; ++i) c += qc.has(s1[i]);
   return c;
 }
 
 }  // namespace host
 }  // namespace bftkv
 
-struct bftkv_graph { bftkv::host::Graph g; };
+struct bftkv_graph {
+  bftkv::host::Graph g;
+  // ChooseQuorum results per rw flag set, valid while g.epoch stands still
+  struct QuorumCacheEntry { uint64_t epoch; std::vector<bftkv::host::QC> qcs; };
+  std::map<int, QuorumCacheEntry> quorum_cache;
+};
 
 struct bftkv_quorum {
   std::vector<bftkv::host::QC> qcs;
@@ -267,21 +304,43 @@ struct bftkv_quorum {
 
   bool is_quorum(const uint64_t* ids, uint32_t n) const {       // wotqs.go:144-154
     if (qcs.empty()) return false;
-    for (auto& qc : qcs) if (qc.f > 0 && bftkv::host::intersection_count(ids, n, qc.nodes) < qc.min) return false;
+    for (auto& qc : qcs) if (qc.f > 0 && bftkv::host::intersection_count(ids, n, qc) < qc.min) return false;
     return true;
   }
   bool is_threshold(const uint64_t* ids, uint32_t n) const {    // wotqs.go:156-166
     if (qcs.empty()) return false;
-    for (auto& qc : qcs) if (qc.threshold > 0 && bftkv::host::intersection_count(ids, n, qc.nodes) < qc.threshold) return false;
+    for (auto& qc : qcs) if (qc.threshold > 0 && bftkv::host::intersection_count(ids, n, qc) < qc.threshold) return false;
     return true;
   }
   bool is_sufficient(const uint64_t* ids, uint32_t n) const {   // wotqs.go:168-175
-    for (auto& qc : qcs) if (qc.suff > 0 && bftkv::host::intersection_count(ids, n, qc.nodes) >= qc.suff) return true;
+    for (auto& qc : qcs) if (qc.suff > 0 && bftkv::host::intersection_count(ids, n, qc) >= qc.suff) return true;
     return false;
   }
   bool reject(const uint64_t* ids, uint32_t n) const {          // wotqs.go:177-184
-    for (auto& qc : qcs) if (qc.f == 0 || bftkv::host::intersection_count(ids, n, qc.nodes) <= qc.f) return false;
+    for (auto& qc : qcs) if (qc.f == 0 || bftkv::host::intersection_count(ids, n, qc) <= qc.f) return false;
     return true;
   }
   int get_threshold() const { int t = 0; for (auto& qc : qcs) t += qc.threshold; return t; }   // wotqs.go:186-192
+};
+
+// Running tally of one growing node list against a quorum: the collectors call IsSufficient / Reject after every
+// reply (client.go:153, crypto_pgp.go:493), which costs the reference O(k * n) per call; per-clique counters make
+// each step O(#cliques) with identical answers (same multiplicity rule as intersection()).
+struct bftkv_tally {
+  const bftkv_quorum* q;
+  std::vector<int> count;
+  explicit bftkv_tally(const bftkv_quorum* quorum) : q(quorum), count(quorum->qcs.size(), 0) {}
+  void add(uint64_t id) { for (size_t i = 0; i < q->qcs.size(); ++i) count[i] += q->qcs[i].has(id); }
+  bool is_sufficient() const { for (size_t i = 0; i < count.size(); ++i) if (q->qcs[i].suff > 0 && count[i] >= q->qcs[i].suff) return true; return false; }
+  bool is_threshold() const {
+    if (count.empty()) return false;
+    for (size_t i = 0; i < count.size(); ++i) if (q->qcs[i].threshold > 0 && count[i] < q->qcs[i].threshold) return false;
+    return true;
+  }
+  bool is_quorum() const {
+    if (count.empty()) return false;
+    for (size_t i = 0; i < count.size(); ++i) if (q->qcs[i].f > 0 && count[i] < q->qcs[i].min) return false;
+    return true;
+  }
+  bool reject() const { for (size_t i = 0; i < count.size(); ++i) if (q->qcs[i].f == 0 || count[i] <= q->qcs[i].f) return false; return true; }
 };

@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_
   if (di >= pk_count[1]) return;
   const uint32_t ri = dsa_list[di];
   const uint32_t key = (uint32_t)recs[ri].key_slot;      // parse-time fields only: the status byte is the hash stream's
-  const uint32_t body_off = recs[ri].body_off;
+  const uint64_t body_off = recs[ri].body_off;
   const uint32_t off0 = recs[ri].mpi_off[0], off1 = recs[ri].mpi_off[1], bits0 = recs[ri].mpi_bits[0], bits1 = recs[ri].mpi_bits[1];
   U256 q, r, s_, w;
   for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];

@@ -45,7 +45,7 @@ HOST_EXPORTS = [
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
-    "bftkv_host_quorum_cert_verify",
+    "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats",
 ]
 
 _ready = False
@@ -265,6 +265,15 @@ class Graph:
 
     def Revoke(self, i: int):
         _lib().bftkv_host_graph_revoke(self.h, i)
+
+    def set_caching(self, on: bool) -> None:
+        """Selector cache per graph epoch (on by default); off = the reference's recompute-per-call cost."""
+        _lib().bftkv_host_graph_set_caching(self.h, 1 if on else 0)
+
+    def cache_stats(self):
+        e, h, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib().bftkv_host_graph_cache_stats(self.h, C.byref(e), C.byref(h), C.byref(m))
+        return {"epoch": e.value, "hits": h.value, "misses": m.value}
 
     def GetReachableNodes(self, sid: int, distance: int) -> List[int]:
         n = C.c_uint32(0)

@@ -73,6 +73,11 @@ int bftkv_host_graph_reachable(bftkv_graph* g, uint64_t sid, int distance, uint6
 int bftkv_host_graph_cliques(bftkv_graph* g, uint64_t sid, int distance, uint64_t* ids_out, uint32_t ids_cap,
                              uint32_t* sizes_out, int32_t* weights_out, uint32_t cliques_cap, uint32_t* n_cliques_out);
 
+/* Selector caching.  The reference redoes the clique search on every ChooseQuorum
+ * (wotqs.go:95-127 -> graph.go:297-362); here every graph mutation bumps an epoch and both the GetCliques results and
+ * the finished quorums are kept until the epoch moves.  On by default; off reproduces the reference's cost. */
+int bftkv_host_graph_set_caching(bftkv_graph* g, int on);
+int bftkv_host_graph_cache_stats(const bftkv_graph* g, uint64_t* epoch, uint64_t* hits, uint64_t* misses);
 /* wot.ChooseQuorum(rw) (wotqs.go:117-127) from the graph's self vertex. */
 bftkv_quorum* bftkv_host_choose_quorum(bftkv_graph* g, int rw);
 /* A quorum from explicit cliques (tests, replay tools). */

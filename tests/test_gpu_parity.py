@@ -368,6 +368,35 @@ def test_dsa_fixed_base_tables_both_widths(gpu_ctx):
         gpu_ctx.set_dsa_window_bits(0)
 
 
+def test_signature_blob_beyond_4gib(gpu_ctx):
+    """Offsets are 64-bit end to end: a 4.3 GiB signature blob (a small mixed RSA/DSA corpus tiled) verifies tile for tile
+    like the first copy.  Sized for the 288 GB part: ~15 M packets, ~11 GB of arena."""
+    cl = cb.make_cluster(16, dsa_fraction=0.25)
+    mods, exps = cb.signer_tables(cl)
+    signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
+    c = cb.make_write_corpus(cl, 256, batch_signer=signer, seed=31,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.05, cb.MUT_ONE_SHORT: 0.2})
+    _ring_and_ctx(gpu_ctx, cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+    err0, nver0, vd0 = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    st0, _ = gpu_ctx.last_statuses()
+    T = int((4.3 * 2**30) // len(c.ss_blob)) + 1
+    sb = np.tile(c.ss_blob, T)
+    assert len(sb) > 2**32
+    tb = np.tile(c.tbss_blob, T)
+    step_t, step_s = np.uint64(c.tbss_off[-1]), np.uint64(c.ss_off[-1])
+    to = (np.arange(T, dtype=np.uint64)[:, None] * step_t + c.tbss_off[None, :-1].astype(np.uint64)).reshape(-1)
+    so = (np.arange(T, dtype=np.uint64)[:, None] * step_s + c.ss_off[None, :-1].astype(np.uint64)).reshape(-1)
+    to = np.concatenate([to, [np.uint64(T) * step_t]]).astype(np.uint64)
+    so = np.concatenate([so, [np.uint64(T) * step_s]]).astype(np.uint64)
+    err, nver, vd = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, _ = gpu_ctx.last_statuses()
+    assert (err.reshape(T, -1) == err0[None, :]).all() and (nver.reshape(T, -1) == nver0[None, :]).all()
+    assert (vd.reshape(T, -1) == vd0[None, :]).all()
+    assert (st.reshape(T, -1) == st0[None, :]).all()
+    gpu_ctx.quorum_destroy(qh)
+
+
 def test_bad_arguments_and_reentrancy(gpu_ctx):
     """Infrastructure errors are return codes (never verdicts); one context may be called from several threads."""
     import threading

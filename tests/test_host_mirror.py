@@ -95,7 +95,7 @@ def _random_world(rng):
         members = [m for ids in cliques for m in ids]
         signers = [int(x) for x in rng.choice(members, size=int(rng.integers(0, min(6, len(members)) + 1)), replace=False)]
         spec[i] = signers
-        for tgt in rng.choice(members, size=int(rng.integers(0, 4)), replace=False):   # the periphery trusts some members
+        for tgt in rng.choice(members, size=min(len(members), int(rng.integers(0, 4))), replace=False):   # the periphery trusts some members
             spec[int(tgt)] = spec[int(tgt)] + [i]
     order = list(spec.keys())
     rng.shuffle(order)
@@ -130,6 +130,56 @@ def test_graph_and_choose_quorum_match_oracle(H):
                 l = [int(x) for x in rng.choice(universe, size=int(rng.integers(0, 25)))]
                 assert hq.IsQuorum(l) == oq.is_quorum(l) and hq.IsThreshold(l) == oq.is_threshold(l)
                 assert hq.IsSufficient(l) == oq.is_sufficient(l) and hq.Reject(l) == oq.reject(l)
+
+
+def test_selector_cache_tracks_graph_epoch(H):
+    """ChooseQuorum from the per-epoch cache equals a fresh clique search (and the oracle) across
+    interleaved AddNodes / Revoke, and repeated calls between mutations are hits."""
+    import time
+    rng = np.random.default_rng(12)
+    flags = [W.AUTH, W.AUTH | W.PEER, W.AUTH | W.CERT, W.READ, W.WRITE, W.READ | W.WRITE]
+    for trial in range(25):
+        nodes, cliques = _random_world(rng)
+        og, cg, ug = W.Graph(), H.Graph(), H.Graph()
+        ug.set_caching(False)
+        self_id = int(rng.choice([i for i, _ in nodes]))
+        half = len(nodes) // 2
+        steps = [("add", nodes[:half]), ("self", self_id), ("add", nodes[half:])]
+        others = [i for i, _ in nodes if i != self_id]
+        steps += [("revoke", int(v)) for v in rng.choice(others, size=min(2, len(others)), replace=False)]
+        steps.insert(min(4, len(steps)), ("add", [(777000 + trial, [self_id])]))
+        for kind, arg in steps:
+            if kind == "add":
+                og.add_nodes(arg); cg.AddNodes(arg); ug.AddNodes(arg)
+            elif kind == "self":
+                og.set_self([arg]); cg.SetSelfNodes([arg]); ug.SetSelfNodes([arg])
+            else:
+                og.revoke(arg); cg.Revoke(arg); ug.Revoke(arg)
+            for rep in range(2):                       # second round must come from the cache
+                for rw in flags:
+                    want = [(q.f, q.min, q.threshold, q.suff, q.nodes) for q in W.Wot(og).choose_quorum(rw).qcs]
+                    assert H.wotqs.New(cg).ChooseQuorum(rw).qcs() == want, (trial, kind, rw)
+                    assert H.wotqs.New(ug).ChooseQuorum(rw).qcs() == want
+        st = cg.cache_stats()
+        assert st["hits"] >= len(steps) * len(flags) and st["epoch"] >= len(steps)
+        assert ug.cache_stats()["hits"] == 0
+    # cost at BASELINE configs[3] scale: one 256-clique, recomputed per call vs served from the cache
+    ids = list(range(1, 257))
+    world = [(i, [j for j in ids if j != i]) for i in ids]
+    cg, ug = H.Graph(), H.Graph()
+    ug.set_caching(False)
+    for g in (cg, ug):
+        g.AddNodes(world); g.SetSelfNodes([1])
+    t = {}
+    for name, g in (("cached", cg), ("recompute", ug)):
+        H.wotqs.New(g).ChooseQuorum(W.AUTH | W.PEER)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            q = H.wotqs.New(g).ChooseQuorum(W.AUTH | W.PEER)
+        t[name] = (time.perf_counter() - t0) / 20
+    assert q.qcs()[0][:4] == (84, 253, 169, 170) or q.qcs()[0][0] == 84
+    print("ChooseQuorum n=256: recompute %.3f ms, cached %.3f ms" % (t["recompute"] * 1e3, t["cached"] * 1e3))
+    assert t["cached"] * 3 < t["recompute"]
 
 
 def test_max_timestamped_value_matches_oracle(H):
@@ -182,6 +232,9 @@ def test_vote_fold_matches_reference_fold(H):
     hq = H.Quorum.from_qcs([(q.f, q.min, q.threshold, q.suff, q.nodes) for q in oq.qcs])
     rounds = [[(int(p), bool(rng.random() < 0.7)) for p in rng.permutation(list(range(1, 11)) + list(range(20, 26)))[:int(rng.integers(0, 17))]]
               for _ in range(100)]
+    # the same peer answering twice counts twice (intersection() keeps duplicates of its first argument)
+    rounds += [[(int(p), bool(rng.random() < 0.7)) for p in rng.choice(list(range(1, 6)) + [20, 21, 99], size=int(rng.integers(0, 17)))]
+               for _ in range(100)]
     consumed, thr = H.Client.vote_fold(hq, rounds)
     for rs, c, t in zip(rounds, consumed, thr):
         actives, failure, n = [], [], 0
