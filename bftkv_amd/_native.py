@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify",
 ]
 
 _lib = None
@@ -64,6 +64,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_error_string.restype = C.c_char_p
     lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
     lib.bftkv_gpu_set_dsa_window_bits.argtypes = [vp, u32]
+    lib.bftkv_gpu_message_verify.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p]
@@ -155,6 +156,26 @@ class Context:
                 setattr(arr[i], name, C.cast(cb, C.c_void_p) if cb is not None else None)
                 setattr(arr[i], name + "_len", len(b))
         self._check(self.lib.bftkv_gpu_keyring_set(self.h, arr, len(keys)), "keyring_set")
+
+    def message_verify(self, messages):
+        """Signature half of PGPMessage.Decrypt for a batch of already-decrypted packet sequences (bftkv_gpu_message_verify).
+        Returns (status[n], signer_key_id[n], peer_id[n], [plain bytes], [file name bytes])."""
+        n = len(messages)
+        blob = np.frombuffer(b"".join(messages), dtype=np.uint8) if n and sum(map(len, messages)) else np.zeros(1, dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+        st = np.zeros(max(1, n), dtype=np.uint8)
+        signer = np.zeros(max(1, n), dtype=np.uint64)
+        peer = np.zeros(max(1, n), dtype=np.uint64)
+        plain = np.zeros(max(1, int(off[n])), dtype=np.uint8)
+        poff = np.zeros(n + 1, dtype=np.uint64)
+        fn = np.zeros((max(1, n), 256), dtype=np.uint8)
+        fl = np.zeros(max(1, n), dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_message_verify(self.h, n, _ptr(np.ascontiguousarray(blob)), _ptr(off), _ptr(st), _ptr(signer), _ptr(peer),
+                                                      _ptr(plain), len(plain), _ptr(poff), _ptr(fn), _ptr(fl)), "message_verify")
+        plains = [plain[int(poff[i]):int(poff[i + 1])].tobytes() for i in range(n)]
+        names = [fn[i, :int(fl[i])].tobytes() for i in range(n)]
+        return st[:n], signer[:n], peer[:n], plains, names
 
     def set_dsa_window_bits(self, bits: int) -> None:
         """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""

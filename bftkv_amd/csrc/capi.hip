@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 // the parse): SHA-256 midstates -> per-signature digests; joined before the compare.  Leaves SigRec
 // statuses final.
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
-                 const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr) {
+                 const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
+                 const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr) {
   hipStream_t s = c->stream, sh = c->stream_h;
   if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
@@ -274,7 +275,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                        c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
                        d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_list3072.as<uint32_t>(), c->pk_list4096.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
-                       c->hash_mask.as<uint32_t>(), d_sig_class);
+                       c->hash_mask.as<uint32_t>(), d_sig_class, d_msg_slot, d_msg_hash);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   if (total && c->have_dsa_keys) {
@@ -984,4 +985,5 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"
 #include "batcher_capi.inc"
+#include "message_capi.inc"
 #include "host_capi.inc"

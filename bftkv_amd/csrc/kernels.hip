@@ -284,7 +284,9 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
                                                     uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_list3072, uint32_t* __restrict__ pk_list4096,
                                                     uint32_t* __restrict__ pk_count /*[0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096*/,
                                                     uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask,
-                                                    const uint8_t* __restrict__ sig_class /*per item or null*/) {
+                                                    const uint8_t* __restrict__ sig_class /*per item or null*/,
+                                                    const uint32_t* __restrict__ msg_slot /*per item or null*/,
+                                                    const uint8_t* __restrict__ msg_hash /*per item, with msg_slot*/) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
     bool have_issuer = false;
     uint64_t issuer = 0;
     if (!parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, 0)) st = ST_PARSE_ERROR;
-    else if (!have_issuer) st = ST_NO_ISSUER;
+    else if (!have_issuer && !msg_slot) st = ST_NO_ISSUER;
     else {
       // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
       const uint32_t only_ent = cert_ent ? cert_ent[rec.item] : 0xFFFFFFFFu;
@@ -323,7 +325,11 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       // device table -- the host de-duplicates identical material, bftkv_gpu_keyring_set)
       int32_t slot = -1;
       const uint32_t cls = sig_class ? sig_class[rec.item] : 0;
-      for (uint32_t k = 0; k < kt.n_keys; ++k) {
+      // Signed message (openpgp.ReadMessage): the key was chosen from the ONE-PASS packet (md.SignedBy = keys[0]) and the
+      // body was hashed with the one-pass packet's algorithm; the trailing signature only supplies suffix, tag and MPIs.
+      const uint8_t sig_hash_id = rec.hash_id;
+      if (msg_slot) { slot = (int32_t)msg_slot[rec.item]; rec.hash_id = msg_hash[rec.item]; }
+      for (uint32_t k = 0; k < kt.n_keys && !msg_slot; ++k) {
         const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
         if (kt.key_id[k] == issuer && usable &&
             (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
@@ -338,7 +344,7 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
       // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
-      else if (!sig_class_ok(cls, rec.sig_type)) st = ST_HASH_UNSUPPORTED;
+      else if (!msg_slot && !sig_class_ok(cls, rec.sig_type)) st = ST_HASH_UNSUPPORTED;
       else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {
@@ -346,6 +352,8 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
         st = ST_PENDING_HASH;
         if (rec.hash_id != HASH_SHA256) atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot));
         if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
+        else if ((rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) && sig_hash_id != rec.hash_id)
+          rec.after_tag = ST_BAD_SIG;   // rsa.VerifyPKCS1v15(sig.Hash, digest of another algorithm): length mismatch
         else if (rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) {
           const uint32_t mod_bits = kt.mod_bits[slot];
           const uint32_t kbytes = (mod_bits + 7) >> 3;

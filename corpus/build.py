@@ -451,3 +451,26 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
         reqs = [tbss_parts[i] + sigpkt(ss_parts[i], None) for i in range(n_items)]
     return WriteCorpus(cluster, n_items, tb, to, sb, so, total, mutation, expected_valid=expected_valid,
                        sig_count=per_item_counts.astype(np.int32), requests=reqs)
+
+
+# ------------------------------------------------------------------------------------------------
+# Transport messages (crypto_pgp.go:419-451): the signed packet sequence openpgp.Encrypt wraps in the
+# encrypted container -- one-pass signature, literal data (binary, file name = base64(nonce), time 0),
+# signature over the literal body.
+# ------------------------------------------------------------------------------------------------
+def signed_message(kp: KeyPair, plain: bytes, nonce: bytes, rng: Optional[DRBG] = None, shape: str = "go") -> bytes:
+    """shape "go": literal data as x/crypto's partialLengthWriter frames it (one run of power-of-two partial chunks per
+    Write: 2 header bytes, the file name, 4 time bytes, the body; Close() ends with a zero-length chunk) -- restated from
+    memory; shape "definite": one definite-length literal packet."""
+    import base64
+    from oracle import message as om
+    fname = base64.standard_b64encode(nonce)
+    ops = om.one_pass_packet(0x00, 8, kp.algo, kp.key_id)
+    if shape == "definite":
+        lit = om.literal_packet(fname, plain)
+    else:
+        chunks = []
+        for part in (2, len(fname), 4, len(plain)):
+            chunks += om.go_partial_chunks(part)
+        lit = om.literal_packet(fname, plain, partial=chunks)
+    return ops + lit + detach_sign(kp, plain, rng)

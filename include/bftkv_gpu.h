@@ -93,6 +93,29 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint
  * the width, 0 returns to the default.  Takes effect at the next bftkv_gpu_keyring_set. */
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t bits);
 
+/* ---- transport message signatures: the signature half of PGPMessage.Decrypt (crypto/pgp/crypto_pgp.go:453-471) ----
+ * Every request and reply is an OpenPGP message encrypted to the peer and signed by the sender
+ * (crypto_pgp.go:419-451; server.go:563; transport/transport.go:116-125).  Opening the container (session-key
+ * decryption, AES-CFB, MDC) is private-key / symmetric work and stays with the caller; this call takes the plaintext
+ * packet sequence found inside -- [one-pass signature] [literal data] [signature], MDC trailer removed -- for a batch of
+ * messages and does what openpgp.ReadMessage does from there: md.SignedBy = KeysByIdUsage(one-pass key id, sign)[0],
+ * hash the literal body with the ONE-PASS packet's algorithm, VerifySignature with the trailing signature packet.
+ *   status_out[i]       BFTKV_MSG_* below
+ *   signer_key_id_out   m.SignedByKeyId (0 when the message was unsigned or unreadable)
+ *   peer_id_out         GetCertById(SignedByKeyId): the id when a keyring entity has it as PRIMARY key id, else 0
+ *   plain_out/_off_out  literal bodies, concatenated (partial body lengths removed); plain_out may be NULL
+ *   fname_out           [n][256] literal file names = base64(nonce) (crypto_pgp.go:464), fname_len_out their lengths
+ * Fenced shapes are reported as BFTKV_MSG_UNSUPPORTED, never guessed. */
+#define BFTKV_MSG_OK 0               /* verified: Decrypt returns (plain, nonce, peer, nil) */
+#define BFTKV_MSG_SIGNATURE_ERROR 1  /* m.SignatureError != nil: Decrypt returns that error */
+#define BFTKV_MSG_READ_ERROR 2       /* openpgp.ReadMessage failed: crypto.ErrDecryptionFailed */
+#define BFTKV_MSG_NOT_SIGNED 3       /* crypto.ErrInvalidTransportSecurityData */
+#define BFTKV_MSG_UNVERIFIED 4       /* signed, but no usable signing key with that id: Decrypt returns a NIL error */
+#define BFTKV_MSG_UNSUPPORTED 5      /* compressed packet, text-mode / v3 / partial-length signature, MD5 / RIPEMD-160 */
+int bftkv_gpu_message_verify(bftkv_gpu_ctx* ctx, uint32_t n_msgs, const uint8_t* msgs, const uint64_t* msg_off, uint8_t* status_out,
+                             uint64_t* signer_key_id_out, uint64_t* peer_id_out, uint8_t* plain_out, uint64_t plain_cap,
+                             uint64_t* plain_off_out, uint8_t* fname_out, uint8_t* fname_len_out);
+
 /* ---- quorum: replaces wotq / qc (quorum/wotqs/wotqs.go:16-26) ------------------------------- */
 typedef struct {
   int32_t f, min, threshold, suff;       /* as computed by wot.newQC (wotqs.go:36-70) */

@@ -344,3 +344,85 @@ def test_audit_plain_storage_db(gpu_ctx, tmp_path):
     recs = audit.audit_plain_db(gpu_ctx, str(db), pubring, members[2])
     got = {os.path.basename(r.path): r.status for r in recs}
     assert got == want and set(want.values()) >= {"ok", "insufficient", "malformed"}
+
+
+def test_transport_message_signatures(gpu_ctx):
+    """bftkv_gpu_message_verify == oracle.message.read_signed_message on gpg-made messages, generator-made
+    ones judged by gpg, the outcome table, and a mutated batch from a mixed RSA/DSA cluster."""
+    import json
+    import os
+    from oracle import message as om
+    from oracle import openpgp as pgp
+    from corpus.keys import DRBG
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpg_messages.json")) as f:
+        vec = json.load(f)
+
+    def check(ring_blob, msgs, expect_ok=None):
+        ents = pgp.read_entities(ring_blob)
+        kr = col.Keyring(ents)
+        gpu_ctx.keyring_set(H.abi_keys(kr))
+        st, signer, peer, plains, names = gpu_ctx.message_verify(msgs)
+        for i, m in enumerate(msgs):
+            r = om.read_signed_message(ents, m)
+            assert st[i] == r.status, (i, st[i], r.status, r.sig_status)
+            if r.status not in (om.MSG_READ_ERROR, om.MSG_UNSUPPORTED):
+                assert plains[i] == r.plain and names[i] == r.file_name
+                assert int(signer[i]) == r.signed_by_key_id and int(peer[i]) == (r.peer or 0)
+            if expect_ok is not None:
+                assert (st[i] == om.MSG_OK) == expect_ok[i]
+        return st
+
+    d = vec["D"]
+    st = check(bytes.fromhex(vec["D_pubring"]), [bytes.fromhex(x["msg"]) for x in d] + [bytes.fromhex(x["tampered"]) for x in d],
+               [x["gpg_good"] for x in d] + [x["gpg_tampered_good"] for x in d])
+    assert (st[:len(d)] == 0).all() and (st[len(d):] != 0).all()
+    e = vec["E"]
+    check(bytes.fromhex(vec["E_pubring"]), [bytes.fromhex(x["msg"]) for x in e], [x["gpg_good"] for x in e])
+
+    # outcome table + mutated batch
+    cl = cb.make_cluster(16, dsa_fraction=0.25, n_outsiders=2)
+    rng = DRBG("msgbatch")
+    ring_blob = b"".join(r.entity for r in cl.replicas)
+    nrng = np.random.default_rng(8)
+    msgs = []
+    for i in range(600):
+        kp = cl.replicas[i % 16] if i % 23 else cl.outsiders[i % 2]
+        body = nrng.integers(0, 256, size=int(nrng.integers(0, 3000)), dtype=np.uint8).tobytes()
+        m = bytearray(cb.signed_message(kp, body, bytes(nrng.integers(0, 256, size=16, dtype=np.uint8)), rng, "go" if i % 3 else "definite"))
+        k = i % 11
+        if k == 1:
+            m[int(nrng.integers(0, len(m)))] ^= 1 << int(nrng.integers(0, 8))      # anywhere: header, lengths, body, signature
+        elif k == 2:
+            m = m[:int(nrng.integers(0, len(m)))]                                  # truncated
+        elif k == 3:
+            m[-5] ^= 0x40                                                          # signature value
+        msgs.append(bytes(m))
+    kp = cl.replicas[1]
+    sig = cb.detach_sign(kp, b"request", rng)
+    ops = om.one_pass_packet(0, 8, kp.algo, kp.key_id)
+    lit = om.literal_packet(b"f", b"request")
+    unk = pgp.new_format_header(60, 3) + b"abc"
+    dsa_kp = next(r for r in cl.replicas if r.algo == cb.PK_DSA)
+    dsa_sig = cb.detach_sign(dsa_kp, b"request", rng)
+    msgs += [lit, om.one_pass_packet(0, 8, kp.algo, cl.replicas[2].key_id) + lit + sig, om.one_pass_packet(0, 10, kp.algo, kp.key_id) + lit + sig,
+             ops + lit + lit, ops + lit, unk + ops + unk + lit + unk + sig, om.one_pass_packet(0, 8, kp.algo, kp.key_id, is_last=False) + lit + sig,
+             om.one_pass_packet(0x10, 8, kp.algo, kp.key_id) + lit + sig, ops, b"", ops + lit[:5], b"\x00" + ops + lit + sig,
+             om.one_pass_packet(1, 8, kp.algo, kp.key_id) + lit + sig, pgp.new_format_header(8, 2) + b"\x00\x00" + ops + lit + sig,
+             ops + ops + lit + sig, ops + lit + sig + b"\x00garbage", ops + om.literal_packet(b"f", b"request", partial=[1, 0, 2]) + sig,
+             om.one_pass_packet(0, 8, dsa_kp.algo, dsa_kp.key_id) + lit + dsa_sig,
+             om.one_pass_packet(0, 10, dsa_kp.algo, dsa_kp.key_id) + lit + dsa_sig,      # body hashed with SHA-512: tag mismatch
+             om.one_pass_packet(0, 8, kp.algo, dsa_kp.key_id) + lit + sig]               # key and signature algorithms differ
+    # signature packets that NAME SHA-512 while the one-pass packet (and the signer) used SHA-256: dsa.Verify never looks
+    # at the packet's hash id, rsa.VerifyPKCS1v15 refuses the 32-byte digest
+    import hashlib
+    for who in (dsa_kp, kp):
+        pre = bytearray(cb.sig_prefix(0x00, who.algo, cb._hashed_area(who.key_id)))
+        pre[3] = 10
+        dg = hashlib.sha256(b"request" + cb.hash_suffix(bytes(pre))).digest()
+        msgs.append(om.one_pass_packet(0, 8, who.algo, who.key_id) + lit + cb.make_sig_packet(who, bytes(pre), dg, rng))
+    n_named = len(msgs)
+    st = check(ring_blob, msgs)
+    assert st[n_named - 2] == om.MSG_OK and st[n_named - 1] == om.MSG_SIGNATURE_ERROR
+    counts = np.bincount(st, minlength=6)
+    assert counts[om.MSG_OK] > 300 and counts[om.MSG_SIGNATURE_ERROR] > 30 and counts[om.MSG_READ_ERROR] > 10
+    assert counts[om.MSG_UNVERIFIED] > 10 and counts[om.MSG_NOT_SIGNED] >= 1 and counts[om.MSG_UNSUPPORTED] >= 3
