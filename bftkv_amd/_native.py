@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_destroy.restype = None
     lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
     lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p]
+    lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
     lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
@@ -378,6 +379,20 @@ class Batcher:
         if rc:
             raise NativeError("batcher signature_verify failed: %d" % rc)
         return int(err[0])
+
+    def message_verify(self, msg: bytes):
+        """One transport message through the batcher: (status, signer_key_id, peer_id, plain, file_name)."""
+        st = np.zeros(1, dtype=np.uint8)
+        ids = np.zeros(2, dtype=np.uint64)
+        plain = np.zeros(max(1, len(msg)), dtype=np.uint8)
+        plen = np.zeros(1, dtype=np.uint64)
+        fn = np.zeros(256, dtype=np.uint8)
+        fl = np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_message_verify(self.h, msg, len(msg), _ptr(st), ids.ctypes.data, ids.ctypes.data + 8, _ptr(plain),
+                                                       len(plain), _ptr(plen), _ptr(fn), _ptr(fl))
+        if rc:
+            raise NativeError("batcher message_verify failed: %d" % rc)
+        return int(st[0]), int(ids[0]), int(ids[1]), plain[:int(plen[0])].tobytes(), fn[:int(fl[0])].tobytes()
 
     def stats(self):
         st = (C.c_uint64 * 4)()

@@ -984,6 +984,6 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
 
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"
-#include "batcher_capi.inc"
 #include "message_capi.inc"
+#include "batcher_capi.inc"
 #include "host_capi.inc"

@@ -167,6 +167,12 @@ int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const 
 int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sig,
                                        uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out);
 /* stats[0] calls served, stats[1] device batches launched, stats[2] largest batch */
+/* One transport message (bftkv_gpu_message_verify for a single caller): blocks until its batch has run.  plain_out
+ * receives the literal body (BFTKV_E_NOMEM if plain_cap is too small; msg_len always suffices), fname_out[256] the
+ * file name. */
+int bftkv_gpu_batcher_message_verify(bftkv_gpu_batcher* b, const uint8_t* msg, uint64_t msg_len, uint8_t* status_out,
+                                     uint64_t* signer_key_id_out, uint64_t* peer_id_out, uint8_t* plain_out, uint64_t plain_cap,
+                                     uint64_t* plain_len_out, uint8_t* fname_out, uint8_t* fname_len_out);
 int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
 
 /* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */

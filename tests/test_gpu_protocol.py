@@ -292,6 +292,15 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
     b = Batcher(gpu_ctx, max_items=32, max_wait_us=20000)
     got = [None] * c.n_items
     sig_got = [None] * 16
+    msg_got = [None] * 24
+    from corpus.keys import DRBG
+    mrng = DRBG("batcher-msgs")
+    msgs = [cb.signed_message(cl.replicas[i % 4] if i % 5 else cl.outsiders[0], b"body%d" % i, b"nonce-%010d" % i, mrng, "go" if i % 2 else "definite")
+            for i in range(24)]
+    msgs[3] = msgs[3][:-2] + bytes([msgs[3][-2] ^ 1]) + msgs[3][-1:]
+
+    def msg_worker(i):
+        msg_got[i] = b.message_verify(msgs[i])
 
     def worker(i):
         got[i] = b.collective_verify(qh, c.tbss(i), c.ss_data(i))
@@ -301,6 +310,7 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
         s = cb.detach_sign(cl.client, tbs if i % 2 == 0 else tbs + b"!")
         sig_got[i] = b.signature_verify(tbs, s, cert_key_id=cl.client.key_id if i % 4 < 2 else None)
     ths = [threading.Thread(target=worker, args=(i,)) for i in range(c.n_items)] + [threading.Thread(target=sig_worker, args=(i,)) for i in range(16)]
+    ths += [threading.Thread(target=msg_worker, args=(i,)) for i in range(24)]
     for t in ths:
         t.start()
     for t in ths:
@@ -309,7 +319,13 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
     b.close()
     assert got == want and 0 < sum(g == 0 for g in got) < len(got)
     assert sig_got == [0 if i % 2 == 0 else 1 for i in range(16)]
-    assert st["calls"] == c.n_items + 16 and st["batches"] < st["calls"] / 2 and st["max_batch"] > 4
+    assert st["calls"] == c.n_items + 16 + 24 and st["batches"] < st["calls"] / 2 and st["max_batch"] > 4
+    import base64
+    for i, (mst, signer, peer, plain, fname) in enumerate(msg_got):
+        who = cl.replicas[i % 4] if i % 5 else cl.outsiders[0]
+        assert mst == (4 if i % 5 == 0 else (1 if i == 3 else 0)), (i, mst)          # outsider: unverified; tampered: signature error
+        assert plain == b"body%d" % i and base64.standard_b64decode(fname) == b"nonce-%010d" % i
+        assert signer == who.key_id and peer == (who.key_id if i % 5 else 0)
     gpu_ctx.quorum_destroy(qh)
 
 
