@@ -95,6 +95,7 @@ struct bftkv_gpu_ctx {
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
+  std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
   hipEvent_t ev[8] = {};   // 0 start, 1 parsed, 2 modexp done, 3 compare done, 4 end, 5 hash start, 6 hash done
   bool have_timing = false;
@@ -596,6 +597,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
+  for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);

@@ -213,10 +213,14 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
   }
 }
 
-// r = prod_j base_j ^ e_j mod p, e_j up to 256 bits (little-endian words taken from 76-limb numbers' low part)
+// r = prod_j base_j ^ e_j mod p, e_j up to 256 bits (radix-2^28 limbs; 10 limbs = 280 bits cover them).
+// Straus' simultaneous exponentiation with 4-bit windows: per base the multiples b^1 .. b^15 (Montgomery form) go to a
+// global table (4.5 KB per base, written and re-read by the same quad), then 70 windows of 4 shared squarings and at
+// most one table multiplication per base.  28 = 7 * 4, so a window digit never straddles two limbs.
+constexpr int MULTIEXP_WIN = 4, MULTIEXP_ENT = 15;
 __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
                                                         const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
-                                                        const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][76]*/,
+                                                        const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][15][76]*/,
                                                         uint32_t* __restrict__ out_limbs) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   QUAD_SETUP();
@@ -225,32 +229,42 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
   const uint32_t n0inv = mt.n0inv[mi];
-  // bases into the Montgomery domain (global scratch, re-read 256 times: L2 resident)
   for (uint32_t j = 0; j < k_bases; ++j) {
     const uint64_t sj = (uint64_t)op * k_bases + j;
+    uint32_t* tab = scratch + sj * MULTIEXP_ENT * MONT_N + qlane * L;
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = base_limbs[sj * MONT_N + qlane * L + k];
-    MONT(t, r2);
+    MONT(y, r2);                                                     // b * R
 #pragma unroll
-    for (int k = 0; k < L; ++k) scratch[sj * MONT_N + qlane * L + k] = t[k];
+    for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; if (active) tab[k] = y[k]; }
+    for (int d = 1; d < MULTIEXP_ENT; ++d) {                         // b^(d+1) = b^d * b, a = b stays in LDS
+      MONT(t, y);
+#pragma unroll
+      for (int k = 0; k < L; ++k) { y[k] = t[k]; if (active) tab[(uint64_t)d * MONT_N + k] = t[k]; }
+    }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");                 // the quad's own table rows are read back below
 #pragma unroll
   for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
   MONT(y, r2);                                                       // Montgomery one
-  for (int bit = 279; bit >= 0; --bit) {                             // 10 limbs = 280 bits cover any 256-bit exponent
+  for (int w = 280 / MULTIEXP_WIN - 1; w >= 0; --w) {
+    for (int sq = 0; sq < MULTIEXP_WIN; ++sq) {
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = y[k];
-    MONT(t, y);
+      for (int k = 0; k < L; ++k) a_lds[k] = y[k];
+      MONT(t, y);
 #pragma unroll
-    for (int k = 0; k < L; ++k) y[k] = t[k];
+      for (int k = 0; k < L; ++k) y[k] = t[k];
+    }
+    const int bit = w * MULTIEXP_WIN;
     for (uint32_t j = 0; j < k_bases; ++j) {
       const uint64_t sj = (uint64_t)op * k_bases + j;
-      const bool b = (exp_limbs[sj * MONT_N + bit / MONT_W] >> (bit % MONT_W)) & 1u;
-      if (!__any(b)) continue;
+      const uint32_t d = active ? ((exp_limbs[sj * MONT_N + bit / MONT_W] >> (bit % MONT_W)) & 15u) : 0u;
+      if (!__any(d != 0)) continue;
+      const uint32_t* row = scratch + (sj * MULTIEXP_ENT + (d ? d - 1 : 0)) * MONT_N + qlane * L;
 #pragma unroll
-      for (int k = 0; k < L; ++k) a_lds[k] = scratch[sj * MONT_N + qlane * L + k];
+      for (int k = 0; k < L; ++k) a_lds[k] = row[k];
       MONT(t, y);
-      if (b) {
+      if (d) {
 #pragma unroll
         for (int k = 0; k < L; ++k) y[k] = t[k];
       }
