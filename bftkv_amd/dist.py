@@ -21,19 +21,34 @@ def max_shard(n_items: int, world: int) -> int:
     return (n_items + world - 1) // world
 
 
+_consts = {}
+
+
+def _bit_consts(device):
+    """(weights, shifts) uint8 [8] on `device`, created once per device (no per-step host-to-device copies)."""
+    key = str(device)
+    if key not in _consts:
+        _consts[key] = (torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=device),
+                        torch.arange(8, dtype=torch.uint8, device=device))
+    return _consts[key]
+
+
 def pack_verdicts(ok: torch.Tensor, n_slots: int) -> torch.Tensor:
     """ok: bool/uint8 [n_local] (1 = CollectiveSignature.Verify returned nil) -> uint8 bitmap of
     ceil(n_slots/8) bytes, bit i of byte i//8 = item i (LSB first), zero padded to n_slots."""
     nbytes = (n_slots + 7) // 8
-    pad = torch.zeros(nbytes * 8, dtype=torch.uint8, device=ok.device)
-    pad[:ok.numel()] = ok.to(torch.uint8)
-    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=ok.device)
-    return (pad.view(nbytes, 8).to(torch.int32) * weights).sum(dim=1).to(torch.uint8)
+    weights, _ = _bit_consts(ok.device)
+    ok = ok.to(torch.uint8)
+    if ok.numel() != nbytes * 8:
+        pad = torch.zeros(nbytes * 8, dtype=torch.uint8, device=ok.device)
+        pad[:ok.numel()] = ok
+        ok = pad
+    return (ok.view(nbytes, 8) * weights).sum(dim=1, dtype=torch.uint8)      # distinct bits: the byte sum cannot overflow
 
 
 def unpack_verdicts(bits: torch.Tensor, n_slots: int) -> torch.Tensor:
-    shifts = torch.arange(8, dtype=torch.int32, device=bits.device)
-    return ((bits.to(torch.int32).unsqueeze(1) >> shifts) & 1).reshape(-1)[:n_slots].to(torch.uint8)
+    _, shifts = _bit_consts(bits.device)
+    return ((bits.unsqueeze(1) >> shifts) & 1).reshape(-1)[:n_slots]
 
 
 def allgather_verdicts(local_ok: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
@@ -48,6 +63,9 @@ def allgather_verdicts(local_ok: torch.Tensor, n_items: int, group=None) -> torc
         return unpack_verdicts(bits, n_items)
     gathered = torch.empty(world * bits.numel(), dtype=torch.uint8, device=bits.device)
     dist.all_gather_into_tensor(gathered, bits, group=group)
+    if n_items % world == 0:
+        # equal shards: rank r's bits are the first `slots` of its row
+        return unpack_verdicts(gathered, gathered.numel() * 8).view(world, -1)[:, :slots].reshape(-1)
     out = torch.empty(n_items, dtype=torch.uint8, device=bits.device)
     for r in range(world):
         lo, hi = shard_range(n_items, r, world)
