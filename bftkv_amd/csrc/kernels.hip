@@ -162,13 +162,16 @@ struct WalkStep {
   uint8_t status;      // ST_PENDING_PARSE for signature packets, final otherwise
 };
 
-__host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
+// `hdr(i)` yields stream byte pos+i (i < 6): straight from memory on the host / generic path, from registers on the
+// device fast path below.
+template <typename HDR>
+__host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, uint64_t end) {
   WalkStep r;
   r.event = true;
   r.status = ST_PARSE_ERROR;
   r.body_off = pos;
   r.body_len = 0;
-  uint32_t b0 = base[pos];
+  uint32_t b0 = hdr(0);
   if ((b0 & 0x80) == 0) { r.next = pos + 1; return r; }  // "tag byte does not have MSB set"
   uint32_t tag;
   uint64_t start, ln;
@@ -179,19 +182,19 @@ __host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint
     uint32_t nb = 1u << lt;
     if (pos + 1 + nb > end) { r.next = end; return r; }
     ln = 0;
-    for (uint32_t i = 0; i < nb; ++i) ln = (ln << 8) | base[pos + 1 + i];
+    for (uint32_t i = 0; i < nb; ++i) ln = (ln << 8) | hdr(1 + i);
     start = pos + 1 + nb;
   } else {
     tag = b0 & 0x3F;
     if (pos + 1 >= end) { r.next = end; return r; }
-    uint32_t b1 = base[pos + 1];
+    uint32_t b1 = hdr(1);
     if (b1 < 192) { ln = b1; start = pos + 2; }
     else if (b1 < 224) {
       if (pos + 2 >= end) { r.next = end; return r; }
-      ln = ((b1 - 192) << 8) + base[pos + 2] + 192; start = pos + 3;
+      ln = ((b1 - 192) << 8) + hdr(2) + 192; start = pos + 3;
     } else if (b1 == 255) {
       if (pos + 6 > end) { r.next = end; return r; }
-      ln = ((uint64_t)base[pos + 2] << 24) | ((uint64_t)base[pos + 3] << 16) | ((uint64_t)base[pos + 4] << 8) | base[pos + 5];
+      ln = ((uint64_t)hdr(2) << 24) | ((uint64_t)hdr(3) << 16) | ((uint64_t)hdr(4) << 8) | hdr(5);
       start = pos + 6;
     } else { r.next = end; r.status = ST_UNSUPPORTED; return r; }  // partial body length: fenced
   }
@@ -206,6 +209,26 @@ __host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint
   }
   r.status = ST_PENDING_PARSE;
   return r;
+}
+
+__host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
+  return walk_step([&](uint32_t i) -> uint32_t { return base[pos + i]; }, pos, end);
+}
+
+// Device walk: the whole header (<= 6 bytes) arrives with ONE memory round trip -- three independent aligned dword
+// loads and a funnel shift -- instead of up to three dependent byte loads; the per-item walk is a chain of ~53 such
+// steps and nothing but load latency.  Needs 12 readable bytes from the aligned address, else the byte path.
+__device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t pos, uint64_t end) {
+  const uint64_t a = pos & ~3ull;
+  if (a + 12 <= end && ((uintptr_t)base & 3u) == 0) {
+    const uint32_t* wp = (const uint32_t*)(base + a);
+    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    const uint32_t sh = (uint32_t)(pos & 3u) * 8u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);     // bytes pos .. pos+3
+    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);     // bytes pos+4 .. pos+7
+    return walk_step([&](uint32_t i) -> uint32_t { return ((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4)))) & 0xFFu; }, pos, end);
+  }
+  return walk_next(base, pos, end);
 }
 
 // Per-item scratch of the counting pass: the first WALK_CAP packet events of an item as
@@ -229,7 +252,7 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   uint32_t base = FILL ? rec_base[item] : 0;
   bool trailing_skip = false;   // silently skipped packet(s) after the last event
   while (pos < end) {
-    WalkStep w = walk_next(sig_blob, pos, end);
+    WalkStep w = walk_next_dev(sig_blob, pos, end);
     pos = w.next;
     if (!w.event) { trailing_skip = true; continue; }
     trailing_skip = false;
@@ -407,7 +430,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
   uint32_t n = 0;
   uint32_t base = FILL ? out_base[item] : 0;
   while (pos < end) {
-    WalkStep w = walk_next(sig_blob, pos, end);
+    WalkStep w = walk_next_dev(sig_blob, pos, end);
     pos = w.next;
     if (!w.event) continue;                               // unknown packet type: skipped by Next
     if (w.status == ST_NOT_SIGNATURE) continue;           // other packet types fall through the type switch

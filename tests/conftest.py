@@ -14,6 +14,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # Some GPU tests share the process with PyTorch, which ships its own libamdhip64: whichever HIP runtime is loaded
+    # first serves both (same soname), loading torch's second leaves it without devices.  Load torch's first.
+    import torch  # noqa: F401
     from bftkv_amd import Context
     ctx = Context(0)
     yield ctx
