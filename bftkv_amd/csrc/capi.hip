@@ -81,7 +81,7 @@ struct bftkv_gpu_ctx {
   std::vector<KeyEntry> ring, certs;   // processed rows: node keyring, then certificate-only entities
   uint32_t n_ring_entities = 0;
   std::map<std::string, bool> cert_valid;   // certificate bytes -> openpgp.ReadEntity would accept it
-  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab, k_dsaslot;
+  DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab, k_dsaslot, k_sorted_id, k_sorted_slot;
   // fixed-base DSA tables: built once per distinct key material, kept across key-table uploads
   DevBuf dsa_comb;
   uint32_t dsa_wbits = 8, dsa_wbits_pinned = 0;
@@ -244,8 +244,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
   HIPCHK(c, hipEventRecord(c->ev[5], sh));
   hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
-  const uint32_t nb = (n_items + 63) / 64;
-  hipLaunchKernelGGL(k_walk<false>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+  hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>());
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>());
@@ -268,15 +267,15 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * 4 * MONT_L4096 * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
-  // sequential fill only for items whose event list overflowed the scratch (a no-op grid otherwise)
-  hipLaunchKernelGGL(k_walk<true>, dim3(nb), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), (uint8_t*)nullptr, (WalkEnt*)nullptr);
+  // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
+  hipLaunchKernelGGL(k_walk<true>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr);
   if (total) {
     hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, d_ss_off, c->base.as<uint32_t>(),
                        c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
                        d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_list3072.as<uint32_t>(), c->pk_list4096.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
-                       c->hash_mask.as<uint32_t>(), d_sig_class, d_msg_slot, d_msg_hash);
+                       c->hash_mask.as<uint32_t>(), d_sig_class, d_msg_slot, d_msg_hash, c->item_flags.as<uint8_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   if (total && c->have_dsa_keys) {
@@ -504,7 +503,14 @@ int upload_key_table(bftkv_gpu_ctx* c) {
     }
     const_cast<KeyEntry&>(e).entity_index = group_ent;
   }
+  // issuer lookup index: ids ascending, ties in table order (std::stable_sort over row numbers)
+  std::vector<uint32_t> sorted_slot(key_id.size());
+  for (size_t i = 0; i < sorted_slot.size(); ++i) sorted_slot[i] = (uint32_t)i;
+  std::stable_sort(sorted_slot.begin(), sorted_slot.end(), [&](uint32_t a, uint32_t b) { return key_id[a] < key_id[b]; });
+  std::vector<uint64_t> sorted_id(key_id.size());
+  for (size_t i = 0; i < sorted_slot.size(); ++i) sorted_id[i] = key_id[sorted_slot[i]];
   int rc;
+  if ((rc = upload(c, c->k_sorted_id, sorted_id)) || (rc = upload(c, c->k_sorted_slot, sorted_slot))) return rc;
   if ((rc = upload(c, c->k_id, key_id)) || (rc = upload(c, c->k_entity, entity)) || (rc = upload(c, c->k_algo, algo)) ||
       (rc = upload(c, c->k_flags, flags)) || (rc = upload(c, c->k_bits, bits)) || (rc = upload(c, c->k_e, e32)) ||
       (rc = upload(c, c->k_n, nl)) || (rc = upload(c, c->k_r2, r2)) || (rc = upload(c, c->k_n0, n0)) ||
@@ -531,6 +537,8 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->h_key_flags = flags;
   c->kt.n_keys = c->n_keys;
   c->kt.key_id = c->k_id.as<uint64_t>();
+  c->kt.sorted_id = c->k_sorted_id.as<uint64_t>();
+  c->kt.sorted_slot = c->k_sorted_slot.as<uint32_t>();
   c->kt.entity = c->k_entity.as<uint32_t>();
   c->kt.pk_algo = c->k_algo.as<uint8_t>();
   c->kt.flags = c->k_flags.as<uint8_t>();
@@ -591,7 +599,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
   (void)hipStreamSynchronize(c->stream_d);
-  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb,
+  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})

@@ -52,6 +52,8 @@ constexpr uint8_t AFTER_TAG_PUBKEY = 0xFF;
 struct KeyTableDev {
   uint32_t n_keys;
   const uint64_t* key_id;     // [n_keys] 64-bit OpenPGP key id (primary or subkey)
+  const uint64_t* sorted_id;  // [n_keys] key ids ascending (ties in table order): issuer lookup by bisection
+  const uint32_t* sorted_slot;// [n_keys] table row of sorted_id[i]
   const uint32_t* entity;     // [n_keys] index of the owning entity (node) in the node table
   const uint8_t* pk_algo;     // [n_keys]
   const uint8_t* flags;       // [n_keys] bit0: usable for signing per KeysByIdUsage; bit1: CanSign(); bit2: primary key of its entity

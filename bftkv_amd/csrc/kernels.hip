@@ -238,44 +238,72 @@ __device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t 
 constexpr uint32_t WALK_CAP = 96;
 struct WalkEnt { uint32_t body_rel; uint32_t body_len_status; };   // len in the low 24 bits, status in the high 8
 
+// One WAVE per item.  A packet stream is a chain -- the position of packet j+1 is known only after the header of
+// packet j -- and walking it one packet per memory round trip made this kernel pure latency (53 dependent misses per
+// write at n = 64).  The wave speculates instead: lane j parses a header at pos + j * (length of the last packet).
+// Lane 0 always stands on a true boundary; lane j is confirmed when every lane before it is and lane j-1's packet ends
+// exactly where lane j started.  Signature packets of one quorum are all the same size (DetachSign: 287 B for RSA-2048),
+// so a whole item is normally confirmed in two rounds; any other stream just confirms fewer lanes per round (>= 1).
 template <bool FILL>
 __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                              uint32_t n_items, uint32_t* __restrict__ counts,
                                              const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
                                              uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch) {
-  uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t item = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
   if (item >= n_items) return;
-  if (FILL && counts[item] <= WALK_CAP) return;     // expanded in parallel by k_parse_body
-  uint64_t pos = sig_off[item], end = sig_off[item + 1];
-  const uint64_t pos0 = pos;
+  if (FILL && counts[item] <= WALK_CAP && !(item_flags[item] & 2)) return;     // expanded in parallel by k_parse_body
+  uint64_t pos = sig_off[item];
+  const uint64_t end = sig_off[item + 1], pos0 = pos;
   uint32_t n = 0;
-  uint32_t base = FILL ? rec_base[item] : 0;
+  const uint32_t base = FILL ? rec_base[item] : 0;
+  uint64_t stride = 0;
   bool trailing_skip = false;   // silently skipped packet(s) after the last event
+  bool force = false;           // an event that does not fit the scratch encoding: the fill pass must write this item
   while (pos < end) {
-    WalkStep w = walk_next_dev(sig_blob, pos, end);
-    pos = w.next;
-    if (!w.event) { trailing_skip = true; continue; }
-    trailing_skip = false;
-    if (!FILL && n < WALK_CAP && w.body_len < (1u << 24) && w.body_off - pos0 < (1ull << 32)) {
-      WalkEnt e;
-      e.body_rel = (uint32_t)(w.body_off - pos0);
-      e.body_len_status = w.body_len | ((uint32_t)w.status << 24);
-      scratch[(uint64_t)item * WALK_CAP + n] = e;
-    } else if (!FILL && n < WALK_CAP) {
-      n = WALK_CAP;      // does not fit the scratch encoding: force the sequential fill for this item
+    const uint64_t p = pos + (uint64_t)lane * stride;
+    const bool act = lane == 0 || (stride != 0 && p < end);
+    WalkStep w;
+    w.next = ~0ull; w.body_off = 0; w.body_len = 0; w.event = false; w.status = ST_PARSE_ERROR;
+    if (act) w = walk_next_dev(sig_blob, p, end);
+    const uint32_t pn_lo = __shfl_up((uint32_t)w.next, 1), pn_hi = __shfl_up((uint32_t)(w.next >> 32), 1);
+    const bool link = act && (lane == 0 || (((uint64_t)pn_hi << 32) | pn_lo) == p);
+    const uint64_t broken = __builtin_amdgcn_ballot_w64(!link);
+    const uint32_t n_conf = broken ? (uint32_t)__builtin_ctzll(broken) : 64u;   // >= 1: lane 0 always links
+    const bool conf = lane < n_conf;
+    const uint64_t evm = __builtin_amdgcn_ballot_w64(conf && w.event);
+    const uint32_t idx = n + (uint32_t)__builtin_popcountll(evm & ((1ull << lane) - 1ull));
+    if (conf && w.event) {
+      if (!FILL) {
+        if (idx < WALK_CAP) {
+          if (w.body_len < (1u << 24) && w.body_off - pos0 < (1ull << 32)) {
+            WalkEnt e;
+            e.body_rel = (uint32_t)(w.body_off - pos0);
+            e.body_len_status = w.body_len | ((uint32_t)w.status << 24);
+            scratch[(uint64_t)item * WALK_CAP + idx] = e;
+          } else force = true;
+        }
+      } else {
+        SigRec rec;
+        rec.body_off = w.body_off; rec.body_len = w.body_len; rec.item = item; rec.key_slot = -1;
+        rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
+        rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
+        rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = w.status;
+        rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
+        recs[base + idx] = rec;
+      }
     }
-    if (FILL) {
-      SigRec rec;
-      rec.body_off = w.body_off; rec.body_len = w.body_len; rec.item = item; rec.key_slot = -1;
-      rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
-      rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
-      rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = w.status;
-      rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
-      recs[base + n] = rec;
-    }
-    ++n;
+    n += (uint32_t)__builtin_popcountll(evm);
+    const uint32_t last = n_conf - 1;
+    const uint64_t next = ((uint64_t)__shfl((uint32_t)(w.next >> 32), last) << 32) | __shfl((uint32_t)w.next, last);
+    trailing_skip = !__shfl((int)w.event, last);
+    stride = next - (pos + (uint64_t)last * stride);
+    pos = next;
   }
-  if (!FILL) { counts[item] = n; item_flags[item] = trailing_skip ? 1 : 0; }
+  if (!FILL) {
+    const bool any_force = __builtin_amdgcn_ballot_w64(force) != 0;
+    if (lane == 0) { counts[item] = n; item_flags[item] = (trailing_skip ? 1 : 0) | (any_force ? 2 : 0); }
+  }
 }
 
 // Wave-aggregated slot allocation: ONE atomic per wave and counter instead of one per lane (534k single-address
@@ -309,7 +337,8 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
                                                     uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask,
                                                     const uint8_t* __restrict__ sig_class /*per item or null*/,
                                                     const uint32_t* __restrict__ msg_slot /*per item or null*/,
-                                                    const uint8_t* __restrict__ msg_hash /*per item, with msg_slot*/) {
+                                                    const uint8_t* __restrict__ msg_hash /*per item, with msg_slot*/,
+                                                    const uint8_t* __restrict__ item_flags) {
   uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= n_recs) return;
   // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
@@ -320,7 +349,7 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
   }
   const uint32_t item = lo;
   SigRec rec;
-  if (counts[item] <= WALK_CAP) {
+  if (counts[item] <= WALK_CAP && !(item_flags[item] & 2)) {
     const WalkEnt e = scratch[(uint64_t)item * WALK_CAP + (ri - rec_base[item])];
     rec.body_off = sig_off[item] + e.body_rel; rec.body_len = e.body_len_status & 0xFFFFFFu; rec.item = item; rec.key_slot = -1;
     rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
@@ -352,12 +381,20 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       // body was hashed with the one-pass packet's algorithm; the trailing signature only supplies suffix, tag and MPIs.
       const uint8_t sig_hash_id = rec.hash_id;
       if (msg_slot) { slot = (int32_t)msg_slot[rec.item]; rec.hash_id = msg_hash[rec.item]; }
-      for (uint32_t k = 0; k < kt.n_keys && !msg_slot; ++k) {
-        const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
-        if (kt.key_id[k] == issuer && usable &&
-            (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
-          slot = (int32_t)k;
-          break;
+      if (!msg_slot) {
+        // bisect the sorted id index, then take the first row IN TABLE ORDER (ties are kept in that order) that qualifies
+        uint32_t lo_i = 0, hi_i = kt.n_keys;
+        while (lo_i < hi_i) {
+          const uint32_t mid = (lo_i + hi_i) >> 1;
+          if (kt.sorted_id[mid] < issuer) lo_i = mid + 1; else hi_i = mid;
+        }
+        for (uint32_t i = lo_i; i < kt.n_keys && kt.sorted_id[i] == issuer; ++i) {
+          const uint32_t k = kt.sorted_slot[i];
+          const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
+          if (usable && (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
+            slot = (int32_t)k;
+            break;
+          }
         }
       }
       rec.key_slot = slot;
@@ -794,20 +831,73 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   const uint32_t kbytes = (kt.mod_bits[key] + 7) >> 3;
   const HashInfo hi = hash_info(rec.hash_id);
   const uint32_t hlen = hi.dlen, plen = hi.plen, tl = hlen + plen;
-  const uint8_t* dgb = (const uint8_t*)(digests + (uint64_t)ri * 16);
-  auto em_b = [&](uint32_t i) -> uint32_t {
-    if (i < hlen) return dgb[hlen - 1 - i];
-    if (i < tl) return digestinfo_byte(rec.hash_id, plen - 1 - (i - hlen));
-    if (i == tl) return 0;
-    if (i < kbytes - 2) return 0xFF;
-    if (i == kbytes - 2) return 1;
-    return 0;
+  // EM as little-endian 32-bit words, least significant first: [ digest | DigestInfo prefix | 00 ] (the variable tail,
+  // tl+1 bytes, staged in LDS by the quad), then FF words, then the 00 01 top.  Each lane builds the 18-word window its
+  // 19 limbs live in, shifts it to a limb boundary once, and slices limbs at compile-time offsets -- ~10 instructions
+  // per limb instead of five branchy byte look-ups.
+  constexpr int EM_TAIL_W = 24;   // >= (64 + 19 + 1) / 4
+  __shared__ uint32_t tail_sh[64 * EM_TAIL_W];
+  uint32_t* tail = tail_sh + (threadIdx.x >> 2) * EM_TAIL_W;
+  const uint32_t* dgw = digests + (uint64_t)ri * 16;
+  const uint32_t hw = hlen >> 2;            // every supported digest length is a multiple of 4
+#pragma unroll
+  for (int t = 0; t < EM_TAIL_W / 4; ++t) {
+    const uint32_t w = (uint32_t)qlane * (EM_TAIL_W / 4) + t;
+    uint32_t v = 0;
+    if (w < hw) v = __builtin_bswap32(dgw[hw - 1 - w]);
+    else {
+#pragma unroll
+      for (uint32_t bq = 0; bq < 4; ++bq) {
+        const uint32_t i = 4 * w + bq;
+        if (i >= hlen && i < tl) v |= digestinfo_byte(rec.hash_id, plen - 1 - (i - hlen)) << (8 * bq);
+      }
+    }
+    tail[w] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  auto em_word = [&](uint32_t w) -> uint32_t {
+    if (4 * w + 3 <= tl) return tail[w];
+    if (4 * w > tl && 4 * w + 3 < kbytes - 2) return 0xFFFFFFFFu;
+    uint32_t v = 0;                          // a word straddling a boundary (the 00 01 top; never the tail for SHA-1/2)
+#pragma unroll
+    for (uint32_t bq = 0; bq < 4; ++bq) {
+      const uint32_t i = 4 * w + bq;
+      uint32_t byte;
+      if (i <= tl) byte = (tail[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      else if (i < kbytes - 2) byte = 0xFF;
+      else byte = (i == kbytes - 2) ? 1u : 0u;
+      v |= byte << (8 * bq);
+    }
+    return v;
   };
+  constexpr int NW = (L * MONT_W + 31) / 32 + 1;
+  const uint32_t bit0 = (uint32_t)qlane * L * MONT_W, w0 = bit0 >> 5, s0 = bit0 & 31u;
+  uint32_t Wd[NW + 1], Wn[NW];
+#pragma unroll
+  for (int i = 0; i <= NW; ++i) Wd[i] = em_word(w0 + i);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) Wn[i] = __builtin_amdgcn_alignbit(Wd[i + 1], Wd[i], s0);
   uint32_t em[L], r[L];
-  const uint32_t* rp = r_limbs + (uint64_t)pi * NL + qlane * L;
+  // r: the block's 64 results are one contiguous run of the work list -- fetch it with fully coalesced dword loads into
+  // LDS (a lane-per-limb-slice read straight from global touches 64 cache lines per instruction)
+  __shared__ uint32_t r_sh[64 * NL];
+  {
+    const uint32_t q0 = (blockIdx.x * blockDim.x) >> 2;
+    const uint32_t n_valid = min(64u, count - q0) * NL;
+    const uint32_t* src = r_limbs + (uint64_t)q0 * NL;
+    for (uint32_t t = threadIdx.x; t < 64 * NL; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
+    __syncthreads();
+  }
+  const uint32_t* rp = r_sh + ((threadIdx.x >> 2) * NL + qlane * L);
   uint32_t diff = 0;
 #pragma unroll
-  for (int k = 0; k < L; ++k) { em[k] = limb28(em_b, qlane * L + k); r[k] = rp[k]; diff |= em[k] ^ r[k]; }
+  for (int k = 0; k < L; ++k) {
+    constexpr int dummy = 0; (void)dummy;
+    const int bit = MONT_W * k, wi = bit >> 5, sh = bit & 31;
+    em[k] = (sh == 0 ? Wn[wi] : __builtin_amdgcn_alignbit(Wn[wi + 1], Wn[wi], sh)) & MONT_MASK;
+    r[k] = rp[k];
+    diff |= em[k] ^ r[k];
+  }
   diff = quad_or(diff);
   bool ok = (diff == 0);
   if (__any(!ok)) {
