@@ -96,6 +96,8 @@ struct bftkv_gpu_ctx {
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp;
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
+  uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
+  uint32_t* d_mail = nullptr;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
   hipEvent_t ev[8] = {};   // 0 start, 1 parsed, 2 modexp done, 3 compare done, 4 end, 5 hash start, 6 hash done
   bool have_timing = false;
@@ -238,7 +240,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
-  HIPCHK(c, c->pk_count.ensure(16));
+  HIPCHK(c, c->pk_count.ensure(32));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
@@ -246,13 +248,27 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>());
+  constexpr uint32_t MAIL_EMPTY = 0xFFFFFFFFu;
+  if (c->h_mail) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
-                     c->total.as<uint32_t>());
-  uint32_t total = 0;
-  HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 16, s));
+                     c->total.as<uint32_t>(), c->d_mail);
+  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 32, s));
   HIPCHK(c, hipMemsetAsync(c->hash_mask.p, 0, sizeof(uint32_t) * (size_t)n_items, s));
-  HIPCHK(c, hipStreamSynchronize(s));
+  uint32_t total = MAIL_EMPTY;
+  if (c->h_mail) {
+    // spin on the mailbox (a few microseconds after the scan retires); give up after 20 ms and synchronise
+    const auto t_spin = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; ++it) {
+      total = __atomic_load_n(&c->h_mail[0], __ATOMIC_ACQUIRE);
+      if (total != MAIL_EMPTY) break;
+      if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (total == MAIL_EMPTY) {
+    HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
   c->last_total = total;
   c->last_items = n_items;
   const size_t tr = total ? total : 1;
@@ -271,11 +287,16 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   hipLaunchKernelGGL(k_walk<true>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr);
   if (total) {
-    hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, d_ss, d_ss_off, c->base.as<uint32_t>(),
-                       c->counts.as<uint32_t>(), n_items, c->walk_scratch.as<WalkEnt>(), c->recs.as<SigRec>(), total, c->kt,
-                       d_cert_ent, c->pk_list.as<uint32_t>(), c->pk_list3072.as<uint32_t>(), c->pk_list4096.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), c->dsa_list.as<uint32_t>(),
-                       c->hash_mask.as<uint32_t>(), d_sig_class, d_msg_slot, d_msg_hash, c->item_flags.as<uint8_t>());
+    ParseArgs pa;
+    pa.sig_blob = d_ss; pa.sig_off = d_ss_off; pa.rec_base = c->base.as<uint32_t>(); pa.counts = c->counts.as<uint32_t>(); pa.n_items = n_items;
+    pa.scratch = c->walk_scratch.as<WalkEnt>(); pa.recs = c->recs.as<SigRec>(); pa.n_recs = total; pa.cert_ent = d_cert_ent;
+    pa.pk_list = c->pk_list.as<uint32_t>(); pa.pk_list3072 = c->pk_list3072.as<uint32_t>(); pa.pk_list4096 = c->pk_list4096.as<uint32_t>();
+    pa.pk_count = c->pk_count.as<uint32_t>(); pa.dsa_list = c->dsa_list.as<uint32_t>(); pa.item_hash_mask = c->hash_mask.as<uint32_t>();
+    pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
+    if ((uint64_t)total >= 16ull * n_items)      // long items (collective signatures): block per item
+      hipLaunchKernelGGL(k_parse_body_items, dim3(n_items), dim3(PARSE_ITEM_BLOCK), 0, s, pa, c->kt);
+    else
+      hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, pa, c->kt);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   if (total && c->have_dsa_keys) {
@@ -293,7 +314,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                        c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
     hipLaunchKernelGGL(k_digest_other, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
   }
   HIPCHK(c, hipEventRecord(c->ev[6], sh));
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
@@ -581,6 +602,9 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   if (hipSetDevice(device_ordinal) != hipSuccess) return BFTKV_E_DEVICE;
   bftkv_gpu_ctx* c = new bftkv_gpu_ctx();
   c->device = device_ordinal;
+  if (hipHostMalloc((void**)&c->h_mail, 64, hipHostMallocMapped) == hipSuccess) {
+    if (hipHostGetDevicePointer((void**)&c->d_mail, c->h_mail, 0) != hipSuccess) { (void)hipHostFree(c->h_mail); c->h_mail = nullptr; c->d_mail = nullptr; }
+  } else c->h_mail = nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
@@ -606,6 +630,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
+  if (c->h_mail) (void)hipHostFree(c->h_mail);
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -930,7 +955,7 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
                      c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
-                     c->total.as<uint32_t>());
+                     c->total.as<uint32_t>(), (uint32_t*)nullptr);
   uint32_t total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

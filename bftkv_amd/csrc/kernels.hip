@@ -327,27 +327,27 @@ __device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
 }
 
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
-__global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
-                                                    const uint32_t* __restrict__ rec_base, const uint32_t* __restrict__ counts,
-                                                    uint32_t n_items, const WalkEnt* __restrict__ scratch,
-                                                    SigRec* __restrict__ recs, uint32_t n_recs,
-                                                    KeyTableDev kt, const uint32_t* __restrict__ cert_ent,
-                                                    uint32_t* __restrict__ pk_list, uint32_t* __restrict__ pk_list3072, uint32_t* __restrict__ pk_list4096,
-                                                    uint32_t* __restrict__ pk_count /*[0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096*/,
-                                                    uint32_t* __restrict__ dsa_list, uint32_t* __restrict__ item_hash_mask,
-                                                    const uint8_t* __restrict__ sig_class /*per item or null*/,
-                                                    const uint32_t* __restrict__ msg_slot /*per item or null*/,
-                                                    const uint8_t* __restrict__ msg_hash /*per item, with msg_slot*/,
-                                                    const uint8_t* __restrict__ item_flags) {
-  uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ri >= n_recs) return;
-  // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
-  uint32_t lo = 0, hi = n_items;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (rec_base[mid] <= ri) lo = mid; else hi = mid;
-  }
-  const uint32_t item = lo;
+struct ParseArgs {
+  const uint8_t* sig_blob; const uint64_t* sig_off; const uint32_t* rec_base; const uint32_t* counts; uint32_t n_items;
+  const WalkEnt* scratch; SigRec* recs; uint32_t n_recs; const uint32_t* cert_ent;
+  uint32_t *pk_list, *pk_list3072, *pk_list4096;
+  uint32_t* pk_count;          // [0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096, [4] some hash other than SHA-256
+  uint32_t* dsa_list; uint32_t* item_hash_mask;
+  const uint8_t* sig_class;    // per item or null
+  const uint32_t* msg_slot;    // per item or null
+  const uint8_t* msg_hash;     // per item, with msg_slot
+  const uint8_t* item_flags;
+};
+
+__device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev& kt, uint32_t ri, uint32_t item) {
+  const uint8_t* __restrict__ sig_blob = a.sig_blob; const uint64_t* __restrict__ sig_off = a.sig_off;
+  const uint32_t* __restrict__ rec_base = a.rec_base; const uint32_t* __restrict__ counts = a.counts;
+  const WalkEnt* __restrict__ scratch = a.scratch; SigRec* __restrict__ recs = a.recs;
+  const uint32_t* __restrict__ cert_ent = a.cert_ent;
+  uint32_t* __restrict__ pk_list = a.pk_list; uint32_t* __restrict__ pk_list3072 = a.pk_list3072; uint32_t* __restrict__ pk_list4096 = a.pk_list4096;
+  uint32_t* __restrict__ pk_count = a.pk_count; uint32_t* __restrict__ dsa_list = a.dsa_list; uint32_t* __restrict__ item_hash_mask = a.item_hash_mask;
+  const uint8_t* __restrict__ sig_class = a.sig_class; const uint32_t* __restrict__ msg_slot = a.msg_slot;
+  const uint8_t* __restrict__ msg_hash = a.msg_hash; const uint8_t* __restrict__ item_flags = a.item_flags;
   SigRec rec;
   if (counts[item] <= WALK_CAP && !(item_flags[item] & 2)) {
     const WalkEnt e = scratch[(uint64_t)item * WALK_CAP + (ri - rec_base[item])];
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
       else {
         // everything below is only reached when the hash tag matches (k_digest decides)
         st = ST_PENDING_HASH;
-        if (rec.hash_id != HASH_SHA256) atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot));
+        if (rec.hash_id != HASH_SHA256) { atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot)); pk_count[4] = 1u; }
         if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
         else if ((rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) && sig_hash_id != rec.hash_id)
           rec.after_tag = ST_BAD_SIG;   // rsa.VerifyPKCS1v15(sig.Hash, digest of another algorithm): length mismatch
@@ -454,6 +454,29 @@ __global__ void __launch_bounds__(256) k_parse_body(const uint8_t* __restrict__ 
   recs[ri] = rec;
 }
 
+// Record-major grid (thread per packet, the item found by bisection over the scan): batches of short items -- single
+// signatures, certificate checks, transport messages.
+__global__ void __launch_bounds__(256) k_parse_body(ParseArgs a, KeyTableDev kt) {
+  const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= a.n_recs) return;
+  // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
+  uint32_t lo = 0, hi = a.n_items;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.rec_base[mid] <= ri) lo = mid; else hi = mid;
+  }
+  parse_one(a, kt, ri, lo);
+}
+
+// Item-major grid (block per item): collective signatures carry tens of packets per item, the block's lanes read one
+// contiguous ss.Data and one scratch row, and nobody bisects.
+constexpr int PARSE_ITEM_BLOCK = 128;
+__global__ void __launch_bounds__(PARSE_ITEM_BLOCK) k_parse_body_items(ParseArgs a, KeyTableDev kt) {
+  const uint32_t item = blockIdx.x;
+  const uint32_t cnt = a.counts[item], base = a.rec_base[item];
+  for (uint32_t j = threadIdx.x; j < cnt; j += PARSE_ITEM_BLOCK) parse_one(a, kt, base + j, item);
+}
+
 // PGPSignature.Signers (crypto_pgp.go:373-390): parse-only walk, issuers looked up among PRIMARY
 // key ids (getCertById, :206-219); the walk ends at the first Reader.Next error.
 template <bool FILL>
@@ -491,8 +514,11 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
 }
 
 // single-block exclusive scan (n up to a few million): each thread scans a contiguous chunk
+// `host_total` (optional) is a mapped, pinned host word: the host spins on it instead of paying an interrupt-driven
+// stream synchronisation for the one number it needs (arena and grid sizes) in the middle of the pipeline.
 __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict__ counts, uint32_t n,
-                                                      uint32_t* __restrict__ base, uint32_t* __restrict__ total) {
+                                                      uint32_t* __restrict__ base, uint32_t* __restrict__ total,
+                                                      uint32_t* __restrict__ host_total) {
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
   uint32_t chunk = (n + 1023) / 1024;
@@ -509,7 +535,10 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict
   }
   uint32_t run = (t == 0) ? 0 : part[t - 1];
   for (uint32_t i = lo; i < hi; ++i) { base[i] = run; run += counts[i]; }
-  if (t == 1023) *total = part[1023];
+  if (t == 1023) {
+    *total = part[1023];
+    if (host_total) { __hip_atomic_store(host_total, part[1023], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -701,7 +730,9 @@ __global__ void __launch_bounds__(256) k_digest_sha256(const uint8_t* __restrict
 __global__ void __launch_bounds__(256, 4) k_digest_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                          const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                          const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
-                                                         uint32_t n_recs, uint32_t* __restrict__ digests) {
+                                                         uint32_t n_recs, uint32_t* __restrict__ digests,
+                                                         const uint32_t* __restrict__ any_other /*set by k_parse_body*/) {
+  if (*any_other == 0) return;        // every signature of the batch is SHA-256 (the path's default): nothing to read
   digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests);
 }
 
