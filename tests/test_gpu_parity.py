@@ -567,3 +567,76 @@ def test_verdict_bitmap_pack_unpack_on_device(gpu_ctx):
         assert bits.cpu().numpy().tobytes() == np.packbits(ok, bitorder="little").tobytes()
         assert (D.unpack_verdicts(bits, n).cpu().numpy() == ok).all()
         assert (D.allgather_verdicts(t == 1, n).cpu().numpy() == ok).all()
+
+
+def test_random_packet_framings_follow_the_oracle(gpu_ctx):
+    """The packet walk speculates on packet positions (k_walk): random streams mixing signature packets of different sizes,
+    unknown and non-signature packets in every header format, stray bytes, truncations and more than WALK_CAP events per
+    item must still yield the oracle's packet sequence, statuses, early-exit position and verdict."""
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(7, dsa_fraction=0.3)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    rng = np.random.default_rng(77)
+    from corpus.keys import DRBG
+    srng = DRBG("framing-fuzz")
+
+    def hdr(tag, ln, fmt):
+        if fmt == 0:                                   # new format, shortest legal length encoding
+            if ln < 192: return bytes([0xC0 | tag, ln])
+            if ln < 8384: return bytes([0xC0 | tag, ((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+            return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+        if fmt == 1: return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")          # new format, 5-octet length
+        if fmt == 2 and tag < 16 and ln < 256: return bytes([0x80 | (tag << 2)]) + bytes([ln])
+        if fmt == 3 and tag < 16 and ln < 65536: return bytes([0x80 | (tag << 2) | 1]) + ln.to_bytes(2, "big")
+        if tag < 16: return bytes([0x80 | (tag << 2) | 2]) + ln.to_bytes(4, "big")
+        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+
+    tbs_l, ss_l = [], []
+    for i in range(160):
+        tbs = rng.bytes(int(rng.integers(0, 300)))
+        sigs = [cb.detach_sign(r, tbs, srng) for r in cl.replicas]
+        parts = []
+        n_parts = int(rng.integers(1, 12)) if i % 10 else int(rng.integers(100, 140))      # every 10th: > WALK_CAP events
+        for _ in range(n_parts):
+            k = int(rng.integers(0, 12))
+            if k < 5:                                   # a signature, re-framed in a random header format
+                s = sigs[int(rng.integers(0, len(sigs)))]
+                body = s[3:] if s[1] >= 192 else s[2:]
+                parts.append(hdr(2, len(body), int(rng.integers(0, 5))) + body)
+            elif k < 7:                                 # unknown packet type, silently skipped
+                ln = int(rng.integers(0, 400))
+                parts.append(hdr(int(rng.choice([20, 40, 60, 63])), ln, int(rng.integers(0, 2))) + rng.bytes(ln))
+            elif k < 9:                                 # known non-signature packet (user id / literal / marker-like)
+                ln = int(rng.integers(0, 60))
+                parts.append(hdr(int(rng.choice([13, 11, 6, 14])), ln, int(rng.integers(0, 5))) + rng.bytes(ln))
+            elif k == 9:                                # small packets back to back
+                parts.append(b"".join(hdr(13, 1, 2) + b"x" for _ in range(int(rng.integers(1, 9)))))
+            elif k == 10 and i % 3 == 0:                # stray byte without the tag MSB: ends the stream
+                parts.append(bytes([int(rng.integers(0, 128))]))
+            else:
+                parts.append(sigs[int(rng.integers(0, len(sigs)))])
+        data = b"".join(parts)
+        if i % 7 == 3 and len(data) > 4:
+            data = data[:int(rng.integers(1, len(data)))]                               # truncated somewhere
+        tbs_l.append(tbs); ss_l.append(data)
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    n_long = 0
+    for i in range(160):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
+        got = list(st[st_item == i])
+        assert got[:len(r.statuses)] == r.statuses, (i, got[:12], r.statuses[:12])
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), i
+        n_long += len(got) > 96
+    assert n_long >= 8 and (err == 0).any() and (err != 0).any()
+    # Signers (parse-only walk) over the same streams
+    ids, off = gpu_ctx.signers(sb, so)
+    for i in range(0, 160, 9):
+        want = col.signers(kr, SignaturePacket(1, 0, False, ss_l[i] or None, None))
+        assert [int(x) for x in ids[int(off[i]):int(off[i + 1])]] == want, i
+    gpu_ctx.quorum_destroy(qh)
