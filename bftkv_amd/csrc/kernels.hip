@@ -42,12 +42,17 @@ __host__ __device__ __forceinline__ bool known_tag(uint32_t tag) {
   return tag < 32 && ((0x00066BFEu >> tag) & 1u);  // {1..9,11,13,14,17,18}
 }
 
+// Signature.parse.  An embedded-signature subpacket (type 32) makes x/crypto parse recursively; here the nesting depth is
+// a template parameter (fenced at 2), so the whole parser inlines into its kernels -- device-side recursion
+// would mean real function calls with a scratch stack in the packet-parse kernel.
 // subpacket area walk; returns false on structural/unsupported error
-__host__ __device__ bool parse_subpackets(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
-                                          bool& have_issuer, uint64_t& issuer, int depth);
+template <int DEPTH>
+__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
+                                                            bool& have_issuer, uint64_t& issuer);
 
-__host__ __device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
-                                        uint64_t& issuer, int depth) {
+template <int DEPTH>
+__host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
+                                                          uint64_t& issuer) {
   if (blen < 1) return false;
   if (body[0] != 4) return false;  // v3 handled by the caller, others unsupported
   if (blen < 6) return false;
@@ -63,14 +68,14 @@ __host__ __device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigR
   rec.hashed_len = (uint16_t)hl;
   bool have_ctime = false;
   have_issuer = false;
-  if (!parse_subpackets(body + 6, hl, true, have_ctime, have_issuer, issuer, depth)) return false;
+  if (!parse_subpackets_t<DEPTH>(body + 6, hl, true, have_ctime, have_issuer, issuer)) return false;
   if (!have_ctime) return false;
   uint32_t p = 6 + hl;
   if (p + 2 > blen) return false;
   uint32_t ul = ((uint32_t)body[p] << 8) | body[p + 1];
   p += 2;
   if (p + ul > blen) return false;
-  if (!parse_subpackets(body + p, ul, false, have_ctime, have_issuer, issuer, depth)) return false;
+  if (!parse_subpackets_t<DEPTH>(body + p, ul, false, have_ctime, have_issuer, issuer)) return false;
   p += ul;
   if (p + 2 > blen) return false;
   rec.hash_tag[0] = body[p];
@@ -92,8 +97,9 @@ __host__ __device__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigR
   return true;
 }
 
-__host__ __device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
-                                          bool& have_issuer, uint64_t& issuer, int depth) {
+template <int DEPTH>
+__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
+                                                            bool& have_issuer, uint64_t& issuer) {
   uint32_t p = 0;
   while (p < len) {
     uint32_t b = a[p], ln;
@@ -141,9 +147,11 @@ __host__ __device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool h
       case 32: {
         if (!hashed) break;
         // embedded signature: the reference parses it recursively and fails the outer parse on error
-        if (depth >= 2) return false;  // bounded recursion on the device (fenced)
-        SigRec tmp; bool hi; uint64_t iss;
-        if (!parse_sig_body(body, bl, tmp, hi, iss, depth + 1)) return false;
+        if constexpr (DEPTH >= 2) return false;  // bounded nesting (fenced)
+        else {
+          SigRec tmp; bool hi; uint64_t iss;
+          if (!parse_sig_body_t<DEPTH + 1>(body, bl, tmp, hi, iss)) return false;
+        }
         break;
       }
       default:
@@ -151,6 +159,11 @@ __host__ __device__ bool parse_subpackets(const uint8_t* a, uint32_t len, bool h
     }
   }
   return true;
+}
+
+__host__ __device__ __forceinline__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
+                                                        uint64_t& issuer, int /*depth: callers start at 0*/) {
+  return parse_sig_body_t<0>(body, blen, rec, have_issuer, issuer);
 }
 
 // One packet.Read framing step at stream position pos of [.., end): header only.
