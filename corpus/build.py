@@ -458,19 +458,51 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
 # encrypted container -- one-pass signature, literal data (binary, file name = base64(nonce), time 0),
 # signature over the literal body.
 # ------------------------------------------------------------------------------------------------
+def one_pass_packet(sig_type: int, hash_id: int, pk_algo: int, key_id: int, is_last: bool = True) -> bytes:
+    body = bytes([3, sig_type, hash_id, pk_algo]) + struct.pack(">Q", key_id) + bytes([1 if is_last else 0])
+    return _hdr(4, len(body)) + body
+
+
+def go_partial_chunks(n: int) -> List[int]:
+    """Powers of two x/crypto's partialLengthWriter cuts one Write of n bytes into (largest power <= 2^14 that fits)."""
+    out = []
+    while n > 0:
+        for power in range(14, -1, -1):
+            if n >= (1 << power):
+                out.append(power)
+                n -= 1 << power
+                break
+    return out
+
+
+def literal_packet(file_name: bytes, body: bytes, partial: Optional[List[int]] = None, is_binary: bool = True, time: int = 0) -> bytes:
+    """Literal data packet; ``partial`` = powers of two of the leading partial-length chunks, the rest closes the packet."""
+    content = (b"b" if is_binary else b"t") + bytes([len(file_name)]) + file_name + struct.pack(">I", time) + body
+    if not partial:
+        return _hdr(11, len(content)) + content
+    out = bytearray([0xC0 | 11])
+    p = 0
+    for power in partial:
+        ln = 1 << power
+        assert p + ln <= len(content)
+        out += bytes([224 + power]) + content[p:p + ln]
+        p += ln
+    out += _hdr(11, len(content) - p)[1:] + content[p:]
+    return bytes(out)
+
+
 def signed_message(kp: KeyPair, plain: bytes, nonce: bytes, rng: Optional[DRBG] = None, shape: str = "go") -> bytes:
     """shape "go": literal data as x/crypto's partialLengthWriter frames it (one run of power-of-two partial chunks per
     Write: 2 header bytes, the file name, 4 time bytes, the body; Close() ends with a zero-length chunk) -- restated from
     memory; shape "definite": one definite-length literal packet."""
     import base64
-    from oracle import message as om
     fname = base64.standard_b64encode(nonce)
-    ops = om.one_pass_packet(0x00, 8, kp.algo, kp.key_id)
+    ops = one_pass_packet(0x00, HASH_SHA256, kp.algo, kp.key_id)
     if shape == "definite":
-        lit = om.literal_packet(fname, plain)
+        lit = literal_packet(fname, plain)
     else:
         chunks = []
         for part in (2, len(fname), 4, len(plain)):
-            chunks += om.go_partial_chunks(part)
-        lit = om.literal_packet(fname, plain, partial=chunks)
+            chunks += go_partial_chunks(part)
+        lit = literal_packet(fname, plain, partial=chunks)
     return ops + lit + detach_sign(kp, plain, rng)
