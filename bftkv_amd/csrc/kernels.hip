@@ -560,28 +560,48 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict
 // 64-byte block at an arbitrarily aligned address as 16 big-endian words: 17 aligned dword loads
 // funnel-shifted with v_alignbyte_b32 (the bytes before/after the block inside the same aligned
 // dwords are readable: they belong to the same allocation).
-__device__ __forceinline__ void load_block_be(const uint8_t* p, uint32_t (&w)[16]) {
+__device__ __forceinline__ void load_block_raw(const uint8_t* p, uint32_t (&t)[17]) {
   const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
   const uint32_t* ap = (const uint32_t*)((uintptr_t)p & ~(uintptr_t)3);
-  uint32_t t[17];
 #pragma unroll
   for (int i = 0; i < 16; ++i) t[i] = ap[i];
   t[16] = mis ? ap[16] : 0;
+}
+__device__ __forceinline__ void block_raw_to_be(const uint8_t* p, const uint32_t (&t)[17], uint32_t (&w)[16]) {
+  const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
 #pragma unroll
   for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(__builtin_amdgcn_alignbyte(t[i + 1], t[i], mis));
 }
+__device__ __forceinline__ void load_block_be(const uint8_t* p, uint32_t (&w)[16]) {
+  uint32_t t[17];
+  load_block_raw(p, t);
+  block_raw_to_be(p, t, w);
+}
 
+// Thread per item, one compression after the other: the loop is a chain of (uncoalesced) block loads and 64 rounds.
+// The next block's 17 dwords are requested before the current block is compressed, so the load latency hides behind
+// the rounds (two blocks per trip, no register shuffling).
 __global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                    uint32_t n_items, uint32_t* __restrict__ mid /*[n][8]*/) {
   uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   const uint8_t* p = tbs_blob + tbs_off[item];
-  uint64_t len = tbs_off[item + 1] - tbs_off[item];
+  const uint64_t nblk = (tbs_off[item + 1] - tbs_off[item]) >> 6;
   uint32_t s[8];
   sha256_init(s);
-  for (uint64_t blk = 0; blk < (len >> 6); ++blk) {
-    uint32_t w[16];
-    load_block_be(p + blk * 64, w);
+  uint32_t ta[17], tb[17], w[16];
+  if (nblk) load_block_raw(p, ta);
+  uint64_t blk = 0;
+  for (; blk + 1 < nblk; blk += 2) {
+    load_block_raw(p + (blk + 1) * 64, tb);
+    block_raw_to_be(p + blk * 64, ta, w);
+    sha256_compress(s, w);
+    if (blk + 2 < nblk) load_block_raw(p + (blk + 2) * 64, ta);
+    block_raw_to_be(p + (blk + 1) * 64, tb, w);
+    sha256_compress(s, w);
+  }
+  if (blk < nblk) {
+    block_raw_to_be(p + blk * 64, ta, w);
     sha256_compress(s, w);
   }
 #pragma unroll
