@@ -33,9 +33,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--items", type=int, default=10000, help="signed writes per GPU per step")
     ap.add_argument("--replicas", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=1, help="batches in flight per GPU (separate verifier contexts / HIP streams); "
-                    "with 2 the packet walk and parse of step i+1 overlap the modexp of step i (+5 %, measured); the default 1 keeps "
-                    "per-kernel durations un-stretched so that the live roofline numbers and the rocprofv3 summary agree")
+    ap.add_argument("--inflight", type=int, default=1, help="batches (steps) in flight per GPU, each on its own verifier context / "
+                    "HIP streams.  2 overlaps the walk/parse of step i+1 and the compare/tally of step i-1 with the modexp of step i "
+                    "(+6 %% throughput, profiles/r01_v8_*), but then two modexp kernels also share the GPU and a launch's duration no "
+                    "longer says anything about the kernel: the default 1 keeps the roofline line meaningful")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corpus-cache", default="", help="path prefix of an .npz cache of the generated corpus (profiling reruns)")
     args = ap.parse_args()
@@ -107,8 +108,13 @@ def main():
         cx.collective_verify_dev(qhs[i % n_ctx], args.items, d_tbs.data_ptr(), d_tbs_off.data_ptr(), d_ss.data_ptr(), d_ss_off.data_ptr(),
                                  int(corpus.ss_off[-1]), e.data_ptr(), nv.data_ptr(), vd.data_ptr())
 
+    step_rsa_ms, step_total_ms = [], []
+
     def complete(i):
         ctxs[i % n_ctx].sync()
+        tm_i = ctxs[i % n_ctx].last_timing()        # HIP events recorded on the kernels' own streams during this step
+        step_rsa_ms.append(tm_i["rsa"])
+        step_total_ms.append(tm_i["total"])
         if world > 1:
             # per-write verdict bitmap (1 bit per write), all-gathered over RCCL/xGMI so that every
             # rank holds every verdict -- as every replica of the reference reaches every decision
@@ -128,13 +134,15 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    del step_rsa_ms[:], step_total_ms[:]
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel timing: a few non-overlapped calls on one context (HIP events on the kernel's own stream)
+    timed_rsa_ms, timed_total_ms = list(step_rsa_ms), list(step_total_ms)      # the K timed steps
+    # phase breakdown of an isolated call: a few non-overlapped calls on one context
     rsa_ms, tot_ms = [], []
     for _ in range(3):
         submit(0)
@@ -160,7 +168,7 @@ def main():
     if rank == 0:
         verifies_per_s = total_sigs * args.steps / elapsed
         verdicts_per_s = total_items * args.steps / elapsed
-        rsa_avg_s = float(np.mean(rsa_ms)) * 1e-3
+        rsa_avg_s = float(np.mean(timed_rsa_ms)) * 1e-3      # average k_rsa_modexp launch duration over the timed region
         alg_bytes = int(corpus.tbss_off[-1]) + corpus.n_sigs * RSA_BYTES + (args.items + 7) // 8
         achieved = alg_bytes / rsa_avg_s / 1e9
         traffic, traffic_src = measured_traffic("k_rsa_modexp") if args.items == 10000 and n == 64 else (None, None)
@@ -186,7 +194,9 @@ def main():
             "quorum_verdicts_per_sec": verdicts_per_s,
             "sufficient_fraction": float((err == 0).mean()),
             "pubkey_ops_per_step_per_gpu": int(counters["pubkey_ops"]),
-            "kernel_ms": {"single_call_total": float(np.mean(tot_ms)), "k_rsa_modexp": float(np.mean(rsa_ms)), "single_call_phases": tm},
+            "kernel_ms": {"k_rsa_modexp": float(np.mean(timed_rsa_ms)), "step_device_span": float(np.mean(timed_total_ms)),
+                          "measured": "HIP events of the %d timed steps (%d in flight)" % (len(timed_rsa_ms), n_ctx),
+                          "isolated_call": {"total": float(np.mean(tot_ms)), "k_rsa_modexp": float(np.mean(rsa_ms)), "phases": tm}},
             "roofline": {"bound": "hbm", "kernel": "k_rsa_modexp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
