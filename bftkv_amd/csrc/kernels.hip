@@ -1,17 +1,19 @@
 // HIP kernels of the bftkv batched quorum verifier (gfx950 / MI355X only).
 //
-//   k_walk<COUNT|FILL>    per item: walk the OpenPGP packet HEADERS of the signature stream
-//                         (x/crypto packet.Read framing) -> one SigRec per packet event
-//   k_scan_counts         exclusive scan of per-item record counts
-//   k_parse_body          per packet: Signature.parse (subpackets, MPIs), KeysByIdUsage lookup, every
-//                         check that does not need the digest; queues public-key work
+//   k_walk<COUNT|FILL>    wave per item: speculative walk of the OpenPGP packet HEADERS of the signature stream
+//                         (x/crypto packet.Read framing) -> one event per packet (scratch row, or SigRec when > 96)
+//   k_scan_counts         exclusive scan of per-item event counts; the total also goes to a pinned host mailbox
+//   k_parse_body[_items]  per packet: Signature.parse (subpackets, MPIs), KeysByIdUsage lookup (bisection), every
+//                         check that does not need the digest; queues public-key work (RSA by size class, DSA)
 //   k_sha256_mid          SHA-256 midstate of every item's signed payload, computed ONCE per item
 //                         (the reference re-hashes the whole payload per signature,
-//                          crypto/pgp/crypto_pgp.go:490)
-//   k_digest              per signature: finish the hash with the hash suffix, hash-tag check
-//   k_rsa_modexp          s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h);
-//                         runs CONCURRENTLY with the two hash kernels (separate HIP stream)
-//   k_rsa_compare         EMSA-PKCS1-v1_5 from the digest, compare with s^e mod n
+//                          crypto/pgp/crypto_pgp.go:490); k_hash_mid_other: SHA-1/224/384/512 on demand
+//   k_digest_sha256/other per signature: finish the hash with the hash suffix, hash-tag check
+//   k_rsa_modexp<L>       s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h);
+//                         runs CONCURRENTLY with the hash kernels (separate HIP stream)
+//   k_rsa_compare<L>      EMSA-PKCS1-v1_5 from the digest, compare with s^e mod n
+//   k_dsa_inv/_mul/_modexp  dsa.Verify: s^-1 mod q and u2 on a third stream, u1 after the digests, g^u1 y^u2 mod p
+//                         from HBM-resident fixed-base window tables (k_dsa_build_comb), v mod q == r in place
 //   k_modexp              generic b^x mod n (corpus signing, threshold-RSA partial signatures)
 //   k_tally               per item: wavefront ballots over the verified signers -> per-clique
 //                         counts -> IsSufficient / IsThreshold / IsQuorum / Reject bits
