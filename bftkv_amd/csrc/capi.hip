@@ -275,12 +275,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
   HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
   HIPCHK(c, c->r.ensure(sizeof(uint32_t) * MONT_N * tr));
-  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? 4 * MONT_L3072 : MONT_N) * tr));
+  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? MONT_TPI_BIG * MONT_L3072 : MONT_N) * tr));
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
   HIPCHK(c, c->pk_list3072.ensure(c->have_rsa3072 ? sizeof(uint32_t) * tr : 16));
   HIPCHK(c, c->pk_list4096.ensure(c->have_rsa4096 ? sizeof(uint32_t) * tr : 16));
-  if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * 4 * MONT_L3072 * tr));
-  if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * 4 * MONT_L4096 * tr));
+  if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * MONT_TPI_BIG * MONT_L3072 * tr));
+  if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * MONT_TPI_BIG * MONT_L4096 * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
   // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
@@ -321,27 +321,29 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
   if (total) {
     const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-    hipLaunchKernelGGL(k_rsa_modexp<MONT_L>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
+    hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>());
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
     if (c->have_rsa3072)
-      hipLaunchKernelGGL(k_rsa_modexp<MONT_L3072>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_modexp<MONT_L3072, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>());
     if (c->have_rsa4096)
-      hipLaunchKernelGGL(k_rsa_modexp<MONT_L4096>, qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
   if (total) {
     const dim3 cg((total * 4 + 255) / 256);
-    hipLaunchKernelGGL(k_rsa_compare<MONT_L>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    const dim3 cg8(((uint64_t)total * MONT_TPI_BIG + 255) / 256);
+    hipLaunchKernelGGL((k_rsa_compare<MONT_L, MONT_TPI>), cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa3072)
-      hipLaunchKernelGGL(k_rsa_compare<MONT_L3072>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_compare<MONT_L3072, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa4096)
-      hipLaunchKernelGGL(k_rsa_compare<MONT_L4096>, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_compare<MONT_L4096, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
   }
   // DSA signatures (if any): u1 depends on the digest, so the table multiplications run after the join; the
@@ -384,8 +386,8 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
   if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
     if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
     for (uint32_t j = 0; j < k.e_len; ++j) e.e = (e.e << 8) | k.e[j];
-    // size class: limbs per number 76 / 112 / 148 for moduli up to 2048 / 3072 / 4096 bits (R = 2^(28 N) > 4n)
-    const int nlimbs = e.bits <= 2048 ? MONT_N : (e.bits <= 3072 ? MONT_TPI * MONT_L3072 : MONT_TPI * MONT_L4096);
+    // size class: limbs per number 76 / 112 / 152 for moduli up to 2048 / 3072 / 4096 bits (R = 2^(28 N) > 4n)
+    const int nlimbs = e.bits <= 2048 ? MONT_N : (e.bits <= 3072 ? MONT_TPI_BIG * MONT_L3072 : MONT_TPI_BIG * MONT_L4096);
     if (e.bits > 4096) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
     else if (!hostbn::mont_setup(k.n, k.n_len, nlimbs, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
   } else if (k.pk_algo == PK_DSA) {

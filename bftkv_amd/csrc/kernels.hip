@@ -437,9 +437,9 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
           uint32_t lead = 0;
           while (lead < nb && mp[lead] == 0) ++lead;
           const uint32_t vbytes = nb - lead;
-          // size class of the modulus: 0 <= 2048 bits (76 limbs), 1 <= 3072 (112), 2 <= 4096 (148)
+          // size class of the modulus: 0 <= 2048 bits (76 limbs), 1 <= 3072 (112), 2 <= 4096 (152)
           const uint32_t cls_sz = mod_bits <= 2048 ? 0u : (mod_bits <= 3072 ? 1u : 2u);
-          const uint32_t cap_bytes = (cls_sz == 0 ? MONT_N : cls_sz == 1 ? 4 * MONT_L3072 : 4 * MONT_L4096) * MONT_W / 8;
+          const uint32_t cap_bytes = (cls_sz == 0 ? MONT_N : cls_sz == 1 ? MONT_TPI_BIG * MONT_L3072 : MONT_TPI_BIG * MONT_L4096) * MONT_W / 8;
           if (mod_bits == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;          // > 4096 bits or no Montgomery form
           else if (kbytes < hlen + plen + 11) rec.after_tag = ST_BAD_SIG;       // rsa.VerifyPKCS1v15: k < tLen+11
           else if (vbytes > cap_bytes) rec.after_tag = ST_BAD_SIG;              // value >= R: fenced
@@ -780,19 +780,20 @@ constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
 enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
 
 // r = s^e mod n (+ possibly n) for every queued signature; canonical radix-2^28 limbs to r_limbs.
-template <int L>   // limbs per lane: 19 (<= 2048-bit moduli), 28 (<= 3072), 37 (<= 4096)
+template <int L, int TPI>   // limbs per lane x lanes per number: 19x4 (<= 2048-bit moduli), 14x8 (<= 3072), 19x8 (<= 4096)
 __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                           const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
                                                           KeyTableDev kt, uint32_t* __restrict__ r_limbs,
                                                           uint32_t* __restrict__ xr_scratch) {
-  constexpr int NL = MONT_TPI * L;
-  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * NL];
-  __shared__ uint32_t x_sh[QUADS_PER_BLOCK * NL];
+  constexpr int NL = TPI * L;
+  constexpr int GROUPS = RSA_BLOCK / TPI;      // numbers per block
+  __shared__ uint32_t a_sh[GROUPS * NL];
+  __shared__ uint32_t x_sh[GROUPS * NL];
   const uint32_t count = *pk_count_ptr;
-  if (blockIdx.x * QUADS_PER_BLOCK >= count) return;   // whole block idle
-  const uint32_t quad = threadIdx.x >> 2;
-  const int qlane = threadIdx.x & 3;
-  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
+  if (blockIdx.x * GROUPS >= count) return;   // whole block idle
+  const uint32_t quad = threadIdx.x / TPI;
+  const int qlane = threadIdx.x % TPI;
+  const uint32_t gq = blockIdx.x * GROUPS + quad;
   const bool active = gq < count;
   const uint32_t pi = active ? gq : (count - 1);
   const uint32_t ri = pk_list[pi];
@@ -856,7 +857,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      mont_mul(y, a_rd, b, n, n0inv, qlane);
+      mont_mul<L, TPI>(y, a_rd, b, n, n0inv, qlane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // ---- next step (scalar control flow)
       if (kind == OP_TO_MONT && (e_u & (e_u - 1u)) != 0 && !(sc_u && __builtin_popcount(e_u) == 2)) {
@@ -868,7 +869,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
       --bitpos;
       kind = (bitpos >= 0) ? OP_SQR : OP_MUL1;
     }
-    canonicalize(y, qlane);
+    canonicalize<L, TPI>(y, qlane);
     if (live && active) {
       uint32_t* out = r_limbs + (uint64_t)pi * NL + qlane * L;
 #pragma unroll
@@ -878,16 +879,17 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
   }
 }
 
-// EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); 4 lanes per signature.
-template <int L>
+// EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); TPI lanes per signature.
+template <int L, int TPI>
 __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, const uint32_t* __restrict__ pk_list,
                                                      const uint32_t* __restrict__ pk_count_ptr, KeyTableDev kt,
                                                      const uint32_t* __restrict__ r_limbs, const uint32_t* __restrict__ digests) {
-  constexpr int NL = MONT_TPI * L;
+  constexpr int NL = TPI * L;
+  constexpr int GROUPS = 256 / TPI;
   const uint32_t count = *pk_count_ptr;
-  const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  const int qlane = threadIdx.x & 3;
-  if ((blockIdx.x * blockDim.x) >> 2 >= count) return;
+  const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) / TPI;
+  const int qlane = threadIdx.x % TPI;
+  if ((blockIdx.x * blockDim.x) / TPI >= count) return;
   const bool active = gq < count;
   const uint32_t pi = active ? gq : (count - 1);
   const uint32_t ri = pk_list[pi];
@@ -902,13 +904,13 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   // 19 limbs live in, shifts it to a limb boundary once, and slices limbs at compile-time offsets -- ~10 instructions
   // per limb instead of five branchy byte look-ups.
   constexpr int EM_TAIL_W = 24;   // >= (64 + 19 + 1) / 4
-  __shared__ uint32_t tail_sh[64 * EM_TAIL_W];
-  uint32_t* tail = tail_sh + (threadIdx.x >> 2) * EM_TAIL_W;
+  __shared__ uint32_t tail_sh[GROUPS * EM_TAIL_W];
+  uint32_t* tail = tail_sh + (threadIdx.x / TPI) * EM_TAIL_W;
   const uint32_t* dgw = digests + (uint64_t)ri * 16;
   const uint32_t hw = hlen >> 2;            // every supported digest length is a multiple of 4
 #pragma unroll
-  for (int t = 0; t < EM_TAIL_W / 4; ++t) {
-    const uint32_t w = (uint32_t)qlane * (EM_TAIL_W / 4) + t;
+  for (int t = 0; t < EM_TAIL_W / TPI; ++t) {
+    const uint32_t w = (uint32_t)qlane * (EM_TAIL_W / TPI) + t;
     uint32_t v = 0;
     if (w < hw) v = __builtin_bswap32(dgw[hw - 1 - w]);
     else {
@@ -946,15 +948,15 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   uint32_t em[L], r[L];
   // r: the block's 64 results are one contiguous run of the work list -- fetch it with fully coalesced dword loads into
   // LDS (a lane-per-limb-slice read straight from global touches 64 cache lines per instruction)
-  __shared__ uint32_t r_sh[64 * NL];
+  __shared__ uint32_t r_sh[GROUPS * NL];
   {
-    const uint32_t q0 = (blockIdx.x * blockDim.x) >> 2;
-    const uint32_t n_valid = min(64u, count - q0) * NL;
+    const uint32_t q0 = (blockIdx.x * blockDim.x) / TPI;
+    const uint32_t n_valid = min((uint32_t)GROUPS, count - q0) * NL;
     const uint32_t* src = r_limbs + (uint64_t)q0 * NL;
-    for (uint32_t t = threadIdx.x; t < 64 * NL; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
+    for (uint32_t t = threadIdx.x; t < GROUPS * NL; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
     __syncthreads();
   }
-  const uint32_t* rp = r_sh + ((threadIdx.x >> 2) * NL + qlane * L);
+  const uint32_t* rp = r_sh + ((threadIdx.x / TPI) * NL + qlane * L);
   uint32_t diff = 0;
 #pragma unroll
   for (int k = 0; k < L; ++k) {
@@ -964,17 +966,17 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
     r[k] = rp[k];
     diff |= em[k] ^ r[k];
   }
-  diff = quad_or(diff);
+  diff = grp_or<TPI>(diff);
   bool ok = (diff == 0);
   if (__any(!ok)) {
     const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
     uint32_t diff2 = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) em[k] += np[k];
-    canonicalize(em, qlane);
+    canonicalize<L, TPI>(em, qlane);
 #pragma unroll
     for (int k = 0; k < L; ++k) diff2 |= em[k] ^ r[k];
-    diff2 = quad_or(diff2);
+    diff2 = grp_or<TPI>(diff2);
     ok = ok || (diff2 == 0);
   }
   if (active && pending && qlane == 0) recs[ri].status = ok ? ST_OK : ST_BAD_SIG;

@@ -24,8 +24,11 @@ constexpr uint32_t MONT_MASK = (1u << MONT_W) - 1;
 constexpr int MONT_TPI = 4;     // lanes per number
 constexpr int MONT_L = 19;      // limbs per lane of the default (<= 2048-bit) instantiation
 constexpr int MONT_N = MONT_TPI * MONT_L;  // 76 limbs = 2128 bits
-constexpr int MONT_L3072 = 28, MONT_L4096 = 37;   // R = 2^3136 / 2^4144
-constexpr int MONT_NMAX = MONT_TPI * MONT_L4096;  // 148 limbs: stride of per-key limb arrays
+// Larger moduli keep 14 / 19 limbs per lane and spread a number over EIGHT lanes instead (112 / 152 limbs, R = 2^3136 /
+// 2^4256): 28 or 37 limbs per lane would need > 256 VGPRs and spill (measured: 15x slower than the MAC count predicts).
+constexpr int MONT_TPI_BIG = 8;
+constexpr int MONT_L3072 = 14, MONT_L4096 = 19;
+constexpr int MONT_NMAX = MONT_TPI_BIG * MONT_L4096;  // 152 limbs: stride of per-key limb arrays
 
 // DPP controls
 constexpr int DPP_QUAD_BCAST0 = 0x00;          // quad_perm:[0,0,0,0]
@@ -43,9 +46,36 @@ __device__ __forceinline__ uint32_t dpp_quad_shr1(uint32_t v) {
 __device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHL1, 0xF, 0xF, true);
 }
+constexpr int DPP_ROW_SHR1 = 0x111;            // lane i <- lane i-1 within a row of 16, 0 before the start
+constexpr int DPP_ROW_SHR4 = 0x114;            // lane i <- lane i-4 within a row of 16
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t dpp_row_shr4(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR4, 0xF, 0xF, true);
+}
 __device__ __forceinline__ uint32_t quad_or(uint32_t v) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_SWAP1, 0xF, 0xF, false);
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_SWAP2, 0xF, 0xF, false);
+  return v;
+}
+
+// Group = the TPI (4 or 8) adjacent lanes that hold one number; glane = lane index inside the group.
+template <int TPI>
+__device__ __forceinline__ uint32_t grp_bcast0(uint32_t v, int glane) {   // the value of group lane 0, in every lane
+  const uint32_t q = dpp_quad_bcast0(v);
+  if constexpr (TPI == 4) return q;
+  else { const uint32_t u = dpp_row_shr4(q); return (glane & 4) ? u : q; }   // upper quad takes the lower quad's
+}
+template <int TPI>
+__device__ __forceinline__ uint32_t grp_shr1(uint32_t v) {                // lane i <- lane i-1; group lane 0: caller masks
+  if constexpr (TPI == 4) return dpp_quad_shr1(v);
+  else return dpp_row_shr1(v);
+}
+template <int TPI>
+__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
+  v = quad_or(v);
+  if constexpr (TPI == 8) v |= (uint32_t)__shfl_xor((int)v, 4);
   return v;
 }
 
@@ -57,20 +87,20 @@ __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 //   a_lds : this number's N limbs of operand a in LDS (all 4 lanes of the quad pass the same pointer)
 //   b, n  : this lane's L limbs (lane l of the quad holds limbs [l*L, l*L+L))
 //   n0inv : -n^-1 mod 2^28
-//   qlane : lane index within the quad (0..3)
-template <int L>
+//   qlane : lane index within the group (0..TPI-1)
+template <int L, int TPI = MONT_TPI>
 __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_lds,
                                          const uint32_t (&b)[L], const uint32_t (&n)[L],
                                          uint32_t n0inv, int qlane) {
-  // A column receives up to 2N = 8L products of < 2^56: 8L <= 255 fits 64 bits (L = 19, 28); beyond that
-  // (L = 37) the live columns are carry-normalised at every block boundary.
-  constexpr bool NORM = 8 * L > 255;
+  // A column receives up to 2N = 2*TPI*L products of < 2^56: up to 255 of them fit 64 bits (76 and 112 limbs); beyond
+  // that (152 limbs) the live columns are carry-normalised at every block boundary.
+  constexpr bool NORM = 2 * TPI * L > 255;
   uint64_t Q[2 * L - 1];
 #pragma unroll
   for (int k = 0; k < L + (NORM ? 1 : 0); ++k) Q[k] = 0;
 
 #pragma unroll 1
-  for (int blk = 0; blk < MONT_TPI; ++blk) {
+  for (int blk = 0; blk < TPI; ++blk) {
     const uint32_t* ap = a_lds + blk * L;
 #pragma unroll
     for (int r = 0; r < L; ++r) {
@@ -83,7 +113,7 @@ __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_l
       }
       // Montgomery factor from quad lane 0's column r
       uint32_t m = ((uint32_t)Q[r] * n0inv) & MONT_MASK;
-      m = dpp_quad_bcast0(m);
+      m = grp_bcast0<TPI>(m, qlane);
 #pragma unroll
       for (int k = 0; k < L; ++k) Q[r + k] = mad64(m, n[k], Q[r + k]);
       // retire column r: push its carry into column r+1 (value-preserving in every lane;
@@ -121,7 +151,7 @@ __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_l
     c = v >> MONT_W;
   }
   if (NORM) c += Q[L];   // the top carry of the last block boundary belongs to the next lane's column 0
-  uint32_t clo = dpp_quad_shr1((uint32_t)c), chi = dpp_quad_shr1((uint32_t)(c >> 32));
+  uint32_t clo = grp_shr1<TPI>((uint32_t)c), chi = grp_shr1<TPI>((uint32_t)(c >> 32));
   uint64_t cin = (qlane == 0) ? 0 : (((uint64_t)chi << 32) | clo);
   uint64_t v0 = (uint64_t)out[0] + cin;
   out[0] = (uint32_t)v0 & MONT_MASK;
@@ -133,12 +163,12 @@ __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_l
 // Exact canonical form (every limb < 2^28) of a lazily-normal number (limbs <= 2^28 + small).
 // Step s lets a carry hop from quad lane s-1 to lane s; lane l generates no new carry after
 // step l, so TPI steps suffice.
-template <int L>
+template <int L, int TPI = MONT_TPI>
 __device__ __forceinline__ void canonicalize(uint32_t (&x)[L], int qlane) {
   uint32_t cout = 0;
 #pragma unroll
-  for (int step = 0; step < MONT_TPI; ++step) {
-    uint32_t c = dpp_quad_shr1(cout);
+  for (int step = 0; step < TPI; ++step) {
+    uint32_t c = grp_shr1<TPI>(cout);
     if (qlane == 0) c = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) {

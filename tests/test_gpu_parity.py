@@ -622,11 +622,20 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx):
         if i % 7 == 3 and len(data) > 4:
             data = data[:int(rng.integers(1, len(data)))]                               # truncated somewhere
         tbs_l.append(tbs); ss_l.append(data)
+    # a packet too long for the 24-bit length field of the walk's scratch row: the item takes the direct-record path
+    tbs = b"big packet in the stream"
+    sigs = [cb.detach_sign(r, tbs, srng) for r in cl.replicas]
+    tbs_l.append(tbs)
+    ss_l.append(sigs[0] + hdr(13, (1 << 24) + 5, 1) + bytes((1 << 24) + 5) + b"".join(sigs[1:]))
+    n_all = len(tbs_l)
     tb, to = _cat(tbs_l)
     sb, so = _cat(ss_l)
     err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
     st, st_item = gpu_ctx.last_statuses()
     n_long = 0
+    r_big = col.collective_verify(kr, tbs_l[-1], SignaturePacket(1, 0, False, ss_l[-1], None), q)
+    assert list(st[st_item == n_all - 1])[:len(r_big.statuses)] == r_big.statuses and (err[-1] == 0) == (r_big.err is None)
+    assert 3 in list(st[st_item == n_all - 1])         # the oversized user-id packet is an event (not a signature)
     for i in range(160):
         r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
         got = list(st[st_item == i])
