@@ -138,15 +138,15 @@ def _cache_path(kind: str) -> str:
 
 
 def load_keys(kind: str, count: int) -> List[Dict[str, int]]:
-    """kind: 'rsa2048' or 'dsa2048'.  Returns the first ``count`` keys, generating and extending the
-    on-disk cache when it is short."""
+    """kind: 'rsa2048', 'rsa3072', 'rsa4096' or 'dsa2048'.  Returns the first ``count`` keys, generating and extending
+    the on-disk cache when it is short."""
     path = _cache_path(kind)
     keys: List[Dict[str, str]] = []
     if os.path.exists(path):
         with open(path) as f:
             keys = json.load(f)["keys"]
     if len(keys) < count:
-        gen = gen_rsa if kind.startswith("rsa") else gen_dsa
+        gen = (lambda i: gen_rsa(i, bits=int(kind[3:]))) if kind.startswith("rsa") else gen_dsa
         for i in range(len(keys), count):
             k = gen(i)
             keys.append({name: "%x" % v for name, v in k.items()})

@@ -649,3 +649,73 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx):
         want = col.signers(kr, SignaturePacket(1, 0, False, ss_l[i] or None, None))
         assert [int(x) for x in ids[int(off[i]):int(off[i + 1])]] == want, i
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_mixed_modulus_sizes_2048_3072_4096(gpu_ctx):
+    """One batch whose signers hold RSA-2048, -3072 and -4096 keys (own work lists, 4 / 8 / 8 lanes per number): verdicts and
+    per-packet statuses follow the oracle, including values >= n, long MPIs, e = 3 on a 3072-bit key and corrupted values."""
+    from corpus.keys import DRBG, load_keys
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle import wotqs as W
+    from oracle.packet import SignaturePacket
+    rng = DRBG("mixed-sizes")
+    keys = []
+    for kind, cnt in (("rsa2048", 2), ("rsa3072", 2), ("rsa4096", 2)):
+        for i, mat in enumerate(load_keys(kind, cnt)):
+            kp = cb.make_keypair(cb.PK_RSA, mat, "%s-%d <k@bftkv.example>" % (kind, i))
+            cb.build_entity(kp, [], rng)
+            keys.append(kp)
+    # a 3072-bit key with e = 3 (generic exponent ladder on the 8-lane kernel)
+    m3 = load_keys("rsa3072", 2)[1]
+    if ((m3["p"] - 1) * (m3["q"] - 1)) % 3 != 0:
+        kp = cb.make_keypair(cb.PK_RSA, {"p": m3["p"], "q": m3["q"], "e": 3}, "rsa3072-e3 <k@bftkv.example>")
+        cb.build_entity(kp, [], rng)
+        keys[3] = kp
+    ents = [pgp.read_entities(k.entity)[0] for k in keys]
+    kr = col.Keyring(keyring=ents)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    q = W.WotQ([W.new_qc([k.key_id for k in keys], len(keys), W.AUTH, 0)])
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    nrng = np.random.default_rng(33)
+    tbs_l, ss_l = [], []
+    for i in range(40):
+        tbs = nrng.bytes(int(nrng.integers(0, 200)))
+        parts = []
+        for j, kp in enumerate(keys):
+            pkt = bytearray(cb.detach_sign(kp, tbs))
+            k = (kp.n.bit_length() + 7) // 8
+            hdr = len(pkt) - (k + 2 + 26)              # header length: body = 22 prefix + 2 + 2 + (2 + k)
+            mpi_at = hdr + 26
+            s = int.from_bytes(pkt[mpi_at + 2:], "big")
+            variant = (i + j) % 7
+            if variant == 1 and s + kp.n < 1 << (8 * k):               # s + n verifies (no s < n check in Go <= 1.13)
+                pkt[mpi_at + 2:] = (s + kp.n).to_bytes(k, "big")
+            elif variant == 2:                                          # value longer than the modulus: not the x-shortcut path
+                big = s + kp.n * 5
+                body = bytes(pkt[hdr:mpi_at]) + big.bit_length().to_bytes(2, "big") + big.to_bytes((big.bit_length() + 7) // 8, "big")
+                pkt = bytearray(cb._hdr(2, len(body)) + body)
+            elif variant == 3:
+                pkt[-2] ^= 0x04                                         # corrupted value
+            elif variant == 4:                                          # leading zero byte in the MPI
+                body = bytes(pkt[hdr:mpi_at]) + (8 * (k + 1)).to_bytes(2, "big") + b"\x00" + s.to_bytes(k, "big")
+                pkt = bytearray(cb._hdr(2, len(body)) + body)
+            parts.append(bytes(pkt))
+        order = nrng.permutation(len(parts))
+        tbs_l.append(tbs)
+        ss_l.append(b"".join(parts[int(o)] for o in order))
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    seen = set()
+    for i in range(40):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i], None), q)
+        got = list(st[st_item == i])
+        assert got[:len(r.statuses)] == r.statuses, (i, got, r.statuses)
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), i
+        seen.update(got)
+    assert 0 in seen and 8 in seen
+    cnt = gpu_ctx.last_counters()
+    assert cnt["pubkey_ops"] == 40 * len(keys)
+    gpu_ctx.quorum_destroy(qh)
