@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <chrono>
 #include <condition_variable>
@@ -229,7 +230,11 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 // statuses final.
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
-                 const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr) {
+                 const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
+                 const std::function<int(hipStream_t)>* upload_tbs = nullptr) {
+  // upload_tbs (host-buffer entry point): the signed payloads are still in host memory.  Only the hash stream reads them,
+  // so their copy is issued on that stream AFTER the modexp has been launched and runs beside it; the signature stream
+  // (which the walk, the parse and the modexp need) was copied before the call.
   hipStream_t s = c->stream, sh = c->stream_h;
   if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
@@ -245,7 +250,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
   HIPCHK(c, hipEventRecord(c->ev[5], sh));
-  hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
+  if (!upload_tbs)
+    hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>());
   constexpr uint32_t MAIL_EMPTY = 0xFFFFFFFFu;
@@ -306,18 +312,22 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                        c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>());
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream_d));
   }
+  auto hash_stream_work = [&]() -> int {
   // hash stream: digests need the parsed records
-  HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
-  if (total) {
-    // other hashes: a no-op grid unless some signature asked for them
-    hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
-                       c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
-    hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
-    hipLaunchKernelGGL(k_digest_other, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
-  }
-  HIPCHK(c, hipEventRecord(c->ev[6], sh));
+    HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
+    if (total) {
+      // other hashes: a no-op grid unless some signature asked for them
+      hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
+                         c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
+      hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+                         c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+      hipLaunchKernelGGL(k_digest_other, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+                         c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], sh));
+    return 0;
+  };
+  if (!upload_tbs) { int hrc = hash_stream_work(); if (hrc) return hrc; }
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
   if (total) {
     const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
@@ -333,6 +343,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
   }
   HIPCHK(c, hipEventRecord(c->ev[2], s));
+  if (upload_tbs) {
+    int hrc = (*upload_tbs)(sh);
+    if (hrc) return hrc;
+    hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
+    if ((hrc = hash_stream_work())) return hrc;
+  }
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
   if (total) {
     const dim3 cg((total * 4 + 255) / 256);
@@ -736,19 +752,17 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
   return 0;
 }
 
-int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
-                                    const uint8_t* ss, const uint64_t* ss_off, uint64_t ss_len, uint8_t* err_out,
-                                    uint32_t* nver_out, uint8_t* verdict_out) {
-  (void)ss_len;
-  if (!c) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                  const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                  uint8_t* verdict_out, const std::function<int(hipStream_t)>* upload_tbs) {
+  // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
   if (n_items == 0) return 0;
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
@@ -765,35 +779,46 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_ite
   return 0;
 }
 
+int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                    const uint8_t* ss, const uint64_t* ss_off, uint64_t ss_len, uint8_t* err_out,
+                                    uint32_t* nver_out, uint8_t* verdict_out) {
+  (void)ss_len;
+  if (!c) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, nullptr);
+}
+
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                 const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                 uint8_t* verdict_out) {
   if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
-    int rco;
-    if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
-      return rco;
-    const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
-    HIPCHK(c, c->in_tbs.ensure(tl + 64));
-    HIPCHK(c, c->in_ss.ensure(sl + 64));
-    HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
-    HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
-    HIPCHK(c, c->o_err.ensure(n_items));
-    HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
-    HIPCHK(c, c->o_verdict.ensure(n_items));
-    if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, c->stream));
-    if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ss, sl, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
-  }
-  int rc = bftkv_gpu_collective_verify_dev(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(),
-                                           c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), ss_off[n_items],
-                                           c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>());
+  std::lock_guard<std::mutex> lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context
+  HIPCHK(c, hipSetDevice(c->device));
+  int rco;
+  if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
+    return rco;
+  const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
+  HIPCHK(c, c->in_tbs.ensure(tl + 64));
+  HIPCHK(c, c->in_ss.ensure(sl + 64));
+  HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  HIPCHK(c, c->o_err.ensure(n_items));
+  HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
+  HIPCHK(c, c->o_verdict.ensure(n_items));
+  // the signature streams and the offsets first: the walk, the parse and the modexp need nothing else
+  if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ss, sl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
+  // the signed payloads go over PCIe while the modexp runs (run_pipeline calls this once the modexp is launched)
+  const std::function<int(hipStream_t)> upload_tbs = [&](hipStream_t sh) -> int {
+    if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, sh));
+    return 0;
+  };
+  int rc = collective_verify_impl(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
+                                  c->in_ss_off.as<uint64_t>(), c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>(),
+                                  &upload_tbs);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
   if (nver_out) HIPCHK(c, hipMemcpyAsync(nver_out, c->o_nver.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, c->stream));
   if (verdict_out) HIPCHK(c, hipMemcpyAsync(verdict_out, c->o_verdict.p, n_items, hipMemcpyDeviceToHost, c->stream));
