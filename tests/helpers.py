@@ -53,3 +53,54 @@ def oracle_collective(kr, q, corpus, i):
     from oracle.packet import SignaturePacket
     ss = SignaturePacket(Type=1, Data=corpus.ss_data(i) or None)
     return col.collective_verify(kr, corpus.tbss(i), ss, q)
+
+
+def random_framing_streams(cl, n_items, seed=77):
+    """Random OpenPGP packet streams around the signatures of cluster ``cl``: signature packets re-framed in every header
+    format, unknown and non-signature packets, stray bytes, truncations, and items with more than 96 packet events.
+    Returns (tbs_list, stream_list, hdr, signing_rng)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    from corpus.keys import DRBG
+    srng = DRBG("framing-fuzz")
+
+    def hdr(tag, ln, fmt):
+        if fmt == 0:                                   # new format, shortest legal length encoding
+            if ln < 192: return bytes([0xC0 | tag, ln])
+            if ln < 8384: return bytes([0xC0 | tag, ((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+            return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+        if fmt == 1: return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")          # new format, 5-octet length
+        if fmt == 2 and tag < 16 and ln < 256: return bytes([0x80 | (tag << 2)]) + bytes([ln])
+        if fmt == 3 and tag < 16 and ln < 65536: return bytes([0x80 | (tag << 2) | 1]) + ln.to_bytes(2, "big")
+        if tag < 16: return bytes([0x80 | (tag << 2) | 2]) + ln.to_bytes(4, "big")
+        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+
+    tbs_l, ss_l = [], []
+    for i in range(n_items):
+        tbs = rng.bytes(int(rng.integers(0, 300)))
+        sigs = [cb.detach_sign(r, tbs, srng) for r in cl.replicas]
+        parts = []
+        n_parts = int(rng.integers(1, 12)) if i % 10 else int(rng.integers(100, 140))      # every 10th: > WALK_CAP events
+        for _ in range(n_parts):
+            k = int(rng.integers(0, 12))
+            if k < 5:                                   # a signature, re-framed in a random header format
+                s = sigs[int(rng.integers(0, len(sigs)))]
+                body = s[3:] if s[1] >= 192 else s[2:]
+                parts.append(hdr(2, len(body), int(rng.integers(0, 5))) + body)
+            elif k < 7:                                 # unknown packet type, silently skipped
+                ln = int(rng.integers(0, 400))
+                parts.append(hdr(int(rng.choice([20, 40, 60, 63])), ln, int(rng.integers(0, 2))) + rng.bytes(ln))
+            elif k < 9:                                 # known non-signature packet (user id / literal / marker-like)
+                ln = int(rng.integers(0, 60))
+                parts.append(hdr(int(rng.choice([13, 11, 6, 14])), ln, int(rng.integers(0, 5))) + rng.bytes(ln))
+            elif k == 9:                                # small packets back to back
+                parts.append(b"".join(hdr(13, 1, 2) + b"x" for _ in range(int(rng.integers(1, 9)))))
+            elif k == 10 and i % 3 == 0:                # stray byte without the tag MSB: ends the stream
+                parts.append(bytes([int(rng.integers(0, 128))]))
+            else:
+                parts.append(sigs[int(rng.integers(0, len(sigs)))])
+        data = b"".join(parts)
+        if i % 7 == 3 and len(data) > 4:
+            data = data[:int(rng.integers(1, len(data)))]                               # truncated somewhere
+        tbs_l.append(tbs); ss_l.append(data)
+    return tbs_l, ss_l, hdr, srng

@@ -28,6 +28,24 @@ def test_c_oracle_matches_python_oracle(n, dsa, items):
     assert ops > 0 and (err == 0).any() and (err == 2).any()
 
 
+def test_c_oracle_matches_python_oracle_on_random_framings():
+    """Random packet framings (every header format, unknown / non-signature packets, stray bytes, truncations, > 96 events):
+    the C port walks them exactly like the Python oracle -- the same streams the GPU walk is checked on."""
+    cl = cb.make_cluster(7, dsa_fraction=0.3)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    tbs_l, ss_l, _, _ = H.random_framing_streams(cl, 90)
+    n_err = 0
+    for t, s in zip(tbs_l, ss_l):
+        r = col.collective_verify(kr, t, SignaturePacket(1, 0, False, s or None, None), q)
+        tr, nv, e = co.trace_item(t, s)
+        assert tr == r.statuses and nv == len(r.verified) and (e == 0) == (r.err is None)
+        n_err += r.err is not None
+    assert 0 < n_err < 90
+
+
 def test_collective_semantics_on_mutations():
     cl = cb.make_cluster(4)
     kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
