@@ -45,7 +45,7 @@ HOST_EXPORTS = [
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
-    "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats",
+    "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
 ]
 
 _ready = False
@@ -57,6 +57,7 @@ def _lib():
     if not _ready:
         vp = C.c_void_p
         lib.bftkv_host_graph_new.restype = vp
+        lib.bftkv_host_message_frame.argtypes = [C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
         lib.bftkv_host_choose_quorum.restype = vp
         lib.bftkv_host_choose_quorum.argtypes = [vp, C.c_int]
         lib.bftkv_host_quorum_from_qcs.restype = vp
@@ -495,3 +496,23 @@ class Server:
         if rc:
             raise _native.NativeError("server_write_verify failed: %d" % rc)
         return err
+
+
+def message_frame(msg: bytes):
+    """Framing half of the transport message check (bftkv_host_message_frame, no GPU): returns a dict with
+    framing (BFTKV_MSG_* or 0xFF = trailing signature found), signer, hash_id, plain, file_name, sig (the trailing packet)."""
+    lib = _lib()
+    st = C.c_uint8(0)
+    signer = C.c_uint64(0)
+    hid = C.c_uint8(0)
+    plain = np.zeros(max(1, len(msg)), dtype=np.uint8)
+    plen = C.c_uint64(0)
+    fn = np.zeros(256, dtype=np.uint8)
+    fl = C.c_uint8(0)
+    so, sl = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.bftkv_host_message_frame(msg, len(msg), C.byref(st), C.byref(signer), C.byref(hid), plain.ctypes.data, len(plain), C.byref(plen),
+                                      fn.ctypes.data, C.byref(fl), C.byref(so), C.byref(sl))
+    if rc:
+        raise RuntimeError("bftkv_host_message_frame: %d" % rc)
+    return {"framing": st.value, "signer": signer.value, "hash_id": hid.value, "plain": plain[:plen.value].tobytes(),
+            "file_name": fn[:fl.value].tobytes(), "sig": msg[so.value:so.value + sl.value]}

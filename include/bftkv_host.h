@@ -182,6 +182,18 @@ int bftkv_host_max_timestamped_value(const bftkv_quorum* q, uint32_t n_reads, co
                                      const uint8_t* value_blob, const uint64_t* value_off, const uint64_t* reply_off,
                                      int64_t* value_idx_out);
 
+/* Framing half of the transport message check (crypto_pgp.go:453-471 -> openpgp.ReadMessage / readSignedMessage), no
+ * GPU and no keyring involved: walks [one-pass signature] [literal data] [signature] of ONE already-decrypted message.
+ *   framing_out   BFTKV_MSG_READ_ERROR / _NOT_SIGNED / _UNSUPPORTED / _SIGNATURE_ERROR (literal not followed by a
+ *                 signature packet), or 0xFF: a signature packet follows and the verdict is the device's
+ *                 (bftkv_gpu_message_verify additionally reports _UNVERIFIED when the keyring has no signing key for it)
+ *   signer_out    one-pass key id; hash_out: one-pass hash id; plain: literal body (partial lengths removed)
+ *   sig_off/len   the trailing signature packet inside msg (when framing_out == 0xFF)
+ * bftkv_gpu_message_verify performs exactly this walk before it batches the signatures. */
+int bftkv_host_message_frame(const uint8_t* msg, uint64_t len, uint8_t* framing_out, uint64_t* signer_out, uint8_t* hash_out,
+                             uint8_t* plain_out, uint64_t plain_cap, uint64_t* plain_len_out, uint8_t* fname_out /*[256]*/,
+                             uint8_t* fname_len_out, uint64_t* sig_off_out, uint64_t* sig_len_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,3 +265,59 @@ def test_emsa_encode_matches_oracle_and_kat(H):
         H.emsa_encode(10, b"x" * 64, 600)        # padlen < 3 => crypto.ErrInvalidInput
     em = H.emsa_encode(8, hashlib.sha256(kat["rsa"]["tbs"].encode()).digest(), n.bit_length())
     assert pow(int(kat["rsa"]["sha256_pkcs1v15_sig"], 16), kat["rsa"]["e"], n) == int.from_bytes(em, "big")
+
+
+def test_message_framing_matches_oracle(H):
+    """bftkv_host_message_frame (the host walk bftkv_gpu_message_verify performs before batching) against
+    oracle.message.read_signed_message on the gpg-made messages, the generator's, and the outcome table."""
+    import json
+    from corpus import build as cb
+    from corpus.keys import DRBG
+    from oracle import message as om
+    from oracle import openpgp as pgp
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpg_messages.json")) as f:
+        vec = json.load(f)
+
+    def check(ents, m):
+        r = om.read_signed_message(ents, m)
+        f = H.message_frame(m)
+        if r.status in (om.MSG_READ_ERROR, om.MSG_NOT_SIGNED):
+            assert f["framing"] == r.status, (f["framing"], r.status)
+        elif r.status == om.MSG_UNVERIFIED:
+            assert f["framing"] != om.MSG_READ_ERROR and f["framing"] != om.MSG_NOT_SIGNED          # key-dependent: decided by the caller
+        elif r.status == om.MSG_UNSUPPORTED:
+            assert f["framing"] in (om.MSG_UNSUPPORTED, 0xFF)                                       # 0xFF: the device fences (v3 signature)
+        elif r.sig_status is not None:
+            assert f["framing"] == 0xFF and len(f["sig"]) > 0 and f["sig"][0] & 0x80                  # a signature was evaluated
+        else:
+            assert f["framing"] == om.MSG_SIGNATURE_ERROR                                            # structural: nothing to evaluate
+        if r.status not in (om.MSG_READ_ERROR, om.MSG_UNSUPPORTED):
+            assert f["plain"] == r.plain and f["file_name"] == r.file_name and f["signer"] == r.signed_by_key_id
+        return f
+
+    ents = pgp.read_entities(bytes.fromhex(vec["D_pubring"]))
+    for d in vec["D"]:
+        f = check(ents, bytes.fromhex(d["msg"]))
+        assert f["framing"] == 0xFF and f["hash_id"] in (8, 10)
+        check(ents, bytes.fromhex(d["tampered"]))
+    ents = pgp.read_entities(bytes.fromhex(vec["E_pubring"]))
+    for e in vec["E"]:
+        check(ents, bytes.fromhex(e["msg"]))
+    cl = cb.make_cluster(4, n_outsiders=1)
+    rng = DRBG("frame-cases")
+    ents = pgp.read_entities(b"".join(r.entity for r in cl.replicas))
+    kp = cl.replicas[1]
+    sig = cb.detach_sign(kp, b"request", rng)
+    ops = om.one_pass_packet(0, 8, kp.algo, kp.key_id)
+    lit = om.literal_packet(b"f", b"request")
+    unk = pgp.new_format_header(60, 3) + b"abc"
+    v3 = bytearray(sig); v3[3] = 3
+    cases = [lit, ops + lit + lit, ops + lit, unk + ops + unk + lit + unk + sig, om.one_pass_packet(0, 8, kp.algo, kp.key_id, is_last=False) + lit + sig,
+             om.one_pass_packet(0x10, 8, kp.algo, kp.key_id) + lit + sig, ops, b"", ops + lit[:5], b"\x00" + ops + lit + sig,
+             om.one_pass_packet(1, 8, kp.algo, kp.key_id) + lit + sig, pgp.new_format_header(8, 2) + b"\x00\x00" + ops + lit + sig,
+             ops + ops + lit + sig, ops + lit + sig + b"\x00garbage", ops + om.literal_packet(b"f", b"request", partial=[1, 0, 2]) + sig,
+             ops + lit + bytes(v3), cb.signed_message(cl.outsiders[0], b"join", b"n" * 16, rng)]
+    got = [check(ents, m)["framing"] for m in cases]
+    assert got[0] == om.MSG_NOT_SIGNED and got[1] == got[2] == om.MSG_SIGNATURE_ERROR and got[3] == 0xFF
+    assert got[4] == got[5] == got[6] == got[7] == got[8] == got[9] == om.MSG_READ_ERROR
+    assert got[10] == got[11] == got[12] == om.MSG_UNSUPPORTED and got[13] == got[14] == got[15] == 0xFF
