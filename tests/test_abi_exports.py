@@ -47,3 +47,16 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_headers_are_plain_c():
+    """The drop-in boundary is a C ABI: both headers must compile as C99 on their own (what cgo's preamble does)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not on PATH")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    for h in ("bftkv_gpu.h", "bftkv_host.h"):
+        r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", os.path.join(inc, h)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
