@@ -58,8 +58,9 @@ def _worker(rank, world, port, n_items, q):
         dist.destroy_process_group()
 
 
-def test_allgather_verdicts_world2_gloo():
-    world, n_items = 2, 21
+@pytest.mark.parametrize("n_items", [21, 20, 16])      # ragged shards; equal shards (the bench's case) with and without padding bits
+def test_allgather_verdicts_world2_gloo(n_items):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
