@@ -1,17 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on BASELINE.json configs[1]:
-"64-replica quorum, 10k RSA-2048 signed writes, single MI355X batched verify".
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configs.
 
-One "step" = one pass of the whole hot path (packet parse -> SHA-256 -> RSA-2048 verify -> quorum
-tally) over one batch of synthetic signed writes that is ALREADY RESIDENT IN HBM when the timed
-region starts.  N>1: one process per GPU, every rank verifies its own shard of writes (weak scaling)
-and the per-write verdict bitmaps are all-gathered over RCCL inside every step.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+
+  --config 2 (default)  configs[1]: 64-replica quorum, 10k RSA-2048 signed writes per GPU, batched verify
+  --config 3            configs[2]: 64-replica quorum (half DSA-2048/256), 100k signed read replies over 10k variables,
+                        reply verdicts on the GPU -> maxTimestampedValue per variable (protocol/client.go:181-205)
+  --config 4            configs[3]: 256 replicas, 1M-write storm sharded over the ranks (strong scaling), RCCL all-gather
+                        of the per-write verdict bitmaps
+  --config 5            configs[4]: threshold share-combine, 10k operations per scheme, sharded by operation
+
+One "step" = one pass of the whole hot path over one batch that is ALREADY RESIDENT IN HBM when the timed region starts.
+N > 1: one process per GPU.  Started under torchrun (RANK / WORLD_SIZE in the environment) it is one rank; started
+plainly with --gpus N it re-executes itself under `python -m torch.distributed.run` with N ranks.  torch.distributed is
+used for the rendezvous, the barriers and the max-over-ranks of the elapsed time only; the data-path exchange (all-gather of
+verdict bitmaps) is the library's own RCCL call on the verifier's HIP stream (bftkv_gpu_allgather_errs_dev).
+
+`--dry-run` (CPU, gloo) exercises the launcher, the sharding and the exchange step with the verify call stubbed out by the
+corpus' expected verdicts: it is what tests/test_bench_launcher.py runs; it prints no performance number.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,228 +35,251 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-INT_MAC_PEAK = 29.1e12         # measured v_mad_u64_u32 lane-ops/s on MI355X (tools/microbench, profiles/)
+# Integer roof.  v_mad_u64_u32 is a quarter-rate VALU op: 16 lanes per SIMD and clock.
+INT_MAC_THEORETICAL = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes/clk x max clock (MI355X_MICROARCH.md chip table) = 39.3 T/s
+INT_MAC_MEASURED = 29.1e12     # tools/microbench/valu_rates.hip at 8 waves/SIMD, clock as sustained under that load (profiles/)
 RSA_BYTES = 291                # algorithmic bytes per RSA-2048 signature verify
-MADS_PER_VERIFY = 18 * 2 * 76 * 76   # 18 Montgomery products x (76x76 a*b + 76x76 m*n) limb MACs
+DSA_BYTES = 99                 # per DSA-2048/256 signature verify
+MACS_PER_RSA_VERIFY = 18 * 2 * 76 * 76     # 18 Montgomery products x (76x76 a*b + 76x76 m*n) limb MACs
+MACS_PER_DSA_VERIFY = 66 * 2 * 76 * 76     # <= 64 table multiplications + entering and leaving the Montgomery domain
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------------
+# launcher and process group
+# ------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--items", type=int, default=10000, help="signed writes per GPU per step")
-    ap.add_argument("--replicas", type=int, default=64)
-    ap.add_argument("--inflight", type=int, default=1, help="batches (steps) in flight per GPU, each on its own verifier context / "
-                    "HIP streams.  2 overlaps the walk/parse of step i+1 and the compare/tally of step i-1 with the modexp of step i "
-                    "(+6 %% throughput, profiles/r01_v8_*), but then two modexp kernels also share the GPU and a launch's duration no "
-                    "longer says anything about the kernel: the default 1 keeps the roofline line meaningful")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--items", type=int, default=0, help="cfg 2: signed writes per GPU and step (default 10000); cfg 3: variables "
+                    "(default 10000, ~10 replies each); cfg 4: writes of the whole storm (default 1000000); cfg 5: operations per scheme (10000)")
+    ap.add_argument("--replicas", type=int, default=0, help="clique size (default 64; 256 for cfg 4)")
+    ap.add_argument("--distinct", type=int, default=2500, help="cfg 4: distinctly signed writes the resident batch is tiled from")
+    ap.add_argument("--chunk", type=int, default=125000, help="cfg 4: writes per verifier call (the resident batch)")
+    ap.add_argument("--inflight", type=int, default=1, help="cfg 2: batches in flight per GPU, each on its own verifier context "
+                    "(2 overlaps walk/parse and compare/tally of neighbouring steps with the modexp; then a launch's duration no "
+                    "longer measures the kernel, so the default 1 keeps the roofline line meaningful)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corpus-cache", default="", help="path prefix of an .npz cache of the generated corpus (profiling reruns)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, sharding and exchange step only (no GPU, no number)")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    from bftkv_amd import Context
+
+def relaunch(args):
+    """--gpus N without a torchrun environment: start N ranks of this script, one per GPU, and pass their output through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Dist:
+    """Rank bookkeeping; torch.distributed only for rendezvous, barriers and the reduction of the timing."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = args.dry_run
+        self.dist = None
+        if self.dry:
+            self.dev = torch.device("cpu")
+        else:
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.dry:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def max_float(self, v):
+        if not self.dist:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_ints(self, vals):
+        if not self.dist:
+            return [int(v) for v in vals]
+        t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(v) for v in t.tolist()]
+
+    def comm_init(self, ctxs):
+        """The library's own RCCL communicator on every verifier context: rank 0 draws the unique id
+        (bftkv_gpu_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins."""
+        from bftkv_amd import Context
+        torch = self.torch
+        for cx in ctxs:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                uid = torch.from_numpy(Context.comm_unique_id().copy())
+            if self.dist:
+                u = uid.to(self.dev)
+                self.dist.broadcast(u, src=0)
+                uid = u.cpu()
+            cx.comm_init(self.world, self.rank, uid.numpy())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# shared pieces of the verify workloads (cfg 2, 3, 4)
+# ------------------------------------------------------------------------------------------------------------------
+def gpu_signers(ctx, cl):
+    """RSA signatures and DSA nonce powers of the corpus generator computed on this GPU (generic modexp kernel)."""
     from corpus import build as cb
+    mods, exps = cb.signer_tables(cl)   # replicas in order, then the client
 
-    ctx = Context(local_rank)
-    n = args.replicas
-    cl = cb.make_cluster(n)
-
-    # ---- synthetic signed writes; RSA signatures made on this GPU (generic modexp kernel)
-    mods, exps = cb.signer_tables(cl)   # replicas in order, then the client (corpus/build.py BatchSigner)
-
-    def gpu_signer(em, key_index):
+    def rsa(em, key_index):
         return ctx.modexp(em, key_index.astype(np.uint32), mods, exps)
+    dsa = None
+    if any(r.algo == cb.PK_DSA for r in cl.replicas):
+        ps, gs = cb.dsa_pow_tables(cl)
 
-    t0 = time.time()
-    cache = None
-    if args.corpus_cache:
-        cache = "%s.n%d.i%d.r%d.npz" % (args.corpus_cache, n, args.items, rank)
-    if cache and os.path.exists(cache):
-        z = np.load(cache)
-        corpus = cb.WriteCorpus(cl, args.items, z["tb"], z["to"], z["sb"], z["so"], int(z["n_sigs"]), z["mut"])
-    else:
-        corpus = cb.make_write_corpus(cl, args.items, seed=cb.MASTER_SEED + rank, batch_signer=gpu_signer, with_client_sig=True)
-        if cache:
-            np.savez(cache, tb=corpus.tbss_blob, to=corpus.tbss_off, sb=corpus.ss_blob, so=corpus.ss_off,
-                     n_sigs=corpus.n_sigs, mut=corpus.mutation)
-    t_corpus = time.time() - t0
+        def dsa(key_index, ks):
+            base = np.ascontiguousarray(gs[key_index])
+            ex = np.stack([np.frombuffer(int(k).to_bytes(32, "big"), dtype=np.uint8) for k in ks])
+            out = ctx.modexp_ops(base, key_index.astype(np.uint32), ps, ex)
+            return [int.from_bytes(out[i].tobytes(), "big") for i in range(len(ks))]
+    return rsa, dsa
 
-    # keyring + quorum through the C ABI (clique of all replicas, AUTH rule: wotqs.go:36-70); one verifier context per
-    # batch in flight (each owns its HIP streams and device arena)
-    keys = [{"key_id": r.key_id, "entity_id": r.key_id, "pk_algo": r.algo, "usable_sign": True,
-             "n": r.n.to_bytes(256, "big"), "e": r.e.to_bytes(3, "big")} for r in cl.replicas]
-    f, mn, thr, suff = cb.quorum_numbers(n)
-    n_ctx = max(1, args.inflight)
-    ctxs = [ctx] + [Context(local_rank) for _ in range(n_ctx - 1)]
-    qhs = []
-    for cx in ctxs:
-        cx.keyring_set(keys)
-        qhs.append(cx.quorum_create([(f, mn, thr, suff, [r.key_id for r in cl.replicas])]))
-    qh = qhs[0]
 
-    d_tbs = torch.from_numpy(corpus.tbss_blob).to(dev)
-    d_tbs_off = torch.from_numpy(corpus.tbss_off.astype(np.int64)).to(dev)
-    d_ss = torch.from_numpy(corpus.ss_blob).to(dev)
-    d_ss_off = torch.from_numpy(corpus.ss_off.astype(np.int64)).to(dev)
-    outs = [(torch.zeros(args.items, dtype=torch.uint8, device=dev), torch.zeros(args.items, dtype=torch.int32, device=dev),
-             torch.zeros(args.items, dtype=torch.uint8, device=dev)) for _ in ctxs]
-    from bftkv_amd import dist as D
-    torch.cuda.synchronize()
+def abi_keys_of(cl):
+    """bftkv_gpu_pubkey records of the clique members (what the cgo shim extracts from the node's keyring)."""
+    from corpus import build as cb
+    keys = []
+    for r in cl.replicas:
+        if r.algo == cb.PK_RSA:
+            keys.append({"key_id": r.key_id, "entity_id": r.key_id, "pk_algo": r.algo, "usable_sign": True,
+                         "n": r.n.to_bytes(256, "big"), "e": r.e.to_bytes(3, "big")})
+        else:
+            keys.append({"key_id": r.key_id, "entity_id": r.key_id, "pk_algo": r.algo, "usable_sign": True,
+                         "n": r.p.to_bytes(256, "big"), "e": r.q.to_bytes(32, "big"), "g": r.g.to_bytes(256, "big"),
+                         "y": r.y.to_bytes(256, "big")})
+    return keys
 
-    def submit(i):
-        cx, (e, nv, vd) = ctxs[i % n_ctx], outs[i % n_ctx]
-        cx.collective_verify_dev(qhs[i % n_ctx], args.items, d_tbs.data_ptr(), d_tbs_off.data_ptr(), d_ss.data_ptr(), d_ss_off.data_ptr(),
-                                 int(corpus.ss_off[-1]), e.data_ptr(), nv.data_ptr(), vd.data_ptr())
 
-    step_rsa_ms, step_total_ms = [], []
+class Verifier:
+    """n_ctx verifier contexts over one resident batch: submit(i) launches the pipeline and the exchange step of batch i on
+    context i % n_ctx, complete(i) waits for it and collects the HIP-event durations of that step."""
 
-    def complete(i):
-        ctxs[i % n_ctx].sync()
-        tm_i = ctxs[i % n_ctx].last_timing()        # HIP events recorded on the kernels' own streams during this step
-        step_rsa_ms.append(tm_i["rsa"])
-        step_total_ms.append(tm_i["total"])
-        if world > 1:
-            # per-write verdict bitmap (1 bit per write), all-gathered over RCCL/xGMI so that every
-            # rank holds every verdict -- as every replica of the reference reaches every decision
-            return D.allgather_verdicts(outs[i % n_ctx][0] == 0, args.items * world)
-        return None
+    def __init__(self, D, cl, n_items, tb, to, sb, so, n_ctx=1, ctx0=None, ss_len=None):
+        from bftkv_amd import Context
+        from corpus import build as cb
+        self.D, self.n_items, self.n_ctx = D, n_items, n_ctx
+        self.slots = n_items                       # every rank contributes the same number of bitmap bits
+        self.rsa_ms, self.dsa_ms, self.hash_ms, self.total_ms = [], [], [], []
+        self.gathers = 0
+        self.ss_len = int(so[-1]) if ss_len is None else ss_len
+        torch = D.torch
+        if D.dry:
+            self.ctxs = []
+            return
+        self.ctxs = [ctx0 or Context(D.local_rank)] + [Context(D.local_rank) for _ in range(n_ctx - 1)]
+        f, mn, thr, suff = cb.quorum_numbers(cl.n)
+        keys = abi_keys_of(cl)
+        self.qhs = []
+        for cx in self.ctxs:
+            cx.keyring_set(keys)
+            self.qhs.append(cx.quorum_create([(f, mn, thr, suff, [r.key_id for r in cl.replicas])]))
+        D.comm_init(self.ctxs)
+        dev = D.dev
+        self.d_tbs = torch.from_numpy(tb).to(dev) if isinstance(tb, np.ndarray) else tb
+        self.d_ss = torch.from_numpy(sb).to(dev) if isinstance(sb, np.ndarray) else sb
+        self.d_tbs_off = torch.from_numpy(to.astype(np.int64)).to(dev) if isinstance(to, np.ndarray) else to
+        self.d_ss_off = torch.from_numpy(so.astype(np.int64)).to(dev) if isinstance(so, np.ndarray) else so
+        nbytes = (self.slots + 7) // 8
+        self.outs = [(torch.zeros(n_items, dtype=torch.uint8, device=dev), torch.zeros(n_items, dtype=torch.int32, device=dev),
+                      torch.zeros(n_items, dtype=torch.uint8, device=dev), torch.zeros(D.world * nbytes, dtype=torch.uint8, device=dev))
+                     for _ in self.ctxs]
+        torch.cuda.synchronize()
 
-    def run(k):
-        """k steps, up to n_ctx batches in flight: step i+1 is submitted before step i is waited for."""
+    def submit(self, i):
+        k = i % self.n_ctx
+        cx, (e, nv, vd, bits) = self.ctxs[k], self.outs[k]
+        cx.collective_verify_dev(self.qhs[k], self.n_items, self.d_tbs.data_ptr(), self.d_tbs_off.data_ptr(), self.d_ss.data_ptr(),
+                                 self.d_ss_off.data_ptr(), self.ss_len, e.data_ptr(), nv.data_ptr(), vd.data_ptr())
+        # exchange step, enqueued behind the tally on the verifier's own stream: no host synchronisation in between
+        cx.allgather_errs_dev(e.data_ptr(), self.n_items, self.slots, bits.data_ptr())
+        self.gathers += 1
+
+    def complete(self, i):
+        k = i % self.n_ctx
+        self.ctxs[k].sync()
+        tm = self.ctxs[k].last_timing()        # HIP events recorded on the kernels' own streams during this step
+        self.rsa_ms.append(tm["rsa"]); self.dsa_ms.append(tm["dsa"]); self.hash_ms.append(tm["hash"]); self.total_ms.append(tm["total"])
+        self.last_tm = tm
+
+    def run(self, k):
+        """k batches, up to n_ctx in flight: batch i+1 is submitted before batch i is waited for."""
         for i in range(k):
-            submit(i)
-            if i >= n_ctx - 1:
-                complete(i - (n_ctx - 1))
-        for i in range(max(0, k - (n_ctx - 1)), k):
-            complete(i)
+            self.submit(i)
+            if i >= self.n_ctx - 1:
+                self.complete(i - (self.n_ctx - 1))
+        for i in range(max(0, k - (self.n_ctx - 1)), k):
+            self.complete(i)
 
-    run(args.warmup)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    del step_rsa_ms[:], step_total_ms[:]
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timed_rsa_ms, timed_total_ms = list(step_rsa_ms), list(step_total_ms)      # the K timed steps
-    # phase breakdown of an isolated call: a few non-overlapped calls on one context
-    rsa_ms, tot_ms = [], []
-    for _ in range(3):
-        submit(0)
-        complete(0)
-        tm = ctx.last_timing()
-        rsa_ms.append(tm["rsa"])
-        tot_ms.append(tm["total"])
-    d_err, d_nver, d_verdict = outs[0]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([corpus.n_sigs, args.items], dtype=torch.int64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_sigs, total_items = int(cnt[0].item()), int(cnt[1].item())
-    else:
-        total_sigs, total_items = corpus.n_sigs, args.items
+    def reset_timing(self):
+        del self.rsa_ms[:], self.dsa_ms[:], self.hash_ms[:], self.total_ms[:]
 
-    counters = ctx.last_counters()
-    err = d_err.cpu().numpy()
-    nver = d_nver.cpu().numpy()
+    def results(self, k=0):
+        e, nv, vd, bits = self.outs[k]
+        return e.cpu().numpy(), nv.cpu().numpy(), bits.cpu().numpy()
 
-    if rank == 0:
-        verifies_per_s = total_sigs * args.steps / elapsed
-        verdicts_per_s = total_items * args.steps / elapsed
-        rsa_avg_s = float(np.mean(timed_rsa_ms)) * 1e-3      # average k_rsa_modexp launch duration over the timed region
-        alg_bytes = int(corpus.tbss_off[-1]) + corpus.n_sigs * RSA_BYTES + (args.items + 7) // 8
-        achieved = alg_bytes / rsa_avg_s / 1e9
-        traffic, traffic_src = measured_traffic("k_rsa_modexp") if args.items == 10000 and n == 64 else (None, None)
-        out = {
-            "metric": "pgp_rsa2048_signature_verifies_per_sec",
-            "value": verifies_per_s,
-            "unit": "verifies/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "%d-replica quorum, %d RSA-2048 signed writes per GPU (cfg2 of BASELINE.json), "
-                                   "%d signature packets per GPU, 1.0%% corrupt / 0.5%% unknown issuer / 0.5%% duplicate / "
-                                   "1.0%% one-short" % (n, args.items, corpus.n_sigs),
-                       "replicas": n, "writes_per_gpu": args.items, "sigs_per_gpu": corpus.n_sigs,
-                       "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps" % world,
-                       "batches_in_flight": n_ctx},
-            "quorum_verdicts_per_sec": verdicts_per_s,
-            "sufficient_fraction": float((err == 0).mean()),
-            "pubkey_ops_per_step_per_gpu": int(counters["pubkey_ops"]),
-            "kernel_ms": {"k_rsa_modexp": float(np.mean(timed_rsa_ms)), "step_device_span": float(np.mean(timed_total_ms)),
-                          "measured": "HIP events of the %d timed steps (%d in flight)" % (len(timed_rsa_ms), n_ctx),
-                          "isolated_call": {"total": float(np.mean(tot_ms)), "k_rsa_modexp": float(np.mean(rsa_ms)), "phases": tm}},
-            "roofline": {"bound": "hbm", "kernel": "k_rsa_modexp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"},
-            "int_mac": {"achieved": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s, "peak": INT_MAC_PEAK,
-                        "frac": counters["pubkey_ops"] * MADS_PER_VERIFY / rsa_avg_s / INT_MAC_PEAK,
-                        "unit": "u32xu32+u64 MAC/s (v_mad_u64_u32 lanes)"},
-            "corpus_build_s": t_corpus,
-        }
-        if world == 1:
-            # the same batch handed over in HOST buffers (what a cgo caller does): H2D copy + pipeline + D2H of the verdicts.
-            # Reported beside the headline, never as `value` (inputs resident in HBM).
-            hb = []
-            for _ in range(3):
-                t_h = time.perf_counter()
-                e_h, _, _ = ctx.collective_verify(qh, corpus.tbss_blob, corpus.tbss_off, corpus.ss_blob, corpus.ss_off)
-                hb.append(time.perf_counter() - t_h)
-            assert (e_h == err).all()
-            hb_s = min(hb)
-            out["host_buffers"] = {"ms_per_step": hb_s * 1e3, "verifies_per_sec": corpus.n_sigs / hb_s,
-                                   "bytes_over_pcie": int(corpus.tbss_off[-1]) + int(corpus.ss_off[-1]) + 16 * args.items,
-                                   "note": "pageable host memory in, verdicts out; best of 3"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cl, corpus, err, nver)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    for cx in ctxs:
-        cx.close()
+    def check_gather(self, err, bits):
+        """Every rank's row of the gathered bitmap must be that rank's verdicts; this rank checks its own row and the
+        population count of all rows against the all-reduced count of accepted writes."""
+        nbytes = (self.slots + 7) // 8
+        rows = np.unpackbits(bits.reshape(self.D.world, nbytes), axis=1, bitorder="little")[:, :self.n_items]
+        own_ok = bool((rows[self.D.rank] == (err == 0)).all())
+        total_ok = self.D.sum_ints([int((err == 0).sum())])[0]
+        return own_ok and int(rows.sum()) == total_ok
+
+    def close(self):
+        for cx in self.ctxs:
+            cx.close()
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json,
-    made by tools/profile_bench.sh + tools/summarize_profile.py: separate rocprofv3 --pmc passes over this
-    same command, gfx950 FETCH_SIZE correction applied).  None when no summary is present."""
-    import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
-        best = p
-    if not best:
-        return None, None
-    with open(best) as f:
-        d = json.load(f)
-    k = d["kernels"].get("bftkv::" + kernel) or d["kernels"].get("bftkv::" + kernel + "<19>")
-    return (k["hbm_bytes_corrected"] if k else None), os.path.relpath(best, ROOT)
+def dry_exchange(D, ok_local, slots):
+    """Stub of bftkv_gpu_allgather_errs_dev for --dry-run: same bitmap layout (bftkv_amd/dist.py), gloo instead of RCCL."""
+    from bftkv_amd import dist as BD
+    torch = D.torch
+    bits = BD.pack_verdicts(torch.from_numpy(ok_local.astype(np.uint8)), slots)
+    if D.world == 1:
+        return bits.numpy()
+    out = torch.empty(D.world * bits.numel(), dtype=torch.uint8)
+    D.dist.all_gather_into_tensor(out, bits)
+    return out.numpy()
 
 
 def effective_cores():
@@ -258,41 +295,605 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(cl, corpus, gpu_err, gpu_nver):
-    """The reference-shaped CPU path (oracle/c/oracle.c, 'port') on this box's host cores, on the same
-    writes; also the bit-exact verdict check of the GPU results (checker role only)."""
+def c_oracle_for(cl):
     from oracle.cbind import COracle
     from tests import helpers as H
     kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
     co = COracle()
     co.set_keyring(kr)
     co.set_quorum(q)
-    cores = effective_cores()
-    n = corpus.n_items
-    # single-thread rate on a bounded sample (~5 s of CPU work), then all usable cores on the whole batch
-    m1 = min(n, 2000)
-    sub = (corpus.tbss_blob, corpus.tbss_off[:m1 + 1], corpus.ss_blob, corpus.ss_off[:m1 + 1])
+    return co
+
+
+def cpu_collective(cl, tb, to, sb, so, budget_s=25.0):
+    """The reference-shaped CPU path (oracle/c/oracle.c: per-signature re-hash, per-signature IsSufficient, early exit) on
+    this box's host cores over the given items: checker of the GPU verdicts and the reported CPU baseline.  Thread counts are
+    swept within a time budget; returns (err, n_verified, public-key ops, best seconds, threads, single-thread ops/s)."""
+    co = c_oracle_for(cl)
+    n = len(to) - 1
+    m1 = max(1, min(n, n // 50))
     t0 = time.perf_counter()
-    _, _, ops1 = co.collective_verify(*sub, n_threads=1)
+    _, _, ops1 = co.collective_verify(tb, to[:m1 + 1], sb, so[:m1 + 1], n_threads=1)
     t1 = time.perf_counter() - t0
-    best, best_threads = None, cores
+    cores = effective_cores()
     cands = sorted({cores} | {t for t in (16, 32, 64, 128, 256) if t <= (os.cpu_count() or 1)})
+    best = None
+    spent = 0.0
+    res = None
     for nt in cands:
-        for _ in range(2):
+        if best is not None and spent + best[0] > budget_s:
+            break
+        t0 = time.perf_counter()
+        cerr, cnver, ops = co.collective_verify(tb, to, sb, so, n_threads=nt)
+        dt = time.perf_counter() - t0
+        spent += dt
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+        res = (cerr, cnver, ops)
+    return res[0], res[1], res[2], best[0], best[1], ops1 / t1
+
+
+def measured_traffic(cfg, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of this config (profiles/*_pmc_summary.json,
+    made by tools/profile_bench.sh + tools/summarize_profile.py: separate rocprofv3 --pmc passes over this same command,
+    gfx950 FETCH_SIZE correction applied).  None when no summary is present."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_cfg%d_pmc_summary.json" % cfg)))
+    if not cands and cfg == 2:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v?_pmc_summary.json")))
+    if not cands:
+        return None, None
+    with open(cands[-1]) as f:
+        d = json.load(f)
+    for name, k in d["kernels"].items():
+        if name.split("<")[0] == "bftkv::" + kernel:
+            return k["hbm_bytes_corrected"], os.path.relpath(cands[-1], ROOT)
+    return None, os.path.relpath(cands[-1], ROOT)
+
+
+def roofline(cfg, kernel, alg_bytes, launch_ms, note):
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms else 0.0
+    traffic, src = measured_traffic(cfg, kernel)
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "launch_ms": launch_ms, "note": note}
+
+
+def int_mac(macs, launch_ms, sclk_mhz=None):
+    a = macs / (launch_ms * 1e-3) if launch_ms else 0.0
+    out = {"achieved": a, "peak": INT_MAC_MEASURED, "frac": a / INT_MAC_MEASURED, "unit": "u32xu32+u64 MAC/s (v_mad_u64_u32 lanes)",
+           "peak_source": "tools/microbench/valu_rates.hip on MI355X, 8 waves/SIMD (profiles/r01_valu_issue_rates_microbench.txt): "
+                          "the rate the part sustains at the clock it settles to under an all-MAC load",
+           "peak_theoretical": INT_MAC_THEORETICAL, "frac_of_theoretical": a / INT_MAC_THEORETICAL,
+           "theoretical_source": "256 CU x 4 SIMD x 16 lanes/clk (quarter-rate VALU op) x 2.4 GHz max clock"}
+    if sclk_mhz:
+        out["sclk_mhz_during_timed_region"] = sclk_mhz
+        out["peak_at_observed_clock"] = 256 * 4 * 16 * sclk_mhz * 1e6
+        out["frac_at_observed_clock"] = a / out["peak_at_observed_clock"]
+    return out
+
+
+class ClockSampler:
+    """Shader clock during the timed region, sampled from rocm-smi on a side thread (rank 0 only; None when unavailable)."""
+
+    def __init__(self):
+        import threading
+        self.samples, self.stop = [], False
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        while not self.stop:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz", out)
+                if m:
+                    self.samples.append(int(m.group(1)))
+            except Exception:
+                return
+            time.sleep(0.05)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        self.t.join(timeout=6)
+
+    def mean(self):
+        return float(np.mean(self.samples)) if self.samples else None
+
+
+def timed_region(D, run, steps, warmup, reset=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    run(warmup)
+    D.barrier()
+    D.sync()
+    if reset:
+        reset()
+    t0 = time.perf_counter()
+    run(steps)
+    D.sync()
+    D.barrier()
+    return D.max_float(time.perf_counter() - t0)
+
+
+def base_line(args, D, metric, unit, value, elapsed, dtype, workload, extra_cfg, scaling="weak"):
+    cfg = {"workload": workload, "parallelism": "one process per GPU x%d" % D.world}
+    cfg.update(extra_cfg)
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic", "config": cfg}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 2: 64-replica quorum, 10k RSA-2048 signed writes per GPU
+# ------------------------------------------------------------------------------------------------------------------
+def load_or_make(args, tag, rank, make):
+    """corpus cache for profiling reruns (--corpus-cache): arrays of a WriteCorpus-like object"""
+    if not args.corpus_cache:
+        return make()
+    path = "%s.%s.r%d.npz" % (args.corpus_cache, tag, rank)
+    if os.path.exists(path):
+        z = np.load(path, allow_pickle=False)
+        return {k: z[k] for k in z.files}
+    d = make()
+    np.savez(path, **d)
+    return d
+
+
+def write_corpus_arrays(c):
+    return {"tb": c.tbss_blob, "to": c.tbss_off, "sb": c.ss_blob, "so": c.ss_off, "n_sigs": np.array(c.n_sigs),
+            "expected_valid": c.expected_valid, "sig_count": c.sig_count}
+
+
+def bench_cfg2(args, D):
+    from corpus import build as cb
+    n = args.replicas or 64
+    items = args.items or 10000
+    cl = cb.make_cluster(n)
+    t0 = time.time()
+    ctx0 = None
+    if D.dry:
+        signer = None
+    else:
+        from bftkv_amd import Context
+        ctx0 = Context(D.local_rank)
+        signer, _ = gpu_signers(ctx0, cl)
+    rates = {cb.MUT_ONE_SHORT: 0.3, cb.MUT_BAD_MPI: 0.2} if D.dry else None      # the dry run's few items must not all agree
+    z = load_or_make(args, "cfg2.n%d.i%d" % (n, items), D.rank, lambda: write_corpus_arrays(
+        cb.make_write_corpus(cl, items, seed=cb.MASTER_SEED + D.rank, batch_signer=signer, with_client_sig=True, mutation_rates=rates)))
+    n_sigs = int(z["n_sigs"])
+    t_corpus = time.time() - t0
+    V = Verifier(D, cl, items, z["tb"], z["to"], z["sb"], z["so"], n_ctx=max(1, args.inflight), ctx0=ctx0)
+    want_ok = z["expected_valid"] >= cl.suff
+
+    if D.dry:
+        gathered = []
+
+        def run(k):
+            for _ in range(k):
+                gathered.append(dry_exchange(D, want_ok, items))
+                V.gathers += 1
+        elapsed = timed_region(D, run, args.steps, args.warmup)
+        rows = np.unpackbits(gathered[-1].reshape(D.world, -1), axis=1, bitorder="little")[:, :items]
+        tot = D.sum_ints([int(want_ok.sum())])[0]
+        if D.rank == 0:
+            print(json.dumps({"dry_run": True, "config": 2, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup,
+                              "allgathers_in_step_loop": V.gathers, "gather_rows": int(rows.shape[0]),
+                              "gathered_ok": int(rows.sum()), "sum_of_rank_ok": tot,
+                              "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed}), flush=True)
+        return
+
+    with ClockSampler() as clk:
+        elapsed = timed_region(D, V.run, args.steps, args.warmup, V.reset_timing)
+    sclk = clk.mean()
+    timed_rsa, timed_total, timed_hash = list(V.rsa_ms), list(V.total_ms), list(V.hash_ms)
+    iso = []
+    for _ in range(3):           # phase breakdown of an isolated call: non-overlapped calls on one context
+        V.submit(0); V.complete(0)
+        iso.append(dict(V.last_tm))
+    err, nver, bits = V.results(0)
+    gather_ok = V.check_gather(err, bits)
+    total_sigs, total_items = D.sum_ints([n_sigs, items])
+    counters = V.ctxs[0].last_counters()
+    if D.rank == 0:
+        rsa_ms = float(np.mean(timed_rsa))
+        alg_bytes = int(z["to"][-1]) + n_sigs * RSA_BYTES + (items + 7) // 8
+        out = base_line(args, D, "pgp_rsa2048_signature_verifies_per_sec", "verifies/s", total_sigs * args.steps / elapsed, elapsed, "u32",
+                        "%d-replica quorum, %d RSA-2048 signed writes per GPU (cfg2 of BASELINE.json), %d signature packets per GPU, "
+                        "1.0%% corrupt / 0.5%% unknown issuer / 0.5%% duplicate / 1.0%% one-short" % (n, items, n_sigs),
+                        {"replicas": n, "writes_per_gpu": items, "sigs_per_gpu": n_sigs, "batches_in_flight": V.n_ctx,
+                         "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps on the verifier's stream" % D.world})
+        out.update({
+            "value_counts": "signature packets of the batch (every packet parsed and hash-tag checked; public-key operations only up to "
+                            "the reference's early exit, see pubkey_ops_per_step_per_gpu)",
+            "quorum_verdicts_per_sec": total_items * args.steps / elapsed,
+            "pubkey_ops_per_step_per_gpu": int(counters["pubkey_ops"]),
+            "useful_verifies_per_sec": None,
+            "sufficient_fraction": float((err == 0).mean()),
+            "verdicts_match_construction": bool(((err == 0) == want_ok).all()),
+            "allgather": {"calls_in_timed_region": args.steps, "bytes_per_rank": (items + 7) // 8, "rows_consistent": gather_ok,
+                          "via": "bftkv_gpu_allgather_errs_dev (library RCCL, verifier stream)"},
+            "kernel_ms": {"k_rsa_modexp": rsa_ms, "hash_stream": float(np.mean(timed_hash)), "step_device_span": float(np.mean(timed_total)),
+                          "measured": "HIP events of the %d timed steps (%d in flight)" % (len(timed_rsa), V.n_ctx),
+                          "isolated_call": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]}},
+            "roofline": roofline(2, "k_rsa_modexp", alg_bytes, rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"),
+            "int_mac": int_mac(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, rsa_ms, sclk),
+            "corpus_build_s": t_corpus,
+        })
+        if D.world == 1:
+            # the same batch handed over in HOST buffers (what a cgo caller does): H2D copy + pipeline + D2H of the verdicts.
+            # Reported beside the headline, never as `value` (inputs resident in HBM).
+            hb = []
+            for _ in range(3):
+                t_h = time.perf_counter()
+                e_h, _, _ = V.ctxs[0].collective_verify(V.qhs[0], z["tb"], z["to"], z["sb"], z["so"])
+                hb.append(time.perf_counter() - t_h)
+            assert (e_h == err).all()
+            out["host_buffers"] = {"ms_per_step": min(hb) * 1e3, "verifies_per_sec": n_sigs / min(hb),
+                                   "bytes_over_pcie": int(z["to"][-1]) + int(z["so"][-1]) + 16 * items,
+                                   "note": "pageable host memory in, verdicts out; best of 3"}
+        if D.world == 1 and not args.no_cpu_baseline:
+            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"])
+            out["useful_verifies_per_sec"] = ops * args.steps / elapsed
+            out["cpu_baseline"] = {
+                "value": ops / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "sample": "all %d writes of the GPU batch (%d public-key ops after the reference's early exit at suff=%d), best thread count "
+                          "%d of a sweep up to %d logical CPUs (usable per affinity/cgroup: %d); OpenSSL libcrypto bignum/SHA (faster than "
+                          "Go math/big)" % (items, ops, cl.suff, nt, os.cpu_count() or 1, effective_cores()),
+                "verdicts_per_sec": items / best, "single_thread_verifies_per_sec": st1,
+                "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all())}
+        print(json.dumps(out), flush=True)
+    V.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 3: 100k mixed RSA / DSA signed read replies -> maxTimestampedValue per variable
+# ------------------------------------------------------------------------------------------------------------------
+def bench_cfg3(args, D):
+    from corpus import build as cb
+    from bftkv_amd import Context, host as HM
+    n = args.replicas or 64
+    n_vars_total = args.items or 10000
+    from bftkv_amd import dist as BD
+    lo, hi = BD.shard_range(n_vars_total, D.rank, D.world)      # variables are independent: shard by variable
+    n_vars = hi - lo
+    cl = cb.make_cluster(n, dsa_fraction=0.5)
+    ctx0 = Context(D.local_rank)
+    rsa_signer, dsa_pow = gpu_signers(ctx0, cl)
+    t0 = time.time()
+    rc = cb.make_read_corpus(cl, n_vars, seed=cb.MASTER_SEED + D.rank, batch_signer=rsa_signer, dsa_batch_pow=dsa_pow)
+    t_corpus = time.time() - t0
+    n_replies = len(rc.reply_var)
+    V = Verifier(D, cl, n_replies, rc.tbss_blob, rc.tbss_off, rc.ss_blob, rc.ss_off, ctx0=ctx0)
+    # the read quorum: the n_storage storage nodes under the READ rule (wotqs.go:36-70: threshold = f + 1)
+    ns = len(rc.storage_ids)
+    f = (ns - 1) // 3
+    q_read = HM.Quorum.from_qcs([(f, 3 * f + 1, f + 1, f + (ns - f) // 2 + 1, rc.storage_ids)])
+    vals = np.frombuffer(b"".join(rc.write_value), dtype=np.uint8).reshape(len(rc.write_value), -1)
+    vlen = vals.shape[1]
+    reply_t = rc.write_t[rc.reply_write]
+    winners = [None]
+
+    def tally(err):
+        """Client.Read's fold over the replies whose <x,v,t,sig,ss> verified (protocol/client.go:181-205) through the host
+        mirror (bftkv_host_max_timestamped_value); replies that fail verification are dropped as failures."""
+        ok = err == 0
+        cnt = np.bincount(rc.reply_var[ok], minlength=n_vars)
+        roff = np.zeros(n_vars + 1, dtype=np.uint64)
+        roff[1:] = np.cumsum(cnt, dtype=np.uint64)
+        peers = np.ascontiguousarray(rc.reply_peer[ok]); ts = np.ascontiguousarray(reply_t[ok])
+        vb = np.ascontiguousarray(vals[rc.reply_write[ok]].reshape(-1))
+        vo = (np.arange(len(peers) + 1, dtype=np.uint64) * vlen)
+        return HM.max_timestamped_value_raw(q_read, n_vars, peers, ts, vb, vo, roff)
+
+    def run(k):
+        for i in range(k):
+            V.submit(i); V.complete(i)
+            err = V.outs[0][0].cpu().numpy()            # 1 byte per reply back to the host
+            winners[0] = tally(err)
+
+    with ClockSampler() as clk:
+        elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
+    sclk = clk.mean()
+    err, nver, bits = V.results(0)
+    gather_ok = V.check_gather(err, bits)
+    counters = V.ctxs[0].last_counters()
+    n_dsa_ops = int(counters["dsa_ops"])
+    tot_sigs, tot_replies, tot_vars = D.sum_ints([rc.n_sigs, n_replies, n_vars])
+    win = winners[0]
+    if D.rank == 0:
+        rsa_ms, dsa_ms = float(np.mean(V.rsa_ms)), float(np.mean(V.dsa_ms))
+        n_rsa_ops = int(counters["pubkey_ops"]) - n_dsa_ops
+        dom = "k_dsa_modexp" if dsa_ms >= rsa_ms else "k_rsa_modexp"
+        alg_bytes = int(rc.tbss_off[-1]) + n_rsa_ops * RSA_BYTES + n_dsa_ops * DSA_BYTES + (n_replies + 7) // 8
+        out = base_line(args, D, "pgp_mixed_rsa_dsa_signature_verifies_per_sec", "verifies/s", tot_sigs * args.steps / elapsed, elapsed, "u32",
+                        "%d-replica quorum (half RSA-2048, half DSA-2048/256), %d signed read replies <x,v,t,sig,ss> over %d variables per GPU "
+                        "(cfg3 of BASELINE.json: %d distinct stored packets, 2 timestamps per variable, 1%% of the variables with a conflicting "
+                        "value), %d signature packets; reply verdicts on the GPU, then maxTimestampedValue per variable over the %d-node read "
+                        "quorum" % (n, n_replies, n_vars, rc.writes.n_items, rc.n_sigs, ns),
+                        {"replicas": n, "replies_per_gpu": n_replies, "variables_per_gpu": n_vars, "sigs_per_gpu": rc.n_sigs,
+                         "parallelism": "shard-by-variable x%d, RCCL all-gather of reply-verdict bitmaps" % D.world})
+        out.update({
+            "reply_verdicts_per_sec": tot_replies * args.steps / elapsed, "read_verdicts_per_sec": tot_vars * args.steps / elapsed,
+            "pubkey_ops_per_step_per_gpu": {"rsa": n_rsa_ops, "dsa": n_dsa_ops},
+            "reads_answered_fraction": float(np.mean(win >= 0)), "replies_accepted_fraction": float((err == 0).mean()),
+            "allgather": {"calls_in_timed_region": args.steps, "bytes_per_rank": (n_replies + 7) // 8, "rows_consistent": gather_ok},
+            "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_dsa_mul+k_dsa_modexp": dsa_ms, "hash_stream": float(np.mean(V.hash_ms)),
+                          "step_device_span": float(np.mean(V.total_ms)), "measured": "HIP events of the %d timed steps" % len(V.rsa_ms),
+                          "last_call": V.last_tm},
+            "roofline": roofline(3, dom, alg_bytes, max(rsa_ms, dsa_ms), "integer-VALU bound; see int_mac"),
+            "int_mac": int_mac(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * MACS_PER_DSA_VERIFY, rsa_ms + dsa_ms, sclk),
+            "corpus_build_s": t_corpus,
+        })
+        if D.world == 1 and not args.no_cpu_baseline:
+            # the CPU path on the DISTINCT stored packets (a reply is a byte-identical copy of one of them), mapped to the replies
+            w = rc.writes
+            cerr_w, cnver_w, ops_w, best, nt, st1 = cpu_collective(cl, w.tbss_blob, w.tbss_off, w.ss_blob, w.ss_off)
+            cerr, cnver = cerr_w[rc.reply_write], cnver_w[rc.reply_write]
+            # read tally restated by the oracle (oracle/collective.py max_timestamped_value) over the CPU verdicts
+            from oracle import collective as col
+            from oracle import wotqs
+            qo = wotqs.WotQ([wotqs.QC(nodes=list(rc.storage_ids), f=f, min=3 * f + 1, threshold=f + 1, suff=f + (ns - f) // 2 + 1)])
+            okc = cerr == 0
+            t_c0 = time.perf_counter()
+            want = []
+            order = np.argsort(rc.reply_var, kind="stable")
+            bounds = np.searchsorted(rc.reply_var[order], np.arange(n_vars + 1))
+            for j in range(n_vars):
+                rs = [(int(rc.reply_peer[r]), int(reply_t[r]), rc.write_value[rc.reply_write[r]]) for r in order[bounds[j]:bounds[j + 1]] if okc[r]]
+                want.append(col.max_timestamped_value(rs, qo))
+            t_tally = time.perf_counter() - t_c0
+            got = []
+            okg = np.nonzero(err == 0)[0]
+            first = np.concatenate([[0], np.cumsum(np.bincount(rc.reply_var[err == 0], minlength=n_vars))])
+            for j in range(n_vars):
+                r = okg[first[j] + win[j]] if win[j] >= 0 else -1
+                got.append(None if r < 0 else (rc.write_value[rc.reply_write[r]], int(reply_t[r])))
+            reads_same = all((a is None and b is None) or (a is not None and b is not None and a[0] == b[0] and a[1] == b[1])
+                             for a, b in zip(got, want))
+            ops_all = int(cnver_w.astype(np.int64)[rc.reply_write].sum())    # lower bound of the CPU's ops over all replies
+            out["cpu_baseline"] = {
+                "value": ops_w / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "sample": "the %d distinct stored packets the %d replies are copies of (%d public-key ops after the early exit, about half "
+                          "DSA), best thread count %d (usable per affinity/cgroup: %d); OpenSSL libcrypto; read tally: Python oracle, %.2f s "
+                          "for %d variables" % (w.n_items, n_replies, ops_w, nt, effective_cores(), t_tally, n_vars),
+                "reply_verdicts_per_sec": w.n_items / best, "single_thread_verifies_per_sec": st1,
+                "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
+                "read_answers_identical_to_oracle": bool(reads_same), "min_cpu_pubkey_ops_all_replies": ops_all}
+        print(json.dumps(out), flush=True)
+    V.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 4: 256 replicas, 1M-write storm sharded over the ranks
+# ------------------------------------------------------------------------------------------------------------------
+def bench_cfg4(args, D):
+    from corpus import build as cb
+    from bftkv_amd import Context
+    torch = D.torch
+    n = args.replicas or 256
+    total_writes = args.items or 1000000
+    share = total_writes // D.world                      # strong scaling: the storm is split over the ranks
+    chunk = min(args.chunk, share)
+    distinct = min(args.distinct, chunk)
+    tiles = chunk // distinct
+    chunk = tiles * distinct
+    calls = max(1, share // chunk)
+    cl = cb.make_cluster(n)
+    ctx0 = Context(D.local_rank)
+    rsa_signer, _ = gpu_signers(ctx0, cl)
+    t0 = time.time()
+    rates = {cb.MUT_BAD_MPI: 0.001, cb.MUT_UNKNOWN_ISSUER: 0.0005, cb.MUT_DUP_SIGNER: 0.0005, cb.MUT_ONE_SHORT: 0.001}
+    z = load_or_make(args, "cfg4.n%d.d%d" % (n, distinct), D.rank, lambda: write_corpus_arrays(
+        cb.make_write_corpus(cl, distinct, seed=cb.MASTER_SEED + D.rank, batch_signer=rsa_signer, mutation_rates=rates)))
+    t_corpus = time.time() - t0
+    n_sigs_base = int(z["n_sigs"])
+    # the resident batch: `tiles` copies of the distinct writes, laid out back to back in HBM (distinct memory per copy)
+    dev = D.dev
+    d_tb = torch.from_numpy(z["tb"]).to(dev).repeat(tiles)
+    d_sb = torch.from_numpy(z["sb"]).to(dev).repeat(tiles)
+
+    def tile_off(off):
+        o = torch.from_numpy(off.astype(np.int64)).to(dev)
+        step = int(off[-1])
+        body = (o[:-1].unsqueeze(0) + torch.arange(tiles, device=dev, dtype=torch.int64).unsqueeze(1) * step).reshape(-1)
+        return torch.cat([body, torch.tensor([tiles * step], device=dev, dtype=torch.int64)])
+    d_to, d_so = tile_off(z["to"]), tile_off(z["so"])
+    V = Verifier(D, cl, chunk, d_tb, d_to, d_sb, d_so, ctx0=ctx0, ss_len=tiles * int(z["so"][-1]))
+
+    def run(k):
+        for i in range(k):
+            for _ in range(calls):                      # the rank's share of the storm, one resident batch at a time
+                V.submit(0); V.complete(0)
+
+    with ClockSampler() as clk:
+        elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
+    sclk = clk.mean()
+    err, nver, bits = V.results(0)
+    gather_ok = V.check_gather(err, bits)
+    counters = V.ctxs[0].last_counters()
+    n_sigs_call = n_sigs_base * tiles
+    tot_sigs, tot_writes = D.sum_ints([n_sigs_call * calls, chunk * calls])
+    if D.rank == 0:
+        rsa_ms, hash_ms = float(np.mean(V.rsa_ms)), float(np.mean(V.hash_ms))
+        alg_bytes = tiles * int(z["to"][-1]) + n_sigs_call * RSA_BYTES + (chunk + 7) // 8
+        want_ok = np.tile(z["expected_valid"] >= cl.suff, tiles)
+        out = base_line(args, D, "pgp_rsa2048_signature_verifies_per_sec", "verifies/s", tot_sigs * args.steps / elapsed, elapsed, "u32",
+                        "%d-replica quorum, write storm of %d signed writes per step over %d GPU(s) (cfg4 of BASELINE.json): each rank verifies "
+                        "its %d writes as %d call(s) over a resident batch of %d writes = %d tiles of %d distinctly signed writes "
+                        "(171..256 signatures and a %.1f KB payload each; mutations at 0.1%%), %d signature packets per call" %
+                        (n, chunk * calls * D.world, D.world, chunk * calls, calls, chunk, tiles, distinct,
+                         float(z["to"][-1]) / distinct / 1024, n_sigs_call),
+                        {"replicas": n, "writes_per_step": chunk * calls * D.world, "writes_per_gpu_per_step": chunk * calls,
+                         "writes_per_call": chunk, "sigs_per_call": n_sigs_call, "distinct_writes": distinct, "tiles": tiles,
+                         "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps per call" % D.world}, scaling="strong")
+        out.update({
+            "data": "synthetic: %d distinctly signed writes tiled %dx in HBM (every copy is parsed, hashed and verified again; nothing is "
+                    "cached across items)" % (distinct, tiles),
+            "quorum_verdicts_per_sec": tot_writes * args.steps / elapsed,
+            "pubkey_ops_per_call": int(counters["pubkey_ops"]),
+            "sufficient_fraction": float((err == 0).mean()),
+            "verdicts_match_construction": bool(((err == 0) == want_ok).all()),
+            "allgather": {"calls_in_timed_region": args.steps * calls, "bytes_per_rank": (chunk + 7) // 8, "rows_consistent": gather_ok},
+            "kernel_ms": {"k_rsa_modexp": rsa_ms, "hash_stream": hash_ms, "call_device_span": float(np.mean(V.total_ms)),
+                          "measured": "HIP events of the %d timed calls" % len(V.rsa_ms), "last_call": V.last_tm},
+            "roofline": roofline(4, "k_rsa_modexp", alg_bytes, rsa_ms, "integer-VALU bound; see int_mac"),
+            "int_mac": int_mac(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, rsa_ms, sclk),
+            "corpus_build_s": t_corpus,
+        })
+        if D.world == 1 and not args.no_cpu_baseline:
+            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"])
+            out["cpu_baseline"] = {
+                "value": ops / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "sample": "the %d distinct writes of the batch (%d public-key ops after the early exit at suff=%d; the reference re-hashes the "
+                          "%.1f KB payload for every signature), best thread count %d (usable per affinity/cgroup: %d); OpenSSL libcrypto" %
+                          (distinct, ops, cl.suff, float(z["to"][-1]) / distinct / 1024, nt, effective_cores()),
+                "verdicts_per_sec": distinct / best, "single_thread_verifies_per_sec": st1,
+                "gpu_verdicts_identical_to_cpu": bool((np.tile(cerr, tiles) == err).all() and (np.tile(cnver, tiles) == nver).all())}
+        print(json.dumps(out), flush=True)
+    V.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 5: threshold share-combine, 10k operations per scheme
+# ------------------------------------------------------------------------------------------------------------------
+def bench_cfg5(args, D):
+    from corpus import build as cb
+    from bftkv_amd import Context, dist as BD
+    from bftkv_amd._native import _ints_to_be, _ptr
+    torch = D.torch
+    n_total = args.items or 10000
+    lo, hi = BD.shard_range(n_total, D.rank, D.world)    # operations are independent: shard by operation, no exchange step
+    N = hi - lo
+    gold = os.path.join(ROOT, "tests", "golden")
+    kat = json.load(open(os.path.join(gold, "threshold_kat.json")))
+    k0 = json.load(open(os.path.join(gold, "keys_dsa2048.json")))["keys"][0]
+    as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
+    t0 = time.time()
+    tc = cb.make_threshold_corpus(N, int(kat["rsa"]["n"], 16), int(kat["sss"]["pb"], 16), as_int(k0["p"]), as_int(k0["q"]),
+                                  seed=cb.MASTER_SEED + D.rank)
+    t_corpus = time.time() - t0
+    ctx = Context(D.local_rank)
+    lib, h, dev = ctx.lib, ctx.h, D.dev
+    flat = lambda rows: [v for r in rows for v in r]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # inputs resident in HBM: big-endian numbers as the reference serialises them (big.Int.Bytes, left-padded)
+    d = {"rsa_f": up(_ints_to_be(flat(tc.rsa_factors), 256)), "sss_x": up(tc.sss_xs), "sss_y": up(_ints_to_be(flat(tc.sss_ys), 256)),
+         "s_x": up(tc.s_xs), "s_y": up(_ints_to_be(flat(tc.s_ys), 32)), "r_x": up(tc.r_xs), "r_ri": up(_ints_to_be(flat(tc.r_ri), 256)),
+         "r_vi": up(_ints_to_be(flat(tc.r_vi), 32))}
+    o = {"rsa": torch.zeros((N, 256), dtype=torch.uint8, device=dev), "sss": torch.zeros((N, 256), dtype=torch.uint8, device=dev),
+         "s": torch.zeros((N, 32), dtype=torch.uint8, device=dev), "r": torch.zeros((N, 32), dtype=torch.uint8, device=dev),
+         "st_sss": torch.zeros(N + 8, dtype=torch.uint8, device=dev), "st_s": torch.zeros(N + 8, dtype=torch.uint8, device=dev),
+         "st_r": torch.zeros(N + 8, dtype=torch.uint8, device=dev)}
+    m_rsa, m_sss = _ints_to_be([tc.rsa_n], 256), _ints_to_be([tc.sss_mod], 256)
+    m_q, m_p = _ints_to_be([tc.dsa_q], 32), _ints_to_be([tc.dsa_p], 256)
+    P = lambda t: t.data_ptr()
+    import ctypes as C
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps + args.warmup + 4)]
+    stream = torch.cuda.ExternalStream(ctx.lib.bftkv_gpu_stream(ctx.h), device=dev)
+    spans = []
+    step_no = [0]
+
+    def one_step():
+        e = ev[step_no[0] % len(ev)]
+        step_no[0] += 1
+        e[0].record(stream)
+        # RSA: S = prod of the 10 partial signatures mod N (rsa.go:318-329)
+        ctx._check(lib.bftkv_gpu_modmul_product_dev(h, N, 10, P(d["rsa_f"]), 256, None, 1, _ptr(m_rsa), P(o["rsa"])), "modmul_product_dev")
+        e[1].record(stream)
+        # SSS: calculateSecret over k = 7 shares mod the 2048-bit prime (sss.go:69-107)
+        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, 7, P(d["sss_x"]), P(d["sss_y"]), 256, None, 1, _ptr(m_sss), P(o["sss"]), P(o["st_sss"])), "lagrange_dev")
+        e[2].record(stream)
+        # threshold DSA: calculateS over 2t = 8 shares mod q (dsa_core.go:389-403) ...
+        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, 8, P(d["s_x"]), P(d["s_y"]), 32, None, 1, _ptr(m_q), P(o["s"]), P(o["st_s"])), "lagrange_dev")
+        e[3].record(stream)
+        # ... and CalculateR over 2t = 8 partial r's (dsa.go:33-52)
+        ctx._check(lib.bftkv_gpu_dsa_calculate_r_dev(h, N, 8, P(d["r_x"]), P(d["r_ri"]), 256, P(d["r_vi"]), 32, None, 1, _ptr(m_p), _ptr(m_q),
+                                                     P(o["r"]), P(o["st_r"])), "calculate_r_dev")
+        e[4].record(stream)
+        return e
+
+    def run(k):
+        es = [one_step() for _ in range(k)]
+        ctx.sync()
+        for e in es:
+            spans.append([e[i].elapsed_time(e[i + 1]) for i in range(4)])
+
+    elapsed = timed_region(D, run, args.steps, args.warmup, lambda: spans.clear())
+    res = {k: o[k].cpu().numpy() for k in o}
+    tot_ops = D.sum_ints([3 * N])[0]
+    if D.rank == 0:
+        sp = np.mean(np.array(spans), axis=0)
+        names = ["rsa_combine_n10", "sss_calculate_secret_k7_2048", "dsa_calculate_s_2t8_q256", "dsa_calculate_r_2t8_2048_256"]
+        # dominant: CalculateR.  Algorithmic bytes per op (SURVEY.md 8(d)): 2t x (|p| + |q|) in, |q| out
+        alg_r = N * (8 * (256 + 32) + 32)
+        alg_all = N * ((10 + 1) * 256 + (7 + 1) * 256 + 7 * 4 + (8 + 1) * 32 + 8 * 4 + 8 * (256 + 32) + 8 * 4 + 32)
+        out = base_line(args, D, "threshold_share_combine_ops_per_sec", "ops/s", tot_ops * args.steps / elapsed, elapsed, "u32",
+                        "threshold share-combine (cfg5 of BASELINE.json): per step %d operations of each scheme over %d GPU(s) -- RSA calculateSignature "
+                        "(product of 10 partial signatures mod the 2048-bit N of rsa/test.pkcs8), SSS calculateSecret (k=7 of n=10, mod the 2048-bit "
+                        "prime of sss_test.go), threshold-DSA combine = calculateS (2t=8, 256-bit q) + CalculateR (2t=8, 2048/256-bit group); one "
+                        "operation = one scheme-level combine (3 per index)" % (n_total, D.world),
+                        {"ops_per_scheme": n_total, "ops_per_scheme_per_gpu": N, "schemes": 3,
+                         "parallelism": "shard-by-operation x%d, no exchange step (results go back to the one client that asked)" % D.world},
+                        scaling="strong")
+        out.update({
+            "per_scheme_ops_per_sec_per_gpu": {names[i]: N / (sp[i] * 1e-3) for i in range(4)},
+            "kernel_ms": {names[i]: float(sp[i]) for i in range(4)},
+            "roofline": roofline(5, "k_multiexp", alg_r, float(sp[3]),
+                                 "launch span of the CalculateR call (k_lagrange_inv/terms, 2 x k_multiexp, k_u256_inv_modq, k_limbs_mod_q); "
+                                 "10k operations are 625 waves: latency-, not bandwidth- or MAC-bound"),
+            "algorithmic_bytes_per_step": alg_all,
+            "corpus_build_s": t_corpus,
+        })
+        if D.world == 1 and not args.no_cpu_baseline:
+            from oracle import threshold as T
+            S, S2 = min(N, 300), min(N, 24)
+            toi = lambda row: int.from_bytes(row.tobytes(), "big")
             t0 = time.perf_counter()
-            cerr, cnver, ops = co.collective_verify(corpus.tbss_blob, corpus.tbss_off, corpus.ss_blob, corpus.ss_off, n_threads=nt)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, best_threads = dt, nt
-    cores = best_threads
-    identical = bool((cerr == gpu_err).all() and (cnver == gpu_nver).all())
-    return {"value": ops / best, "unit": "verifies/s", "cores": cores, "kind": "port",
-            "sample": "all %d writes of the GPU batch (%d public-key ops after the reference's early exit at suff=%d), "
-                      "best thread count %d of a sweep up to %d logical CPUs (usable per affinity/cgroup: %d); OpenSSL libcrypto "
-                      "bignum/SHA (faster than Go math/big)" % (n, ops, cl.suff, cores, os.cpu_count() or 1, effective_cores()),
-            "verdicts_per_sec": n / best,
-            "single_thread_verifies_per_sec": ops1 / t1,
-            "gpu_verdicts_identical_to_cpu": identical}
+            w_rsa = [T.calculate_signature(tc.rsa_factors[i], tc.rsa_n) for i in range(S)]
+            t_rsa = (time.perf_counter() - t0) / S
+            t0 = time.perf_counter()
+            w_sss = [T.calculate_s(list(zip([int(v) for v in tc.sss_xs[i]], tc.sss_ys[i])), tc.sss_mod) for i in range(S)]
+            t_sss = (time.perf_counter() - t0) / S
+            t0 = time.perf_counter()
+            w_s = [T.calculate_s(list(zip([int(v) for v in tc.s_xs[i]], tc.s_ys[i])), tc.dsa_q) for i in range(S)]
+            t_s = (time.perf_counter() - t0) / S
+            t0 = time.perf_counter()
+            w_r = []
+            for i in range(S2):
+                try:
+                    w_r.append(T.calculate_r([(int(tc.r_xs[i][j]), tc.r_ri[i][j].to_bytes(256, "big"), tc.r_vi[i][j]) for j in range(8)], tc.dsa_p, tc.dsa_q))
+                except ValueError:
+                    w_r.append(None)
+            t_r = (time.perf_counter() - t0) / S2
+            same = (all(toi(res["rsa"][i]) == w_rsa[i] for i in range(S)) and all(toi(res["sss"][i]) == w_sss[i] for i in range(S)) and
+                    all(toi(res["s"][i]) == w_s[i] for i in range(S)) and
+                    all((w_r[i] is None and res["st_r"][i] != 0) or (w_r[i] is not None and res["st_r"][i] == 0 and toi(res["r"][i]) == w_r[i]) for i in range(S2)) and
+                    not res["st_sss"][:N].any() and not res["st_s"][:N].any())
+            per3 = t_rsa + t_sss + t_s + t_r
+            out["cpu_baseline"] = {"value": 3.0 / per3, "unit": "ops/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle/threshold.py (CPython big integers, one thread) on the first %d operations of each scheme "
+                                             "(%d for CalculateR): %.0f / %.0f / %.0f / %.0f us per RSA / SSS / calculateS / CalculateR" %
+                                             (S, S2, t_rsa * 1e6, t_sss * 1e6, t_s * 1e6, t_r * 1e6),
+                                   "gpu_results_identical_to_cpu": bool(same)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args))
+    if args.dry_run and args.config != 2:
+        sys.exit("--dry-run covers the launcher / exchange path of --config 2")
+    D = Dist(args)
+    try:
+        {2: bench_cfg2, 3: bench_cfg3, 4: bench_cfg4, 5: bench_cfg5}[args.config](args, D)
+    finally:
+        D.close()
 
 
 if __name__ == "__main__":

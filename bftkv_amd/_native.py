@@ -41,6 +41,8 @@ EXPORTS = [
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
+    "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
+    "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
 ]
 
 _lib = None
@@ -95,6 +97,13 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
+    lib.bftkv_gpu_modexp_ops.argtypes = lib.bftkv_gpu_modexp.argtypes
+    lib.bftkv_gpu_allgather_errs_dev.argtypes = [vp, u8p, u32, u32, u8p]
+    lib.bftkv_gpu_modmul_product_dev.argtypes = lib.bftkv_gpu_modmul_product.argtypes
+    lib.bftkv_gpu_lagrange_combine_dev.argtypes = lib.bftkv_gpu_lagrange_combine.argtypes
+    lib.bftkv_gpu_dsa_calculate_r_dev.argtypes = lib.bftkv_gpu_dsa_calculate_r.argtypes
+    lib.bftkv_gpu_sss_distribute_dev.argtypes = lib.bftkv_gpu_sss_distribute.argtypes
+    lib.bftkv_gpu_modinv_dev.argtypes = lib.bftkv_gpu_modinv.argtypes
     for name in EXPORTS:
         if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream",
                         "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy"):
@@ -243,12 +252,12 @@ class Context:
     def last_counters(self):
         c = (C.c_uint64 * 4)()
         self._check(self.lib.bftkv_gpu_last_counters(self.h, c), "last_counters")
-        return {"packets": c[0], "pubkey_ops": c[1], "items": c[2]}
+        return {"packets": c[0], "pubkey_ops": c[1], "items": c[2], "dsa_ops": c[3]}
 
     def last_timing(self):
         ms = (C.c_float * 8)()
         self._check(self.lib.bftkv_gpu_last_timing(self.h, ms), "last_timing")
-        return {"total": ms[0], "parse": ms[1], "hash": ms[2], "rsa": ms[3], "tally": ms[4], "compare": ms[5]}
+        return {"total": ms[0], "parse": ms[1], "hash": ms[2], "rsa": ms[3], "tally": ms[4], "compare": ms[5], "dsa": ms[6]}
 
     def signers(self, ss_blob, ss_off):
         n = len(ss_off) - 1
@@ -280,6 +289,10 @@ class Context:
 
     def allgather_verdicts(self, local_ptr: int, nbytes: int, out_ptr: int):
         self._check(self.lib.bftkv_gpu_allgather_verdicts(self.h, local_ptr, nbytes, out_ptr), "allgather_verdicts")
+
+    def allgather_errs_dev(self, err_ptr: int, n_items: int, slots: int, out_ptr: int):
+        """Asynchronous on the context's stream: pack err == 0 into a bitmap of ceil(slots/8) bytes, all-gather rank-major."""
+        self._check(self.lib.bftkv_gpu_allgather_errs_dev(self.h, err_ptr, n_items, slots, out_ptr), "allgather_errs_dev")
 
     # ---- threshold share combine (config 5); numbers are Python ints at this level
     def modmul_product(self, factors, moduli, mod_idx, nbytes: int = 256):
@@ -339,6 +352,16 @@ class Context:
         st = np.zeros(len(values) + 8, dtype=np.uint8)
         self._check(self.lib.bftkv_gpu_modinv(self.h, len(values), _ptr(v), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out), _ptr(st)), "modinv")
         return [int.from_bytes(out[i].tobytes(), "big") for i in range(len(values))], st[:len(values)]
+
+    def modexp_ops(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
+        """out[i] = base[i] ^ exps[i] mod mods[mod_idx[i]] (one exponent per operation: CalculatePartialR, dsa.go:27-31)."""
+        base, mods, exps = _u8(base), _u8(mods), _u8(exps)
+        mod_idx = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        assert exps.shape[0] == base.shape[0]
+        out = np.zeros_like(base)
+        self._check(self.lib.bftkv_gpu_modexp_ops(self.h, base.shape[0], _ptr(base), base.shape[1], _ptr(mod_idx), mods.shape[0],
+                                                  _ptr(mods), _ptr(exps), exps.shape[1], _ptr(out)), "modexp_ops")
+        return out
 
     def modexp(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
         """base [n, nbytes] u8 BE; mods [m, nbytes]; exps [m, exp_len] -> [n, nbytes]."""

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <functional>
 #include <map>
 #include <chrono>
@@ -95,12 +96,13 @@ struct bftkv_gpu_ctx {
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
-  DevBuf st_tmp, item_tmp;
+  DevBuf st_tmp, item_tmp, bits_tmp;
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
+  std::map<std::string, std::array<DevBuf, 3>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
   uint32_t* d_mail = nullptr;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
-  hipEvent_t ev[8] = {};   // 0 start, 1 parsed, 2 modexp done, 3 compare done, 4 end, 5 hash start, 6 hash done
+  hipEvent_t ev[10] = {};  // 0 start, 1 parsed, 2 modexp done, 3 compare + DSA done, 4 end, 5 hash start, 6 hash done, 7 DSA inverses done, 8 compare done
   bool have_timing = false;
   void* rccl_comm = nullptr;   // ncclComm_t
   int n_ranks = 1, rank = 0;
@@ -362,6 +364,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       hipLaunchKernelGGL((k_rsa_compare<MONT_L4096, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
   }
+  HIPCHK(c, hipEventRecord(c->ev[8], s));
   // DSA signatures (if any): u1 depends on the digest, so the table multiplications run after the join; the
   // inverses were started on their own stream right after the parse.  Grids cover every signature and exit on
   // the device-side count, so no host read-back sits between the kernels.
@@ -645,10 +648,11 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
-                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp})
+                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
+  for (auto& kv : c->modtab_cache) for (DevBuf& b : kv.second) b.release();
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -929,7 +933,8 @@ int bftkv_gpu_last_timing(bftkv_gpu_ctx* c, float ms[8]) {
   HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[5], c->ev[6]));   // hash stream: midstates + digests (overlaps the modexp)
   HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[1], c->ev[2]));   // k_rsa_modexp on its own stream
   HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));   // tally
-  HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[2], c->ev[3]));   // compare (incl. waiting for the hash stream)
+  HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[2], c->ev[8]));   // compare (incl. waiting for the hash stream)
+  HIPCHK(c, hipEventElapsedTime(&ms[6], c->ev[8], c->ev[3]));   // k_dsa_mul + k_dsa_modexp (0 without DSA keys)
   return 0;
 }
 
@@ -1001,22 +1006,23 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   return 0;
 }
 
-int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
-                     uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
-  if (!c || nbytes == 0 || nbytes > 256 || (n_ops && (!base || !mod_idx || !mods || !exps || !out))) return BFTKV_E_INVALID;
+static int modexp_impl(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
+                       uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, bool exp_per_op, uint8_t* out) {
+  if (!c || nbytes == 0 || nbytes > 256 || exp_len == 0 || (n_ops && (!base || !mod_idx || !mods || !exps || !out))) return BFTKV_E_INVALID;
   if (n_ops == 0) return 0;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   std::vector<uint32_t> nl((size_t)n_mods * MONT_N), r2((size_t)n_mods * MONT_N), n0(n_mods);
   const uint32_t ew = (exp_len + 3) / 4;
-  std::vector<uint32_t> ex((size_t)n_mods * ew, 0);
+  const size_t n_exp = exp_per_op ? n_ops : n_mods;
+  std::vector<uint32_t> ex(n_exp * ew, 0);
   for (uint32_t m = 0; m < n_mods; ++m) {
     if (hostbn::bit_length(mods + (size_t)m * nbytes, nbytes) > 2048) return fail(c, BFTKV_E_UNSUPPORTED, "modulus wider than 2048 bits");
     if (!hostbn::mont_setup(mods + (size_t)m * nbytes, nbytes, MONT_N, &nl[(size_t)m * MONT_N], &r2[(size_t)m * MONT_N], &n0[m]))
       return fail(c, BFTKV_E_UNSUPPORTED, "even modulus");
-    hostbn::from_be(exps + (size_t)m * exp_len, exp_len, &ex[(size_t)m * ew], (int)ew);
   }
+  for (size_t m = 0; m < n_exp; ++m) hostbn::from_be(exps + m * exp_len, exp_len, &ex[m * ew], (int)ew);
   for (uint32_t i = 0; i < n_ops; ++i) if (mod_idx[i] >= n_mods) return fail(c, BFTKV_E_INVALID, "mod_idx out of range");
   DevBuf d_nl, d_r2, d_n0, d_ex, d_mi, d_in, d_inl, d_outl, d_out;
   struct Guard { std::vector<DevBuf*> v; ~Guard() { for (auto* b : v) b->release(); } } g{{&d_nl, &d_r2, &d_n0, &d_ex, &d_mi, &d_in, &d_inl, &d_outl, &d_out}};
@@ -1034,13 +1040,23 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint
                      d_inl.as<uint32_t>());
   hipLaunchKernelGGL(k_modexp, dim3((n_ops + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s, n_ops,
                      d_inl.as<uint32_t>(), d_mi.as<uint32_t>(), d_nl.as<uint32_t>(), d_r2.as<uint32_t>(), d_n0.as<uint32_t>(),
-                     d_ex.as<uint32_t>(), ew, d_outl.as<uint32_t>());
+                     d_ex.as<uint32_t>(), ew, exp_per_op ? 1u : 0u, d_outl.as<uint32_t>());
   hipLaunchKernelGGL(k_limbs_to_bytes, dim3((n_ops * nbytes + 255) / 256), dim3(256), 0, s, d_outl.as<uint32_t>(), nbytes, n_ops,
                      d_out.as<uint8_t>());
   HIPCHK(c, hipMemcpyAsync(out, d_out.p, (size_t)n_ops * nbytes, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
+                     uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
+  return modexp_impl(c, n_ops, base, nbytes, mod_idx, n_mods, mods, exps, exp_len, false, out);
+}
+
+int bftkv_gpu_modexp_ops(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
+                         uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
+  return modexp_impl(c, n_ops, base, nbytes, mod_idx, n_mods, mods, exps, exp_len, true, out);
 }
 
 }  // extern "C"

@@ -1219,8 +1219,8 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
 __global__ void __launch_bounds__(RSA_BLOCK) k_modexp(uint32_t n_ops, const uint32_t* __restrict__ base_limbs /*[n_ops][76]*/,
                                                       const uint32_t* __restrict__ mod_idx, const uint32_t* __restrict__ n_limbs,
                                                       const uint32_t* __restrict__ r2_limbs, const uint32_t* __restrict__ n0inv_tab,
-                                                      const uint32_t* __restrict__ exp_words /*[n_mods][exp_nwords] little-endian*/,
-                                                      uint32_t exp_nwords, uint32_t* __restrict__ out_limbs) {
+                                                      const uint32_t* __restrict__ exp_words /*[n_mods | n_ops][exp_nwords] little-endian*/,
+                                                      uint32_t exp_nwords, uint32_t exp_per_op, uint32_t* __restrict__ out_limbs) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   __shared__ uint32_t x_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_modexp(uint32_t n_ops, const uint
 #pragma unroll
   for (int k = 0; k < L; ++k) n[k] = n_limbs[(uint64_t)mi * MONT_N + qlane * L + k];
   const uint32_t n0inv = n0inv_tab[mi];
-  const uint32_t* ew = exp_words + (uint64_t)mi * exp_nwords;
+  const uint32_t* ew = exp_words + (uint64_t)(exp_per_op ? op : mi) * exp_nwords;   // per modulus (RSA private keys) or per operation
   // steps: -2: xR = mont(x, R^2); -1: y = mont(1, R^2) = R mod n; then per exponent bit a
   // squaring (even step) and a multiplication by xR (odd step); last: mont(y, 1).
   const int nbits = (int)exp_nwords * 32;

@@ -470,6 +470,23 @@ class Client:
         return res
 
 
+def max_timestamped_value_raw(q: Quorum, n_reads: int, peers: np.ndarray, ts: np.ndarray, value_blob: np.ndarray, value_off: np.ndarray,
+                              read_off: np.ndarray) -> np.ndarray:
+    """bftkv_host_max_timestamped_value on flat arrays (batch callers): replies of read i are rows read_off[i]..read_off[i+1];
+    returns per read the row index (relative to the read's first row... see below) of a reply carrying the winning <t, v>, or -1
+    for errInProgress.  The index is relative to read_off[i]."""
+    out = np.zeros(max(1, n_reads), dtype=np.int64)
+    peers = np.ascontiguousarray(peers, dtype=np.uint64); ts = np.ascontiguousarray(ts, dtype=np.uint64)
+    value_blob = np.ascontiguousarray(value_blob, dtype=np.uint8) if value_blob.size else np.zeros(1, dtype=np.uint8)
+    value_off = np.ascontiguousarray(value_off, dtype=np.uint64); read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    p = lambda a: a.ctypes.data if a.size else None
+    rc = _lib().bftkv_host_max_timestamped_value(q.h, n_reads, p(peers), p(ts), value_blob.ctypes.data, value_off.ctypes.data,
+                                                 read_off.ctypes.data, out.ctypes.data)
+    if rc:
+        raise RuntimeError("max_timestamped_value: %d" % rc)
+    return out[:n_reads]
+
+
 class Server:
     """The verification site of protocol.Server.write (protocol/server.go:286-302) over a GPU context."""
 

@@ -286,6 +286,18 @@ BatchSigner = Callable[[np.ndarray, np.ndarray], np.ndarray]
 -> sig[n,256] uint8."""
 
 
+DsaBatchPow = Callable[[np.ndarray, List[int]], List[int]]
+"""(key_index[n] int32 into cluster.replicas (DSA keys), nonces k[n]) -> [g_key^k mod p_key] as Python ints."""
+
+
+def dsa_pow_tables(cluster: Cluster):
+    """(moduli p [n,256], bases g [n,256]) big-endian uint8 per replica for a modexp-based DsaBatchPow (RSA replicas get
+    the dummy modulus 3 / base 1 and are never indexed)."""
+    ps = np.stack([np.frombuffer((k.p if k.algo == PK_DSA else 3).to_bytes(256, "big"), dtype=np.uint8) for k in cluster.replicas])
+    gs = np.stack([np.frombuffer((k.g if k.algo == PK_DSA else 1).to_bytes(256, "big"), dtype=np.uint8) for k in cluster.replicas])
+    return ps, gs
+
+
 def signer_tables(cluster: Cluster):
     """(moduli[n+1,256], private exponents[n+1,256]) big-endian uint8 for a modexp-based BatchSigner: rows are the
     replicas in order, then the client (RSA keys only; DSA replicas get a dummy odd modulus and are never indexed)."""
@@ -311,10 +323,15 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
                       min_sigs: Optional[int] = None, max_sigs: Optional[int] = None,
                       mutation_rates: Optional[Dict[int, float]] = None,
                       batch_signer: Optional[BatchSigner] = None, keep_requests: bool = False,
-                      with_client_sig: bool = True) -> WriteCorpus:
+                      with_client_sig: bool = True, items: Optional[Sequence[Tuple[bytes, bytes, int]]] = None,
+                      dsa_batch_pow: Optional["DsaBatchPow"] = None) -> WriteCorpus:
     """Signed writes as they reach Server.write (protocol/server.go:286-300): per item the TBSS
     payload ``Serialize(x,v,t,sig)`` and ``ss.Data`` = concatenated detached signatures of a
-    shuffled subset of clique members over that payload (collectSignatures, client.go:125-170)."""
+    shuffled subset of clique members over that payload (collectSignatures, client.go:125-170).
+    ``items``: explicit (x, v, t) per write instead of key%08d / random value / t = 1 + i (read corpora store several
+    versions of one variable).  ``dsa_batch_pow``: batched g^k mod p for the DSA signers (else Python ``pow`` per signature)."""
+    if items is not None:
+        n_items = len(items)
     rng = DRBG("writes", seed, cluster.n, n_items)
     nprng = np.random.default_rng(seed ^ (n_items * 2654435761 & 0xFFFFFFFF))
     n = cluster.n
@@ -346,9 +363,11 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
     # client signatures over tbs = Serialize(x,v,t) (client.go:127-131), signed in one batch
     tbs_list = []
     for i in range(n_items):
-        x = b"key%08d" % i
-        v = nprng.bytes(value_len)
-        tbs_list.append(serialize_tbs(x, v, 1 + i))
+        if items is not None:
+            x, v, t = items[i]
+        else:
+            x, v, t = b"key%08d" % i, nprng.bytes(value_len), 1 + i
+        tbs_list.append(serialize_tbs(x, v, t))
     csigs: List[Optional[bytes]] = [None] * n_items
     if with_client_sig:
         cprefix = sig_prefix(0x00, cluster.client.algo, _hashed_area(cluster.client.key_id))
@@ -416,6 +435,25 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
             kp = cluster.replicas[sig_key[j]]
             packets[j] = make_sig_packet(kp, sig_prefix_l[j], digests[j],
                                          sig_value=int.from_bytes(sv[r].tobytes(), "big"))
+    dsa_rows = [j for j in range(total) if sig_key[j] >= 0 and cluster.replicas[sig_key[j]].algo == PK_DSA]
+    if dsa_rows and dsa_batch_pow is not None:
+        # r = (g^k mod p) mod q for every DSA signature in one batch; s = k^-1 (z + x r) mod q on the host
+        ks = []
+        for j in dsa_rows:
+            kp = cluster.replicas[sig_key[j]]
+            ks.append(1 + rng.below(kp.q - 1))
+        gk = dsa_batch_pow(np.array([sig_key[j] for j in dsa_rows], dtype=np.int32), ks)
+        for j, k, r_full in zip(dsa_rows, ks, gk):
+            kp = cluster.replicas[sig_key[j]]
+            r = r_full % kp.q
+            z = int.from_bytes(digests[j][:(kp.q.bit_length() + 7) // 8], "big")
+            sv = pow(k, -1, kp.q) * (z + kp.x * r) % kp.q
+            if r == 0 or sv == 0:
+                continue                                   # (probability 2^-256) falls through to the per-signature path
+            rb = r.to_bytes((r.bit_length() + 7) // 8, "big")
+            sb_ = sv.to_bytes((sv.bit_length() + 7) // 8, "big")
+            body = sig_prefix_l[j] + b"\x00\x00" + digests[j][:2] + go_mpi_bytes(rb) + go_mpi_bytes(sb_)
+            packets[j] = _hdr(2, len(body)) + body
     for j in range(total):
         if packets[j] is None:
             kidx = sig_key[j]
@@ -451,6 +489,126 @@ def make_write_corpus(cluster: Cluster, n_items: int, *, seed: int = MASTER_SEED
         reqs = [tbss_parts[i] + sigpkt(ss_parts[i], None) for i in range(n_items)]
     return WriteCorpus(cluster, n_items, tb, to, sb, so, total, mutation, expected_valid=expected_valid,
                        sig_count=per_item_counts.astype(np.int32), requests=reqs)
+
+
+# ------------------------------------------------------------------------------------------------
+# signed-read corpus (BASELINE configs[2]): replies <x,v,t,sig,ss> of storage nodes to Client.Read
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ReadCorpus:
+    writes: WriteCorpus           # the DISTINCT stored packets (several versions per variable)
+    n_vars: int
+    storage_ids: List[int]        # node ids of the read quorum's members (storage nodes: they answer, they do not sign)
+    reply_var: np.ndarray         # int32 [n_replies] variable of the reply
+    reply_peer: np.ndarray        # uint64 [n_replies] responder id
+    reply_write: np.ndarray       # int32 [n_replies] index into ``writes`` of the packet the responder returned
+    write_t: np.ndarray           # uint64 [n_writes]
+    write_value: List[bytes]      # value v of each stored packet
+    tbss_blob: np.ndarray         # the reply batch as the verifier sees it: one copy of the stored packet per reply
+    tbss_off: np.ndarray
+    ss_blob: np.ndarray
+    ss_off: np.ndarray
+    n_sigs: int                   # signature packets in the reply batch
+
+
+def make_read_corpus(cluster: Cluster, n_vars: int, *, n_storage: int = 10, seed: int = MASTER_SEED, value_len: int = 64,
+                     p_stale: float = 0.15, p_conflict_var: float = 0.01, p_silent: float = 0.02,
+                     mutation_rates: Optional[Dict[int, float]] = None, batch_signer: Optional[BatchSigner] = None,
+                     dsa_batch_pow: Optional[DsaBatchPow] = None) -> ReadCorpus:
+    """Read replies as Client.Read folds them (protocol/client.go:206-279): every storage node of the read quorum returns
+    the packet <x,v,t,sig,ss> it stores for the variable.  Per variable two versions exist (t = 1, 2); a responder returns
+    the latest one, a stale one with probability ``p_stale``, nothing with ``p_silent``; ``p_conflict_var`` of the variables
+    carry a second, equally signed value at t = 2 that some responders return (the equivocation case of client.go:304-353).
+    Each stored packet is collectively signed by a shuffled >= suff subset of the clique (as make_write_corpus)."""
+    nprng = np.random.default_rng(seed ^ 0x5EAD)
+    items: List[Tuple[bytes, bytes, int]] = []
+    var_writes: List[List[int]] = []
+    for j in range(n_vars):
+        x = b"key%08d" % j
+        ws = []
+        for t in (1, 2):
+            ws.append(len(items)); items.append((x, nprng.bytes(value_len), t))
+        if nprng.random() < p_conflict_var:
+            ws.append(len(items)); items.append((x, nprng.bytes(value_len), 2))
+        var_writes.append(ws)
+    w = make_write_corpus(cluster, len(items), seed=seed, mutation_rates=mutation_rates, batch_signer=batch_signer,
+                          items=items, dsa_batch_pow=dsa_batch_pow)
+    storage_ids = [0x5700000000000000 + k for k in range(n_storage)]
+    rv, rp, rw = [], [], []
+    for j in range(n_vars):
+        ws = var_writes[j]
+        for k in range(n_storage):
+            u = nprng.random()
+            if u < p_silent:
+                continue
+            if u < p_silent + p_stale:
+                wi = ws[0]
+            elif len(ws) == 3 and nprng.random() < 0.3:
+                wi = ws[2]
+            else:
+                wi = ws[1]
+            rv.append(j); rp.append(storage_ids[k]); rw.append(wi)
+    rw_a = np.array(rw, dtype=np.int64)
+
+    def gather(blob, off):
+        lens = (off[1:] - off[:-1]).astype(np.int64)[rw_a]
+        out_off = np.zeros(len(rw_a) + 1, dtype=np.uint64)
+        out_off[1:] = np.cumsum(lens, dtype=np.uint64)
+        out = np.empty(int(out_off[-1]), dtype=np.uint8)
+        for r in range(len(rw_a)):
+            a = int(off[rw_a[r]])
+            out[int(out_off[r]):int(out_off[r + 1])] = blob[a:a + int(lens[r])]
+        return out, out_off
+    tb, to = gather(w.tbss_blob, w.tbss_off)
+    sb, so = gather(w.ss_blob, w.ss_off)
+    return ReadCorpus(w, n_vars, storage_ids, np.array(rv, dtype=np.int32), np.array(rp, dtype=np.uint64), rw_a.astype(np.int32),
+                      np.array([it[2] for it in items], dtype=np.uint64), [it[1] for it in items], tb, to, sb, so,
+                      int(w.sig_count[rw_a].sum()))
+
+
+# ------------------------------------------------------------------------------------------------
+# threshold share-combine corpus (BASELINE configs[4]): inputs of the combine step of each scheme
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ThresholdCorpus:
+    n_ops: int
+    rsa_n: int                    # modulus of crypto/threshold/rsa/test.pkcs8
+    rsa_factors: List[List[int]]  # [n_ops][10] partial signatures m^d_i mod N (rsa.go:318-329 multiplies them)
+    sss_mod: int                  # the 2048-bit prime pb of crypto/sss/sss_test.go:15-47
+    sss_xs: np.ndarray            # int32 [n_ops][7]
+    sss_ys: List[List[int]]
+    dsa_p: int
+    dsa_q: int
+    s_xs: np.ndarray              # int32 [n_ops][8]  calculateS shares (dsa_core.go:389-403)
+    s_ys: List[List[int]]
+    r_xs: np.ndarray              # int32 [n_ops][8]  CalculateR partial r's (dsa.go:33-52)
+    r_ri: List[List[int]]
+    r_vi: List[List[int]]
+
+
+def make_threshold_corpus(n_ops: int, rsa_n: int, sss_mod: int, dsa_p: int, dsa_q: int, seed: int = MASTER_SEED,
+                          n_shares: int = 10, rsa_k: int = 10, sss_k: int = 7, dsa_2t: int = 8) -> ThresholdCorpus:
+    """Seeded inputs of the four combine operations at the reference's parameters (n = 10 shares; RSA: all 10 fragments'
+    partial signatures; SSS: k = 7; threshold DSA: 2t = 8).  Values are uniform residues: the combine arithmetic does not
+    care whether they came from a real dealing (tests/test_gpu_threshold.py covers real dealings against the reference's
+    known answers)."""
+    nprng = np.random.default_rng(seed ^ 0x7455)
+
+    def residues(count, mod):
+        nb = (mod.bit_length() + 7) // 8 + 8
+        raw = nprng.bytes(count * nb)
+        return [int.from_bytes(raw[i * nb:(i + 1) * nb], "big") % mod for i in range(count)]
+
+    def xs(k):
+        return np.ascontiguousarray(np.stack([nprng.permutation(n_shares)[:k] + 1 for _ in range(n_ops)]).astype(np.int32))
+
+    def rows(vals, k):
+        return [vals[i * k:(i + 1) * k] for i in range(n_ops)]
+    return ThresholdCorpus(n_ops, rsa_n, rows(residues(n_ops * rsa_k, rsa_n), rsa_k), sss_mod, xs(sss_k),
+                           rows(residues(n_ops * sss_k, sss_mod), sss_k), dsa_p, dsa_q, xs(dsa_2t),
+                           rows(residues(n_ops * dsa_2t, dsa_q), dsa_2t), xs(dsa_2t),
+                           rows([1 + v for v in residues(n_ops * dsa_2t, dsa_p - 1)], dsa_2t),
+                           rows(residues(n_ops * dsa_2t, dsa_q), dsa_2t))
 
 
 # ------------------------------------------------------------------------------------------------

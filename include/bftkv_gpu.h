@@ -200,6 +200,12 @@ int bftkv_gpu_modexp(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, ui
                      const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
                      const uint8_t* exps, uint32_t exp_len, uint8_t* out);
 
+/* same with ONE EXPONENT PER OPERATION (exps: [n_ops][exp_len]): out[i] = base[i] ^ exp[i] mod mod[mod_idx[i]] --
+ * the partial r_i = g^a_i mod p of threshold DSA, dsaGroupOperations.CalculatePartialR (crypto/threshold/dsa/dsa.go:27-31). */
+int bftkv_gpu_modexp_ops(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base, uint32_t nbytes,
+                         const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
+                         const uint8_t* exps, uint32_t exp_len, uint8_t* out);
+
 /* ---- multi-GPU: all-gather of verdict bitmaps over RCCL ----------------------------- */
 /* One context per GPU/process.  uid: 128 opaque bytes from bftkv_gpu_comm_unique_id on rank 0, distributed by
  * the caller (the Go shim: over its own transport).  librccl.so.1 is dlopen'ed on first use. */
@@ -207,6 +213,13 @@ int bftkv_gpu_comm_unique_id(uint8_t uid_out[128]);
 int bftkv_gpu_comm_init(bftkv_gpu_ctx* ctx, int n_ranks, int rank, const uint8_t uid[128]);
 /* local_bits: nbytes DEVICE bytes of this rank; all_bits_out: n_ranks*nbytes DEVICE bytes, rank-major. */
 int bftkv_gpu_allgather_verdicts(bftkv_gpu_ctx* ctx, const uint8_t* local_bits, uint64_t nbytes, uint8_t* all_bits_out);
+/* The exchange step of the path as ONE asynchronous call on the context's stream, to be issued right behind
+ * bftkv_gpu_collective_verify_dev (no host synchronisation in between): packs err_dev[0..n_items) -- the err_out of that
+ * call; bit = 1 where it is BFTKV_ERR_NONE -- into a bitmap of ceil(slots/8) bytes (slots >= n_items: the largest shard,
+ * so that every rank contributes the same byte count; bit i of byte i/8 = item i, zero padded) and all-gathers the
+ * bitmaps rank-major into all_bits_out[n_ranks * ceil(slots/8)] (DEVICE).  Every rank then holds the verdict of every
+ * write, as every replica of the reference reaches every decision (protocol/server.go:300).  Wait with bftkv_gpu_sync. */
+int bftkv_gpu_allgather_errs_dev(bftkv_gpu_ctx* ctx, const uint8_t* err_dev, uint32_t n_items, uint32_t slots, uint8_t* all_bits_out);
 
 /* ---- threshold-signature share combine (BASELINE config 5) ------------------------------------ */
 /* Numbers are big-endian, nbytes each (<= 256); moduli must be odd; mod_idx[op] selects the modulus.
@@ -236,9 +249,26 @@ int bftkv_gpu_sss_distribute(bftkv_gpu_ctx* ctx, uint32_t n_polys, uint32_t n_sh
 int bftkv_gpu_modinv(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods,
                      const uint8_t* mods, uint8_t* out, uint8_t* status_out);
 
+/* The same five with the PER-OPERATION arrays (factors / xs / ys / ri / vi / coeffs / values / mod_idx / outputs / status)
+ * already resident in HBM and the results left there: asynchronous on the context's stream until bftkv_gpu_sync.
+ * mods / p / q stay HOST pointers (a few hundred bytes per distinct modulus, cached per context by value); mod_idx /
+ * group_idx may be NULL (every operation uses modulus 0), out-of-range indices are clamped. */
+int bftkv_gpu_modmul_product_dev(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const uint8_t* factors, uint32_t nbytes,
+                                 const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods, uint8_t* out);
+int bftkv_gpu_lagrange_combine_dev(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const int32_t* xs, const uint8_t* ys,
+                                   uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods,
+                                   uint8_t* out, uint8_t* status_out);
+int bftkv_gpu_dsa_calculate_r_dev(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const int32_t* xs, const uint8_t* ri, uint32_t pbytes,
+                                  const uint8_t* vi, uint32_t qbytes, const uint32_t* group_idx, uint32_t n_groups,
+                                  const uint8_t* p, const uint8_t* q, uint8_t* r_out, uint8_t* status_out);
+int bftkv_gpu_sss_distribute_dev(bftkv_gpu_ctx* ctx, uint32_t n_polys, uint32_t n_shares, uint32_t k, const uint8_t* coeffs, uint32_t nbytes,
+                                 const uint32_t* mod_idx, uint32_t n_mods, const uint8_t* mods, uint8_t* shares_out);
+int bftkv_gpu_modinv_dev(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods,
+                         const uint8_t* mods, uint8_t* out, uint8_t* status_out);
+
 /* ---- timing of the last *_dev verify call (HIP events on the context's stream) ---------------- */
 /* ms[0] whole call, ms[1] walk+parse, ms[2] hash stream (midstates+digests, overlaps the modexp),
- * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream) */
+ * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream), ms[6] k_dsa_mul + k_dsa_modexp */
 int bftkv_gpu_last_timing(bftkv_gpu_ctx* ctx, float ms[8]);
 void* bftkv_gpu_stream(bftkv_gpu_ctx* ctx);   /* hipStream_t of the context */
 

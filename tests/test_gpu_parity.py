@@ -291,6 +291,23 @@ def test_rccl_allgather_entry_points_single_rank(gpu_ctx):
     assert torch.equal(D.allgather_verdicts(ok, 11), ok)
 
 
+def test_exchange_step_on_the_verifier_stream(gpu_ctx):
+    """bftkv_gpu_allgather_errs_dev: the err bytes of a verify call packed into the verdict bitmap on the device and gathered
+    rank-major, asynchronously on the context's stream (one rank here: its row is the output)."""
+    import torch
+    uid = __import__("bftkv_amd").Context.comm_unique_id()
+    gpu_ctx.comm_init(1, 0, uid)
+    rng = np.random.default_rng(8)
+    for n, slots in ((1, 1), (7, 8), (8, 8), (9, 16), (1000, 1003), (100000, 100000)):
+        err = rng.choice(np.array([0, 2], dtype=np.uint8), size=n)
+        d_err = torch.from_numpy(err).to("cuda:0")
+        out = torch.full(((slots + 7) // 8,), 0xAA, dtype=torch.uint8, device="cuda:0")
+        gpu_ctx.allgather_errs_dev(d_err.data_ptr(), n, slots, out.data_ptr())
+        gpu_ctx.sync()
+        want = np.packbits(np.concatenate([err == 0, np.zeros(((slots + 7) // 8) * 8 - n, dtype=bool)]), bitorder="little")
+        assert out.cpu().numpy().tobytes() == want.tobytes()
+
+
 def test_cfg4_shape_256_replicas(gpu_ctx):
     """BASELINE configs[3] shape: 256-replica clique (f=85, suff=171), 171..256 packets per write -- exercises the
     sequential-walk fallback (more than WALK_CAP packet events per item); verdicts vs construction and vs the oracle."""

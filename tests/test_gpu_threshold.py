@@ -143,3 +143,68 @@ def test_partial_sign_with_negative_fragments(gpu_ctx):
     p = int(r["p"], 16)
     vals, st = gpu_ctx.modinv([p, 0, 3 * p, 5, n + 7], [n], [0] * 5)
     assert list(st) == [1, 1, 1, 0, 0] and vals[3] == pow(5, -1, n) and vals[4] == pow(7, -1, n)
+
+
+def test_device_resident_entry_points_match_the_host_ones(gpu_ctx):
+    """The *_dev forms (inputs already in HBM, results left there, asynchronous until bftkv_gpu_sync) compute what the
+    host-pointer forms compute: they share one body, the difference is only who moves the bytes."""
+    import torch
+    from bftkv_amd._native import _ints_to_be, _ptr
+    from corpus import build as cb
+    g_ = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keys_dsa2048.json")))["keys"][0]
+    as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
+    N = 300
+    tc = cb.make_threshold_corpus(N, int(KAT["rsa"]["n"], 16), int(KAT["sss"]["pb"], 16), as_int(g_["p"]), as_int(g_["q"]), seed=77)
+    lib, h = gpu_ctx.lib, gpu_ctx.h
+    flat = lambda rows: [v for r in rows for v in r]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    toi = lambda row: int.from_bytes(row.tobytes(), "big")
+    P = lambda t: t.data_ptr()
+    # RSA combine
+    o = torch.zeros((N, 256), dtype=torch.uint8, device="cuda:0")
+    f = up(_ints_to_be(flat(tc.rsa_factors), 256))
+    m = _ints_to_be([tc.rsa_n], 256)
+    gpu_ctx._check(lib.bftkv_gpu_modmul_product_dev(h, N, 10, P(f), 256, None, 1, _ptr(m), P(o)), "modmul_product_dev")
+    gpu_ctx.sync()
+    assert [toi(r) for r in o.cpu().numpy()] == [T.calculate_signature(tc.rsa_factors[i], tc.rsa_n) for i in range(N)]
+    assert [toi(r) for r in o.cpu().numpy()] == gpu_ctx.modmul_product(tc.rsa_factors, [tc.rsa_n], [0] * N)
+    # Lagrange combine (SSS and calculateS), with an explicit device mod_idx that needs clamping on one row
+    for xs, ys, mod, nb, k in ((tc.sss_xs, tc.sss_ys, tc.sss_mod, 256, 7), (tc.s_xs, tc.s_ys, tc.dsa_q, 32, 8)):
+        o = torch.zeros((N, nb), dtype=torch.uint8, device="cuda:0")
+        st = torch.zeros(N + 8, dtype=torch.uint8, device="cuda:0")
+        mi = torch.zeros(N, dtype=torch.int32, device="cuda:0")
+        mi[5] = 9                                                     # out of range: clamped to the last modulus (= 0)
+        mb = _ints_to_be([mod], nb)
+        d_x, d_y = up(xs), up(_ints_to_be(flat(ys), nb))            # keep the tensors alive: the call is asynchronous
+        gpu_ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, k, P(d_x), P(d_y), nb, P(mi), 1, _ptr(mb), P(o), P(st)), "lagrange_dev")
+        gpu_ctx.sync()
+        want = [T.calculate_s(list(zip([int(v) for v in xs[i]], ys[i])), mod) for i in range(N)]
+        assert [toi(r) for r in o.cpu().numpy()] == want and not st.cpu().numpy()[:N].any()
+    # CalculateR
+    o = torch.zeros((N, 32), dtype=torch.uint8, device="cuda:0")
+    st = torch.zeros(N + 8, dtype=torch.uint8, device="cuda:0")
+    pb, qb = _ints_to_be([tc.dsa_p], 256), _ints_to_be([tc.dsa_q], 32)
+    d_x, d_ri, d_vi = up(tc.r_xs), up(_ints_to_be(flat(tc.r_ri), 256)), up(_ints_to_be(flat(tc.r_vi), 32))
+    gpu_ctx._check(lib.bftkv_gpu_dsa_calculate_r_dev(h, N, 8, P(d_x), P(d_ri), 256, P(d_vi), 32,
+                                                     None, 1, _ptr(pb), _ptr(qb), P(o), P(st)), "calculate_r_dev")
+    gpu_ctx.sync()
+    got, stn = o.cpu().numpy(), st.cpu().numpy()
+    for i in range(0, N, 13):
+        rs = [(int(tc.r_xs[i][j]), tc.r_ri[i][j].to_bytes(256, "big"), tc.r_vi[i][j]) for j in range(8)]
+        assert stn[i] == 0 and toi(got[i]) == T.calculate_r(rs, tc.dsa_p, tc.dsa_q)
+
+
+def test_partial_r_is_a_per_operation_exponent(gpu_ctx):
+    """CalculatePartialR (crypto/threshold/dsa/dsa.go:27-31): r_i = g^a_i mod p, one exponent per operation."""
+    g_ = KAT["dsa_group"]
+    p, q, g = int(g_["p"], 16), int(g_["q"], 16), int(g_["g"], 16)
+    rng = np.random.default_rng(12)
+    n = 70
+    a = [int.from_bytes(rng.bytes(40), "big") % q for _ in range(n)]
+    a[0], a[1] = 0, 1
+    nb = (p.bit_length() + 7) // 8
+    base = np.frombuffer(b"".join(g.to_bytes(nb, "big") for _ in range(n)), dtype=np.uint8).reshape(n, nb).copy()
+    mods = np.frombuffer(p.to_bytes(nb, "big"), dtype=np.uint8).reshape(1, nb).copy()
+    exps = np.frombuffer(b"".join(x.to_bytes(20, "big") for x in a), dtype=np.uint8).reshape(n, 20).copy()
+    out = gpu_ctx.modexp_ops(base, np.zeros(n, dtype=np.uint32), mods, exps)
+    assert [int.from_bytes(out[i].tobytes(), "big") for i in range(n)] == [int.from_bytes(T.calculate_partial_r(g, x, p), "big") for x in a]

@@ -1,0 +1,14 @@
+#!/bin/bash
+# One GPU-box visit: the -m gpu tests, then every bench config once (short), everything logged under gpurun_out/$1/.
+TAG=${1:-run}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+  tail -5 $OUT/pytest.log
+fi
+for cfg in ${CONFIGS:-2 3 4 5}; do
+  timeout 900 python bench.py --config $cfg --steps ${STEPS:-5} --warmup 2 > $OUT/bench_cfg$cfg.json 2> $OUT/bench_cfg$cfg.err; echo "cfg$cfg rc=$?"
+  tail -c 1500 $OUT/bench_cfg$cfg.json; tail -3 $OUT/bench_cfg$cfg.err
+done
