@@ -41,7 +41,7 @@ EXPORTS = [
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
-    "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
+    "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
 ]
 
@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
+    lib.bftkv_gpu_set_early_exit.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_modexp_ops.argtypes = lib.bftkv_gpu_modexp.argtypes
     lib.bftkv_gpu_allgather_errs_dev.argtypes = [vp, u8p, u32, u32, u8p]
     lib.bftkv_gpu_modmul_product_dev.argtypes = lib.bftkv_gpu_modmul_product.argtypes
@@ -186,6 +187,10 @@ class Context:
         plains = [plain[int(poff[i]):int(poff[i + 1])].tobytes() for i in range(n)]
         names = [fn[i, :int(fl[i])].tobytes() for i in range(n)]
         return st[:n], signer[:n], peer[:n], plains, names
+
+    def set_early_exit(self, on: bool) -> None:
+        """collective_verify: stop verifying where the reference stops reading (default) / verify every packet."""
+        self._check(self.lib.bftkv_gpu_set_early_exit(self.h, 1 if on else 0), "set_early_exit")
 
     def set_dsa_window_bits(self, bits: int) -> None:
         """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""

@@ -96,7 +96,8 @@ struct bftkv_gpu_ctx {
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
-  DevBuf st_tmp, item_tmp, bits_tmp;
+  DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
+  bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
   std::map<std::string, std::array<DevBuf, 3>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
@@ -233,7 +234,9 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
-                 const std::function<int(hipStream_t)>* upload_tbs = nullptr) {
+                 const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr) {
+  // plan_q (CollectiveSignature.Verify with the early exit enabled): public-key work is queued in two phases by k_plan
+  // instead of by the parse -- see kernels.hip "two-phase planning".
   // upload_tbs (host-buffer entry point): the signed payloads are still in host memory.  Only the hash stream reads them,
   // so their copy is issued on that stream AFTER the modexp has been launched and runs beside it; the signature stream
   // (which the walk, the parse and the modexp need) was copied before the call.
@@ -247,7 +250,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
-  HIPCHK(c, c->pk_count.ensure(32));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256
+  HIPCHK(c, c->pk_count.ensure(64));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256,
+                                       // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start)
+  if (plan_q) HIPCHK(c, c->plan_cut.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
@@ -260,7 +265,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->h_mail) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>(), c->d_mail);
-  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 32, s));
+  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 64, s));
   HIPCHK(c, hipMemsetAsync(c->hash_mask.p, 0, sizeof(uint32_t) * (size_t)n_items, s));
   uint32_t total = MAIL_EMPTY;
   if (c->h_mail) {
@@ -301,17 +306,30 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pa.pk_list = c->pk_list.as<uint32_t>(); pa.pk_list3072 = c->pk_list3072.as<uint32_t>(); pa.pk_list4096 = c->pk_list4096.as<uint32_t>();
     pa.pk_count = c->pk_count.as<uint32_t>(); pa.dsa_list = c->dsa_list.as<uint32_t>(); pa.item_hash_mask = c->hash_mask.as<uint32_t>();
     pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
+    pa.defer_queue = plan_q ? 1u : 0u;
     if ((uint64_t)total >= 128ull * n_items)     // very long items (n = 256 cliques: 171+ packets): block per item, no bisection
                                                  // (measured at 53 packets per item: 237 us item-major vs 210 us record-major)
       hipLaunchKernelGGL(k_parse_body_items, dim3(n_items), dim3(PARSE_ITEM_BLOCK), 0, s, pa, c->kt);
     else
       hipLaunchKernelGGL(k_parse_body, dim3((total + 255) / 256), dim3(256), 0, s, pa, c->kt);
   }
+  uint32_t* const cnt_p = c->pk_count.as<uint32_t>();
+  const uint32_t* const start0 = cnt_p + 12;        // phase 1 starts every work list at 0
+  PlanArgs pl{};
+  if (total && plan_q) {
+    pl.recs = c->recs.as<SigRec>(); pl.rec_base = c->base.as<uint32_t>(); pl.counts = c->counts.as<uint32_t>(); pl.n_items = n_items;
+    pl.pk_list = c->pk_list.as<uint32_t>(); pl.dsa_list = c->dsa_list.as<uint32_t>(); pl.pk_list3072 = c->pk_list3072.as<uint32_t>();
+    pl.pk_list4096 = c->pk_list4096.as<uint32_t>(); pl.pk_count = cnt_p; pl.plan_cut = c->plan_cut.as<uint32_t>(); pl.verdict = nullptr;
+    int min_suff = 0;
+    for (int i = 0; i < plan_q->n_qcs; ++i) if (plan_q->suff[i] > 0 && (min_suff == 0 || plan_q->suff[i] < min_suff)) min_suff = plan_q->suff[i];
+    pl.margin = 1u + (uint32_t)min_suff / 64u;
+    hipLaunchKernelGGL(k_plan<1>, dim3((n_items + 3) / 4), dim3(256), 0, s, pl, c->kt, *plan_q);
+  }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   if (total && c->have_dsa_keys) {
     HIPCHK(c, hipStreamWaitEvent(c->stream_d, c->ev[1], 0));
     hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, c->stream_d, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>());
+                       c->pk_count.as<uint32_t>(), start0, c->kt, c->dsa_u.as<uint32_t>());
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream_d));
   }
   auto hash_stream_work = [&]() -> int {
@@ -331,19 +349,20 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   };
   if (!upload_tbs) { int hrc = hash_stream_work(); if (hrc) return hrc; }
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
-  if (total) {
-    const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-    const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
+  const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
+  const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
+  auto launch_modexp = [&](const uint32_t* start) {
     hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>());
+                       cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>());
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
     if (c->have_rsa3072)
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L3072, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>());
+                         cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>());
     if (c->have_rsa4096)
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
-  }
+                         cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
+  };
+  if (total) launch_modexp(start0);
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   if (upload_tbs) {
     int hrc = (*upload_tbs)(sh);
@@ -352,28 +371,49 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     if ((hrc = hash_stream_work())) return hrc;
   }
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
-  if (total) {
-    const dim3 cg((total * 4 + 255) / 256);
-    const dim3 cg8(((uint64_t)total * MONT_TPI_BIG + 255) / 256);
+  const dim3 cg((total * 4 + 255) / 256);
+  const dim3 cg8(((uint64_t)total * MONT_TPI_BIG + 255) / 256);
+  auto launch_compare = [&](const uint32_t* start) {
     hipLaunchKernelGGL((k_rsa_compare<MONT_L, MONT_TPI>), cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
+                       cnt_p, start, c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa3072)
       hipLaunchKernelGGL((k_rsa_compare<MONT_L3072, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>() + 2, c->kt, c->r3072.as<uint32_t>(), c->digests.as<uint32_t>());
+                         cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa4096)
       hipLaunchKernelGGL((k_rsa_compare<MONT_L4096, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>() + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
-  }
-  HIPCHK(c, hipEventRecord(c->ev[8], s));
+                         cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
+  };
   // DSA signatures (if any): u1 depends on the digest, so the table multiplications run after the join; the
   // inverses were started on their own stream right after the parse.  Grids cover every signature and exit on
   // the device-side count, so no host read-back sits between the kernels.
+  auto launch_dsa = [&](const uint32_t* start) {
+    hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                       cnt_p, start, c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
+    hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                       c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
+  };
+  if (total) launch_compare(start0);
+  HIPCHK(c, hipEventRecord(c->ev[8], s));
   if (total && c->have_dsa_keys) {
     HIPCHK(c, hipStreamWaitEvent(s, c->ev[7], 0));
-    hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
-    hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
-                       c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), c->kt, c->dsa_u.as<uint32_t>());
+    launch_dsa(start0);
+  }
+  if (total && plan_q) {
+    // phase 2: tally what phase 1 verified; whatever an item still lacks comes from its remaining packets
+    HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
+    HIPCHK(c, c->o_verdict.ensure(n_items));
+    hipLaunchKernelGGL(k_tally, dim3((n_items + 3) / 4), dim3(256), 0, s, c->recs.as<SigRec>(), c->base.as<uint32_t>(), c->counts.as<uint32_t>(),
+                       n_items, c->kt, *plan_q, c->o_verdict.as<uint8_t>(), c->o_nver.as<uint32_t>(), (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_plan_snapshot, dim3(1), dim3(64), 0, s, cnt_p);
+    pl.verdict = c->o_verdict.as<uint8_t>();
+    hipLaunchKernelGGL(k_plan<2>, dim3((n_items + 3) / 4), dim3(256), 0, s, pl, c->kt, *plan_q);
+    const uint32_t* const start1 = cnt_p + 8;
+    if (c->have_dsa_keys)
+      hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start1,
+                         c->kt, c->dsa_u.as<uint32_t>());
+    launch_modexp(start1);
+    launch_compare(start1);
+    if (c->have_dsa_keys) launch_dsa(start1);
   }
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipGetLastError());
@@ -648,7 +688,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
-                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp})
+                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
@@ -678,6 +718,13 @@ void* bftkv_gpu_stream(bftkv_gpu_ctx* c) { return c ? (void*)c->stream : nullptr
 int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
   if (!c) return BFTKV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* c, int on) {
+  if (!c) return BFTKV_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->early_exit = on != 0;
   return 0;
 }
 
@@ -766,7 +813,8 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   if (n_items == 0) return 0;
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs))) return rc;
+  const QuorumDev qd = quorum_dev(c, q);
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();

@@ -18,6 +18,7 @@ enum SigStatus : uint8_t {
   ST_BAD_SIG = 8,
   ST_KEY_CANNOT_SIGN = 9,
   ST_UNSUPPORTED = 10,
+  ST_NOT_EXAMINED = 11,    // behind the early exit of CollectiveSignature.Verify: the reference never reads this packet
   // internal, never returned:
   ST_PENDING_PARSE = 99,   // signature packet located, body not parsed yet
   ST_PENDING_HASH = 100,   // parsed, key found; digest not computed yet
@@ -42,7 +43,8 @@ struct SigRec {
   uint8_t pk_algo, hash_id, sig_type, status;
   uint8_t after_tag;      // status once the hash tag has matched; AFTER_TAG_PUBKEY: the public-key operation decides
   uint8_t flags;          // bit0: signature value may be >= 2^(8k) (no x-shortcut in the exponent ladder)
-  uint8_t pad[2];
+  uint8_t q_kind1;        // 1 + public-key work list the record belongs on (0: none) -- set by the parse, never by the hash stream
+  uint8_t queued;         // the record has been put on that list (k_parse_body directly, or k_plan in two-phase calls)
   uint32_t pk_idx;        // index in the public-key work list
 };
 constexpr uint8_t AFTER_TAG_PUBKEY = 0xFF;

@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
         rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
         rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
         rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = w.status;
-        rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
+        rec.after_tag = 0; rec.flags = 0; rec.q_kind1 = rec.queued = 0; rec.pk_idx = 0xFFFFFFFFu;
         recs[base + idx] = rec;
       }
     }
@@ -352,6 +352,7 @@ struct ParseArgs {
   const uint32_t* msg_slot;    // per item or null
   const uint8_t* msg_hash;     // per item, with msg_slot
   const uint8_t* item_flags;
+  uint32_t defer_queue;        // two-phase calls: k_plan decides which records join the work lists
 };
 
 __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev& kt, uint32_t ri, uint32_t item) {
@@ -370,7 +371,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     rec.mpi_off[0] = rec.mpi_off[1] = 0; rec.mpi_bits[0] = rec.mpi_bits[1] = 0;
     rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
     rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = (uint8_t)(e.body_len_status >> 24);
-    rec.after_tag = 0; rec.flags = 0; rec.pad[0] = rec.pad[1] = 0; rec.pk_idx = 0xFFFFFFFFu;
+    rec.after_tag = 0; rec.flags = 0; rec.q_kind1 = rec.queued = 0; rec.pk_idx = 0xFFFFFFFFu;
     if (rec.status != ST_PENDING_PARSE) { recs[ri] = rec; return; }
   } else {
     rec = recs[ri];                                  // written by the sequential k_walk<true>
@@ -458,12 +459,15 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
       }
     }
   }
-  // queue the public-key work: one atomic per wave and list
-  uint32_t* const lists[4] = {pk_list, dsa_list, pk_list3072, pk_list4096};
+  rec.q_kind1 = (uint8_t)(q_kind + 1);
+  if (!a.defer_queue) {
+    // queue the public-key work: one atomic per wave and list
+    uint32_t* const lists[4] = {pk_list, dsa_list, pk_list3072, pk_list4096};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t idx = wave_alloc(pk_count + k, q_kind == k);
-    if (q_kind == k) { rec.pk_idx = idx; lists[k][idx] = ri; }
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t idx = wave_alloc(pk_count + k, q_kind == k);
+      if (q_kind == k) { rec.pk_idx = idx; rec.queued = 1; lists[k][idx] = ri; }
+    }
   }
   rec.status = st;
   recs[ri] = rec;
@@ -783,17 +787,19 @@ enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 }
 template <int L, int TPI>   // limbs per lane x lanes per number: 19x4 (<= 2048-bit moduli), 14x8 (<= 3072), 19x8 (<= 4096)
 __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                           const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
+                                                          const uint32_t* __restrict__ pk_start_ptr,
                                                           KeyTableDev kt, uint32_t* __restrict__ r_limbs,
                                                           uint32_t* __restrict__ xr_scratch) {
   constexpr int NL = TPI * L;
   constexpr int GROUPS = RSA_BLOCK / TPI;      // numbers per block
   __shared__ uint32_t a_sh[GROUPS * NL];
   __shared__ uint32_t x_sh[GROUPS * NL];
-  const uint32_t count = *pk_count_ptr;
-  if (blockIdx.x * GROUPS >= count) return;   // whole block idle
+  // work = list entries [start, count): phase 1 of a call starts at 0, phase 2 where phase 1 ended (k_plan)
+  const uint32_t count = *pk_count_ptr, start = *pk_start_ptr;
+  if (start + blockIdx.x * GROUPS >= count) return;   // whole block idle
   const uint32_t quad = threadIdx.x / TPI;
   const int qlane = threadIdx.x % TPI;
-  const uint32_t gq = blockIdx.x * GROUPS + quad;
+  const uint32_t gq = start + blockIdx.x * GROUPS + quad;
   const bool active = gq < count;
   const uint32_t pi = active ? gq : (count - 1);
   const uint32_t ri = pk_list[pi];
@@ -882,14 +888,15 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
 // EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); TPI lanes per signature.
 template <int L, int TPI>
 __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, const uint32_t* __restrict__ pk_list,
-                                                     const uint32_t* __restrict__ pk_count_ptr, KeyTableDev kt,
+                                                     const uint32_t* __restrict__ pk_count_ptr, const uint32_t* __restrict__ pk_start_ptr,
+                                                     KeyTableDev kt,
                                                      const uint32_t* __restrict__ r_limbs, const uint32_t* __restrict__ digests) {
   constexpr int NL = TPI * L;
   constexpr int GROUPS = 256 / TPI;
-  const uint32_t count = *pk_count_ptr;
-  const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) / TPI;
+  const uint32_t count = *pk_count_ptr, start = *pk_start_ptr;
+  const uint32_t gq = start + (blockIdx.x * blockDim.x + threadIdx.x) / TPI;
   const int qlane = threadIdx.x % TPI;
-  if ((blockIdx.x * blockDim.x) / TPI >= count) return;
+  if (start + (blockIdx.x * blockDim.x) / TPI >= count) return;
   const bool active = gq < count;
   const uint32_t pi = active ? gq : (count - 1);
   const uint32_t ri = pk_list[pi];
@@ -950,7 +957,7 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   // LDS (a lane-per-limb-slice read straight from global touches 64 cache lines per instruction)
   __shared__ uint32_t r_sh[GROUPS * NL];
   {
-    const uint32_t q0 = (blockIdx.x * blockDim.x) / TPI;
+    const uint32_t q0 = start + (blockIdx.x * blockDim.x) / TPI;
     const uint32_t n_valid = min((uint32_t)GROUPS, count - q0) * NL;
     const uint32_t* src = r_limbs + (uint64_t)q0 * NL;
     for (uint32_t t = threadIdx.x; t < GROUPS * NL; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
@@ -990,8 +997,9 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
 constexpr int DSA_U_WORDS = 24;
 __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
+                                                const uint32_t* __restrict__ pk_start,
                                                 KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/) {
-  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t di = pk_start[1] + blockIdx.x * blockDim.x + threadIdx.x;
   if (di >= pk_count[1]) return;
   const uint32_t ri = dsa_list[di];
   const uint32_t key = (uint32_t)recs[ri].key_slot;      // parse-time fields only: the status byte is the hash stream's
@@ -1019,9 +1027,9 @@ __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_
 
 // After the digests: u1 = z*w mod q replaces w in the row; refused signatures get their final status here.
 __global__ void __launch_bounds__(64) k_dsa_mul(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
-                                                const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
                                                 const uint32_t* __restrict__ digests, uint32_t* __restrict__ dsa_u) {
-  const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t di = pk_start[1] + blockIdx.x * blockDim.x + threadIdx.x;
   if (di >= pk_count[1]) return;
   const uint32_t ri = dsa_list[di];
   const SigRec rec = recs[ri];
@@ -1111,15 +1119,15 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
 // The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each quad lane
 // folds its 19 limbs, the quad adds up, 35 shift-subtract steps finish), then (v mod q) == r.
 __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
-                                                          const uint32_t* __restrict__ pk_count, KeyTableDev kt,
+                                                          const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
                                                           const uint32_t* __restrict__ dsa_u) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
-  const uint32_t count = pk_count[1];
-  if (blockIdx.x * QUADS_PER_BLOCK >= count) return;
+  const uint32_t count = pk_count[1], start = pk_start[1];
+  if (start + blockIdx.x * QUADS_PER_BLOCK >= count) return;
   const uint32_t quad = threadIdx.x >> 2;
   const int qlane = threadIdx.x & 3;
-  const uint32_t gq = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const uint32_t gq = start + blockIdx.x * QUADS_PER_BLOCK + quad;
   const bool active = gq < count;
   const uint32_t di = active ? gq : (count - 1);
   const uint32_t ri = dsa_list[di];
@@ -1376,6 +1384,97 @@ __global__ void __launch_bounds__(256) k_tally(const SigRec* __restrict__ recs, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// two-phase planning of the public-key work (CollectiveSignature.Verify only)
+// ------------------------------------------------------------------------------------------------
+// PGPCollectiveSignature.Verify returns at the first packet after which IsSufficient holds (crypto_pgp.go:491-496) and
+// never reads the rest of ss.Data -- at n = 64 that is 43 of 53 packets on average.  Phase 1 therefore queues, per item,
+// the candidate packets (parsed, key found, everything checked that precedes the hash) up to the position where the tally
+// WOULD become sufficient if they all verified, plus `margin` more clique members so that an isolated bad signature does
+// not cost a second pass.  After phase 1's tally, phase 2 queues what is left of the items that are still insufficient.
+// The reference's exit position is never before phase 1's cut, so every packet the reference examines is examined here.
+struct PlanArgs {
+  SigRec* recs; const uint32_t* rec_base; const uint32_t* counts; uint32_t n_items;
+  uint32_t *pk_list, *dsa_list, *pk_list3072, *pk_list4096;
+  uint32_t* pk_count;          // [0..3] list lengths; [8..11] receive the phase-1 lengths (= phase 2's start)
+  uint32_t* plan_cut;          // [n_items] records covered so far
+  const uint8_t* verdict;      // phase 2: verdict bits of the phase-1 tally
+  uint32_t margin;
+};
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_plan(PlanArgs a, KeyTableDev kt, QuorumDev q) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (wave >= a.n_items) return;
+  const uint32_t base = a.rec_base[wave], cnt = a.counts[wave];
+  uint32_t* const lists[4] = {a.pk_list, a.dsa_list, a.pk_list3072, a.pk_list4096};
+  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (PHASE == 1) {
+    uint32_t cq[MAX_QC];
+#pragma unroll
+    for (int c = 0; c < MAX_QC; ++c) cq[c] = 0;
+    uint32_t covered = cnt;
+    bool done = false;
+    for (uint32_t off = 0; off < cnt && !done; off += 64) {
+      const uint32_t i = off + lane;
+      uint32_t kind = 0, ent = 0;
+      if (i < cnt) {
+        kind = a.recs[base + i].q_kind1;
+        if (kind) ent = kt.entity[a.recs[base + i].key_slot];
+      }
+      const bool cand = kind != 0;
+      bool reached = false;
+#pragma unroll
+      for (int c = 0; c < MAX_QC; ++c) {
+        if (c < q.n_qcs) {
+          const bool mem = cand && q.member[(uint64_t)c * q.n_entities + ent];
+          const uint64_t mm = __builtin_amdgcn_ballot_w64(mem);
+          const uint32_t run = cq[c] + (uint32_t)__builtin_popcountll(mm & below) + (mem ? 1u : 0u);
+          if (mem && q.suff[c] > 0 && run >= (uint32_t)q.suff[c] + a.margin) reached = true;
+          cq[c] += (uint32_t)__builtin_popcountll(mm);
+        }
+      }
+      const uint64_t rm = __builtin_amdgcn_ballot_w64(reached);
+      uint32_t last = 63;
+      if (rm) { last = (uint32_t)__builtin_ctzll(rm); done = true; covered = off + last + 1; }
+      const bool want = cand && lane <= last;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool mine = want && kind == (uint32_t)k + 1;
+        const uint32_t idx = wave_alloc(a.pk_count + k, mine);
+        if (mine) { a.recs[base + i].pk_idx = idx; a.recs[base + i].queued = 1; lists[k][idx] = base + i; }
+      }
+    }
+    if (lane == 0) a.plan_cut[wave] = covered;
+  } else {
+    if (a.verdict[wave] & V_IS_SUFFICIENT) return;
+    const uint32_t from = a.plan_cut[wave];
+    for (uint32_t off = from; off < cnt; off += 64) {
+      const uint32_t i = off + lane;
+      uint32_t kind = 0;
+      bool want = false;
+      if (i < cnt) {
+        const SigRec r = a.recs[base + i];
+        kind = r.q_kind1;
+        want = kind != 0 && !r.queued && r.status == ST_PENDING_RSA;     // hash tag matched (the hash stream has been joined)
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool mine = want && kind == (uint32_t)k + 1;
+        const uint32_t idx = wave_alloc(a.pk_count + k, mine);
+        if (mine) { a.recs[base + i].pk_idx = idx; a.recs[base + i].queued = 1; lists[k][idx] = base + i; }
+      }
+    }
+    if (lane == 0) a.plan_cut[wave] = cnt;
+  }
+}
+
+// the work-list lengths at the end of phase 1 become phase 2's start offsets
+__global__ void k_plan_snapshot(uint32_t* __restrict__ pk_count) {
+  if (threadIdx.x < 4) pk_count[8 + threadIdx.x] = pk_count[threadIdx.x];
+}
+
 __global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, uint8_t* __restrict__ e) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) e[i] = (v[i] & V_IS_SUFFICIENT) ? 0 : 2;   // BFTKV_ERR_NONE : BFTKV_ERR_INSUFFICIENT_SIGNATURES
@@ -1385,7 +1484,8 @@ __global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, ui
 __global__ void k_export_status(const SigRec* __restrict__ recs, uint32_t n, uint8_t* __restrict__ st, uint32_t* __restrict__ item) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  st[i] = recs[i].status;
+  const uint8_t v = recs[i].status;
+  st[i] = v >= ST_PENDING_PARSE ? (uint8_t)ST_NOT_EXAMINED : v;     // left pending: behind the reference's early exit
   if (item) item[i] = recs[i].item;
 }
 

@@ -48,6 +48,7 @@ typedef struct bftkv_gpu_ctx bftkv_gpu_ctx;
 #define BFTKV_ST_BAD_SIG 8
 #define BFTKV_ST_KEY_CANNOT_SIGN 9
 #define BFTKV_ST_UNSUPPORTED 10
+#define BFTKV_ST_NOT_EXAMINED 11     /* behind the early exit of CollectiveSignature.Verify: the reference never reads it */
 
 /* error identities of crypto/crypto.go:16-33 the shim maps verdicts to */
 #define BFTKV_ERR_NONE 0
@@ -141,6 +142,14 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_i
                                     const uint8_t* ss_blob, const uint64_t* ss_off, uint64_t ss_blob_len,
                                     uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out);
 int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
+/* PGPCollectiveSignature.Verify returns at the first packet after which q.IsSufficient(verified) holds and never reads the
+ * rest of ss.Data (crypto_pgp.go:491-496).  By default the batched call does the same amount of public-key work: per item
+ * it verifies the packets up to the position where the quorum would be sufficient if they all verified (plus a small
+ * margin), tallies, and verifies the remaining packets only of the items that are still insufficient.  err_out,
+ * n_verified_out and verdict_out are those of the reference either way (verdict_out = predicate bits of the signers
+ * verified until the exit); packets behind the exit report BFTKV_ST_NOT_EXAMINED.  on = 0 verifies every packet of
+ * every item (diagnostics: verdict_out then covers the full signer list). */
+int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* ctx, int on);
 
 /* ---- Signature.Verify / VerifyWithCertificate, batched (crypto_pgp.go:319-344) ---------------- */
 /* err_out[i] = BFTKV_ERR_NONE iff sig.Data holds >= 1 packet and every CheckDetachedSignature call

@@ -37,7 +37,7 @@ def test_modexp_matches_pow(gpu_ctx):
 
 
 @pytest.mark.parametrize("n,items", [(4, 100), (10, 60), (64, 24)])
-def test_collective_verify_matches_oracle(gpu_ctx, n, items):
+def test_collective_verify_matches_oracle(gpu_ctx, exit_mode, n, items):
     cl = cb.make_cluster(n)
     rates = {cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_BAD_TAG: 0.1}
     c = cb.make_write_corpus(cl, items, mutation_rates=rates)
@@ -70,6 +70,26 @@ def _cat(parts):
     off = np.zeros(len(parts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
     return np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)[:int(off[-1])].copy(), off
+
+
+@pytest.fixture(params=[True, False], ids=["early-exit", "every-packet"])
+def exit_mode(gpu_ctx, request):
+    """CollectiveSignature.Verify in both modes: public-key work stops where the reference stops reading (the default), or
+    every packet of every item is verified (diagnostics).  err, n_verified and the statuses up to the exit are the same."""
+    gpu_ctx.set_early_exit(request.param)
+    yield request.param
+    gpu_ctx.set_early_exit(True)
+
+
+def _check_ok_counts(st, st_item, c, suff, early):
+    ok = np.bincount(st_item[st == 0], minlength=c.n_items)
+    if not early:
+        assert (ok == c.expected_valid).all()
+        assert not (st == 11).any()
+        return
+    want_ok = c.expected_valid >= suff
+    assert (ok[~want_ok] == c.expected_valid[~want_ok]).all()          # insufficient items: every packet was examined
+    assert (ok[want_ok] >= suff).all() and (ok[want_ok] <= c.expected_valid[want_ok]).all()
 
 
 def test_signature_verify_and_with_certificate(gpu_ctx):
@@ -154,7 +174,7 @@ def test_quorum_tally_over_id_lists(gpu_ctx):
         gpu_ctx.quorum_destroy(qh)
 
 
-def test_malformed_and_edge_streams(gpu_ctx):
+def test_malformed_and_edge_streams(gpu_ctx, exit_mode):
     """Ragged / empty / malformed inputs: statuses and verdicts follow the oracle packet by packet."""
     cl = cb.make_cluster(4)
     kr = _ring_and_ctx(gpu_ctx, cl)
@@ -242,7 +262,7 @@ def test_golden_gpg_vectors_on_gpu(gpu_ctx):
         assert checked == len(vec[group])
 
 
-def test_full_size_properties_cfg2(gpu_ctx):
+def test_full_size_properties_cfg2(gpu_ctx, exit_mode):
     """BASELINE configs[1] shape (64 replicas, suff 43) at 1,500 writes / ~80k signatures, signed on the GPU:
     verdicts follow from how the corpus was built -- no oracle in the loop."""
     cl = cb.make_cluster(64)
@@ -262,7 +282,14 @@ def test_full_size_properties_cfg2(gpu_ctx):
     assert ((verdict & 4) != 0).tolist() == want_ok.tolist()
     st, st_item = gpu_ctx.last_statuses()
     assert len(st) == c.n_sigs and (np.bincount(st_item, minlength=c.n_items) == c.sig_count).all()
-    assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+    _check_ok_counts(st, st_item, c, suff, exit_mode)
+    ops = gpu_ctx.last_counters()["pubkey_ops"]
+    if exit_mode:
+        # the reference examines (at least) suff packets of a sufficient write and all packets of an insufficient one
+        floor = int(np.where(want_ok, suff, c.expected_valid).sum())
+        assert floor <= ops <= floor + 0.06 * c.n_sigs, (floor, ops, c.n_sigs)
+    else:
+        assert ops >= 0.93 * c.n_sigs
     # idempotence: same inputs, same outputs
     err2, nver2, verdict2 = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
     assert (err2 == err).all() and (nver2 == nver).all() and (verdict2 == verdict).all()
@@ -308,7 +335,54 @@ def test_exchange_step_on_the_verifier_stream(gpu_ctx):
         assert out.cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_cfg4_shape_256_replicas(gpu_ctx):
+def test_two_phase_planning_reaches_the_reference_exit(gpu_ctx):
+    """Phase 1 verifies up to the optimistic exit (+ margin); phase 2 must pick up every item that several bad signatures,
+    signers from outside the clique, or a second clique push beyond it.  Statuses up to the reference's exit, n_verified and
+    err follow the oracle; the public-key work stays below 'every packet'."""
+    from oracle import collective as col
+    from oracle import wotqs
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(13)                      # f = 4, suff = 9
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    ids = [r.key_id for r in cl.replicas]
+    # two cliques over the same keyring: the first 10 members (suff 7) and the last 7 (suff 5); IsSufficient is an OR
+    qa, qb = wotqs.new_qc(ids[:10], 10, wotqs.AUTH, 0), wotqs.new_qc(ids[6:], 7, wotqs.AUTH, 0)
+    for q in (H.clique_quorum(cl), wotqs.WotQ([qa, qb]), wotqs.WotQ([qa])):
+        qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+        rng = np.random.default_rng(len(q.qcs) * 7 + q.qcs[0].suff)
+        tbs_l, ss_l = [], []
+        for i in range(120):
+            tbs = rng.bytes(int(rng.integers(1, 120)))
+            order = rng.permutation(13)[:int(rng.integers(5, 14))]
+            parts = []
+            for j in order:
+                s = bytearray(cb.detach_sign(cl.replicas[int(j)], tbs))
+                u = rng.random()
+                if u < 0.25: s[-3] ^= 0x10                                # bad signature value
+                elif u < 0.30: s[len(s) - 256 - 2 - 2] ^= 0x01               # hash tag
+                elif u < 0.35: s = bytearray(cb.detach_sign(cl.outsiders[0], tbs))    # unknown issuer
+                parts.append(bytes(s))
+                if rng.random() < 0.1: parts.append(bytes(s))             # duplicate packet: counted again (wotqs.go:195-206)
+            tbs_l.append(tbs); ss_l.append(b"".join(parts))
+        tb, to = _cat(tbs_l)
+        sb, so = _cat(ss_l)
+        res = {}
+        for early in (True, False):
+            gpu_ctx.set_early_exit(early)
+            err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+            st, st_item = gpu_ctx.last_statuses()
+            res[early] = (err.copy(), nver.copy(), st.copy(), gpu_ctx.last_counters()["pubkey_ops"])
+            for i in range(120):
+                r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i], None), q)
+                assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (i, early)
+                assert list(st[st_item == i][:len(r.statuses)]) == r.statuses, (i, early)
+        gpu_ctx.set_early_exit(True)
+        assert (res[True][0] == res[False][0]).all() and (res[True][1] == res[False][1]).all()
+        assert res[True][3] < res[False][3] and (res[True][2] == 11).any() and (res[True][0] == 0).any() and (res[True][0] == 2).any()
+        gpu_ctx.quorum_destroy(qh)
+
+
+def test_cfg4_shape_256_replicas(gpu_ctx, exit_mode):
     """BASELINE configs[3] shape: 256-replica clique (f=85, suff=171), 171..256 packets per write -- exercises the
     sequential-walk fallback (more than WALK_CAP packet events per item); verdicts vs construction and vs the oracle."""
     cl = cb.make_cluster(256)
@@ -332,7 +406,7 @@ def test_cfg4_shape_256_replicas(gpu_ctx):
     gpu_ctx.quorum_destroy(qh)
 
 
-def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx):
+def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx, exit_mode):
     """BASELINE configs[2] shape: 64 replicas, half RSA-2048 / half DSA-2048-256, collective signatures over reads."""
     cl = cb.make_cluster(64, dsa_fraction=0.5)
     assert sum(r.algo == cb.PK_DSA for r in cl.replicas) == 32
@@ -347,9 +421,9 @@ def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx):
     want_ok = c.expected_valid >= cl.suff
     assert ((err == 0) == want_ok).all() and (nver == np.where(want_ok, cl.suff, c.expected_valid)).all()
     st, st_item = gpu_ctx.last_statuses()
-    assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+    _check_ok_counts(st, st_item, c, cl.suff, exit_mode)
     cnt = gpu_ctx.last_counters()
-    assert cnt["pubkey_ops"] >= 0.9 * c.n_sigs
+    assert cnt["pubkey_ops"] >= (0.7 if exit_mode else 0.9) * c.n_sigs and cnt["dsa_ops"] > 0.25 * cnt["pubkey_ops"]
     for i in (0, 7, 19, 39):
         r = H.oracle_collective(kr, q, c, i)
         assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
@@ -374,7 +448,7 @@ def test_dsa_fixed_base_tables_both_widths(gpu_ctx):
             gpu_ctx.quorum_destroy(qh)
             if want is None:
                 want = (err.copy(), nver.copy(), st.copy())
-                assert (np.bincount(st_item[st == 0], minlength=c.n_items) == c.expected_valid).all()
+                _check_ok_counts(st, st_item, c, cl.suff, True)
                 for i in range(0, c.n_items, 5):
                     r = H.oracle_collective(kr, q, c, i)
                     assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified)
@@ -586,7 +660,7 @@ def test_verdict_bitmap_pack_unpack_on_device(gpu_ctx):
         assert (D.allgather_verdicts(t == 1, n).cpu().numpy() == ok).all()
 
 
-def test_random_packet_framings_follow_the_oracle(gpu_ctx):
+def test_random_packet_framings_follow_the_oracle(gpu_ctx, exit_mode):
     """The packet walk speculates on packet positions (k_walk): random streams mixing signature packets of different sizes,
     unknown and non-signature packets in every header format, stray bytes, truncations and more than WALK_CAP events per
     item must still yield the oracle's packet sequence, statuses, early-exit position and verdict."""
@@ -692,5 +766,12 @@ def test_mixed_modulus_sizes_2048_3072_4096(gpu_ctx):
         seen.update(got)
     assert 0 in seen and 8 in seen
     cnt = gpu_ctx.last_counters()
-    assert cnt["pubkey_ops"] == 40 * len(keys)
+    assert cnt["pubkey_ops"] <= 40 * len(keys)
+    gpu_ctx.set_early_exit(False)
+    try:
+        err_all, nver_all, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+        assert (err_all == err).all() and (nver_all == nver).all()
+        assert gpu_ctx.last_counters()["pubkey_ops"] == 40 * len(keys)
+    finally:
+        gpu_ctx.set_early_exit(True)
     gpu_ctx.quorum_destroy(qh)
