@@ -69,10 +69,10 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_message_verify.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
-    lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p]
-    lib.bftkv_gpu_collective_verify_dev.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, C.c_uint64, u8p, vp, u8p]
+    lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p, u8p]
+    lib.bftkv_gpu_collective_verify_dev.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, C.c_uint64, u8p, vp, u8p, u8p]
     lib.bftkv_gpu_sync.argtypes = [vp]
-    lib.bftkv_gpu_signature_verify.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p]
+    lib.bftkv_gpu_signature_verify.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p, u8p]
     lib.bftkv_gpu_last_statuses.argtypes = [vp, u8p, vp, u32, C.POINTER(u32)]
     lib.bftkv_gpu_last_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_signers.argtypes = [vp, u32, u8p, u64p, u64p, u64p, C.c_uint64]
@@ -87,8 +87,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_create.restype = vp
     lib.bftkv_gpu_batcher_destroy.argtypes = [vp]
     lib.bftkv_gpu_batcher_destroy.restype = None
-    lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
-    lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p]
+    lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p]
+    lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p, u8p]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
@@ -223,15 +223,16 @@ class Context:
         err = np.zeros(n, dtype=np.uint8)
         nver = np.zeros(n, dtype=np.uint32)
         verdict = np.zeros(n, dtype=np.uint8)
+        self.last_fenced = np.zeros(n, dtype=np.uint8)       # fenced_out of this call (see include/bftkv_gpu.h "fenced inputs")
         self._check(self.lib.bftkv_gpu_collective_verify(self.h, quorum, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(ss_blob),
-                                                         _ptr(ss_off), _ptr(err), _ptr(nver), _ptr(verdict)),
+                                                         _ptr(ss_off), _ptr(err), _ptr(nver), _ptr(verdict), _ptr(self.last_fenced)),
                     "collective_verify")
         return err, nver, verdict
 
     def collective_verify_dev(self, quorum: int, n_items: int, tbs_ptr: int, tbs_off_ptr: int, ss_ptr: int, ss_off_ptr: int,
-                              ss_len: int, err_ptr: int, nver_ptr: int, verdict_ptr: int):
+                              ss_len: int, err_ptr: int, nver_ptr: int, verdict_ptr: int, fenced_ptr: int = 0):
         self._check(self.lib.bftkv_gpu_collective_verify_dev(self.h, quorum, n_items, tbs_ptr, tbs_off_ptr, ss_ptr, ss_off_ptr,
-                                                             ss_len, err_ptr, nver_ptr, verdict_ptr), "collective_verify_dev")
+                                                             ss_len, err_ptr, nver_ptr, verdict_ptr, fenced_ptr or None), "collective_verify_dev")
 
     def sync(self):
         self._check(self.lib.bftkv_gpu_sync(self.h), "sync")
@@ -242,8 +243,9 @@ class Context:
         tbs_off, sig_off = _u64(tbs_off), _u64(sig_off)
         ck = None if cert_key_id is None else _u64(cert_key_id)
         err = np.zeros(n, dtype=np.uint8)
+        self.last_fenced = np.zeros(n, dtype=np.uint8)
         self._check(self.lib.bftkv_gpu_signature_verify(self.h, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(sig_blob), _ptr(sig_off),
-                                                        _ptr(ck), _ptr(err)), "signature_verify")
+                                                        _ptr(ck), _ptr(err), _ptr(self.last_fenced)), "signature_verify")
         return err
 
     def last_statuses(self):
@@ -393,17 +395,24 @@ class Batcher:
             self.lib.bftkv_gpu_batcher_destroy(self.h)
             self.h = None
 
-    def collective_verify(self, quorum: int, tbs: bytes, ss: bytes) -> int:
+    def collective_verify(self, quorum: int, tbs: bytes, ss: bytes, raw: bool = False):
+        """raw=True returns (rc, err, fenced) without raising (the fail-closed tests look at err when rc != 0)."""
         err = np.zeros(1, dtype=np.uint8)
-        rc = self.lib.bftkv_gpu_batcher_collective_verify(self.h, quorum, tbs, len(tbs), ss, len(ss), _ptr(err))
+        fenced = np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_collective_verify(self.h, quorum, tbs, len(tbs), ss, len(ss), _ptr(err), _ptr(fenced))
+        if raw:
+            return rc, int(err[0]), int(fenced[0])
         if rc:
             raise NativeError("batcher collective_verify failed: %d" % rc)
         return int(err[0])
 
-    def signature_verify(self, tbs: bytes, sig: bytes, cert_key_id: Optional[int] = None) -> int:
+    def signature_verify(self, tbs: bytes, sig: bytes, cert_key_id: Optional[int] = None, raw: bool = False):
         err = np.zeros(1, dtype=np.uint8)
         ck = None if cert_key_id is None else np.array([cert_key_id], dtype=np.uint64)
-        rc = self.lib.bftkv_gpu_batcher_signature_verify(self.h, tbs, len(tbs), sig, len(sig), _ptr(ck), _ptr(err))
+        fenced = np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_signature_verify(self.h, tbs, len(tbs), sig, len(sig), _ptr(ck), _ptr(err), _ptr(fenced))
+        if raw:
+            return rc, int(err[0]), int(fenced[0])
         if rc:
             raise NativeError("batcher signature_verify failed: %d" % rc)
         return int(err[0])

@@ -65,12 +65,17 @@ struct QuorumHost {
 
 }  // namespace
 
+using ctx_lock = std::lock_guard<std::recursive_mutex>;
+
 struct bftkv_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // main stream: walk, parse, modexp, compare, tally
   hipStream_t stream_h = nullptr;    // hashing stream: runs beside the modexp
   hipStream_t stream_d = nullptr;    // DSA inverses (s^-1 mod q): latency-bound, runs beside both
-  std::mutex mu;
+  // One lock per context, RECURSIVE: the compound host entry points (certificate verification, Server.sign, ...) hold it
+  // from entity resolution to the last pipeline call they make, so that no other thread can change the key table, the
+  // certificate cache or the entity indices in between; the entry points they call re-acquire it.
+  std::recursive_mutex mu;
   std::string err;
 
   // key table
@@ -94,7 +99,7 @@ struct bftkv_gpu_ctx {
 
   // per-call arena
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
-  DevBuf o_err, o_nver, o_verdict;
+  DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
@@ -111,7 +116,8 @@ struct bftkv_gpu_ctx {
 
 void rccl_release(bftkv_gpu_ctx* c);
 extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
-                                         const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class = nullptr);
+                                         const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class = nullptr,
+                                         uint8_t* fenced_out = nullptr);
 
 namespace {
 
@@ -687,7 +693,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream_d);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
-                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->in_tbs, &c->in_tbs_off,
+                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
@@ -723,32 +729,35 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
 
 int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* c, int on) {
   if (!c) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   c->early_exit = on != 0;
   return 0;
 }
 
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && bits != 4 && bits != 8)) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   c->dsa_wbits_pinned = bits;
   return 0;
 }
 
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32_t n_keys) {
   if (!c || (!keys && n_keys)) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<KeyEntry> ring;
   for (uint32_t i = 0; i < n_keys; ++i) {
     KeyEntry e;
     int rc = make_key_entry(c, keys[i], false, &e);
     if (rc) return rc;
+    // identical material under one id (the node's own key sits in both rings) is one row; DIFFERENT material under one
+    // 64-bit id stays in the table in keyring order (KeysByIdUsage returns every candidate; ids can be made to collide with
+    // ~2^32 work, so this must not take the keyring down): lookups take the first usable row and fence the item
     bool dup = false;
     for (auto& o : ring) {
       if (o.key_id == e.key_id) {
         if (o.material == e.material) { dup = true; break; }
-        return fail(c, BFTKV_E_UNSUPPORTED, "two different keys share one 64-bit key id");
+        o.flags |= KEYF_AMBIGUOUS; e.flags |= KEYF_AMBIGUOUS;
       }
     }
     if (!dup) ring.push_back(std::move(e));
@@ -762,7 +771,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
 int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t n_qcs, int* out) {
   if (!c || !out || (!qcs && n_qcs)) return BFTKV_E_INVALID;
   if (n_qcs > MAX_QC) return fail(c, BFTKV_E_UNSUPPORTED, "more than MAX_QC cliques in one quorum");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   QuorumHost q;
   q.live = true;
@@ -794,7 +803,7 @@ int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t 
 
 int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
   if (!c) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
   c->quorums[quorum].member.release();
@@ -805,7 +814,7 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
 
 static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                  uint8_t* verdict_out, const std::function<int(hipStream_t)>* upload_tbs) {
+                                  uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs) {
   // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
@@ -825,6 +834,9 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
     // err = IsSufficient ? nil : ErrInsufficientNumberOfSignatures
     hipLaunchKernelGGL(k_err_from_verdict, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, vd, n_items, err_out);
   }
+  if (fenced_out)
+    hipLaunchKernelGGL(k_fenced_out, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->item_flags.as<uint8_t>(),
+                       c->hash_mask.as<uint32_t>(), n_items, fenced_out);
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipGetLastError());
   c->have_timing = true;
@@ -833,19 +845,19 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
 
 int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                     const uint8_t* ss, const uint64_t* ss_off, uint64_t ss_len, uint8_t* err_out,
-                                    uint32_t* nver_out, uint8_t* verdict_out) {
+                                    uint32_t* nver_out, uint8_t* verdict_out, uint8_t* fenced_out) {
   (void)ss_len;
   if (!c) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, nullptr);
+  ctx_lock lk(c->mu);
+  return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, nullptr);
 }
 
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                 const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                uint8_t* verdict_out) {
+                                uint8_t* verdict_out, uint8_t* fenced_out) {
   if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
-  std::lock_guard<std::mutex> lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context
+  ctx_lock lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context
   HIPCHK(c, hipSetDevice(c->device));
   int rco;
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
@@ -858,6 +870,7 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   HIPCHK(c, c->o_err.ensure(n_items));
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
+  HIPCHK(c, c->o_fenced.ensure(n_items));
   // the signature streams and the offsets first: the walk, the parse and the modexp need nothing else
   if (sl) HIPCHK(c, hipMemcpyAsync(c->in_ss.p, ss, sl, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
@@ -869,8 +882,9 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   };
   int rc = collective_verify_impl(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
                                   c->in_ss_off.as<uint64_t>(), c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>(),
-                                  &upload_tbs);
+                                  fenced_out ? c->o_fenced.as<uint8_t>() : nullptr, &upload_tbs);
   if (rc) return rc;
+  if (fenced_out) HIPCHK(c, hipMemcpyAsync(fenced_out, c->o_fenced.p, n_items, hipMemcpyDeviceToHost, c->stream));
   if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
   if (nver_out) HIPCHK(c, hipMemcpyAsync(nver_out, c->o_nver.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, c->stream));
   if (verdict_out) HIPCHK(c, hipMemcpyAsync(verdict_out, c->o_verdict.p, n_items, hipMemcpyDeviceToHost, c->stream));
@@ -881,8 +895,8 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
 // Signature.Verify over a batch with the keyring of item i restricted to entity index ent[i] (0xFFFFFFFF: the node
 // keyring).  Shared by bftkv_gpu_signature_verify and the Server.sign site of the host mirror.
 int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
-                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class) {
-  std::lock_guard<std::mutex> lk(c->mu);
+                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class, uint8_t* fenced_out) {
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   int rco;
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, sig_off, n_items, "sig_off not monotone from 0")))
@@ -914,6 +928,12 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
   if (rc) return rc;
   hipLaunchKernelGGL(k_sigverify_fold, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(),
                      c->base.as<uint32_t>(), c->counts.as<uint32_t>(), c->item_flags.as<uint8_t>(), n_items, c->o_err.as<uint8_t>());
+  if (fenced_out) {
+    HIPCHK(c, c->o_fenced.ensure(n_items));
+    hipLaunchKernelGGL(k_fenced_out, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->item_flags.as<uint8_t>(),
+                       c->hash_mask.as<uint32_t>(), n_items, c->o_fenced.as<uint8_t>());
+    HIPCHK(c, hipMemcpyAsync(fenced_out, c->o_fenced.p, n_items, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -923,12 +943,13 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
 }
 
 int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
-                               const uint8_t* sig, const uint64_t* sig_off, const uint64_t* cert_key_id, uint8_t* err_out) {
+                               const uint8_t* sig, const uint64_t* sig_off, const uint64_t* cert_key_id, uint8_t* err_out,
+                               uint8_t* fenced_out) {
   if (!c || (n_items && (!tbs_off || !sig_off || !err_out))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
   std::vector<uint32_t> ce;
+  ctx_lock lk(c->mu);      // entity indices resolved here stay valid until the pipeline has consumed them
   if (cert_key_id) {
-    std::lock_guard<std::mutex> lk(c->mu);
     ce.resize(n_items);
     for (uint32_t i = 0; i < n_items; ++i) {
       uint32_t e = 0xFFFFFFFEu;   // an entity that is not in the table: nothing matches
@@ -936,12 +957,12 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t
       ce[i] = e;
     }
   }
-  return signature_verify_entities(c, n_items, tbs, tbs_off, sig, sig_off, cert_key_id ? ce.data() : nullptr, err_out);
+  return signature_verify_entities(c, n_items, tbs, tbs_off, sig, sig_off, cert_key_id ? ce.data() : nullptr, err_out, nullptr, fenced_out);
 }
 
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint32_t cap, uint32_t* n_out) {
   if (!c || !n_out) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   *n_out = c->last_total;
   uint32_t n = c->last_total < cap ? c->last_total : cap;
@@ -958,7 +979,7 @@ int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint3
 
 int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   if (!c || !counters) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t cnt[4] = {0, 0, 0, 0};
   if (c->pk_count.p) HIPCHK(c, hipMemcpy(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost));
@@ -971,7 +992,7 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
 
 int bftkv_gpu_last_timing(bftkv_gpu_ctx* c, float ms[8]) {
   if (!c || !ms) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   if (!c->have_timing) return fail(c, BFTKV_E_STATE, "no timed call yet");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventSynchronize(c->ev[4]));
@@ -990,7 +1011,7 @@ int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* c, int quorum, uint32_t n_lists, const
                            uint8_t* verdict_out) {
   if (!c || (n_lists && (!list_off || !verdict_out))) return BFTKV_E_INVALID;
   if (n_lists == 0) return 0;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
@@ -1018,7 +1039,7 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   // parse-only walk: reuse the parse kernels with no hashing; issuers resolved against PRIMARY
   // key ids only (getCertById, crypto_pgp.go:206-219).
   if (!c || (n_items && (!ss_off || !ids_off_out))) return BFTKV_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   ids_off_out[0] = 0;
   if (n_items == 0) return 0;
@@ -1058,7 +1079,7 @@ static int modexp_impl(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, ui
                        uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, bool exp_per_op, uint8_t* out) {
   if (!c || nbytes == 0 || nbytes > 256 || exp_len == 0 || (n_ops && (!base || !mod_idx || !mods || !exps || !out))) return BFTKV_E_INVALID;
   if (n_ops == 0) return 0;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   std::vector<uint32_t> nl((size_t)n_mods * MONT_N), r2((size_t)n_mods * MONT_N), n0(n_mods);

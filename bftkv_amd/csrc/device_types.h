@@ -91,6 +91,11 @@ constexpr uint8_t KEYF_CERT_ONLY = 8;
 // certificate key whose self-signature forbids data signatures (key flags without Sign): it still verifies the
 // certificate's own self-signatures / bindings (sig_class != 0) but never a detached signature
 constexpr uint8_t KEYF_CERT_CHECK_ONLY = 16;
+// another, different key of the keyring carries the same 64-bit key id: the reference tries every candidate (the second one
+// against a hash that has absorbed the suffix twice); the device takes the first and raises the item's fence flag
+constexpr uint8_t KEYF_AMBIGUOUS = 32;
+// per-item word item_hash_mask: bits 1..4 = midstates wanted besides SHA-256, bit 31 = the item met a fenced input shape
+constexpr uint32_t ITEM_FENCED = 0x80000000u;
 
 // Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.
 constexpr int MAX_QC = 8;

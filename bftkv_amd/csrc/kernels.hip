@@ -45,16 +45,19 @@ __host__ __device__ __forceinline__ bool known_tag(uint32_t tag) {
 }
 
 // Signature.parse.  An embedded-signature subpacket (type 32) makes x/crypto parse recursively; here the nesting depth is
-// a template parameter (fenced at 2), so the whole parser inlines into its kernels -- device-side recursion
-// would mean real function calls with a scratch stack in the packet-parse kernel.
+// a template parameter (bounded at 2: deeper nesting raises the item's `fenced` flag), so the whole parser inlines
+// into its kernels -- device-side recursion would mean real function calls with a scratch stack in the packet-parse kernel.
+struct SubpacketState {
+  bool have_ctime = false, have_issuer = false, have_embedded = false;
+  bool too_deep = false;      // an embedded signature nested deeper than this parser goes: outcome not claimed (fence)
+  uint64_t issuer = 0;
+};
 // subpacket area walk; returns false on structural/unsupported error
 template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* p, uint32_t len, bool hashed, bool& have_ctime,
-                                                            bool& have_issuer, uint64_t& issuer);
+__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* p, uint32_t len, bool hashed, SubpacketState& st);
 
 template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
-                                                          uint64_t& issuer) {
+__host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, uint32_t blen, SigRec& rec, SubpacketState& st) {
   if (blen < 1) return false;
   if (body[0] != 4) return false;  // v3 handled by the caller, others unsupported
   if (blen < 6) return false;
@@ -68,16 +71,14 @@ __host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, u
   uint32_t hl = ((uint32_t)body[4] << 8) | body[5];
   if (6 + hl > blen) return false;
   rec.hashed_len = (uint16_t)hl;
-  bool have_ctime = false;
-  have_issuer = false;
-  if (!parse_subpackets_t<DEPTH>(body + 6, hl, true, have_ctime, have_issuer, issuer)) return false;
-  if (!have_ctime) return false;
+  if (!parse_subpackets_t<DEPTH>(body + 6, hl, true, st)) return false;
+  if (!st.have_ctime) return false;
   uint32_t p = 6 + hl;
   if (p + 2 > blen) return false;
   uint32_t ul = ((uint32_t)body[p] << 8) | body[p + 1];
   p += 2;
   if (p + ul > blen) return false;
-  if (!parse_subpackets_t<DEPTH>(body + p, ul, false, have_ctime, have_issuer, issuer)) return false;
+  if (!parse_subpackets_t<DEPTH>(body + p, ul, false, st)) return false;
   p += ul;
   if (p + 2 > blen) return false;
   rec.hash_tag[0] = body[p];
@@ -100,8 +101,7 @@ __host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, u
 }
 
 template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, uint32_t len, bool hashed, bool& have_ctime,
-                                                            bool& have_issuer, uint64_t& issuer) {
+__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, uint32_t len, bool hashed, SubpacketState& st) {
   uint32_t p = 0;
   while (p < len) {
     uint32_t b = a[p], ln;
@@ -122,9 +122,9 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
     p += ln;
     switch (typ) {
       case 2:
-        if (!hashed) break;
+        if (!hashed) return false;       // "signature creation time in non-hashed area"
         if (bl != 4) return false;
-        have_ctime = true;
+        st.have_ctime = true;
         break;
       case 3: case 9:
         if (!hashed) break;
@@ -134,9 +134,9 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
         break;
       case 16:
         if (bl != 8) return false;
-        issuer = 0;
-        for (int i = 0; i < 8; ++i) issuer = (issuer << 8) | body[i];
-        have_issuer = true;
+        st.issuer = 0;
+        for (int i = 0; i < 8; ++i) st.issuer = (st.issuer << 8) | body[i];
+        st.have_issuer = true;
         break;
       case 25:
         if (!hashed) break;
@@ -147,12 +147,17 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
         if (bl == 0) return false;
         break;
       case 32: {
-        if (!hashed) break;
-        // embedded signature: the reference parses it recursively and fails the outer parse on error
-        if constexpr (DEPTH >= 2) return false;  // bounded nesting (fenced)
+        // embedded signature (the 0x19 cross-certification of a signing subkey, normally in the UNHASHED area): the
+        // reference parses it from either area, refuses a second one and any type other than primary-key binding
+        if (st.have_embedded) return false;                 // "Cannot have multiple embedded signatures"
+        st.have_embedded = true;
+        if constexpr (DEPTH >= 2) { st.too_deep = true; return false; }   // bounded nesting
         else {
-          SigRec tmp; bool hi; uint64_t iss;
-          if (!parse_sig_body_t<DEPTH + 1>(body, bl, tmp, hi, iss)) return false;
+          SigRec tmp; SubpacketState inner;
+          const bool ok = parse_sig_body_t<DEPTH + 1>(body, bl, tmp, inner);
+          if (inner.too_deep) st.too_deep = true;
+          if (!ok) return false;
+          if (tmp.sig_type != 0x19) return false;           // "cross-signature has unexpected type"
         }
         break;
       }
@@ -164,8 +169,13 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
 }
 
 __host__ __device__ __forceinline__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
-                                                        uint64_t& issuer, int /*depth: callers start at 0*/) {
-  return parse_sig_body_t<0>(body, blen, rec, have_issuer, issuer);
+                                                        uint64_t& issuer, bool* too_deep = nullptr) {
+  SubpacketState st;
+  const bool ok = parse_sig_body_t<0>(body, blen, rec, st);
+  have_issuer = st.have_issuer;
+  issuer = st.issuer;
+  if (too_deep) *too_deep = st.too_deep;
+  return ok;
 }
 
 // One packet.Read framing step at stream position pos of [.., end): header only.
@@ -275,6 +285,7 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   uint64_t stride = 0;
   bool trailing_skip = false;   // silently skipped packet(s) after the last event
   bool force = false;           // an event that does not fit the scratch encoding: the fill pass must write this item
+  bool unsup = false;           // a framing this walk does not follow (partial / indeterminate length): the item is fenced
   while (pos < end) {
     const uint64_t p = pos + (uint64_t)lane * stride;
     const bool act = lane == 0 || (stride != 0 && p < end);
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     const bool conf = lane < n_conf;
     const uint64_t evm = __builtin_amdgcn_ballot_w64(conf && w.event);
     const uint32_t idx = n + (uint32_t)__builtin_popcountll(evm & ((1ull << lane) - 1ull));
+    if (conf && w.event && w.status == ST_UNSUPPORTED) unsup = true;
     if (conf && w.event) {
       if (!FILL) {
         if (idx < WALK_CAP) {
@@ -317,7 +329,8 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   }
   if (!FILL) {
     const bool any_force = __builtin_amdgcn_ballot_w64(force) != 0;
-    if (lane == 0) { counts[item] = n; item_flags[item] = (trailing_skip ? 1 : 0) | (any_force ? 2 : 0); }
+    const bool any_unsup = __builtin_amdgcn_ballot_w64(unsup) != 0;
+    if (lane == 0) { counts[item] = n; item_flags[item] = (trailing_skip ? 1 : 0) | (any_force ? 2 : 0) | (any_unsup ? 4 : 0); }
   }
 }
 
@@ -380,11 +393,14 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
   const uint8_t* body = sig_blob + rec.body_off;
   uint8_t st;
   int q_kind = -1;             // public-key work list this record joins (decided below, queued at the end)
-  if (rec.body_len >= 1 && body[0] < 4) st = ST_UNSUPPORTED;   // SignatureV3: fenced
+  // fence: the packet has a shape on which this library does not claim the reference's outcome (DESIGN.md "fenced inputs");
+  // the item's fenced_out flag tells the caller to take the reference path for it
+  bool fence = false;
+  if (rec.body_len >= 1 && body[0] < 4) { st = ST_UNSUPPORTED; fence = true; }   // SignatureV3
   else {
-    bool have_issuer = false;
+    bool have_issuer = false, too_deep = false;
     uint64_t issuer = 0;
-    if (!parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, 0)) st = ST_PARSE_ERROR;
+    if (!parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, &too_deep)) { st = ST_PARSE_ERROR; fence = too_deep; }
     else if (!have_issuer && !msg_slot) st = ST_NO_ISSUER;
     else {
       // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
@@ -416,12 +432,13 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
       rec.key_slot = slot;
       const HashInfo hi = hash_info(rec.hash_id);
       const uint32_t hlen = hi.dlen, plen = hi.plen;
+      if (slot >= 0 && (kt.flags[slot] & KEYF_AMBIGUOUS)) fence = true;    // several different keys under this 64-bit id
       if (slot < 0) st = ST_UNKNOWN_ISSUER;
       // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
       // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
-      else if (!msg_slot && !sig_class_ok(cls, rec.sig_type)) st = ST_HASH_UNSUPPORTED;
-      else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;
+      else if (!msg_slot && !sig_class_ok(cls, rec.sig_type)) { st = ST_HASH_UNSUPPORTED; fence = (cls == 0 && rec.sig_type == 0x01); }
+      else if (hi.family == 0) { st = ST_HASH_UNSUPPORTED; fence = true; }                      // MD5 / RIPEMD-160
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {
         // everything below is only reached when the hash tag matches (k_digest decides)
@@ -441,24 +458,25 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
           // size class of the modulus: 0 <= 2048 bits (76 limbs), 1 <= 3072 (112), 2 <= 4096 (152)
           const uint32_t cls_sz = mod_bits <= 2048 ? 0u : (mod_bits <= 3072 ? 1u : 2u);
           const uint32_t cap_bytes = (cls_sz == 0 ? MONT_N : cls_sz == 1 ? MONT_TPI_BIG * MONT_L3072 : MONT_TPI_BIG * MONT_L4096) * MONT_W / 8;
-          if (mod_bits == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;          // > 4096 bits or no Montgomery form
+          if (mod_bits == 0xFFFFFFFFu) { rec.after_tag = ST_UNSUPPORTED; fence = true; }   // > 4096 bits or no Montgomery form
           else if (kbytes < hlen + plen + 11) rec.after_tag = ST_BAD_SIG;       // rsa.VerifyPKCS1v15: k < tLen+11
-          else if (vbytes > cap_bytes) rec.after_tag = ST_BAD_SIG;              // value >= R: fenced
+          else if (vbytes > cap_bytes) { rec.after_tag = ST_BAD_SIG; fence = true; }   // value >= R: the reference reduces it mod n
           else {
             rec.after_tag = AFTER_TAG_PUBKEY;
             rec.flags = (vbytes > kbytes) ? 1 : 0;
             q_kind = cls_sz == 0 ? 0 : (int)cls_sz + 1;                         // [0] <=2048, [1] DSA, [2] <=3072, [3] <=4096
           }
         } else if (rec.pk_algo == PK_DSA) {
-          if (kt.mod_bits[slot] == 0xFFFFFFFFu) rec.after_tag = ST_UNSUPPORTED;   // fenced key shape
+          if (kt.mod_bits[slot] == 0xFFFFFFFFu) { rec.after_tag = ST_UNSUPPORTED; fence = true; }   // key shape outside the kernels
           else {
             rec.after_tag = AFTER_TAG_PUBKEY;
             q_kind = 1;
           }
-        } else rec.after_tag = ST_UNSUPPORTED;   // ECDSA: out of scope
+        } else { rec.after_tag = ST_UNSUPPORTED; fence = true; }   // ECDSA: out of scope
       }
     }
   }
+  if (fence) atomicOr(&item_hash_mask[rec.item], ITEM_FENCED);
   rec.q_kind1 = (uint8_t)(q_kind + 1);
   if (!a.defer_queue) {
     // queue the public-key work: one atomic per wave and list
@@ -519,7 +537,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
     SigRec tmp;
     bool have_issuer = false;
     uint64_t issuer = 0;
-    if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, 0)) break;   // parse error => Next returns err
+    if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer)) break;   // parse error => Next returns err
     if (!have_issuer) break;                              // nil dereference in the reference: fenced
     for (uint32_t k = 0; k < kt.n_keys; ++k) {
       if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY) && !(kt.flags[k] & KEYF_CERT_ONLY)) {
@@ -1473,6 +1491,13 @@ __global__ void __launch_bounds__(256) k_plan(PlanArgs a, KeyTableDev kt, Quorum
 // the work-list lengths at the end of phase 1 become phase 2's start offsets
 __global__ void k_plan_snapshot(uint32_t* __restrict__ pk_count) {
   if (threadIdx.x < 4) pk_count[8 + threadIdx.x] = pk_count[threadIdx.x];
+}
+
+// per-item fence flag for the caller: the walk met a framing it does not follow, or the parse met a fenced packet shape
+__global__ void k_fenced_out(const uint8_t* __restrict__ item_flags, const uint32_t* __restrict__ item_hash_mask, uint32_t n,
+                             uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((item_flags[i] & 4) || (item_hash_mask[i] & ITEM_FENCED)) ? 1 : 0;
 }
 
 __global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, uint8_t* __restrict__ e) {

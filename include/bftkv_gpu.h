@@ -33,7 +33,7 @@ typedef struct bftkv_gpu_ctx bftkv_gpu_ctx;
 #define BFTKV_E_INVALID (-1)       /* bad argument */
 #define BFTKV_E_DEVICE (-2)        /* HIP runtime failure (message via bftkv_gpu_last_error) */
 #define BFTKV_E_NOMEM (-3)
-#define BFTKV_E_UNSUPPORTED (-4)   /* e.g. two different keys sharing one 64-bit key id, modulus > 2048 bits */
+#define BFTKV_E_UNSUPPORTED (-4)   /* e.g. modulus > 2048 bits in the threshold entry points, more than 8 cliques in one quorum */
 #define BFTKV_E_STATE (-5)         /* keyring / quorum not set */
 
 /* per-packet status (one CheckDetachedSignature-equivalent step) */
@@ -84,8 +84,10 @@ typedef struct {
 } bftkv_gpu_pubkey;
 
 /* keys[] in keyring order (secring entities first, crypto_pgp.go:195-197).  Identical material
- * under one key id (the node's own key appears in both rings) is de-duplicated; different
- * material under one id is BFTKV_E_UNSUPPORTED. */
+ * under one key id (the node's own key appears in both rings) is de-duplicated.  DIFFERENT keys
+ * under one 64-bit id all stay in the table (ids can be made to collide with ~2^32 work; the
+ * reference's KeysByIdUsage returns every candidate): a signature naming such an id is checked
+ * against the first usable candidate and its item is reported through fenced_out. */
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint32_t n_keys);
 
 /* DSA verification (Go crypto/dsa.Verify under packet.PublicKey.VerifySignature) multiplies from per-key
@@ -125,6 +127,15 @@ typedef struct {
 int bftkv_gpu_quorum_create(bftkv_gpu_ctx* ctx, const bftkv_gpu_qc* qcs, uint32_t n_qcs, int* quorum_out);
 int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 
+/* ---- fenced inputs ------------------------------------------------------------------------------------
+ * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs": SignatureV3
+ * packets, partial / indeterminate body lengths on signature packets, text-mode signatures, MD5 / RIPEMD-160, ECDSA,
+ * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2, several different keys under
+ * one key id).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
+ * shape -- its err_out is then NOT a statement about what the reference would decide, and the caller must run the
+ * reference path for that item (the cgo shim calls the wrapped crypto/pgp implementation).  Items with
+ * fenced_out[i] = 0 carry the reference's verdict.  None of the path's own writers produce a fenced shape. */
+
 /* ---- CollectiveSignature.Verify, batched (crypto_pgp.go:485-500) ----------------------------- */
 /* For item i: tbs = tbs_blob[tbs_off[i]..], ss.Data = ss_blob[ss_off[i]..], quorum q.
  *   err_out[i]        BFTKV_ERR_NONE (=> the shim sets ss.Completed = true, crypto_pgp.go:494) or
@@ -134,13 +145,13 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
                                 const uint8_t* tbs_blob, const uint64_t* tbs_off,
                                 const uint8_t* ss_blob, const uint64_t* ss_off,
-                                uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out);
+                                uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out, uint8_t* fenced_out);
 /* same, every pointer a DEVICE pointer (inputs already resident in HBM); asynchronous on the
  * context's stream until bftkv_gpu_sync */
 int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
                                     const uint8_t* tbs_blob, const uint64_t* tbs_off,
                                     const uint8_t* ss_blob, const uint64_t* ss_off, uint64_t ss_blob_len,
-                                    uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out);
+                                    uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out, uint8_t* fenced_out);
 int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
 /* PGPCollectiveSignature.Verify returns at the first packet after which q.IsSufficient(verified) holds and never reads the
  * rest of ss.Data (crypto_pgp.go:491-496).  By default the batched call does the same amount of public-key work: per item
@@ -159,22 +170,25 @@ int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* ctx, int on);
 int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
                                const uint8_t* tbs_blob, const uint64_t* tbs_off,
                                const uint8_t* sig_blob, const uint64_t* sig_off,
-                               const uint64_t* cert_key_id, uint8_t* err_out);
+                               const uint64_t* cert_key_id, uint8_t* err_out, uint8_t* fenced_out);
 
 /* ---- micro-batching of concurrent single calls ---------------------------------------------------- */
 /* The reference verifies ONE message per call, concurrently from one goroutine per HTTP request
  * (transport/http/http.go:85,143 -> protocol/server.go:562-620).  A batcher turns such calls into device batches:
  * each call blocks until its batch -- closed after max_items calls or max_wait_us microseconds, whichever comes
- * first -- has been verified.  Thread-safe; buffers are only read for the duration of the call. */
+ * first -- has been verified.  Thread-safe; buffers are only read for the duration of the call.
+ * FAIL-CLOSED: the status byte is written on every path and is a failure (invalid signature / insufficient signatures /
+ * read error) whenever the return code is not 0 -- a caller that only looks at the status can never read "verified" out
+ * of an infrastructure error (allocation failure, stopped batcher, bad handle). */
 typedef struct bftkv_gpu_batcher bftkv_gpu_batcher;
 bftkv_gpu_batcher* bftkv_gpu_batcher_create(bftkv_gpu_ctx* ctx, uint32_t max_items, uint32_t max_wait_us);
 void bftkv_gpu_batcher_destroy(bftkv_gpu_batcher* b);
 /* CollectiveSignature.Verify(tbs, ss, q) (crypto_pgp.go:485-500): *err_out = BFTKV_ERR_NONE / _INSUFFICIENT_SIGNATURES */
 int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const uint8_t* tbs, uint64_t tbs_len,
-                                        const uint8_t* ss, uint64_t ss_len, uint8_t* err_out);
+                                        const uint8_t* ss, uint64_t ss_len, uint8_t* err_out, uint8_t* fenced_out);
 /* Signature.Verify / VerifyWithCertificate (crypto_pgp.go:319-344); cert_key_id NULL = node keyring */
 int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sig,
-                                       uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out);
+                                       uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out, uint8_t* fenced_out);
 /* stats[0] calls served, stats[1] device batches launched, stats[2] largest batch */
 /* One transport message (bftkv_gpu_message_verify for a single caller): blocks until its batch has run.  plain_out
  * receives the literal body (BFTKV_E_NOMEM if plain_cap is too small; msg_len always suffices), fname_out[256] the

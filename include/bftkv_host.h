@@ -102,6 +102,11 @@ typedef struct {
   const uint8_t* data; uint64_t data_len;
 } bftkv_reply;
 
+/* The verification sites below write one status byte per request / write.  Besides the error identities they mirror, an item
+ * that contains a FENCED input shape (include/bftkv_gpu.h "fenced inputs") reports BFTKV_HOST_ERR_FENCED: no verdict is
+ * claimed for it, the caller runs the reference path. */
+#define BFTKV_HOST_ERR_FENCED 0xFC
+
 /* Client.collectSignatures fold + final verification (client.go:139-169), for a batch of writes.
  * For write w the replies are replies[reply_off[w] .. reply_off[w+1]) in arrival order; each reply's
  * data is a serialized SignaturePacket (packet.ParseSignature).  The fold appends with Combine

@@ -116,7 +116,7 @@ typedef struct {
   int sig_type, pk_algo, hash_id;
   const uint8_t* prefix; int prefix_len;      /* first 6+hl body bytes */
   uint8_t tag[2];
-  int have_issuer; uint64_t issuer; int have_ctime;
+  int have_issuer; uint64_t issuer; int have_ctime; int have_embedded;
   const uint8_t* mpi[2]; int mpi_len[2];
 } psig;
 
@@ -137,7 +137,7 @@ static int parse_subpackets(const uint8_t* a, int len, int hashed, psig* s, int 
     int bl = ln - 1;
     p += ln;
     switch (typ) {
-      case 2: if (!hashed) break; if (bl != 4) return 0; s->have_ctime = 1; break;
+      case 2: if (!hashed) return 0; /* "signature creation time in non-hashed area" */ if (bl != 4) return 0; s->have_ctime = 1; break;
       case 3: case 9: if (!hashed) break; if (bl != 4) return 0; break;
       case 11: case 21: case 22: case 30: break;
       case 16:
@@ -149,10 +149,13 @@ static int parse_subpackets(const uint8_t* a, int len, int hashed, psig* s, int 
       case 25: if (!hashed) break; if (bl != 1) return 0; break;
       case 27: case 29: if (!hashed) break; if (bl == 0) return 0; break;
       case 32: {
-        if (!hashed) break;
-        if (depth >= 2) return 0;
+        /* embedded signature: either area, at most one, must parse and be a primary-key binding (0x19) */
+        if (s->have_embedded) return 0;
+        s->have_embedded = 1;
+        if (depth >= 2) return 0;   /* nesting bound shared with the kernels (deeper: fenced, tests skip such items) */
         psig tmp;
         if (!parse_body(body, bl, &tmp, depth + 1)) return 0;
+        if (tmp.sig_type != 0x19) return 0;
         break;
       }
       default: if (critical) return 0;

@@ -128,6 +128,7 @@ class Signature:
     flag_sign: bool = False
     is_primary_id: Optional[bool] = None
     revocation_reason: Optional[int] = None
+    embedded: Optional["Signature"] = None
 
 
 def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
@@ -156,7 +157,7 @@ def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
         body = sub[1:]
         if typ == 2:  # creation time
             if not hashed:
-                continue
+                raise StructuralError("signature creation time in non-hashed area")
             if len(body) != 4:
                 raise StructuralError("signature creation time not four bytes")
             sig.creation_time = int.from_bytes(body, "big")
@@ -200,10 +201,14 @@ def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
         elif typ == 30:  # features
             if not hashed:
                 continue
-        elif typ == 32:  # embedded signature: parsed recursively by the reference
-            if not hashed:
-                continue
-            parse_signature_body(body)
+        elif typ == 32:
+            # embedded signature (cross-certification of a signing subkey; gpg puts it in the UNHASHED area): parsed
+            # recursively from either area; a second one and any type other than primary-key binding are refused
+            if sig.embedded is not None:
+                raise StructuralError("Cannot have multiple embedded signatures")
+            sig.embedded = parse_signature_body(body)
+            if sig.embedded.sig_type != 0x19:
+                raise StructuralError("cross-signature has unexpected type %d" % sig.embedded.sig_type)
         else:
             if critical:
                 raise UnsupportedError("unknown critical signature subpacket type %d" % typ)

@@ -600,7 +600,12 @@ def test_hashed_area_variants(gpu_ctx):
     ct = b"\x05\x02" + struct.pack(">I", cb.CREATION_TIME)
     iss = lambda k: b"\x09\x10" + struct.pack(">Q", k.key_id)
     notation = lambda n: bytes([192 + ((n + 1 - 192) >> 8), (n + 1 - 192) & 0xFF, 20]) + b"n" * n if n + 1 >= 192 else bytes([n + 1, 20]) + b"n" * n
-    inner = cb.detach_sign(other, b"inner")[3:]          # an embedded signature body
+    inner = cb.detach_sign(other, b"inner")[3:]          # an embedded signature body (type 0x00: not a cross-certification)
+    inner19 = cb.sig_prefix(0x19, other.algo, ct + iss(other)) + b"\x00\x00\xab\xcd" + cb.go_mpi_bytes(b"\x5a" * 256)
+
+    def sub(typ, body):
+        n = len(body) + 1
+        return (bytes([n]) if n < 192 else bytes([((n - 192) >> 8) + 192, (n - 192) & 0xFF])) + bytes([typ]) + body
     cases = {
         "plain": (ct + iss(kp), b""),
         "notation": (ct + notation(30) + iss(kp), b""),
@@ -615,8 +620,14 @@ def test_hashed_area_variants(gpu_ctx):
         "ctime-unhashed-only": (iss(kp), ct),
         "bad-ctime-len": (b"\x04\x02\x00\x00\x01" + iss(kp), b""),
         "zero-len-subpacket": (ct + b"\x00" + iss(kp), b""),
-        "embedded-sig": (ct + bytes([len(inner) + 1, 32]) + inner + iss(kp), b"") if len(inner) + 1 < 192 else (ct + iss(kp), b""),
+        "embedded-sig": (ct + sub(32, inner) + iss(kp), b""),
         "embedded-garbage": (ct + b"\x05\x20abcd" + iss(kp), b""),
+        # the cross-certification shape gpg emits for signing subkeys: a 0x19 signature, usually in the UNHASHED area
+        "embedded-0x19": (ct + sub(32, inner19) + iss(kp), b""),
+        "embedded-0x19-unhashed": (ct + iss(kp), sub(32, inner19)),
+        "embedded-twice": (ct + sub(32, inner19) + iss(kp), sub(32, inner19)),
+        "embedded-wrong-type-unhashed": (ct + iss(kp), sub(32, inner)),
+        "ctime-both-areas": (ct + iss(kp), ct),
         "key-flags+expiry": (ct + b"\x02\x1b\x03" + b"\x05\x03\x00\x00\x10\x00" + b"\x05\x09\x00\x00\x20\x00" + iss(kp), b""),
         "truncated-subpacket": (ct + b"\x30\x14abc", b""),
     }
@@ -643,6 +654,137 @@ def test_hashed_area_variants(gpu_ctx):
     assert outcome["plain"] and outcome["notation"] and outcome["two-octet-len"] and outcome["five-octet-len"] and outcome["issuer-unhashed"]
     assert outcome["issuer-twice"] and not outcome["issuer-twice-rev"] and outcome["unknown-noncritical"] and outcome["key-flags+expiry"]
     assert not outcome["unknown-critical"] and not outcome["no-issuer"] and not outcome["ctime-unhashed-only"] and not outcome["embedded-garbage"]
+    assert outcome["embedded-0x19"] and outcome["embedded-0x19-unhashed"] and not outcome["embedded-twice"]
+    assert not outcome["embedded-wrong-type-unhashed"] and not outcome["ctime-both-areas"] and not outcome["embedded-sig"]
+    assert not gpu_ctx.last_fenced.any()
+
+
+def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
+    """include/bftkv_gpu.h "fenced inputs": shapes the reference accepts and the kernels do not follow raise the item's
+    fenced_out flag (the shim then takes the reference path); ordinary failures -- bad values, unknown issuers, hash-tag
+    mismatches, parse errors -- never do.  The fenced packets here are VALID signatures by clique members, i.e. exactly the
+    inputs on which a silent verdict would disagree with a Go replica."""
+    import hashlib
+    import struct
+    cl = cb.make_cluster(4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    tbs = b"the signed payload of the fence test"
+    good = [cb.detach_sign(r, tbs) for r in cl.replicas]
+    kp = cl.replicas[0]
+    ct = b"\x05\x02" + struct.pack(">I", cb.CREATION_TIME)
+    iss = b"\x09\x10" + struct.pack(">Q", kp.key_id)
+
+    def v4(sig_type=0, hash_id=8, value=None, hashed=None, h=hashlib.sha256, nest=None):
+        hashed = (ct + iss) if hashed is None else hashed
+        prefix = bytes([4, sig_type, kp.algo, hash_id]) + struct.pack(">H", len(hashed)) + hashed
+        digest = h(tbs + cb.hash_suffix(prefix)).digest()
+        sval = kp.rsa_private(cb.emsa(digest, 256)) if value is None else value
+        sb_ = sval.to_bytes(max(256, (sval.bit_length() + 7) // 8), "big")
+        return prefix + b"\x00\x00" + digest[:2] + cb.go_mpi_bytes(sb_)
+    # SignatureV3 (RFC 4880 5.2.2): hashed material = type || creation time, no trailer
+    d3 = hashlib.sha256(tbs + bytes([0]) + struct.pack(">I", cb.CREATION_TIME)).digest()
+    v3 = (bytes([3, 5, 0]) + struct.pack(">I", cb.CREATION_TIME) + struct.pack(">Q", kp.key_id) + bytes([kp.algo, 8]) + d3[:2] +
+          cb.go_mpi_bytes(kp.rsa_private(cb.emsa(d3, 256)).to_bytes(256, "big")))
+    body = v4()
+    partial = bytes([0xC2, 0xE0 + 7]) + body[:128] + cb._hdr(2, len(body) - 128)[1:] + body[128:]      # 2^7-byte first chunk
+    indeterminate = bytes([0x80 | (2 << 2) | 3]) + body
+    deep = v4()
+    for _ in range(3):                                                                             # embedded nesting depth 3
+        n = len(deep) + 1
+        enc = bytes([((n - 192) >> 8) + 192, (n - 192) & 0xFF]) if n >= 192 else bytes([n])
+        hashed = ct + iss + enc + bytes([32]) + deep
+        deep = bytes([4, 0x19, kp.algo, 8]) + struct.pack(">H", len(hashed)) + hashed + b"\x00\x00\x00\x00" + cb.go_mpi_bytes(b"\x01" * 256)
+    fenced_cases = {
+        "v3": cb._hdr(2, len(v3)) + v3,
+        "partial-length": partial,
+        "indeterminate-length": indeterminate,
+        "text-mode": cb._hdr(2, len(v4(sig_type=1))) + v4(sig_type=1),
+        "md5": cb._hdr(2, len(v4(hash_id=1, h=hashlib.md5))) + v4(hash_id=1, h=hashlib.md5),
+        "value-beyond-R": cb._hdr(2, len(v4(value=kp.rsa_private(5) + (1 << 2200)))) + v4(value=kp.rsa_private(5) + (1 << 2200)),
+        "nesting-3": cb._hdr(2, len(deep)) + deep,
+    }
+    bad_mpi = bytearray(good[1]); bad_mpi[-7] ^= 2
+    bad_tag = bytearray(good[2]); bad_tag[len(bad_tag) - 260] ^= 0x40
+    plain_cases = {
+        "all-good": b"".join(good),
+        "bad-value": bytes(bad_mpi) + good[0] + good[2] + good[3],
+        "bad-tag": bytes(bad_tag) + good[0],
+        "unknown-issuer": cb.detach_sign(cl.outsiders[0], tbs) + b"".join(good),
+        "garbage": b"\x01\x02\x03",
+        "unknown-packet-type": bytes([0xC0 | 60, 3]) + b"abc" + b"".join(good),
+        "empty": b"",
+        "non-0x00-type": cb._hdr(2, len(v4(sig_type=2))) + v4(sig_type=2),          # hashForSignature refuses it in the reference too
+        "truncated": good[0][:100],
+    }
+    names = list(fenced_cases) + list(plain_cases)
+    ss_l = [fenced_cases[n] + good[1] + good[2] + good[3] for n in fenced_cases] + [plain_cases[n] for n in plain_cases]
+    tb, to = _cat([tbs] * len(ss_l))
+    sb, so = _cat(ss_l)
+    for early in (True, False):
+        gpu_ctx.set_early_exit(early)
+        err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+        fenced = gpu_ctx.last_fenced.copy()
+        for i, n in enumerate(names):
+            assert fenced[i] == (1 if n in fenced_cases else 0), (n, early, fenced[i])
+            if not fenced[i]:                                  # un-fenced items carry the reference's verdict
+                r = H.oracle_collective(kr, q, type("C", (), {"tbss": lambda self, i: tbs, "ss_data": lambda self, i: ss_l[i]})(), i)
+                assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (n, early)
+    gpu_ctx.set_early_exit(True)
+    # Signature.Verify reports the same flags
+    e1 = gpu_ctx.signature_verify(tb, to, sb, so)
+    assert list(gpu_ctx.last_fenced) == [1 if n in fenced_cases else 0 for n in names] and len(e1) == len(names)
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_two_keys_under_one_key_id(gpu_ctx):
+    """Key ids are 64 bits of a SHA-1: two different keys can be made to share one.  The keyring must load (round 1 refused
+    it, which let any peer that registers such a pair switch the verifier off); signatures naming the id are checked against
+    the first candidate and their items are fenced, everything else is untouched."""
+    cl = cb.make_cluster(4)
+    kr = H.oracle_keyring(cl)
+    keys = H.abi_keys(kr)
+    twin = dict(keys[1])
+    twin["key_id"] = keys[0]["key_id"]                 # replica 1's key material under replica 0's id, after the original
+    twin["entity_id"] = keys[1]["entity_id"]
+    gpu_ctx.keyring_set(keys + [twin])
+    qh = gpu_ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+    tbs = b"collision"
+    s = [cb.detach_sign(r, tbs) for r in cl.replicas]
+    ss_l = [s[0] + s[1] + s[2], s[1] + s[2] + s[3], s[3] + s[2] + s[0]]
+    tb, to = _cat([tbs] * 3)
+    sb, so = _cat(ss_l)
+    err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    assert list(gpu_ctx.last_fenced) == [1, 0, 1] and err[1] == 0 and nver[1] == 3
+    assert err[0] == 0 and err[2] == 0                  # the first candidate is the genuine key: it verifies
+    gpu_ctx.quorum_destroy(qh)
+    gpu_ctx.keyring_set(keys)
+
+
+def test_batcher_fails_closed(gpu_ctx):
+    """An infrastructure error must never read as "verified": the status byte is a failure whenever the return code is
+    not 0 (the shim looked at the status only, and 0 means nil error)."""
+    from bftkv_amd._native import Batcher
+    cl = cb.make_cluster(4)
+    _ring_and_ctx(gpu_ctx, cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+    tbs = b"x"
+    ss = b"".join(cb.detach_sign(r, tbs) for r in cl.replicas)
+    b = Batcher(gpu_ctx, max_items=8, max_wait_us=100)
+    try:
+        assert b.collective_verify(qh, tbs, ss, raw=True) == (0, 0, 0)
+        rc, err, _ = b.collective_verify(qh + 1000, tbs, ss, raw=True)          # no such quorum: the device call fails
+        assert rc != 0 and err == 2
+        gpu_ctx.quorum_destroy(qh)
+        rc, err, _ = b.collective_verify(qh, tbs, ss, raw=True)                 # handle destroyed under the caller
+        assert rc != 0 and err == 2
+        rc, err, _ = b.signature_verify(tbs, cb.detach_sign(cl.replicas[0], tbs), raw=True)
+        assert (rc, err) == (0, 0)
+        rc, err, fenced = b.signature_verify(tbs, b"", raw=True)
+        assert rc == 0 and err == 1 and fenced == 0
+    finally:
+        b.close()
 
 
 def test_verdict_bitmap_pack_unpack_on_device(gpu_ctx):
