@@ -516,12 +516,24 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   std::vector<uint32_t> new_slots, new_rows;
   assign(new_slots, new_rows);
   const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
-  const uint32_t want_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : (c->dsa_comb_slot.size() > 4096 ? 4u : 8u);
+  // window width by DSA population: 16 bits (637 MB and <= 32 table multiplications per signature) while the tables of all
+  // keys fit a quarter of the free HBM and there are at most 64 of them, 8 bits (4.96 MB, <= 64) up to 4096 keys, 4 beyond
+  auto policy = [&](size_t n_keys) -> uint32_t {
+    if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
+    if (n_keys <= 64) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+          (n_keys + 1) * dsa_slot_stride(16) * sizeof(uint32_t) * 3 / 2 < (free_b + c->dsa_comb.cap) / 4)
+        return 16u;
+    }
+    return n_keys > 4096 ? 4u : 8u;
+  };
+  const uint32_t want_wbits = policy(c->dsa_comb_slot.size());
   bool restart = false;
   if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256) {   // width change, or mostly stale: restart
     restart = true;
     c->dsa_comb_slot.clear();
-    c->dsa_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : (live > 4096 ? 4u : 8u);
+    c->dsa_wbits = policy(live);
     assign(new_slots, new_rows);
   }
   int rc;
@@ -546,9 +558,10 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
                              rows[new_rows[k]]->qpow.data(), DSA_QTAIL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   DevBuf d_slots, d_rows;
   if ((rc = upload(c, d_slots, new_slots)) || (rc = upload(c, d_rows, new_rows))) { d_slots.release(); d_rows.release(); return rc; }
-  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * (256u / c->dsa_wbits);
+  const uint32_t parts = c->dsa_wbits == 16 ? 16u : 1u;
+  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * (256u / c->dsa_wbits) * parts;
   hipLaunchKernelGGL(k_dsa_build_comb, dim3((n_quads + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
-                     (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>());
+                     (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
   hipError_t e = hipStreamSynchronize(c->stream);
   d_slots.release(); d_rows.release();
   if (e != hipSuccess) return fail(c, BFTKV_E_DEVICE, "k_dsa_build_comb", e);
@@ -608,6 +621,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->n_keys = (uint32_t)key_id.size();
   c->kt.n_keys = c->n_keys;
   c->kt.n_limbs = c->k_n.as<uint32_t>();
+  c->kt.r2_limbs = c->k_r2.as<uint32_t>();          // k_dsa_build_comb reads n, R^2, n0inv and the table seeds
   c->kt.n0inv = c->k_n0.as<uint32_t>();
   c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
   if ((rc = sync_dsa_tables(c, rows, algo, bits))) return rc;
@@ -735,7 +749,7 @@ int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* c, int on) {
 }
 
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
-  if (!c || (bits != 0 && bits != 4 && bits != 8)) return BFTKV_E_INVALID;
+  if (!c || (bits != 0 && bits != 4 && bits != 8 && bits != 16)) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->dsa_wbits_pinned = bits;
   return 0;

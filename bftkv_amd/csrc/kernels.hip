@@ -1069,28 +1069,32 @@ __global__ void __launch_bounds__(64) k_dsa_mul(SigRec* __restrict__ recs, const
   for (int i = 0; i < 8; ++i) o[i] = u1.w[i];
 }
 
-// Fixed-base window tables for one DSA key (see KeyTableDev::dsa_comb).  One quad per (slot, base, window):
-// B = seed^(2^(wbits*w)) by repeated squaring, then the entries B, B^2, ... by repeated multiplication.
+// Fixed-base window tables for one DSA key (see KeyTableDev::dsa_comb).  One quad per (slot, base, window, part):
+// B = seed^(2^(wbits*w)) by repeated squaring; the part's first entry B^(d0) by square-and-multiply over d0; then the
+// part's entries by repeated multiplication with B.  `parts` splits the 2^wbits - 1 digits of a window so that the 16-bit
+// layout (65,535 entries per window) is built by 16x more quads with 16x shorter chains.
 // Runs once per new DSA key (bftkv_gpu_keyring_set / certificate upload), never on the verify path.
 __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, const uint32_t* __restrict__ new_slots /*[n_new]*/,
                                                               const uint32_t* __restrict__ slot_key /*[n_new] key table row*/,
-                                                              KeyTableDev kt, uint32_t* __restrict__ comb) {
+                                                              KeyTableDev kt, uint32_t* __restrict__ comb, uint32_t parts) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
   const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
-  const uint32_t n_quads = n_new * 2u * nwin;
+  const uint32_t n_quads = n_new * 2u * nwin * parts;
   const uint32_t quad = threadIdx.x >> 2;
   const int qlane = threadIdx.x & 3;
   const uint32_t gq0 = blockIdx.x * QUADS_PER_BLOCK + quad;
   const bool active = gq0 < n_quads;
   const uint32_t gq = active ? gq0 : (n_quads - 1);
-  const uint32_t which = gq / (2u * nwin), base = (gq / nwin) & 1u, w = gq % nwin;
+  const uint32_t part = gq % parts, gw = gq / parts;
+  const uint32_t which = gw / (2u * nwin), base = (gw / nwin) & 1u, w = gw % nwin;
   const uint32_t key = slot_key[which];
   uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
   const uint32_t* a_rd = a_sh + quad * MONT_N;
-  uint32_t n[L], b[L], y[L], t[L];
+  uint32_t n[L], b[L], y[L], t[L], one[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
   const uint32_t* sp = kt.dsa_tab + ((uint64_t)key * 2 + base) * MONT_N + qlane * L;
+  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = np[k]; y[k] = sp[k]; }
   const uint32_t n0inv = kt.n0inv[key];
@@ -1106,14 +1110,42 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, co
       for (int k = 0; k < L; ++k) y[k] = t[k];
     }
   }
+  // y = B.  Digits of this part: d0 .. d0 + per - 1 (digit 0 has no entry); b = B^d0 in Montgomery form
+  const uint32_t per = (nent + 1u) / parts;               // 2^wbits / parts
+  const uint32_t d0 = part * per;
+  // one = R mod p = mont(1, R^2)
+#pragma unroll
+  for (int k = 0; k < L; ++k) { a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; b[k] = rp[k]; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  mont_mul(one, a_rd, b, n, n0inv, qlane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int k = 0; k < L; ++k) b[k] = one[k];
+  for (int bit = (int)wbits - 1; bit >= 0; --bit) {         // b = B^d0, left-to-right (uniform trip count, per-quad select)
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = b[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = 0; k < L; ++k) { b[k] = t[k]; a_lds[k] = y[k]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((d0 >> bit) & 1u) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) b[k] = t[k];
+    }
+  }
   uint32_t* out = comb + (uint64_t)new_slots[which] * dsa_slot_stride(wbits) + ((uint64_t)(base * nwin + w) * nent) * MONT_N + qlane * L;
 #pragma unroll
-  for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }       // a = B for the whole chain
+  for (int k = 0; k < L; ++k) a_lds[k] = y[k];       // a = B for the whole chain
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (uint32_t d = 0; d < nent; ++d) {
-    if (active) {
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t d = d0 + j;                        // entry index d - 1 holds B^d
+    if (active && d >= 1) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) out[(uint64_t)d * MONT_N + k] = b[k];
+      for (int k = 0; k < L; ++k) out[(uint64_t)(d - 1) * MONT_N + k] = b[k];
     }
     mont_mul(t, a_rd, b, n, n0inv, qlane);
 #pragma unroll
