@@ -881,7 +881,9 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      mont_mul<L, TPI>(y, a_rd, b, n, n0inv, qlane);
+      // 16 of the 18 products of e = 65537 are squarings: half the a*b limb products (mont28.h, SQR)
+      if (kind == OP_SQR) mont_mul<L, TPI, true>(y, a_rd, b, n, n0inv, qlane);
+      else mont_mul<L, TPI, false>(y, a_rd, b, n, n0inv, qlane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // ---- next step (scalar control flow)
       if (kind == OP_TO_MONT && (e_u & (e_u - 1u)) != 0 && !(sc_u && __builtin_popcount(e_u) == 2)) {
@@ -1321,7 +1323,8 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_modexp(uint32_t n_ops, const uint
       ard = x_rd;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(t, ard, b, n, n0inv, qlane);
+    if (step >= 0 && step < 2 * nbits && (step & 1) == 0) mont_mul<L, MONT_TPI, true>(t, ard, b, n, n0inv, qlane);   // y * y
+    else mont_mul(t, ard, b, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (step == -2) {
 #pragma unroll
