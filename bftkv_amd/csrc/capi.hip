@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
-                 const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr) {
+                 const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0) {
   // plan_q (CollectiveSignature.Verify with the early exit enabled): public-key work is queued in two phases by k_plan
   // instead of by the parse -- see kernels.hip "two-phase planning".
   // upload_tbs (host-buffer entry point): the signed payloads are still in host memory.  Only the hash stream reads them,
@@ -252,7 +252,10 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
   HIPCHK(c, c->item_flags.ensure(n_items + 16));
-  HIPCHK(c, c->walk_scratch.ensure(sizeof(WalkEnt) * WALK_CAP * (size_t)n_items + 16));
+  // walk scratch row: sized from the average stream length (a packet event needs >= 2 stream bytes, a signature ~100..300);
+  // items with more events than the row holds take the sequential fill pass
+  const uint32_t walk_cap = ss_len ? (uint32_t)std::min<uint64_t>(WALK_CAP_MAX, std::max<uint64_t>(WALK_CAP_MIN, ss_len / n_items / 48)) : 96u;
+  HIPCHK(c, c->walk_scratch.ensure(sizeof(WalkEnt) * walk_cap * (size_t)n_items + 16));
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
@@ -266,7 +269,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (!upload_tbs)
     hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>());
+                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>(), walk_cap);
   constexpr uint32_t MAIL_EMPTY = 0xFFFFFFFFu;
   if (c->h_mail) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
@@ -304,11 +307,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
   // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr);
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr, walk_cap);
   if (total) {
     ParseArgs pa;
     pa.sig_blob = d_ss; pa.sig_off = d_ss_off; pa.rec_base = c->base.as<uint32_t>(); pa.counts = c->counts.as<uint32_t>(); pa.n_items = n_items;
-    pa.scratch = c->walk_scratch.as<WalkEnt>(); pa.recs = c->recs.as<SigRec>(); pa.n_recs = total; pa.cert_ent = d_cert_ent;
+    pa.scratch = c->walk_scratch.as<WalkEnt>(); pa.walk_cap = walk_cap; pa.recs = c->recs.as<SigRec>(); pa.n_recs = total; pa.cert_ent = d_cert_ent;
     pa.pk_list = c->pk_list.as<uint32_t>(); pa.pk_list3072 = c->pk_list3072.as<uint32_t>(); pa.pk_list4096 = c->pk_list4096.as<uint32_t>();
     pa.pk_count = c->pk_count.as<uint32_t>(); pa.dsa_list = c->dsa_list.as<uint32_t>(); pa.item_hash_mask = c->hash_mask.as<uint32_t>();
     pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
@@ -329,7 +332,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     int min_suff = 0;
     for (int i = 0; i < plan_q->n_qcs; ++i) if (plan_q->suff[i] > 0 && (min_suff == 0 || plan_q->suff[i] < min_suff)) min_suff = plan_q->suff[i];
     pl.margin = 1u + (uint32_t)min_suff / 64u;
-    hipLaunchKernelGGL(k_plan<1>, dim3((n_items + 3) / 4), dim3(256), 0, s, pl, c->kt, *plan_q);
+    hipLaunchKernelGGL(k_plan<1>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   if (total && c->have_dsa_keys) {
@@ -347,7 +350,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
       hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                          c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
-      hipLaunchKernelGGL(k_digest_other, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
+      hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                          c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
     }
     HIPCHK(c, hipEventRecord(c->ev[6], sh));
@@ -412,7 +415,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                        n_items, c->kt, *plan_q, c->o_verdict.as<uint8_t>(), c->o_nver.as<uint32_t>(), (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_plan_snapshot, dim3(1), dim3(64), 0, s, cnt_p);
     pl.verdict = c->o_verdict.as<uint8_t>();
-    hipLaunchKernelGGL(k_plan<2>, dim3((n_items + 3) / 4), dim3(256), 0, s, pl, c->kt, *plan_q);
+    hipLaunchKernelGGL(k_plan<2>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
     const uint32_t* const start1 = cnt_p + 8;
     if (c->have_dsa_keys)
       hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start1,
@@ -828,7 +831,7 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
 
 static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                  uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs) {
+                                  uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs, uint64_t ss_len) {
   // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
@@ -837,7 +840,7 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
   const QuorumDev qd = quorum_dev(c, q);
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
@@ -860,10 +863,9 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
 int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                     const uint8_t* ss, const uint64_t* ss_off, uint64_t ss_len, uint8_t* err_out,
                                     uint32_t* nver_out, uint8_t* verdict_out, uint8_t* fenced_out) {
-  (void)ss_len;
   if (!c) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
-  return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, nullptr);
+  return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, nullptr, ss_len);
 }
 
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
@@ -896,7 +898,7 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   };
   int rc = collective_verify_impl(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
                                   c->in_ss_off.as<uint64_t>(), c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>(),
-                                  fenced_out ? c->o_fenced.as<uint8_t>() : nullptr, &upload_tbs);
+                                  fenced_out ? c->o_fenced.as<uint8_t>() : nullptr, &upload_tbs, sl);
   if (rc) return rc;
   if (fenced_out) HIPCHK(c, hipMemcpyAsync(fenced_out, c->o_fenced.p, n_items, hipMemcpyDeviceToHost, c->stream));
   if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, c->o_err.p, n_items, hipMemcpyDeviceToHost, c->stream));
@@ -938,7 +940,7 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
     d_cls = c->sig_class.as<uint8_t>();
   }
   int rc = run_pipeline(c, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
-                        c->in_ss_off.as<uint64_t>(), d_cert, d_cls);
+                        c->in_ss_off.as<uint64_t>(), d_cert, d_cls, nullptr, nullptr, nullptr, nullptr, sl);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sigverify_fold, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(),
                      c->base.as<uint32_t>(), c->counts.as<uint32_t>(), c->item_flags.as<uint8_t>(), n_items, c->o_err.as<uint8_t>());

@@ -1,7 +1,7 @@
 // HIP kernels of the bftkv batched quorum verifier (gfx950 / MI355X only).
 //
 //   k_walk<COUNT|FILL>    wave per item: speculative walk of the OpenPGP packet HEADERS of the signature stream
-//                         (x/crypto packet.Read framing) -> one event per packet (scratch row, or SigRec when > 96)
+//                         (x/crypto packet.Read framing) -> one event per packet (scratch row, or SigRec when the row is full)
 //   k_scan_counts         exclusive scan of per-item event counts; the total also goes to a pinned host mailbox
 //   k_parse_body[_items]  per packet: Signature.parse (subpackets, MPIs), KeysByIdUsage lookup (bisection), every
 //                         check that does not need the digest; queues public-key work (RSA by size class, DSA)
@@ -260,7 +260,9 @@ __device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t 
 // (offset of the body relative to the item's stream, body length, status), so that the fill pass is a
 // parallel thread-per-packet expansion instead of a second sequential walk.  Items with more events
 // (n = 256 cliques carry 171) fall back to the sequential k_walk<true>.
-constexpr uint32_t WALK_CAP = 96;
+// (the row length is chosen per call by the host from the average stream length: WALK_CAP_MIN .. WALK_CAP_MAX)
+constexpr uint32_t WALK_CAP_MIN = 32, WALK_CAP_MAX = 320;
+constexpr uint32_t DIGEST_OTHER_MAX_BLOCKS = 4096;
 struct WalkEnt { uint32_t body_rel; uint32_t body_len_status; };   // len in the low 24 bits, status in the high 8
 
 // One WAVE per item.  A packet stream is a chain -- the position of packet j+1 is known only after the header of
@@ -273,7 +275,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                              uint32_t n_items, uint32_t* __restrict__ counts,
                                              const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
-                                             uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch) {
+                                             uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch, uint32_t WALK_CAP) {
   const uint32_t item = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   if (item >= n_items) return;
@@ -357,7 +359,7 @@ __device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
 struct ParseArgs {
   const uint8_t* sig_blob; const uint64_t* sig_off; const uint32_t* rec_base; const uint32_t* counts; uint32_t n_items;
-  const WalkEnt* scratch; SigRec* recs; uint32_t n_recs; const uint32_t* cert_ent;
+  const WalkEnt* scratch; uint32_t walk_cap; SigRec* recs; uint32_t n_recs; const uint32_t* cert_ent;
   uint32_t *pk_list, *pk_list3072, *pk_list4096;
   uint32_t* pk_count;          // [0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096, [4] some hash other than SHA-256
   uint32_t* dsa_list; uint32_t* item_hash_mask;
@@ -378,6 +380,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
   const uint8_t* __restrict__ sig_class = a.sig_class; const uint32_t* __restrict__ msg_slot = a.msg_slot;
   const uint8_t* __restrict__ msg_hash = a.msg_hash; const uint8_t* __restrict__ item_flags = a.item_flags;
   SigRec rec;
+  const uint32_t WALK_CAP = a.walk_cap;
   if (counts[item] <= WALK_CAP && !(item_flags[item] & 2)) {
     const WalkEnt e = scratch[(uint64_t)item * WALK_CAP + (ri - rec_base[item])];
     rec.body_off = sig_off[item] + e.body_rel; rec.body_len = e.body_len_status & 0xFFFFFFu; rec.item = item; rec.key_slot = -1;
@@ -706,8 +709,9 @@ template <bool OTHERS>   // false: SHA-256 only (the path's default, light on re
 __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                             const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                             const uint64_t* __restrict__ mid64, uint32_t n_items,
-                                            SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/) {
-  uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+                                            SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/,
+                                            uint32_t ri_in) {
+  const uint32_t ri = ri_in;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_HASH) return;
@@ -779,7 +783,7 @@ __global__ void __launch_bounds__(256) k_digest_sha256(const uint8_t* __restrict
                                                        const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                        const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                        uint32_t n_recs, uint32_t* __restrict__ digests) {
-  digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests);
+  digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, blockIdx.x * blockDim.x + threadIdx.x);
 }
 // Every other hash.  Capped at 128 VGPRs (4 waves/SIMD): on the default workload this kernel is a grid of
 // immediate exits that runs BESIDE k_rsa_modexp (2 x 190 VGPRs per SIMD) -- with its natural 198 VGPRs it could
@@ -790,7 +794,10 @@ __global__ void __launch_bounds__(256, 4) k_digest_other(const uint8_t* __restri
                                                          uint32_t n_recs, uint32_t* __restrict__ digests,
                                                          const uint32_t* __restrict__ any_other /*set by k_parse_body*/) {
   if (*any_other == 0) return;        // every signature of the batch is SHA-256 (the path's default): nothing to read
-  digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests);
+  // bounded grid (the host launches at most DIGEST_OTHER_MAX_BLOCKS blocks): normally this kernel has nothing to do, and a
+  // grid of one block per 256 records -- 104k blocks for a cfg-4 batch -- spent 40 ms just being dispatched beside the modexp
+  for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n_recs; ri += (uint64_t)gridDim.x * blockDim.x)
+    digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, (uint32_t)ri);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1455,19 +1462,26 @@ struct PlanArgs {
   uint32_t margin;
 };
 
+// One wave per item, 16 items per block.  Work-list slots come from ONE atomic per block and list: every wave first counts
+// what it will queue, the block prefix-sums the counts in LDS, then the waves write.  (Allocating per 64-packet chunk
+// with one atomic per wave made this kernel nothing but a queue of same-address atomics: ~11 ns each, 4.3 ms for the
+// 500k chunks of a cfg-4 batch.)
+constexpr int PLAN_BLOCK = 1024, PLAN_ITEMS = PLAN_BLOCK / 64;
 template <int PHASE>
-__global__ void __launch_bounds__(256) k_plan(PlanArgs a, KeyTableDev kt, QuorumDev q) {
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63;
-  if (wave >= a.n_items) return;
-  const uint32_t base = a.rec_base[wave], cnt = a.counts[wave];
+__global__ void __launch_bounds__(PLAN_BLOCK) k_plan(PlanArgs a, KeyTableDev kt, QuorumDev q) {
+  __shared__ uint32_t cnt_sh[PLAN_ITEMS][4];
+  const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t item = blockIdx.x * PLAN_ITEMS + wib;
+  const bool have = item < a.n_items;
+  const uint32_t base = have ? a.rec_base[item] : 0, cnt = have ? a.counts[item] : 0;
   uint32_t* const lists[4] = {a.pk_list, a.dsa_list, a.pk_list3072, a.pk_list4096};
   const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // ---- pass A: which records does this item queue?  [from, covered) restricted to candidates (PHASE 2: still pending)
+  uint32_t from = 0, covered = cnt;
   if (PHASE == 1) {
     uint32_t cq[MAX_QC];
 #pragma unroll
     for (int c = 0; c < MAX_QC; ++c) cq[c] = 0;
-    uint32_t covered = cnt;
     bool done = false;
     for (uint32_t off = 0; off < cnt && !done; off += 64) {
       const uint32_t i = off + lane;
@@ -1476,12 +1490,11 @@ __global__ void __launch_bounds__(256) k_plan(PlanArgs a, KeyTableDev kt, Quorum
         kind = a.recs[base + i].q_kind1;
         if (kind) ent = kt.entity[a.recs[base + i].key_slot];
       }
-      const bool cand = kind != 0;
       bool reached = false;
 #pragma unroll
       for (int c = 0; c < MAX_QC; ++c) {
         if (c < q.n_qcs) {
-          const bool mem = cand && q.member[(uint64_t)c * q.n_entities + ent];
+          const bool mem = kind != 0 && q.member[(uint64_t)c * q.n_entities + ent];
           const uint64_t mm = __builtin_amdgcn_ballot_w64(mem);
           const uint32_t run = cq[c] + (uint32_t)__builtin_popcountll(mm & below) + (mem ? 1u : 0u);
           if (mem && q.suff[c] > 0 && run >= (uint32_t)q.suff[c] + a.margin) reached = true;
@@ -1489,38 +1502,60 @@ __global__ void __launch_bounds__(256) k_plan(PlanArgs a, KeyTableDev kt, Quorum
         }
       }
       const uint64_t rm = __builtin_amdgcn_ballot_w64(reached);
-      uint32_t last = 63;
-      if (rm) { last = (uint32_t)__builtin_ctzll(rm); done = true; covered = off + last + 1; }
-      const bool want = cand && lane <= last;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool mine = want && kind == (uint32_t)k + 1;
-        const uint32_t idx = wave_alloc(a.pk_count + k, mine);
-        if (mine) { a.recs[base + i].pk_idx = idx; a.recs[base + i].queued = 1; lists[k][idx] = base + i; }
-      }
+      if (rm) { done = true; covered = off + (uint32_t)__builtin_ctzll(rm) + 1; }
     }
-    if (lane == 0) a.plan_cut[wave] = covered;
   } else {
-    if (a.verdict[wave] & V_IS_SUFFICIENT) return;
-    const uint32_t from = a.plan_cut[wave];
-    for (uint32_t off = from; off < cnt; off += 64) {
-      const uint32_t i = off + lane;
-      uint32_t kind = 0;
-      bool want = false;
-      if (i < cnt) {
-        const SigRec r = a.recs[base + i];
-        kind = r.q_kind1;
-        want = kind != 0 && !r.queued && r.status == ST_PENDING_RSA;     // hash tag matched (the hash stream has been joined)
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool mine = want && kind == (uint32_t)k + 1;
-        const uint32_t idx = wave_alloc(a.pk_count + k, mine);
-        if (mine) { a.recs[base + i].pk_idx = idx; a.recs[base + i].queued = 1; lists[k][idx] = base + i; }
-      }
-    }
-    if (lane == 0) a.plan_cut[wave] = cnt;
+    from = have ? a.plan_cut[item] : 0;
+    if (!have || (a.verdict[item] & V_IS_SUFFICIENT)) from = covered;     // nothing left to do for this item
   }
+  auto wants = [&](uint32_t i, uint32_t& kind) -> bool {
+    kind = 0;
+    if (i >= covered) return false;
+    if (PHASE == 1) { kind = a.recs[base + i].q_kind1; return kind != 0; }
+    const SigRec r = a.recs[base + i];
+    kind = r.q_kind1;
+    return kind != 0 && !r.queued && r.status == ST_PENDING_RSA;          // hash tag matched (the hash stream has been joined)
+  };
+  uint32_t n_k[4] = {0, 0, 0, 0};
+  for (uint32_t off = from; off < covered; off += 64) {
+    uint32_t kind;
+    const bool w = wants(off + lane, kind);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) n_k[k] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w && kind == (uint32_t)k + 1));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt_sh[wib][k] = n_k[k];
+  }
+  __syncthreads();
+  // ---- block allocation: thread k < 4 owns list k
+  if (threadIdx.x < 4) {
+    uint32_t tot = 0;
+    for (int w = 0; w < PLAN_ITEMS; ++w) { const uint32_t v = cnt_sh[w][threadIdx.x]; cnt_sh[w][threadIdx.x] = tot; tot += v; }
+    const uint32_t b0 = tot ? atomicAdd(a.pk_count + threadIdx.x, tot) : 0u;
+    for (int w = 0; w < PLAN_ITEMS; ++w) cnt_sh[w][threadIdx.x] += b0;
+  }
+  __syncthreads();
+  // ---- pass B: write
+  uint32_t run_k[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) run_k[k] = cnt_sh[wib][k];
+  for (uint32_t off = from; off < covered; off += 64) {
+    const uint32_t i = off + lane;
+    uint32_t kind;
+    const bool w = wants(i, kind);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool mine = w && kind == (uint32_t)k + 1;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+      if (mine) {
+        const uint32_t idx = run_k[k] + (uint32_t)__builtin_popcountll(m & below);
+        a.recs[base + i].pk_idx = idx; a.recs[base + i].queued = 1; lists[k][idx] = base + i;
+      }
+      run_k[k] += (uint32_t)__builtin_popcountll(m);
+    }
+  }
+  if (have && lane == 0) a.plan_cut[item] = (PHASE == 1) ? covered : cnt;
 }
 
 // the work-list lengths at the end of phase 1 become phase 2's start offsets

@@ -1,0 +1,84 @@
+package pgpgpu
+
+/*
+#include "bftkv_gpu.h"
+*/
+import "C"
+
+import (
+	"github.com/yahoo/bftkv/crypto"
+	"github.com/yahoo/bftkv/node"
+	"github.com/yahoo/bftkv/packet"
+	"github.com/yahoo/bftkv/quorum"
+)
+
+// CollectiveSignature replaces pgp.PGPCollectiveSignature (crypto/pgp/crypto_pgp.go:476-519).
+type CollectiveSignature struct {
+	g       *gpu
+	inner   crypto.CollectiveSignature
+	keyring *keyring
+}
+
+// Verify replaces PGPCollectiveSignature.Verify (crypto_pgp.go:485-500); call sites protocol/server.go:182,237,300,473,
+// protocol/client.go:165,470, api/api.go:130.
+func (cs *CollectiveSignature) Verify(tbs []byte, ss *packet.SignaturePacket, q quorum.Quorum) error {
+	h, err := cs.g.quorumHandle(q)
+	if err != nil {
+		return cs.inner.Verify(tbs, ss, q) // a quorum this package cannot describe: the reference path decides
+	}
+	var e, fenced C.uint8_t
+	rc := C.bftkv_gpu_batcher_collective_verify(cs.g.batcher, h, ptr(tbs), C.uint64_t(len(tbs)), ptr(ss.Data), C.uint64_t(len(ss.Data)), &e, &fenced)
+	if rc != 0 {
+		// infrastructure error: never a verdict.  (The status byte is a failure too -- the library fails closed.)
+		return cs.g.infra(rc, "collective_verify")
+	}
+	if fenced != 0 {
+		// ss.Data holds a shape the kernels do not follow (SignatureV3, partial lengths, MD5, ...): x/crypto decides
+		return cs.inner.Verify(tbs, ss, q)
+	}
+	if e == C.BFTKV_ERR_NONE {
+		ss.Completed = true // crypto_pgp.go:494: the client serialises it afterwards (client.go:102), servers store it
+		return nil
+	}
+	return crypto.ErrInsufficientNumberOfSignatures // crypto/crypto.go:19; compared by identity and by string (X-error)
+}
+
+// Combine replaces crypto_pgp.go:506-515: append, then IsSufficient over the CLAIMED signers (the real check is Verify).
+func (cs *CollectiveSignature) Combine(ss, s *packet.SignaturePacket, q quorum.Quorum) bool {
+	if ss.Type == packet.SignatureTypeNil {
+		ss.Type = s.Type
+	} else if ss.Type != s.Type {
+		return false
+	}
+	ss.Data = append(ss.Data, s.Data...)
+	return q.IsSufficient(cs.Signers(ss))
+}
+
+// Sign needs the node's private key: crypto/pgp (crypto_pgp.go:502-504).
+func (cs *CollectiveSignature) Sign(tbs []byte) (*packet.SignaturePacket, error) { return cs.inner.Sign(tbs) }
+
+// Signers replaces crypto_pgp.go:517-519 -> PGPSignature.Signers (:373-390): parse-only walk, issuers looked up among the
+// primary key ids of the keyring (getCertById).
+func (cs *CollectiveSignature) Signers(ss *packet.SignaturePacket) []node.Node {
+	return signers(cs.g, cs.keyring, ss, cs.inner.Signers)
+}
+
+func signers(g *gpu, kr *keyring, ss *packet.SignaturePacket, fallback func(*packet.SignaturePacket) []node.Node) []node.Node {
+	if ss == nil || len(ss.Data) == 0 {
+		return nil
+	}
+	off := [2]C.uint64_t{0, C.uint64_t(len(ss.Data))}
+	capIds := len(ss.Data)/12 + 1 // a signature packet is never shorter than 12 bytes
+	ids := make([]C.uint64_t, capIds)
+	var idsOff [2]C.uint64_t
+	if rc := C.bftkv_gpu_signers(g.ctx, 1, ptr(ss.Data), &off[0], &ids[0], &idsOff[0], C.uint64_t(capIds)); rc != 0 {
+		return fallback(ss)
+	}
+	var nodes []node.Node
+	for _, id := range ids[:int(idsOff[1])] {
+		if n := kr.GetCertById(uint64(id)); n != nil {
+			nodes = append(nodes, n)
+		}
+	}
+	return nodes
+}

@@ -1,0 +1,178 @@
+package pgpgpu
+
+/*
+#include <stdlib.h>
+#include "bftkv_gpu.h"
+*/
+import "C"
+
+import (
+	"crypto/dsa"
+	"crypto/rsa"
+	"math/big"
+	"sync"
+	"unsafe"
+
+	"golang.org/x/crypto/openpgp"
+	"golang.org/x/crypto/openpgp/packet"
+
+	"github.com/yahoo/bftkv/crypto"
+	"github.com/yahoo/bftkv/node"
+)
+
+// keyring wraps crypto/pgp's PGPKeyring.  PGPKeyring.getKeyring() -- secring entities first, then keyring
+// (crypto_pgp.go:195-197) -- is unexported, so the wrapper watches Register / Remove (crypto_pgp.go:142-177) to keep the
+// same two lists and re-uploads the device key table after every change.
+type keyring struct {
+	inner crypto.Keyring
+	g     *gpu
+
+	mu      sync.Mutex
+	secring openpgp.EntityList
+	pubring openpgp.EntityList
+}
+
+func upsert(ring openpgp.EntityList, nodes []node.Node) openpgp.EntityList {
+	for _, n := range nodes {
+		e := n.Instance().(*openpgp.Entity)
+		found := false
+		for i := range ring {
+			if ring[i].PrimaryKey.KeyId == e.PrimaryKey.KeyId {
+				ring[i] = e
+				found = true
+				break
+			}
+		}
+		if !found {
+			ring = append(ring, e)
+		}
+	}
+	return ring
+}
+
+func (k *keyring) Register(nodes []node.Node, priv bool, self bool) error {
+	if err := k.inner.Register(nodes, priv, self); err != nil {
+		return err
+	}
+	k.mu.Lock()
+	defer k.mu.Unlock()
+	if priv {
+		k.secring = upsert(k.secring, nodes) // crypto_pgp.go:153-155
+	} else {
+		k.pubring = upsert(k.pubring, nodes) // crypto_pgp.go:156-158
+	}
+	return k.sync()
+}
+
+func (k *keyring) Remove(nodes []node.Node) {
+	k.inner.Remove(nodes)
+	k.mu.Lock()
+	defer k.mu.Unlock()
+	var kept openpgp.EntityList
+	for _, e := range k.pubring {
+		drop := false
+		for _, n := range nodes {
+			if n.Id() == e.PrimaryKey.KeyId {
+				drop = true
+			}
+		}
+		if !drop {
+			kept = append(kept, e)
+		}
+	}
+	k.pubring = kept
+	_ = k.sync()
+}
+
+func (k *keyring) GetCertById(id uint64) node.Node { return k.inner.GetCertById(id) }
+func (k *keyring) GetKeyring() []node.Node         { return k.inner.GetKeyring() }
+
+// private entities (the decrypt half of Message stays on the CPU)
+func (k *keyring) privateKeys() openpgp.EntityList {
+	k.mu.Lock()
+	defer k.mu.Unlock()
+	return append(openpgp.EntityList{}, k.secring...)
+}
+
+// usable reproduces what EntityList.KeysByIdUsage(id, packet.KeyFlagSign) filters on: entity not revoked, self-signature
+// not a revocation, key flags absent or containing Sign.
+func usable(e *openpgp.Entity, self *packet.Signature) bool {
+	if len(e.Revocations) > 0 {
+		return false
+	}
+	if self == nil {
+		return true
+	}
+	if self.RevocationReason != nil {
+		return false
+	}
+	return !self.FlagsValid || self.FlagSign
+}
+
+func primarySelfSig(e *openpgp.Entity) *packet.Signature {
+	for _, id := range e.Identities {
+		if id.SelfSignature != nil && id.SelfSignature.IsPrimaryId != nil && *id.SelfSignature.IsPrimaryId {
+			return id.SelfSignature
+		}
+	}
+	for _, id := range e.Identities { // first identity otherwise (Entity.primaryIdentity)
+		return id.SelfSignature
+	}
+	return nil
+}
+
+// sync uploads getKeyring() order to the device (bftkv_gpu_keyring_set).  Key material is copied into C memory: a C
+// struct that holds pointers may not point into Go memory.
+func (k *keyring) sync() error {
+	var keys []C.bftkv_gpu_pubkey
+	var frees []unsafe.Pointer
+	defer func() {
+		for _, p := range frees {
+			C.free(p)
+		}
+	}()
+	cbytes := func(b []byte) (*C.uint8_t, C.uint32_t) {
+		if len(b) == 0 {
+			return nil, 0
+		}
+		p := C.CBytes(b)
+		frees = append(frees, p)
+		return (*C.uint8_t)(p), C.uint32_t(len(b))
+	}
+	add := func(e *openpgp.Entity, pk *packet.PublicKey, self *packet.Signature) {
+		var rec C.bftkv_gpu_pubkey
+		rec.key_id = C.uint64_t(pk.KeyId)
+		rec.entity_id = C.uint64_t(e.PrimaryKey.KeyId)
+		rec.pk_algo = C.uint8_t(pk.PubKeyAlgo)
+		if usable(e, self) {
+			rec.usable_sign = 1
+		}
+		switch pub := pk.PublicKey.(type) {
+		case *rsa.PublicKey:
+			rec.n, rec.n_len = cbytes(pub.N.Bytes())
+			rec.e, rec.e_len = cbytes(big.NewInt(int64(pub.E)).Bytes())
+		case *dsa.PublicKey:
+			rec.n, rec.n_len = cbytes(pub.P.Bytes())
+			rec.e, rec.e_len = cbytes(pub.Q.Bytes())
+			rec.g, rec.g_len = cbytes(pub.G.Bytes())
+			rec.y, rec.y_len = cbytes(pub.Y.Bytes())
+		default:
+			// ECDSA / ElGamal / unknown: uploaded without material; signatures naming the key are fenced
+		}
+		keys = append(keys, rec)
+	}
+	for _, ring := range []openpgp.EntityList{k.secring, k.pubring} {
+		for _, e := range ring {
+			add(e, e.PrimaryKey, primarySelfSig(e))
+			for i := range e.Subkeys {
+				add(e, e.Subkeys[i].PublicKey, e.Subkeys[i].Sig)
+			}
+		}
+	}
+	var p *C.bftkv_gpu_pubkey
+	if len(keys) > 0 {
+		// the array itself lives in Go memory; its pointer FIELDS point to C memory (allowed)
+		p = &keys[0]
+	}
+	return k.g.infra(C.bftkv_gpu_keyring_set(k.g.ctx, p, C.uint32_t(len(keys))), "keyring_set")
+}

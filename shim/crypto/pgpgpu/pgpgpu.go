@@ -1,0 +1,90 @@
+// Package pgpgpu plugs libbftkv_gpu.so (include/bftkv_gpu.h) into bftkv's crypto.Crypto bundle
+// (crypto/crypto.go:103-111): Signature, CollectiveSignature and Message come from the GPU library, everything
+// that needs a private key -- and every input shape the library fences -- stays with crypto/pgp.
+//
+// Use it where the reference calls pgp.New() (cmd/bftkv/main.go:66, api/api.go:37, scripts/test.go:61):
+//
+//	crypt := pgpgpu.New(0)          // device ordinal
+//
+// This file set is written against bftkv @ go.mod:8 (golang.org/x/crypto v0.0.0-20191227163750-53104e6ec876) and
+// needs shim/patches/0001-wotqs-export-cliques.patch.  It is NOT compiled in this repository (the build image has no
+// Go toolchain); the same C entry points are driven by tests/ through ctypes and by tests/c_harness/harness.c.
+package pgpgpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -lbftkv_gpu
+#include <stdlib.h>
+#include "bftkv_gpu.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"sync"
+	"unsafe"
+
+	"github.com/yahoo/bftkv/crypto"
+	"github.com/yahoo/bftkv/crypto/pgp"
+)
+
+// gpu is one verifier context plus its micro-batcher (bftkv_gpu_batcher_*: the reference verifies one message per
+// goroutine, transport/http/http.go:85,143; the batcher turns concurrent calls into device batches).
+type gpu struct {
+	ctx     *C.bftkv_gpu_ctx
+	batcher *C.bftkv_gpu_batcher
+
+	qmu    sync.Mutex
+	quorum map[string]C.int // quorum descriptor -> handle, see quorum.go
+	qorder []string
+}
+
+var errNoDevice = errors.New("pgpgpu: no usable MI355X (bftkv_gpu_init failed); there is no CPU fallback inside the library")
+
+// New mirrors pgp.New() (crypto/pgp/crypto_pgp.go:583-593).
+func New(device int) *crypto.Crypto {
+	c := pgp.New()
+	g := &gpu{quorum: make(map[string]C.int)}
+	if rc := C.bftkv_gpu_init(C.int(device), &g.ctx); rc != 0 {
+		panic(errNoDevice)
+	}
+	// 256 calls or 200 us, whichever comes first (INTEGRATION.md section 2)
+	g.batcher = C.bftkv_gpu_batcher_create(g.ctx, 256, 200)
+	if g.batcher == nil {
+		panic("pgpgpu: bftkv_gpu_batcher_create failed")
+	}
+	kr := &keyring{inner: c.Keyring, g: g}
+	c.Keyring = kr
+	// crypto/pgp's other objects were built around the original keyring by pgp.New(); they keep using it
+	// (same underlying *PGPKeyring), this wrapper only observes Register / Remove.
+	c.Signature = &Signature{g: g, inner: c.Signature}
+	c.CollectiveSignature = &CollectiveSignature{g: g, inner: c.CollectiveSignature, keyring: kr}
+	c.Message = &Message{g: g, inner: c.Message, keyring: kr}
+	return c
+}
+
+// Close releases the device context (the reference has no teardown hook; call it from main's defer).
+func Close(c *crypto.Crypto) {
+	if kr, ok := c.Keyring.(*keyring); ok {
+		C.bftkv_gpu_batcher_destroy(kr.g.batcher)
+		C.bftkv_gpu_destroy(kr.g.ctx)
+	}
+}
+
+// ptr returns the address of the first byte (nil for an empty slice).  The library reads the buffer for the duration of
+// the call only and keeps nothing (cgo pointer rules).
+func ptr(b []byte) *C.uint8_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
+}
+
+// infra turns a negative return code into an error that is NOT one of the crypto.Err* identities: callers such as
+// protocol.Server answer it as an internal failure, never as a verdict.
+func (g *gpu) infra(rc C.int, what string) error {
+	if rc == 0 {
+		return nil
+	}
+	return errors.New("pgpgpu: " + what + ": " + C.GoString(C.bftkv_gpu_last_error(g.ctx)))
+}

@@ -1,11 +1,21 @@
 /* Plain-C caller of libbftkv_gpu.so through the headers under include/ only -- the position a cgo preamble is in.
  *   gcc -std=c99 -I include tests/c_harness/harness.c -L bftkv_amd -lbftkv_gpu -o harness
  * Without a GPU the verifier context cannot be created (and nothing falls back to the CPU); the host-side
- * entry points (packet framing, trust graph, quorum system) run anywhere.  With a GPU (argv[1] = "gpu") it also
- * uploads a keyring-less context and runs an empty batch.  Prints KEY=VALUE lines for tests/test_c_harness.py. */
+ * entry points (packet framing, trust graph, quorum system) run anywhere.  With a GPU (argv[1] = "gpu") it uploads the
+ * 4-key ring of fixture.h, creates the clique quorum and verifies the fixture's 8 signed writes twice: as one batch
+ * (bftkv_gpu_collective_verify) and one by one through the micro-batcher, the way one goroutine per request would; it also
+ * provokes an infrastructure error to show that the status byte fails closed.  Prints KEY=VALUE lines for
+ * tests/test_c_harness.py, which checks them against the oracle. */
 #include <stdio.h>
 #include <string.h>
 #include "bftkv_host.h"
+#include "fixture.h"
+
+static void print_u8(const char* key, const uint8_t* v, int n) {
+  printf("%s=", key);
+  for (int i = 0; i < n; ++i) printf("%s%u", i ? "," : "", (unsigned)v[i]);
+  printf("\n");
+}
 
 int main(int argc, char** argv) {
   bftkv_gpu_ctx* ctx = NULL;
@@ -51,10 +61,57 @@ int main(int argc, char** argv) {
   bftkv_host_graph_free(g);
 
   if (argc > 1 && strcmp(argv[1], "gpu") == 0 && ctx) {
-    uint64_t off0[1] = {0};
-    rc = bftkv_gpu_keyring_set(ctx, NULL, 0);
-    printf("gpu keyring_set_rc=%d\n", rc);
-    (void)off0;
+    /* keyring: the replicas in order (secring-first order is the caller's business, crypto_pgp.go:195-197) */
+    bftkv_gpu_pubkey keys[FX_N_KEYS];
+    memset(keys, 0, sizeof keys);
+    for (int i = 0; i < FX_N_KEYS; ++i) {
+      keys[i].key_id = fx_key_id[i]; keys[i].entity_id = fx_key_id[i]; keys[i].pk_algo = 1; keys[i].usable_sign = 1;
+      keys[i].n = fx_key_n + 256 * i; keys[i].n_len = 256;
+      keys[i].e = fx_key_e + 4 * i; keys[i].e_len = 4;
+    }
+    rc = bftkv_gpu_keyring_set(ctx, keys, FX_N_KEYS);
+    printf("gpu_keyring_set_rc=%d\n", rc);
+    bftkv_gpu_qc clique;
+    clique.f = FX_F; clique.min = FX_MIN; clique.threshold = FX_THRESHOLD; clique.suff = FX_SUFF;
+    clique.node_ids = fx_key_id; clique.n_nodes = FX_N_KEYS;
+    int qh = -1;
+    rc = bftkv_gpu_quorum_create(ctx, &clique, 1, &qh);
+    printf("gpu_quorum_create_rc=%d\n", rc);
+    /* CollectiveSignature.Verify over all writes in one batch (crypto_pgp.go:485-500) */
+    uint8_t err[FX_N_WRITES], verdict[FX_N_WRITES], fenced[FX_N_WRITES];
+    uint32_t nver[FX_N_WRITES];
+    rc = bftkv_gpu_collective_verify(ctx, qh, FX_N_WRITES, fx_tbss, fx_tbss_off, fx_ss, fx_ss_off, err, nver, verdict, fenced);
+    printf("gpu_verify_rc=%d\n", rc);
+    print_u8("gpu_verify_err", err, FX_N_WRITES);
+    print_u8("gpu_verify_fenced", fenced, FX_N_WRITES);
+    printf("gpu_verify_nver=");
+    for (int i = 0; i < FX_N_WRITES; ++i) printf("%s%u", i ? "," : "", nver[i]);
+    printf("\n");
+    for (int i = 0; i < FX_N_WRITES; ++i)
+      if (err[i] != BFTKV_ERR_NONE) { printf("gpu_first_error_string=%s\n", bftkv_gpu_error_string(err[i])); break; }
+    /* the same writes one call at a time through the micro-batcher */
+    bftkv_gpu_batcher* b = bftkv_gpu_batcher_create(ctx, 4, 100);
+    uint8_t berr[FX_N_WRITES], bfen[FX_N_WRITES];
+    int brc = 0;
+    for (int i = 0; i < FX_N_WRITES; ++i)
+      brc |= bftkv_gpu_batcher_collective_verify(b, qh, fx_tbss + fx_tbss_off[i], fx_tbss_off[i + 1] - fx_tbss_off[i], fx_ss + fx_ss_off[i],
+                                                 fx_ss_off[i + 1] - fx_ss_off[i], &berr[i], &bfen[i]);
+    printf("gpu_batcher_rc=%d\n", brc);
+    print_u8("gpu_batcher_err", berr, FX_N_WRITES);
+    /* Signature.Verify of one packet of write 3 (all of its packets are good) against the node keyring */
+    uint8_t serr = 0xEE, sfen = 0xEE;
+    uint64_t one_off[2];
+    one_off[0] = 0; one_off[1] = 287;
+    uint64_t tb_off[2];
+    tb_off[0] = 0; tb_off[1] = fx_tbss_off[4] - fx_tbss_off[3];
+    rc = bftkv_gpu_signature_verify(ctx, 1, fx_tbss + fx_tbss_off[3], tb_off, fx_ss + fx_ss_off[3], one_off, NULL, &serr, &sfen);
+    printf("gpu_signature_verify=%d,%u,%u\n", rc, (unsigned)serr, (unsigned)sfen);
+    /* infrastructure error: no such quorum -- the return code says so AND the status byte is a failure */
+    uint8_t e_bad = 0, f_bad = 0;
+    int rc_bad = bftkv_gpu_batcher_collective_verify(b, qh + 77, fx_tbss, fx_tbss_off[1], fx_ss, fx_ss_off[1], &e_bad, &f_bad);
+    printf("gpu_fail_closed=%d,%u\n", rc_bad < 0, (unsigned)e_bad);
+    bftkv_gpu_batcher_destroy(b);
+    bftkv_gpu_quorum_destroy(ctx, qh);
   }
   if (ctx) bftkv_gpu_destroy(ctx);
   return 0;

@@ -11,16 +11,54 @@ import __graft_entry__ as ge
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")
-def test_c_caller_links_and_runs(tmp_path):
+def _build_and_run(tmp_path, *args):
     ge.build()
     exe = str(tmp_path / "harness")
     libdir = os.path.join(ROOT, "bftkv_amd")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_harness", "harness.c"),
                     "-L", libdir, "-lbftkv_gpu", "-Wl,-rpath," + libdir, "-o", exe], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    r = subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
-    out = dict(line.split("=", 1) for line in r.stdout.decode().splitlines() if "=" in line)
+    return dict(line.split("=", 1) for line in r.stdout.decode().splitlines() if "=" in line)
+
+
+def test_fixture_header_is_current():
+    """fixture.h is generated: the committed text must be what the committed generator produces."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fixture", os.path.join(ROOT, "tests", "c_harness", "make_fixture.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert open(os.path.join(ROOT, "tests", "c_harness", "fixture.h")).read() == m.render()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")
+def test_c_caller_verifies_on_the_gpu(tmp_path):
+    """A plain C99 caller -- the position of the cgo shim -- uploads a keyring, creates a quorum and verifies signed writes
+    on the MI355X, batched and through the micro-batcher; its verdicts are the oracle's."""
+    import importlib.util
+    from tests import helpers as H
+    spec = importlib.util.spec_from_file_location("make_fixture", os.path.join(ROOT, "tests", "c_harness", "make_fixture.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cl, c = m.corpus()
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    want = [H.oracle_collective(kr, q, c, i) for i in range(c.n_items)]
+    out = _build_and_run(tmp_path, "gpu")
+    assert out["init_rc"] == "0" and out["gpu_keyring_set_rc"] == "0" and out["gpu_quorum_create_rc"] == "0" and out["gpu_verify_rc"] == "0"
+    err = [int(v) for v in out["gpu_verify_err"].split(",")]
+    assert err == [0 if r.err is None else 2 for r in want] and 0 in err and 2 in err
+    assert [int(v) for v in out["gpu_verify_nver"].split(",")] == [len(r.verified) for r in want]
+    assert out["gpu_verify_fenced"] == ",".join(["0"] * c.n_items)
+    assert out["gpu_first_error_string"] == "crypto: insufficient number of signatures"
+    assert out["gpu_batcher_rc"] == "0" and [int(v) for v in out["gpu_batcher_err"].split(",")] == err
+    assert out["gpu_signature_verify"] == "0,0,0"
+    assert out["gpu_fail_closed"] == "1,2"
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")
+def test_c_caller_links_and_runs(tmp_path):
+    out = _build_and_run(tmp_path)
     import torch
     if not torch.cuda.is_available():
         assert int(out["init_rc"]) < 0                      # BFTKV_E_DEVICE: no GPU, and no CPU fallback

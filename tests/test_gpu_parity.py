@@ -262,6 +262,30 @@ def test_golden_gpg_vectors_on_gpu(gpu_ctx):
         assert checked == len(vec[group])
 
 
+def test_negative_gpg_vectors_on_gpu(gpu_ctx):
+    """tests/golden/gpg_negative_vectors.json (hand-built edge cases judged by gpg): the HIP path gives the oracle's verdict
+    on every vector and raises the fence flag exactly on the two fenced shapes among them (SignatureV3, text mode)."""
+    import json
+    import os
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    neg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_negative_vectors.json")))
+    kr = col.Keyring(keyring=pgp.read_entities(bytes.fromhex(neg["pubring"])))
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    payload = bytes.fromhex(neg["payload"])
+    sigs = [bytes.fromhex(v["sig"]) for v in neg["vectors"]]
+    tb, to = _cat([payload] * len(sigs))
+    sb, so = _cat(sigs)
+    err = gpu_ctx.signature_verify(tb, to, sb, so)
+    for v, e, f, s in zip(neg["vectors"], err, gpu_ctx.last_fenced, sigs):
+        want = col.signature_verify(kr, payload, SignaturePacket(1, 0, False, s, None)) is None
+        assert (e == 0) == want, v["name"]
+        assert f == (1 if v["name"] in ("signature-v3", "text-mode") else 0), v["name"]
+        if v["strict"]:
+            assert (e == 0) == v["gpg_good"], v["name"]
+
+
 def test_full_size_properties_cfg2(gpu_ctx, exit_mode):
     """BASELINE configs[1] shape (64 replicas, suff 43) at 1,500 writes / ~80k signatures, signed on the GPU:
     verdicts follow from how the corpus was built -- no oracle in the loop."""

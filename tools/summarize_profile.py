@@ -25,6 +25,8 @@ def main(tag, rnd):
     # 2. HBM counters, one pass each
     def agg(path, counter):
         d = collections.defaultdict(list)
+        if not os.path.exists(path):
+            return {}
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
@@ -39,10 +41,12 @@ def main(tag, rnd):
             tmp[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k in tmp:
             sq[k] = {c: sum(v) / len(v) for c, v in tmp[k].items()}
-    out = {"source": "rocprofv3 separate --pmc passes over `python bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+    plain = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
+    out = {"source": "rocprofv3 separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over the bench command of tools/profile_bench.sh "
+                     "(`python bench.py --config N --steps 5 --warmup 2 --no-cpu-baseline`)",
            "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced "
                          "reads -> doubled; WRITE_SIZE taken as is (uncalibrated); both are KiB per dispatch",
-           "workload": json.load(open(os.path.join(src, "bench_plain.json")))["config"], "kernels": {}}
+           "workload": plain["config"], "kernels": {}}
     with open(os.path.join(dst, "%s_pmc_hbm.csv" % rnd), "w") as f:
         f.write("Kernel,AvgDurationNs,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,HBM_bytes_corrected\n")
         for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
