@@ -44,7 +44,7 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
-    "bftkv_host_server_sign_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
+    "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
 ]
 
@@ -97,6 +97,8 @@ def _lib():
         lib.bftkv_host_certs_entity.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_key.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(_native.PubKey)]
         lib.bftkv_host_server_sign_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        lib.bftkv_host_server_read_proof_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        lib.bftkv_host_server_register_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_equivocation_signers.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.bftkv_host_quorum_cert_verify.argtypes = [vp, vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -505,6 +507,25 @@ class Server:
 
     def __init__(self, ctx: _native.Context):
         self.ctx = ctx
+
+    ErrAuthenticationFailure = 0xFB
+    ErrFenced = 0xFC
+
+    def _site(self, fn, name, q: Quorum, requests: Sequence[bytes]) -> np.ndarray:
+        rb, ro = _cat(requests)
+        err = np.zeros(len(requests), dtype=np.uint8)
+        rc = fn(self.ctx.h, q.h, len(requests), rb.ctypes.data, ro.ctypes.data, err.ctypes.data)
+        if rc:
+            raise _native.NativeError("%s failed: %d" % (name, rc))
+        return err
+
+    def read_proof_verify(self, q_auth: Quorum, requests: Sequence[bytes]) -> np.ndarray:
+        """server.go:181-185 for a batch of read requests carrying a proof."""
+        return self._site(_lib().bftkv_host_server_read_proof_verify, "server_read_proof_verify", q_auth, requests)
+
+    def register_verify(self, q_auth: Quorum, requests: Sequence[bytes]) -> np.ndarray:
+        """server.go:452-475 for a batch of register requests."""
+        return self._site(_lib().bftkv_host_server_register_verify, "server_register_verify", q_auth, requests)
 
     def write_verify(self, q: Quorum, requests: Sequence[bytes]) -> np.ndarray:
         rb, ro = _cat(requests)

@@ -170,6 +170,21 @@ int bftkv_host_quorum_cert_verify(bftkv_gpu_ctx* ctx, const bftkv_quorum* q, con
 int bftkv_host_server_sign_verify(bftkv_gpu_ctx* ctx, const bftkv_quorum* q_cert, uint32_t n_requests,
                                   const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
 
+/* Server.read's proof check for a batch of read requests <x, nil, 0, nil, proof> (server.go:181-185, for variables written
+ * with an authentication attribute): CollectiveSignature.Verify(variable, proof, ChooseQuorum(AUTH)) -- the signed bytes
+ * are the VARIABLE NAME.  err_out: 0 ok, BFTKV_HOST_ERR_AUTH_FAILURE (proof missing or insufficient:
+ * bftkv.ErrAuthenticationFailure), 0xFF malformed, BFTKV_HOST_ERR_FENCED. */
+#define BFTKV_HOST_ERR_AUTH_FAILURE 0xFB
+int bftkv_host_server_read_proof_verify(bftkv_gpu_ctx* ctx, bftkv_quorum* q_auth, uint32_t n_requests,
+                                        const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
+
+/* Server.register's verification site (server.go:452-475): sig and ss both present; Issuer(sig) = first entity of sig.Cert
+ * (ReadEntity-valid); VerifyWithCertificate(TBS(req), sig, issuer); then CollectiveSignature.Verify(variable, ss,
+ * ChooseQuorum(AUTH)).  err_out: 0 ok, BFTKV_ERR_INVALID_SIGNATURE, BFTKV_ERR_INSUFFICIENT_SIGNATURES, 0xFF malformed,
+ * 0xFE crypto.ErrCertificateNotFound, BFTKV_HOST_ERR_FENCED. */
+int bftkv_host_server_register_verify(bftkv_gpu_ctx* ctx, bftkv_quorum* q_auth, uint32_t n_requests,
+                                      const uint8_t* req_blob, const uint64_t* req_off, uint8_t* err_out);
+
 /* Equivocation tally of Client.revoke (client.go:304-353) for one variable: values[v] of replies at the same
  * timestamp t != 0, value group g[v]; ids_out: the signer ids (sorted) that appear, by PARSE ONLY
  * (CollectiveSignature.Signers), under two different value groups. */

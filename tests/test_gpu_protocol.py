@@ -442,3 +442,157 @@ def test_transport_message_signatures(gpu_ctx):
     counts = np.bincount(st, minlength=6)
     assert counts[om.MSG_OK] > 300 and counts[om.MSG_SIGNATURE_ERROR] > 30 and counts[om.MSG_READ_ERROR] > 10
     assert counts[om.MSG_UNVERIFIED] > 10 and counts[om.MSG_NOT_SIGNED] >= 1 and counts[om.MSG_UNSUPPORTED] >= 3
+
+
+def test_write_vote_folds_over_gpu_tallies(gpu_ctx):
+    """SURVEY a24, Client.Write / writeWithTimestamp (protocol/client.go:62-123): every Multicast round is a fold over the
+    replies -- success -> actives, IsThreshold(actives) ends it; failure -> failure, Reject(failure) ends it.  The host
+    mirror's fold (bftkv_host_vote_fold) must stop where the reference's callback returns true, and the predicate values it
+    stops on must be the ones the GPU tally (bftkv_gpu_quorum_tally, k_tally_ids) and the oracle compute for those lists."""
+    cl, og, hg, host = _world(10)
+    og.set_self([cl.client.key_id])
+    hg.SetSelfNodes([cl.client.key_id])
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    for rw in (W.AUTH | W.PEER, W.WRITE | W.AUTH, W.READ | W.AUTH):
+        oq = W.Wot(og).choose_quorum(rw)
+        hq = host.wotqs.New(hg).ChooseQuorum(rw)
+        assert hq.qcs() == [(c.f, c.min, c.threshold, c.suff, c.nodes) for c in oq.qcs]
+        qh = gpu_ctx.quorum_create(hq.qcs())
+        peers = [r.key_id for r in cl.replicas] + [cl.client.key_id, 0xDEAD]
+        rng = np.random.default_rng(rw)
+        rounds = []
+        for _ in range(60):
+            order = rng.permutation(len(peers))[:int(rng.integers(1, len(peers) + 1))]
+            p_fail = float(rng.choice([0.0, 0.1, 0.5, 0.9]))
+            rounds.append([(peers[int(i)], bool(rng.random() >= p_fail)) for i in order])
+        consumed, thr = host.Client.vote_fold(hq, rounds)
+        ids, off = [], [0]
+        want_consumed, want_thr = [], []
+        for rd in rounds:
+            actives, failure, n = [], [], 0
+            for peer, ok in rd:                                  # the reference's callback, reply by reply
+                n += 1
+                if ok:
+                    actives.append(peer)
+                    if oq.is_threshold(actives):
+                        break
+                else:
+                    failure.append(peer)
+                    if oq.reject(failure):
+                        break
+            want_consumed.append(n); want_thr.append(oq.is_threshold(actives))
+            ids += actives; off.append(len(ids)); ids += failure; off.append(len(ids))
+        assert list(consumed) == want_consumed and [bool(t) for t in thr] == want_thr
+        v = gpu_ctx.quorum_tally(qh, np.array(ids + [0], dtype=np.uint64)[:len(ids)], np.array(off, dtype=np.uint64))
+        for k, rd in enumerate(rounds):
+            assert bool(v[2 * k] & 2) == want_thr[k]             # IsThreshold(actives) on the device
+            fails = ids[off[2 * k + 1]:off[2 * k + 2]]
+            assert bool(v[2 * k + 1] & 8) == oq.reject(fails)    # Reject(failure) on the device
+        assert any(want_thr) and not all(want_thr)
+        gpu_ctx.quorum_destroy(qh)
+
+
+def test_read_answers_after_gpu_reply_verification(gpu_ctx):
+    """SURVEY a25, BASELINE configs[2] in small: read replies <x,v,t,sig,ss> of a mixed RSA / DSA clique verified on the GPU,
+    the failures dropped, then maxTimestampedValue per variable through the host mirror (protocol/client.go:181-205) --
+    against the oracle's verdict per reply and its restatement of the read tally."""
+    from bftkv_amd import host
+    cl = cb.make_cluster(8, dsa_fraction=0.5)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    rc = cb.make_read_corpus(cl, 40, seed=3, p_stale=0.3, p_conflict_var=0.2, p_silent=0.1,
+                             mutation_rates={cb.MUT_BAD_MPI: 0.15, cb.MUT_ONE_SHORT: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.1})
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    err, nver, _ = gpu_ctx.collective_verify(qh, rc.tbss_blob, rc.tbss_off, rc.ss_blob, rc.ss_off)
+    ns = len(rc.storage_ids)
+    f = (ns - 1) // 3
+    qc = (f, 3 * f + 1, f + 1, f + (ns - f) // 2 + 1, rc.storage_ids)          # the storage nodes under the READ rule (wotqs.go:36-70)
+    hq = host.Quorum.from_qcs([qc])
+    oq = W.WotQ([W.QC(nodes=list(rc.storage_ids), f=qc[0], min=qc[1], threshold=qc[2], suff=qc[3])])
+    reply_t = rc.write_t[rc.reply_write]
+    reads_gpu, reads_oracle = [], []
+    for j in range(rc.n_vars):
+        rows = np.nonzero(rc.reply_var == j)[0]
+        g, o = [], []
+        for r in rows:
+            w = int(rc.reply_write[r])
+            res = H.oracle_collective(kr, q, rc.writes, w)        # a reply is a byte-identical copy of stored packet w
+            assert (err[r] == 0) == (res.err is None) and nver[r] == len(res.verified), (j, r)
+            row = (int(rc.reply_peer[r]), int(reply_t[r]), rc.write_value[w])
+            if err[r] == 0: g.append(row)
+            if res.err is None: o.append(row)
+        reads_gpu.append(g); reads_oracle.append(o)
+    got = host.Client.max_timestamped_value(hq, reads_gpu)
+    want = [col.max_timestamped_value(rs, oq) for rs in reads_oracle]
+    assert [None if a is None else (a[0], a[1]) for a in got] == [None if b is None else (b[0], b[1]) for b in want]
+    assert any(w is None for w in want) and any(w is not None and w[1] == 2 for w in want) and (err != 0).any()
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_read_proof_and_register_sites(gpu_ctx):
+    """Server.read's proof check (protocol/server.go:181-185: CollectiveSignature.Verify(variable, proof, AUTH) --
+    the signed bytes are the variable NAME) and Server.register (server.go:452-475: VerifyWithCertificate(TBS(req), sig,
+    Issuer(sig)), then CollectiveSignature.Verify(variable, ss, AUTH))."""
+    from oracle import openpgp as pgp
+    cl, og, hg, host = _world(10)
+    me = cl.replicas[0].key_id
+    og.set_self([me])
+    hg.SetSelfNodes([me])
+    oq = W.Wot(og).choose_quorum(W.AUTH)
+    hq = host.wotqs.New(hg).ChooseQuorum(host.AUTH)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    suff = oq.qcs[0].suff
+    rng = np.random.default_rng(29)
+    srv = host.Server(gpu_ctx)
+
+    def proof_for(variable, k, spoil=None):
+        members = [cl.replicas[int(i)] for i in rng.permutation(len(cl.replicas))[:k]]
+        parts = [cb.detach_sign(m, variable) for m in members]
+        if spoil == "value": parts[0] = parts[0][:-4] + bytes([parts[0][-4] ^ 1]) + parts[0][-3:]
+        if spoil == "other-bytes": parts = [cb.detach_sign(m, variable + b"?") for m in members]
+        return b"".join(parts)
+    # ---- read proofs
+    reqs, want = [], []
+    for i in range(20):
+        x = b"authvar%02d" % i
+        kind = i % 5
+        if kind == 0: ss = opk.SignaturePacket(1, 0, True, proof_for(x, suff + 1), None)
+        elif kind == 1: ss = opk.SignaturePacket(1, 0, True, proof_for(x, suff - 1), None)
+        elif kind == 2: ss = opk.SignaturePacket(1, 0, True, proof_for(x, suff, spoil="value"), None)
+        elif kind == 3: ss = opk.SignaturePacket(1, 0, True, proof_for(x, suff + 2, spoil="other-bytes"), None)
+        else: ss = None
+        reqs.append(opk.serialize(x, None, 0, None, ss) if ss is not None else opk.serialize(x, None, 0))
+        if ss is None:
+            want.append(srv.ErrAuthenticationFailure)
+        else:
+            want.append(0 if col.collective_verify(kr, x, ss, oq).err is None else srv.ErrAuthenticationFailure)
+    reqs.append(b"\x00\x00\x00"); want.append(0xFF)
+    got = srv.read_proof_verify(hq, reqs)
+    assert list(got) == want and 0 in want and srv.ErrAuthenticationFailure in want
+    # ---- register
+    reqs, want = [], []
+    for i in range(18):
+        x, v, t = b"regvar%02d" % i, cl.client.entity[:64], i + 1
+        tbs = cb.serialize_tbs(x, v, t)
+        kind = i % 6
+        sigdata, cert = cb.detach_sign(cl.client, tbs), cl.client.entity
+        proof = proof_for(x, suff)
+        if kind == 1: sigdata = cb.detach_sign(cl.client, tbs + b"!")
+        if kind == 2: proof = proof_for(x, suff - 1)
+        if kind == 3: cert = None
+        if kind == 4: proof = None
+        sig = opk.SignaturePacket(1, 0, False, sigdata, cert)
+        ss = opk.SignaturePacket(1, 0, False, proof, None) if proof is not None else None
+        reqs.append(opk.serialize(x, v, t, sig, ss) if ss is not None else opk.serialize(x, v, t, sig))
+        if ss is None:
+            want.append(0xFF)
+        else:
+            ents = pgp.read_entities(cert or b"")
+            if not ents: want.append(0xFE)
+            elif col.signature_verify_with_certificate(tbs, sig, ents[0]) is not None: want.append(1)
+            else: want.append(0 if col.collective_verify(kr, x, ss, oq).err is None else 2)
+    got = srv.register_verify(hq, reqs)
+    assert list(got) == want and set(want) == {0, 1, 2, 0xFE, 0xFF}
