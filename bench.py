@@ -37,11 +37,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Integer roof.  v_mad_u64_u32 is a quarter-rate VALU op: 16 lanes per SIMD and clock.
 INT_MAC_THEORETICAL = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes/clk x max clock (MI355X_MICROARCH.md chip table) = 39.3 T/s
-INT_MAC_MEASURED = 29.1e12     # tools/microbench/valu_rates.hip at 8 waves/SIMD, clock as sustained under that load (profiles/)
+INT_MAC_MEASURED = 29.66e12    # tools/microbench/valu_rates.hip at 8 waves/SIMD: 4.64 issue cycles per wave-instruction at the 2.10 GHz the
+                               # part sustains under an all-MAC load (profiles/r02_valu_issue_rates_microbench.txt)
 RSA_BYTES = 291                # algorithmic bytes per RSA-2048 signature verify
 DSA_BYTES = 99                 # per DSA-2048/256 signature verify
-MACS_PER_RSA_VERIFY = 18 * 2 * 76 * 76     # 18 Montgomery products x (76x76 a*b + 76x76 m*n) limb MACs
-MACS_PER_DSA_VERIFY = 66 * 2 * 76 * 76     # <= 64 table multiplications + entering and leaving the Montgomery domain
+# limb MACs actually executed (mont28.h): a general Montgomery product = 76x76 (a*b) + 76x76 (m*n) = 11,552; a squaring forms
+# only the triangles of a*a: 4 lanes x (4 x 190 + 1,444) = 8,816.  e = 65537: 16 squarings + 2 products.
+MACS_PER_RSA_VERIFY = 16 * 8816 + 2 * 11552
+MACS_PER_DSA_VERIFY = 34 * 11552           # 16-bit windows: <= 32 table multiplications + entering and leaving the Montgomery domain
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -362,47 +365,17 @@ def roofline(cfg, kernel, alg_bytes, launch_ms, note):
 def int_mac(macs, launch_ms, sclk_mhz=None):
     a = macs / (launch_ms * 1e-3) if launch_ms else 0.0
     out = {"achieved": a, "peak": INT_MAC_MEASURED, "frac": a / INT_MAC_MEASURED, "unit": "u32xu32+u64 MAC/s (v_mad_u64_u32 lanes)",
-           "peak_source": "tools/microbench/valu_rates.hip on MI355X, 8 waves/SIMD (profiles/r01_valu_issue_rates_microbench.txt): "
-                          "the rate the part sustains at the clock it settles to under an all-MAC load",
+           "peak_source": "tools/microbench/valu_rates.hip on MI355X, 8 waves/SIMD (profiles/r02_valu_issue_rates_microbench.txt): 4.64 issue "
+                          "cycles per wave64 v_mad_u64_u32 at the 2.10 GHz (s_memtime / s_memrealtime) the part sustains under an all-MAC load",
            "peak_theoretical": INT_MAC_THEORETICAL, "frac_of_theoretical": a / INT_MAC_THEORETICAL,
            "theoretical_source": "256 CU x 4 SIMD x 16 lanes/clk (quarter-rate VALU op) x 2.4 GHz max clock"}
     if sclk_mhz:
-        out["sclk_mhz_during_timed_region"] = sclk_mhz
-        out["peak_at_observed_clock"] = 256 * 4 * 16 * sclk_mhz * 1e6
+        out["sclk_mhz_in_kernel"] = sclk_mhz
+        out["sclk_source"] = "s_memtime / s_memrealtime over the first wave of k_rsa_modexp (bftkv_gpu_last_sclk_mhz)"
+        out["peak_at_observed_clock"] = 256 * 4 * 64 / 4.64 * sclk_mhz * 1e6
         out["frac_at_observed_clock"] = a / out["peak_at_observed_clock"]
+        out["observed_clock_note"] = "4.64 issue cycles per wave64 v_mad_u64_u32 (microbench) at the clock this launch ran at"
     return out
-
-
-class ClockSampler:
-    """Shader clock during the timed region, sampled from rocm-smi on a side thread (rank 0 only; None when unavailable)."""
-
-    def __init__(self):
-        import threading
-        self.samples, self.stop = [], False
-        self.t = threading.Thread(target=self._run, daemon=True)
-
-    def _run(self):
-        import re
-        while not self.stop:
-            try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=5).stdout
-                m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz", out)
-                if m:
-                    self.samples.append(int(m.group(1)))
-            except Exception:
-                return
-            time.sleep(0.05)
-
-    def __enter__(self):
-        self.t.start()
-        return self
-
-    def __exit__(self, *a):
-        self.stop = True
-        self.t.join(timeout=6)
-
-    def mean(self):
-        return float(np.mean(self.samples)) if self.samples else None
 
 
 def timed_region(D, run, steps, warmup, reset=None):
@@ -486,9 +459,8 @@ def bench_cfg2(args, D):
                               "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed}), flush=True)
         return
 
-    with ClockSampler() as clk:
-        elapsed = timed_region(D, V.run, args.steps, args.warmup, V.reset_timing)
-    sclk = clk.mean()
+    elapsed = timed_region(D, V.run, args.steps, args.warmup, V.reset_timing)
+    sclk = V.ctxs[0].last_sclk_mhz()
     timed_rsa, timed_total, timed_hash = list(V.rsa_ms), list(V.total_ms), list(V.hash_ms)
     iso = []
     for _ in range(3):           # phase breakdown of an isolated call: non-overlapped calls on one context
@@ -595,9 +567,8 @@ def bench_cfg3(args, D):
             err = V.outs[0][0].cpu().numpy()            # 1 byte per reply back to the host
             winners[0] = tally(err)
 
-    with ClockSampler() as clk:
-        elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
-    sclk = clk.mean()
+    elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
+    sclk = V.ctxs[0].last_sclk_mhz()
     err, nver, bits = V.results(0)
     gather_ok = V.check_gather(err, bits)
     counters = V.ctxs[0].last_counters()
@@ -709,9 +680,8 @@ def bench_cfg4(args, D):
             for _ in range(calls):                      # the rank's share of the storm, one resident batch at a time
                 V.submit(0); V.complete(0)
 
-    with ClockSampler() as clk:
-        elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
-    sclk = clk.mean()
+    elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
+    sclk = V.ctxs[0].last_sclk_mhz()
     err, nver, bits = V.results(0)
     gather_ok = V.check_gather(err, bits)
     counters = V.ctxs[0].last_counters()

@@ -41,7 +41,7 @@ EXPORTS = [
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
-    "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
+    "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
 ]
 
@@ -98,6 +98,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
     lib.bftkv_gpu_set_early_exit.argtypes = [vp, C.c_int]
+    lib.bftkv_gpu_last_sclk_mhz.argtypes = [vp, C.POINTER(C.c_float)]
     lib.bftkv_gpu_modexp_ops.argtypes = lib.bftkv_gpu_modexp.argtypes
     lib.bftkv_gpu_allgather_errs_dev.argtypes = [vp, u8p, u32, u32, u8p]
     lib.bftkv_gpu_modmul_product_dev.argtypes = lib.bftkv_gpu_modmul_product.argtypes
@@ -260,6 +261,11 @@ class Context:
         c = (C.c_uint64 * 4)()
         self._check(self.lib.bftkv_gpu_last_counters(self.h, c), "last_counters")
         return {"packets": c[0], "pubkey_ops": c[1], "items": c[2], "dsa_ops": c[3]}
+
+    def last_sclk_mhz(self) -> float:
+        v = C.c_float(0)
+        self._check(self.lib.bftkv_gpu_last_sclk_mhz(self.h, C.byref(v)), "last_sclk_mhz")
+        return float(v.value)
 
     def last_timing(self):
         ms = (C.c_float * 8)()

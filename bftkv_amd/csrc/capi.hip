@@ -259,8 +259,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
-  HIPCHK(c, c->pk_count.ensure(64));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256,
-                                       // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start)
+  HIPCHK(c, c->pk_count.ensure(96));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256,
+                                       // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start),
+                                       // [16..19] two uint64: clock stamps of k_rsa_modexp (bftkv_gpu_last_sclk_mhz)
   if (plan_q) HIPCHK(c, c->plan_cut.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
@@ -274,7 +275,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->h_mail) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>(), c->d_mail);
-  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 64, s));
+  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 96, s));
   HIPCHK(c, hipMemsetAsync(c->hash_mask.p, 0, sizeof(uint32_t) * (size_t)n_items, s));
   uint32_t total = MAIL_EMPTY;
   if (c->h_mail) {
@@ -362,14 +363,14 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
   auto launch_modexp = [&](const uint32_t* start) {
     hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
-                       cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>());
+                       cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
     if (c->have_rsa3072)
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L3072, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
-                         cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>());
+                         cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
     if (c->have_rsa4096)
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
-                         cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>());
+                         cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
   if (total) launch_modexp(start0);
   HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -1003,6 +1004,16 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   counters[1] = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
   counters[2] = c->last_items;
   counters[3] = cnt[1];
+  return 0;
+}
+
+int bftkv_gpu_last_sclk_mhz(bftkv_gpu_ctx* c, float* mhz) {
+  if (!c || !mhz) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  uint64_t v[2] = {0, 0};
+  if (c->pk_count.p) HIPCHK(c, hipMemcpy(v, (const char*)c->pk_count.p + 64, 16, hipMemcpyDeviceToHost));
+  *mhz = v[1] ? (float)((double)v[0] / (double)v[1] * 100.0) : 0.0f;
   return 0;
 }
 

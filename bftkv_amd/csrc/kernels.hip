@@ -814,9 +814,14 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
                                                           const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
                                                           const uint32_t* __restrict__ pk_start_ptr,
                                                           KeyTableDev kt, uint32_t* __restrict__ r_limbs,
-                                                          uint32_t* __restrict__ xr_scratch) {
+                                                          uint32_t* __restrict__ xr_scratch, uint64_t* __restrict__ clk) {
   constexpr int NL = TPI * L;
   constexpr int GROUPS = RSA_BLOCK / TPI;      // numbers per block
+  // diagnostics: shader-clock ticks (s_memtime) and constant 100 MHz ticks (s_memrealtime) over the life of block 0's first
+  // wave -- the clock the part actually ran this kernel at (bftkv_gpu_last_sclk_mhz); two scalar reads at each end
+  const bool stamp = clk && blockIdx.x == 0 && threadIdx.x == 0;
+  uint64_t t0 = 0, r0 = 0;
+  if (stamp) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
   __shared__ uint32_t a_sh[GROUPS * NL];
   __shared__ uint32_t x_sh[GROUPS * NL];
   // work = list entries [start, count): phase 1 of a call starts at 0, phase 2 where phase 1 ended (k_plan)
@@ -910,6 +915,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
     }
     todo &= ~__builtin_amdgcn_ballot_w64(live);
   }
+  if (stamp && *pk_start_ptr == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
 // EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); TPI lanes per signature.

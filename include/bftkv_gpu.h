@@ -294,6 +294,10 @@ int bftkv_gpu_modinv_dev(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* valu
 /* ms[0] whole call, ms[1] walk+parse, ms[2] hash stream (midstates+digests, overlaps the modexp),
  * ms[3] k_rsa_modexp, ms[4] tally, ms[5] compare (incl. joining the hash stream), ms[6] k_dsa_mul + k_dsa_modexp */
 int bftkv_gpu_last_timing(bftkv_gpu_ctx* ctx, float ms[8]);
+/* shader clock k_rsa_modexp ran at in the last verify call: s_memtime ticks per s_memrealtime (100 MHz) tick over the life
+ * of its first wave; 0 when the call queued no RSA work.  The part clocks down under an all-MAC load, and the integer roof
+ * of the path moves with it. */
+int bftkv_gpu_last_sclk_mhz(bftkv_gpu_ctx* ctx, float* mhz);
 void* bftkv_gpu_stream(bftkv_gpu_ctx* ctx);   /* hipStream_t of the context */
 
 #ifdef __cplusplus

@@ -1,6 +1,11 @@
 // Micro-benchmark: issue cost of the integer/fp64 VALU instructions a big-integer
 // Montgomery kernel is built from, on gfx950.  Standalone (hipcc), not part of the product.
-// Output: cycles per wave-instruction per SIMD at 1/2/4/8 waves per SIMD.
+// Output per instruction and occupancy (1/2/4/8 waves per SIMD): wall time, chip-wide wave-instructions per second, the
+// SHADER CLOCK during the run -- measured inside the kernel as (s_memtime ticks) / (s_memrealtime ticks) x 100 MHz over the
+// whole life of wave 0 -- and from these the cycles one wave-instruction occupies a SIMD's issue port:
+//     cycles/inst/SIMD = wall_time x sclk / (instructions per wave x waves per SIMD).
+// (Round 1 printed wave 0's own cycle count divided by wall time as "eff clk"; wave 0 does not live for the whole launch at
+// 4 and 8 waves per SIMD, so that column fell with the occupancy and said nothing about the clock.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -22,6 +27,7 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed, unsigned 
   for (int i = 0; i < CHAINS; ++i) lo[i] = seed + i;
   double da = 1.0000001 + seed, db = 0.5;
   unsigned long long t0 = __builtin_readcyclecounter();
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) {
@@ -46,10 +52,11 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed, unsigned 
     }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   uint64_t r = 0;
   for (int i = 0; i < CHAINS; ++i) r += acc[i] + lo[i] + (uint64_t)d[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
-  if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
 }
 
 // single dependent chain, one wave per SIMD: latency
@@ -81,7 +88,7 @@ int main() {
   int cus = prop.multiProcessorCount;
   uint64_t* out; unsigned long long* cyc;
   CHECK(hipMalloc(&out, sizeof(uint64_t) * cus * 8 * 256));
-  CHECK(hipMalloc(&cyc, 8));
+  CHECK(hipMalloc(&cyc, 16));
   struct { const char* name; kern_t fn; } ops[] = {
     {"v_mad_u64_u32", k<0>}, {"v_mul_lo_u32", k<1>}, {"v_mul_hi_u32", k<2>}, {"v_mad_u32_u24", k<3>},
     {"v_mul_hi_u32_u24", k<4>}, {"v_fma_f64", k<5>}, {"v_add_co_u32", k<6>}, {"v_lshrrev_b64", k<7>},
@@ -101,12 +108,13 @@ int main() {
       CHECK(hipEventRecord(e1));
       CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-      unsigned long long c; CHECK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+      unsigned long long c[2]; CHECK(hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost));
       double n_inst_per_wave = (double)ITERS * CHAINS;
-      double cyc_per_inst_simd = (double)c / (n_inst_per_wave * wps);  // cycles per wave-instr per SIMD
+      double sclk = c[1] ? (double)c[0] / (double)c[1] * 100e6 : 0.0;   // s_memrealtime ticks at a constant 100 MHz
+      double cyc_per_inst_simd = (ms * 1e-3) * sclk / (n_inst_per_wave * wps);  // SIMD issue-port cycles per wave-instruction
       double ginst = n_inst_per_wave * blocks * 4 / (ms * 1e-3) / 1e9;  // wave-instr/s
-      printf("%-22s waves/SIMD %d  %.3f ms  wave0 cycles %llu  => %.2f cyc/wave-inst/SIMD  %.1f G wave-inst/s (%.2f T lane-op/s)  eff clk %.2f GHz\n",
-             op.name, wps, ms, c, cyc_per_inst_simd, ginst, ginst * 64 / 1e3, (double)c / (ms * 1e-3) / 1e9);
+      printf("%-22s waves/SIMD %d  %.3f ms  %.1f G wave-inst/s (%.2f T lane-op/s)  sclk %.2f GHz  => %.2f cyc/wave-inst/SIMD  (wave 0 alone: %.2f cyc/inst)\n",
+             op.name, wps, ms, ginst, ginst * 64 / 1e3, sclk / 1e9, cyc_per_inst_simd, (double)c[0] / n_inst_per_wave);
     }
   }
   struct { const char* name; kern_t fn; } lats[] = {
