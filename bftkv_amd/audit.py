@@ -1,4 +1,5 @@
-"""Re-verify a stored bftkv database on the GPU.
+"""Re-verify a stored bftkv database on the GPU: storage/plain directories and storage/leveldb
+databases.
 
 The reference's plain storage keeps every accepted write as a file ``hex(x).t`` holding the request bytes
 ``<x,v,t,sig,ss>`` exactly as Server.write received them (storage/plain/plain.go:48-90, protocol/server.go:348).
@@ -6,7 +7,10 @@ The reference's plain storage keeps every accepted write as a file ``hex(x).t`` 
 (``pubring.gpg`` as cmd/bftkv/main.go:70-71 loads it) and runs the verification site of Server.write
 (server.go:286-302) over all stored writes in device batches.  Product path only: host mirror + C ABI + HIP kernels.
 
-CLI:  python -m bftkv_amd.audit --db DIR --pubring FILE --self KEYID_HEX
+``audit_leveldb_db`` does the same for a storage/leveldb database (storage/leveldb/leveldb.go:30-53: key = variable || t as
+8 big-endian bytes, value = the stored packet), read with bftkv_amd/leveldb_reader.py -- no LevelDB library needed.
+
+CLI:  python -m bftkv_amd.audit --db DIR --pubring FILE --self KEYID_HEX [--kind plain|leveldb]
 """
 from __future__ import annotations
 
@@ -56,17 +60,30 @@ def read_plain_db(db_dir: str) -> List[Tuple[str, bytes, int, bytes]]:
 
 
 def audit_plain_db(ctx: Context, db_dir: str, pubring: bytes, self_id: int, batch: int = 4096) -> List[AuditRecord]:
+    return _audit(ctx, read_plain_db(db_dir), pubring, self_id, batch)
+
+
+def read_leveldb_db(db_dir: str) -> List[Tuple[str, bytes, int, bytes]]:
+    """(label, variable, t, stored bytes) of every entry of a storage/leveldb database."""
+    from . import leveldb_reader
+    return [("%s.%d" % (x.hex(), t), x, t, v) for x, t, v in leveldb_reader.bftkv_records(db_dir)]
+
+
+def audit_leveldb_db(ctx: Context, db_dir: str, pubring: bytes, self_id: int, batch: int = 4096) -> List[AuditRecord]:
+    return _audit(ctx, read_leveldb_db(db_dir), pubring, self_id, batch)
+
+
+def _audit(ctx: Context, files, pubring: bytes, self_id: int, batch: int) -> List[AuditRecord]:
     g, _ = load_ring(ctx, pubring)
     g.SetSelfNodes([self_id])
     q = host.wotqs.New(g).ChooseQuorum(host.AUTH)          # Server.write (server.go:300)
     server = host.Server(ctx)
-    files = read_plain_db(db_dir)
     records: List[AuditRecord] = []
     for lo in range(0, len(files), batch):
         chunk = files[lo:lo + batch]
         err = server.write_verify(q, [c[3] for c in chunk])
         for (path, variable, t, blob), e in zip(chunk, err):
-            status = {0: "ok", 2: "insufficient"}.get(int(e), "malformed")
+            status = {0: "ok", 2: "insufficient", 0xFC: "fenced"}.get(int(e), "malformed")
             if status != "malformed":
                 x, _, pt, _, _, _ = host.packet.Parse(blob)
                 if (x or b"") != variable or pt != t:
@@ -81,11 +98,12 @@ def main():
     ap.add_argument("--pubring", required=True)
     ap.add_argument("--self", dest="self_id", required=True, help="key id (hex) of the auditing node's own certificate")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--kind", choices=("plain", "leveldb"), default="plain")
     args = ap.parse_args()
     ctx = Context(args.device)
     with open(args.pubring, "rb") as f:
         ring = f.read()
-    recs = audit_plain_db(ctx, args.db, ring, int(args.self_id, 16))
+    recs = (audit_plain_db if args.kind == "plain" else audit_leveldb_db)(ctx, args.db, ring, int(args.self_id, 16))
     counts: Dict[str, int] = {}
     for r in recs:
         counts[r.status] = counts.get(r.status, 0) + 1

@@ -785,10 +785,10 @@ __global__ void __launch_bounds__(256) k_digest_sha256(const uint8_t* __restrict
                                                        uint32_t n_recs, uint32_t* __restrict__ digests) {
   digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, blockIdx.x * blockDim.x + threadIdx.x);
 }
-// Every other hash.  Capped at 128 VGPRs (4 waves/SIMD): on the default workload this kernel is a grid of
-// immediate exits that runs BESIDE k_rsa_modexp (2 x 190 VGPRs per SIMD) -- with its natural 198 VGPRs it could
-// not be co-scheduled and would hold the hash stream (and with it the compare) until the modexp drained.
-__global__ void __launch_bounds__(256, 4) k_digest_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+// Every other hash (SHA-1 / 224 / 384 / 512).  Round 1 capped this kernel at 128 VGPRs so that its grid of immediate exits
+// could co-schedule beside k_rsa_modexp, at the price of 510 spilled VGPRs in the SHA-512 path; with the bounded grid
+// below an idle launch costs nothing, so the kernel keeps its natural register count and nothing spills.
+__global__ void __launch_bounds__(256) k_digest_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                          const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                          const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                          uint32_t n_recs, uint32_t* __restrict__ digests,

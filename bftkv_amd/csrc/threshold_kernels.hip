@@ -218,13 +218,16 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
 // global table (4.5 KB per base, written and re-read by the same quad), then 70 windows of 4 shared squarings and at
 // most one table multiplication per base.  28 = 7 * 4, so a window digit never straddles two limbs.
 constexpr int MULTIEXP_WIN = 4, MULTIEXP_ENT = 15;
+// `idx_div`: an operation's bases may be split over idx_div consecutive quads (each takes k_bases of them and yields a
+// partial product that k_modmul_product multiplies up): 10,000 combines are only 625 waves on 1024 SIMDs, and a chain of
+// ~900 dependent products per wave is pure latency; the modulus of quad `op` is then that of operation op / idx_div.
 __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
                                                         const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
                                                         const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][15][76]*/,
-                                                        uint32_t* __restrict__ out_limbs) {
+                                                        uint32_t* __restrict__ out_limbs, uint32_t idx_div) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   QUAD_SETUP();
-  const uint32_t mi = mod_idx[op];
+  const uint32_t mi = mod_idx[op / idx_div];
   uint32_t n[L], r2[L], y[L], t[L];
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
@@ -251,7 +254,9 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
     for (int sq = 0; sq < MULTIEXP_WIN; ++sq) {
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = y[k];
-      MONT(t, y);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      mont_mul<MONT_L, MONT_TPI, true>(t, a_rd, y, n, n0inv, qlane);      // squaring: half the a*b limb products (mont28.h)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int k = 0; k < L; ++k) y[k] = t[k];
     }

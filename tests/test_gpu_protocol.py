@@ -362,6 +362,44 @@ def test_audit_plain_storage_db(gpu_ctx, tmp_path):
     assert got == want and set(want.values()) >= {"ok", "insufficient", "malformed"}
 
 
+def test_audit_leveldb_db(gpu_ctx, tmp_path):
+    """a storage/leveldb database (key = x || t_BE, storage/leveldb/leveldb.go:30-53) -- tables, a live log,
+    overwritten and deleted keys -- read without a LevelDB library and re-verified on the GPU."""
+    import struct
+    from bftkv_amd import audit
+    from corpus.keys import DRBG
+    from tests import leveldb_writer as LW
+    cl = cb.make_cluster(10)
+    rng = DRBG("ring")
+    for r in cl.replicas:
+        cb.build_entity(r, [o for o in cl.replicas if o is not r], rng)
+    pubring = b"".join(r.entity for r in cl.replicas) + cl.client.entity
+    c = cb.make_write_corpus(cl, 24, keep_requests=True, mutation_rates={cb.MUT_ONE_SHORT: 0.25, cb.MUT_BAD_MPI: 0.2})
+    key = lambda x, t: x + struct.pack(">Q", t)
+    table, log, want = [], [], {}
+    for i, req in enumerate(c.requests):
+        x, v, t, sig, ss, _ = opk.parse(req)
+        status = "ok" if c.expected_valid[i] >= cl.suff else "insufficient"
+        blob = req
+        if i == 2: blob, status = req[:40], "malformed"
+        if i == 5: t, status = t + 500, ("name-mismatch" if status == "ok" else status)      # stored under another timestamp
+        name = "%s.%d" % (x.hex(), t)
+        if i % 3 == 0:
+            table.append((key(x, t), 10 + i, 1, b"superseded by the log"))                   # older version in a table ...
+            log.append((100 + i, [(1, key(x, t), blob)]))                                    # ... the log holds the current one
+        elif i % 3 == 1:
+            table.append((key(x, t), 10 + i, 1, blob))
+        else:
+            log.append((100 + i, [(1, key(x, t), blob)]))
+        want[name] = status
+    table.append((key(b"deleted", 1), 9, 1, b"gone"))
+    log.append((900, [(0, key(b"deleted", 1), b"")]))
+    LW.write_db(str(tmp_path / "ldb"), [sorted(table)], log)
+    recs = audit.audit_leveldb_db(gpu_ctx, str(tmp_path / "ldb"), pubring, cl.replicas[2].key_id)
+    got = {r.path: r.status for r in recs}
+    assert got == want and set(want.values()) >= {"ok", "insufficient", "malformed"}
+
+
 def test_transport_message_signatures(gpu_ctx):
     """bftkv_gpu_message_verify == oracle.message.read_signed_message on gpg-made messages, generator-made
     ones judged by gpg, the outcome table, and a mutated batch from a mixed RSA/DSA cluster."""
