@@ -351,8 +351,6 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
       hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
                          c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
-      hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                         c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
     }
     HIPCHK(c, hipEventRecord(c->ev[6], sh));
     return 0;
@@ -381,6 +379,13 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     if ((hrc = hash_stream_work())) return hrc;
   }
   HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
+  // digests of the hashes other than SHA-256: on the MAIN stream, after the modexp.  Normally there are none and the kernel
+  // exits on a device-side flag; at its 203 VGPRs it cannot co-schedule beside k_rsa_modexp, and on the hash stream it sat
+  // there until the modexp drained (1.7 ms per step in the trace) holding back the join.
+  if (total)
+    hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
+                       d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
+                       c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
   const dim3 cg((total * 4 + 255) / 256);
   const dim3 cg8(((uint64_t)total * MONT_TPI_BIG + 255) / 256);
   auto launch_compare = [&](const uint32_t* start) {

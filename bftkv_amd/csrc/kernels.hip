@@ -178,6 +178,42 @@ __host__ __device__ __forceinline__ bool parse_sig_body(const uint8_t* body, uin
   return ok;
 }
 
+// SignatureV3.parse (RFC 4880 5.2.2; x/crypto openpgp/packet/signature_v3.go): version 2 or 3, one octet "5", signature type,
+// creation time, 8-octet issuer key id, public-key and hash algorithm, 16-bit hash tag, MPIs.  The hashed material is the
+// 5 bytes type || creation time (body[2..7)) with NO trailer -- rec.hashed_len stays 0 and SIGF_V3 tells the digest kernels.
+constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2;
+__host__ __device__ __forceinline__ bool parse_sig_body_v3(const uint8_t* body, uint32_t blen, SigRec& rec, uint64_t& issuer) {
+  if (blen < 1 || body[0] < 2 || body[0] > 3) return false;      // "signature packet version"
+  if (blen < 19) return false;
+  if (body[1] != 5) return false;                                 // "invalid hashed material length"
+  rec.sig_type = body[2];
+  issuer = 0;
+  for (int i = 0; i < 8; ++i) issuer = (issuer << 8) | body[7 + i];
+  rec.pk_algo = body[15];
+  rec.hash_id = body[16];
+  if (!(rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY || rec.pk_algo == PK_DSA)) return false;
+  const uint32_t h = rec.hash_id;
+  if (!(h == 1 || h == 2 || h == 3 || (h >= 8 && h <= 11))) return false;
+  rec.hashed_len = 0;
+  rec.hash_tag[0] = body[17];
+  rec.hash_tag[1] = body[18];
+  uint32_t p = 19;
+  const int n_mpi = (rec.pk_algo == PK_DSA) ? 2 : 1;
+  rec.mpi_off[1] = 0;
+  rec.mpi_bits[1] = 0;
+  for (int i = 0; i < n_mpi; ++i) {
+    if (p + 2 > blen) return false;
+    const uint32_t bits = ((uint32_t)body[p] << 8) | body[p + 1];
+    const uint32_t nb = (bits + 7) >> 3;
+    p += 2;
+    if (p + nb > blen) return false;
+    rec.mpi_off[i] = p;
+    rec.mpi_bits[i] = (uint16_t)bits;
+    p += nb;
+  }
+  return true;
+}
+
 // One packet.Read framing step at stream position pos of [.., end): header only.
 struct WalkStep {
   uint64_t next;       // stream position after the packet
@@ -399,11 +435,15 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
   // fence: the packet has a shape on which this library does not claim the reference's outcome (DESIGN.md "fenced inputs");
   // the item's fenced_out flag tells the caller to take the reference path for it
   bool fence = false;
-  if (rec.body_len >= 1 && body[0] < 4) { st = ST_UNSUPPORTED; fence = true; }   // SignatureV3
+  const bool v3 = rec.body_len >= 1 && body[0] < 4;                // packet.Read: version < 4 => *packet.SignatureV3
+  if (v3 && msg_slot) { st = ST_UNSUPPORTED; fence = true; }       // transport messages: a v3 trailing signature stays fenced
   else {
     bool have_issuer = false, too_deep = false;
     uint64_t issuer = 0;
-    if (!parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, &too_deep)) { st = ST_PARSE_ERROR; fence = too_deep; }
+    bool parsed;
+    if (v3) { parsed = parse_sig_body_v3(body, rec.body_len, rec, issuer); have_issuer = parsed; }
+    else parsed = parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, &too_deep);
+    if (!parsed) { st = ST_PARSE_ERROR; fence = too_deep; }
     else if (!have_issuer && !msg_slot) st = ST_NO_ISSUER;
     else {
       // VerifyWithCertificate: the keyring is the single entity of the certificate (crypto_pgp.go:333)
@@ -466,7 +506,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
           else if (vbytes > cap_bytes) { rec.after_tag = ST_BAD_SIG; fence = true; }   // value >= R: the reference reduces it mod n
           else {
             rec.after_tag = AFTER_TAG_PUBKEY;
-            rec.flags = (vbytes > kbytes) ? 1 : 0;
+            rec.flags |= (vbytes > kbytes) ? SIGF_LONG_VALUE : 0;
             q_kind = cls_sz == 0 ? 0 : (int)cls_sz + 1;                         // [0] <=2048, [1] DSA, [2] <=3072, [3] <=4096
           }
         } else if (rec.pk_algo == PK_DSA) {
@@ -480,6 +520,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     }
   }
   if (fence) atomicOr(&item_hash_mask[rec.item], ITEM_FENCED);
+  if (v3) rec.flags |= SIGF_V3;
   rec.q_kind1 = (uint8_t)(q_kind + 1);
   if (!a.defer_queue) {
     // queue the public-key work: one atomic per wave and list
@@ -677,19 +718,20 @@ __global__ void __launch_bounds__(64) k_hash_mid_other(const uint8_t* __restrict
 
 struct TailSrc {
   const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
-  const uint8_t* body; uint32_t pre_len;      // first 6+hl bytes of the signature body
+  const uint8_t* body; uint32_t pre_len;      // v4: first 6+hl bytes of the signature body; v3: type || creation time (5 bytes)
+  uint32_t tr_len;                            // v4: the 6-byte trailer 04 FF len32; v3: none
 };
 __device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j) {
   if (j < t.tail_len) return t.tail[j];
   j -= t.tail_len;
   if (j < t.pre_len) return t.body[j];
   j -= t.pre_len;
-  if (j < 6) {
+  if (j < t.tr_len) {
     if (j == 0) return 0x04;
     if (j == 1) return 0xFF;
     return (t.pre_len >> (8 * (5 - j))) & 0xFF;
   }
-  return (j == 6) ? 0x80 : 0;   // first byte after the message: the padding marker
+  return (j == t.tr_len) ? 0x80 : 0;   // first byte after the message: the padding marker
 }
 
 // value of a big-endian byte string as radix-2^28 limb j
@@ -722,10 +764,12 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   TailSrc ts;
   ts.tail_len = (uint32_t)(tlen & bmask);
   ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
-  ts.body = sig_blob + rec.body_off;
-  ts.pre_len = 6u + rec.hashed_len;
-  const uint32_t rem = ts.tail_len + ts.pre_len + 6;     // message bytes still to hash
-  const uint64_t bits = (tlen + ts.pre_len + 6) * 8;
+  const bool v3 = (rec.flags & SIGF_V3) != 0;
+  ts.body = sig_blob + rec.body_off + (v3 ? 2 : 0);
+  ts.pre_len = v3 ? 5u : 6u + rec.hashed_len;
+  ts.tr_len = v3 ? 0u : 6u;
+  const uint32_t rem = ts.tail_len + ts.pre_len + ts.tr_len;     // message bytes still to hash
+  const uint64_t bits = (tlen + ts.pre_len + ts.tr_len) * 8;
   uint32_t* dg = digests + (uint64_t)ri * 16;
   uint32_t tag_hi;
   if (!OTHERS || hi.family == 32) {

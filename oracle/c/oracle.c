@@ -116,7 +116,7 @@ typedef struct {
   int sig_type, pk_algo, hash_id;
   const uint8_t* prefix; int prefix_len;      /* first 6+hl body bytes */
   uint8_t tag[2];
-  int have_issuer; uint64_t issuer; int have_ctime; int have_embedded;
+  int have_issuer; uint64_t issuer; int have_ctime; int have_embedded; int v3;
   const uint8_t* mpi[2]; int mpi_len[2];
 } psig;
 
@@ -187,6 +187,31 @@ static int parse_body(const uint8_t* b, int n, psig* s, int depth) {
   s->tag[0] = b[p]; s->tag[1] = b[p + 1];
   p += 2;
   int nm = (s->pk_algo == 1 || s->pk_algo == 3) ? 1 : 2;
+  for (int i = 0; i < nm; ++i) {
+    if (p + 2 > n) return 0;
+    int bits = (b[p] << 8) | b[p + 1];
+    int nb = (bits + 7) / 8;
+    p += 2;
+    if (p + nb > n) return 0;
+    s->mpi[i] = b + p; s->mpi_len[i] = nb;
+    p += nb;
+  }
+  return 1;
+}
+
+/* SignatureV3.parse: version 2/3, "5", type, creation time, issuer, algorithms, tag, MPIs; hashed material = body[2..7) */
+static int parse_body_v3(const uint8_t* b, int n, psig* s) {
+  memset(s, 0, sizeof *s);
+  if (n < 1 || b[0] < 2 || b[0] > 3 || n < 19 || b[1] != 5) return 0;
+  s->sig_type = b[2]; s->pk_algo = b[15]; s->hash_id = b[16];
+  s->have_ctime = 1; s->have_issuer = 1; s->issuer = 0;
+  for (int i = 0; i < 8; ++i) s->issuer = (s->issuer << 8) | b[7 + i];
+  if (!(s->pk_algo == 1 || s->pk_algo == 3 || s->pk_algo == 17)) return 0;
+  int h = s->hash_id;
+  if (!(h == 1 || h == 2 || h == 3 || (h >= 8 && h <= 11))) return 0;
+  s->prefix = b + 2; s->prefix_len = 5; s->v3 = 1;
+  s->tag[0] = b[17]; s->tag[1] = b[18];
+  int p = 19, nm = (s->pk_algo == 17) ? 2 : 1;
   for (int i = 0; i < nm; ++i) {
     if (p + 2 > n) return 0;
     int bits = (b[p] << 8) | b[p + 1];
@@ -362,9 +387,10 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
       if (known_tag(tag)) { TRACE(ST_NOT_SIGNATURE); return ST_NOT_SIGNATURE; }
       continue;
     }
-    if (ln >= 1 && sd[start] < 4) { TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
     psig s;
-    if (!parse_body(sd + start, (int)ln, &s, 0)) { TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
+    /* packet.Read peeks the version: < 4 => SignatureV3, else Signature */
+    const int parsed = (ln >= 1 && sd[start] < 4) ? parse_body_v3(sd + start, (int)ln, &s) : parse_body(sd + start, (int)ln, &s, 0);
+    if (!parsed) { TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
     if (!s.have_issuer) { TRACE(ST_NO_ISSUER); return ST_NO_ISSUER; }
     /* KeysByIdUsage(issuer, KeyFlagSign) */
     int found = 0;
@@ -382,7 +408,7 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
       if (k->pk_algo == 2 || k->pk_algo == 16) { st = ST_KEY_CANNOT_SIGN; continue; }   /* checked before the hash is touched */
       uint8_t trailer[6] = {4, 0xFF, 0, 0, (uint8_t)(s.prefix_len >> 8), (uint8_t)s.prefix_len};
       h_update(&hc, s.prefix, s.prefix_len);
-      h_update(&hc, trailer, 6);
+      if (!s.v3) h_update(&hc, trailer, 6);            /* VerifySignatureV3: type || creation time only */
       uint8_t dg[64];
       unsigned dl = h_peek(&hc, dg);
       if (dg[0] != s.tag[0] || dg[1] != s.tag[1]) { st = ST_HASH_TAG; continue; }

@@ -263,6 +263,40 @@ def parse_signature_body(body: bytes) -> Signature:
     return sig
 
 
+def parse_signature_v3_body(body: bytes) -> Signature:
+    """SignatureV3.parse (RFC 4880 5.2.2; x/crypto openpgp/packet/signature_v3.go).  hash_suffix = type || creation time,
+    no trailer (VerifySignatureV3).  gpg 2.2.27 verifies signatures of this construction (tests/golden/gpg_negative_vectors.json)."""
+    if len(body) < 1:
+        raise _Truncated()
+    if body[0] < 2 or body[0] > 3:
+        raise UnsupportedError("signature packet version %d" % body[0])
+    if len(body) < 19:
+        raise _Truncated()
+    if body[1] != 5:
+        raise UnsupportedError("invalid hashed material length %d" % body[1])
+    sig = Signature(version=body[0], sig_type=body[2], pk_algo=body[15], hash_id=body[16])
+    sig.creation_time = int.from_bytes(body[3:7], "big")
+    sig.issuer = int.from_bytes(body[7:15], "big")
+    if sig.pk_algo not in (PK_RSA, PK_RSA_SIGN_ONLY, PK_DSA):
+        raise UnsupportedError("public key algorithm %d" % sig.pk_algo)
+    if sig.hash_id not in HASH_BY_ID:
+        raise UnsupportedError("hash function %d" % sig.hash_id)
+    sig.hash_suffix = body[2:7]
+    sig.hash_tag = body[17:19]
+    p = 19
+    for _ in range(2 if sig.pk_algo == PK_DSA else 1):
+        if p + 2 > len(body):
+            raise _Truncated()
+        bits = (body[p] << 8) | body[p + 1]
+        nb = (bits + 7) // 8
+        p += 2
+        if p + nb > len(body):
+            raise _Truncated()
+        sig.mpis.append((bits, body[p:p + nb]))
+        p += nb
+    return sig
+
+
 @dataclass
 class RawPacket:
     tag: int
@@ -464,12 +498,9 @@ def check_detached_signature(keyring: List[Entity], signed: bytes, sigdata: byte
                 per_packet.append(ST_NOT_SIGNATURE)
                 return StepResult(ST_NOT_SIGNATURE, None, pos, per_packet)
             continue  # Reader.Next silently skips unknown packet types
-        if len(pkt.body) >= 1 and pkt.body[0] < 4:
-            # SignatureV3: legal for the reference, never produced by DetachSign.  FENCED.
-            per_packet.append(ST_UNSUPPORTED)
-            return StepResult(ST_UNSUPPORTED, None, pos, per_packet)
         try:
-            sig = parse_signature_body(pkt.body)
+            # packet.Read peeks the version: < 4 => *packet.SignatureV3, else *packet.Signature
+            sig = parse_signature_v3_body(pkt.body) if (len(pkt.body) >= 1 and pkt.body[0] < 4) else parse_signature_body(pkt.body)
         except (StructuralError, UnsupportedError, _Truncated):
             per_packet.append(ST_PARSE_ERROR)
             return StepResult(ST_PARSE_ERROR, None, pos, per_packet)
