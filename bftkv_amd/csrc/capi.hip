@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -102,6 +103,7 @@ struct bftkv_gpu_ctx {
   DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
+  uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
   std::map<std::string, std::array<DevBuf, 3>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
@@ -700,6 +702,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
       hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
+  if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
   *out = c;
   return BFTKV_OK;
 }

@@ -219,8 +219,13 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
 // most one table multiplication per base.  28 = 7 * 4, so a window digit never straddles two limbs.
 constexpr int MULTIEXP_WIN = 4, MULTIEXP_ENT = 15;
 // `idx_div`: an operation's bases may be split over idx_div consecutive quads (each takes k_bases of them and yields a
-// partial product that k_modmul_product multiplies up): 10,000 combines are only 625 waves on 1024 SIMDs, and a chain of
-// ~900 dependent products per wave is pure latency; the modulus of quad `op` is then that of operation op / idx_div.
+// partial product that k_modmul_product multiplies up): 10,000 combines are only 625 waves on 1024 SIMDs, and one wave alone
+// on a SIMD issues a VALU instruction only every ~9.5 cycles (tools/microbench), so a chain of ~900 dependent products per
+// wave is bounded by single-wave issue; the modulus of quad `op` is that of operation op / idx_div.
+//
+// The whole schedule -- table build, squarings, table multiplications, leaving the Montgomery domain -- runs through ONE
+// loop with two multiplier call sites (general and squaring): six inlined copies of mont_mul cost 239 VGPRs (two waves per
+// SIMD); this form allows three.
 __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
                                                         const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
                                                         const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][15][76]*/,
@@ -228,56 +233,74 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   QUAD_SETUP();
   const uint32_t mi = mod_idx[op / idx_div];
-  uint32_t n[L], r2[L], y[L], t[L];
+  uint32_t n[L], y[L], t[L];          // the register operand of every product is y (R^2 is loaded into it where needed)
+  const uint32_t* r2p = mt.r2_limbs + (uint64_t)mi * MONT_N + qlane * L;
 #pragma unroll
-  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  for (int k = 0; k < L; ++k) n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k];
   const uint32_t n0inv = mt.n0inv[mi];
-  for (uint32_t j = 0; j < k_bases; ++j) {
+  // wave-uniform program counter
+  enum : int { P_TO_MONT = 0, P_POWERS, P_ONE, P_SQR, P_TABMUL, P_LEAVE, P_DONE };
+  int phase = P_TO_MONT, w = 280 / MULTIEXP_WIN - 1, sq = 0;
+  uint32_t j = 0, d = 0;           // base index / table digit (P_POWERS: entry being built)
+  uint32_t dig = 0;                // this quad's digit in P_TABMUL
+  while (phase != P_DONE) {
     const uint64_t sj = (uint64_t)op * k_bases + j;
     uint32_t* tab = scratch + sj * MULTIEXP_ENT * MONT_N + qlane * L;
+    // ---- operands: a through LDS, b in registers
+    if (phase == P_TO_MONT) {                       // b_j * R
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = base_limbs[sj * MONT_N + qlane * L + k];
-    MONT(y, r2);                                                     // b * R
+      for (int k = 0; k < L; ++k) { a_lds[k] = base_limbs[sj * MONT_N + qlane * L + k]; y[k] = r2p[k]; }
+    } else if (phase == P_POWERS) {                 // b^(d+1) = b^d * b; a = b_j stays in LDS, y = the previous power
+    } else if (phase == P_ONE) {                    // Montgomery one = mont(1, R^2)
 #pragma unroll
-    for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; if (active) tab[k] = y[k]; }
-    for (int d = 1; d < MULTIEXP_ENT; ++d) {                         // b^(d+1) = b^d * b, a = b stays in LDS
-      MONT(t, y);
-#pragma unroll
-      for (int k = 0; k < L; ++k) { y[k] = t[k]; if (active) tab[(uint64_t)d * MONT_N + k] = t[k]; }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");                 // the quad's own table rows are read back below
-#pragma unroll
-  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-  MONT(y, r2);                                                       // Montgomery one
-  for (int w = 280 / MULTIEXP_WIN - 1; w >= 0; --w) {
-    for (int sq = 0; sq < MULTIEXP_WIN; ++sq) {
+      for (int k = 0; k < L; ++k) { a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; y[k] = r2p[k]; }
+    } else if (phase == P_SQR) {
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = y[k];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      mont_mul<MONT_L, MONT_TPI, true>(t, a_rd, y, n, n0inv, qlane);      // squaring: half the a*b limb products (mont28.h)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (int k = 0; k < L; ++k) y[k] = t[k];
-    }
-    const int bit = w * MULTIEXP_WIN;
-    for (uint32_t j = 0; j < k_bases; ++j) {
-      const uint64_t sj = (uint64_t)op * k_bases + j;
-      const uint32_t d = active ? ((exp_limbs[sj * MONT_N + bit / MONT_W] >> (bit % MONT_W)) & 15u) : 0u;
-      if (!__any(d != 0)) continue;
-      const uint32_t* row = scratch + (sj * MULTIEXP_ENT + (d ? d - 1 : 0)) * MONT_N + qlane * L;
+    } else if (phase == P_TABMUL) {
+      const uint32_t* row = scratch + (sj * MULTIEXP_ENT + (dig ? dig - 1 : 0)) * MONT_N + qlane * L;
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = row[k];
-      MONT(t, y);
-      if (d) {
+    } else {                                        // P_LEAVE: mont(y, 1)
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (phase == P_SQR) mont_mul<MONT_L, MONT_TPI, true>(t, a_rd, y, n, n0inv, qlane);
+    else mont_mul(t, a_rd, y, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- results and next step (scalar control flow)
+    if (phase == P_TO_MONT) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) { y[k] = t[k]; a_lds[k] = t[k]; if (active) tab[k] = t[k]; }      // a = b_j R for the powers
+      d = 1; phase = P_POWERS;
+    } else if (phase == P_POWERS) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) { y[k] = t[k]; if (active) tab[(uint64_t)d * MONT_N + k] = t[k]; }
+      if (++d == MULTIEXP_ENT) {
+        if (++j == k_bases) { j = 0; phase = P_ONE; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }   // own table rows are read back below
+        else phase = P_TO_MONT;
+      }
+    } else {
+      if (phase == P_LEAVE) break;
+      if (phase != P_TABMUL || dig) {
 #pragma unroll
         for (int k = 0; k < L; ++k) y[k] = t[k];
       }
+      // advance: 4 squarings per window, then one table multiplication per base with a non-zero digit somewhere in the wave
+      if (phase == P_ONE) { phase = P_SQR; sq = 0; }
+      else if (phase == P_SQR) { if (++sq == MULTIEXP_WIN) { phase = P_TABMUL; j = 0; } else continue; }
+      else ++j;
+      while (phase == P_TABMUL) {
+        if (j == k_bases) { j = 0; if (--w < 0) phase = P_LEAVE; else { phase = P_SQR; sq = 0; } break; }
+        const int bit = w * MULTIEXP_WIN;
+        const uint64_t sj2 = (uint64_t)op * k_bases + j;
+        dig = active ? ((exp_limbs[sj2 * MONT_N + bit / MONT_W] >> (bit % MONT_W)) & 15u) : 0u;
+        if (__any(dig != 0)) break;
+        ++j;
+      }
     }
   }
-#pragma unroll
-  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-  MONT(t, y);
   canonicalize(t, qlane);
   if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
 }
