@@ -19,6 +19,12 @@ __device__ __constant__ const uint32_t SHA256_K[64] = {
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// three-input XOR as ONE v_bitop3_b32 (truth table 0x96): the sigma functions are rot ^ rot ^ rot/shift, and the compiler
+// only forms bitop3 for Ch / Maj by itself -- 4 of the ~27 VALU instructions of a SHA-256 round
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) {
+  return ((uint64_t)xor3((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) << 32) | xor3((uint32_t)a, (uint32_t)b, (uint32_t)c);
+}
 
 __device__ __forceinline__ void sha256_init(uint32_t (&s)[8]) {
   s[0] = 0x6a09e667; s[1] = 0xbb67ae85; s[2] = 0x3c6ef372; s[3] = 0xa54ff53a;
@@ -32,14 +38,14 @@ __device__ __forceinline__ void sha256_compress(uint32_t (&s)[8], uint32_t (&w)[
   for (int i = 0; i < 64; ++i) {
     if (i >= 16) {
       uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-      uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-      uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+      uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+      uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
       w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
     }
-    uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+    uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
     uint32_t ch = (e & f) ^ (~e & g);
     uint32_t t1 = h + S1 + ch + SHA256_K[i] + w[i & 15];
-    uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+    uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
     uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
     uint32_t t2 = S0 + mj;
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
@@ -64,12 +70,12 @@ __device__ __forceinline__ void sha1_compress(uint32_t (&s)[8], uint32_t (&w)[16
   uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4];
 #pragma unroll
   for (int i = 0; i < 80; ++i) {
-    if (i >= 16) w[i & 15] = rotl(w[(i + 13) & 15] ^ w[(i + 8) & 15] ^ w[(i + 2) & 15] ^ w[i & 15], 1);
+    if (i >= 16) w[i & 15] = rotl(xor3(w[(i + 13) & 15], w[(i + 8) & 15], w[(i + 2) & 15]) ^ w[i & 15], 1);
     uint32_t f, k;
     if (i < 20) { f = (b & c) | (~b & d); k = 0x5a827999; }
-    else if (i < 40) { f = b ^ c ^ d; k = 0x6ed9eba1; }
+    else if (i < 40) { f = xor3(b, c, d); k = 0x6ed9eba1; }
     else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8f1bbcdc; }
-    else { f = b ^ c ^ d; k = 0xca62c1d6; }
+    else { f = xor3(b, c, d); k = 0xca62c1d6; }
     uint32_t t = rotl(a, 5) + f + e + k + w[i & 15];
     e = d; d = c; c = rotl(b, 30); b = a; a = t;
   }
@@ -117,14 +123,14 @@ __device__ __forceinline__ void sha512_compress(uint64_t (&s)[8], uint64_t (&w)[
       const int i = r + j;
       if (r > 0) {
         uint64_t w15 = w[(j + 1) & 15], w2 = w[(j + 14) & 15];
-        uint64_t s0 = rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7);
-        uint64_t s1 = rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6);
+        uint64_t s0 = xor3_64(rotr64(w15, 1), rotr64(w15, 8), w15 >> 7);
+        uint64_t s1 = xor3_64(rotr64(w2, 19), rotr64(w2, 61), w2 >> 6);
         w[j] = w[j] + s0 + w[(j + 9) & 15] + s1;
       }
-      uint64_t S1 = rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41);
+      uint64_t S1 = xor3_64(rotr64(e, 14), rotr64(e, 18), rotr64(e, 41));
       uint64_t ch = (e & f) ^ (~e & g);
       uint64_t t1 = h + S1 + ch + SHA512_K[i] + w[j];
-      uint64_t S0 = rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39);
+      uint64_t S0 = xor3_64(rotr64(a, 28), rotr64(a, 34), rotr64(a, 39));
       uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
       uint64_t t2 = S0 + mj;
       h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;

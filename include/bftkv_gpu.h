@@ -129,8 +129,8 @@ int bftkv_gpu_quorum_create(bftkv_gpu_ctx* ctx, const bftkv_gpu_qc* qcs, uint32_
 int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 
 /* ---- fenced inputs ------------------------------------------------------------------------------------
- * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs": SignatureV3
- * packets, partial / indeterminate body lengths on signature packets, text-mode signatures, MD5 / RIPEMD-160, ECDSA,
+ * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs":
+ * partial / indeterminate body lengths on signature packets, text-mode signatures, MD5 / RIPEMD-160, ECDSA,
  * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2, several different keys under
  * one key id).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
  * shape -- its err_out is then NOT a statement about what the reference would decide, and the caller must run the

@@ -33,7 +33,7 @@ func (cs *CollectiveSignature) Verify(tbs []byte, ss *packet.SignaturePacket, q 
 		return cs.g.infra(rc, "collective_verify")
 	}
 	if fenced != 0 {
-		// ss.Data holds a shape the kernels do not follow (SignatureV3, partial lengths, MD5, ...): x/crypto decides
+		// ss.Data holds a shape the kernels do not follow (partial lengths, text mode, MD5, ...): x/crypto decides
 		return cs.inner.Verify(tbs, ss, q)
 	}
 	if e == C.BFTKV_ERR_NONE {
