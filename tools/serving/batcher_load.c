@@ -1,0 +1,116 @@
+/* Serving-shaped load on the micro-batcher: T caller threads, each issuing ONE CollectiveSignature.Verify per call
+ * (bftkv_gpu_batcher_collective_verify) -- the shape of protocol.Server's goroutine-per-request handlers
+ * (transport/http/http.go:85,143).  Prints throughput and per-call latency percentiles for a sweep of thread counts.
+ *   gcc -O2 -std=gnu99 -I include tools/serving/batcher_load.c -L bftkv_amd -lbftkv_gpu -lpthread -Wl,-rpath,$PWD/bftkv_amd -o batcher_load
+ *   ./batcher_load corpus.bin [max_items=256] [max_wait_us=200]
+ * Not the bench line (bench.py measures resident batches); numbers feed DESIGN.md section 3.4. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "bftkv_gpu.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+typedef struct {
+  uint32_t n_items;
+  uint64_t *tb_off, *ss_off;
+  uint8_t *tb, *ss, *want_ok;
+} corpus;
+
+typedef struct {
+  bftkv_gpu_batcher* b; int qh; const corpus* c; int tid, n_threads; double seconds; volatile int* stop;
+  uint64_t calls, wrong; double* lat; uint64_t lat_cap;
+} worker;
+
+static void* run(void* p) {
+  worker* w = (worker*)p;
+  uint32_t i = (uint32_t)w->tid;
+  while (!*w->stop) {
+    const uint32_t k = i % w->c->n_items;
+    uint8_t err = 0xEE, fenced = 0;
+    const double t0 = now_s();
+    int rc = bftkv_gpu_batcher_collective_verify(w->b, w->qh, w->c->tb + w->c->tb_off[k], w->c->tb_off[k + 1] - w->c->tb_off[k],
+                                                 w->c->ss + w->c->ss_off[k], w->c->ss_off[k + 1] - w->c->ss_off[k], &err, &fenced);
+    const double dt = now_s() - t0;
+    if (rc != 0 || fenced || (err == 0) != (w->c->want_ok[k] != 0)) ++w->wrong;
+    if (w->calls < w->lat_cap) w->lat[w->calls] = dt;
+    ++w->calls;
+    i += (uint32_t)w->n_threads;
+  }
+  return NULL;
+}
+
+static int cmp_d(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s corpus.bin [max_items] [max_wait_us]\n", argv[0]); return 2; }
+  const uint32_t max_items = argc > 2 ? (uint32_t)atoi(argv[2]) : 256, max_wait = argc > 3 ? (uint32_t)atoi(argv[3]) : 200;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("corpus"); return 2; }
+  uint32_t n_keys = 0;
+  if (fread(&n_keys, 4, 1, f) != 1) return 2;
+  bftkv_gpu_pubkey* keys = calloc(n_keys, sizeof *keys);
+  uint64_t* ids = malloc(8 * n_keys);
+  uint8_t* mat = malloc((size_t)260 * n_keys);
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    if (fread(&ids[i], 8, 1, f) != 1 || fread(mat + 260 * i, 260, 1, f) != 1) return 2;
+    keys[i].key_id = keys[i].entity_id = ids[i]; keys[i].pk_algo = 1; keys[i].usable_sign = 1;
+    keys[i].n = mat + 260 * i; keys[i].n_len = 256; keys[i].e = mat + 260 * i + 256; keys[i].e_len = 4;
+  }
+  int32_t qn[4];
+  corpus c;
+  if (fread(qn, 4, 4, f) != 4 || fread(&c.n_items, 4, 1, f) != 1) return 2;
+  c.tb_off = malloc(8 * (c.n_items + 1)); c.ss_off = malloc(8 * (c.n_items + 1));
+  if (fread(c.tb_off, 8, c.n_items + 1, f) != c.n_items + 1 || fread(c.ss_off, 8, c.n_items + 1, f) != c.n_items + 1) return 2;
+  c.tb = malloc(c.tb_off[c.n_items]); c.ss = malloc(c.ss_off[c.n_items]); c.want_ok = malloc(c.n_items);
+  if (fread(c.tb, 1, c.tb_off[c.n_items], f) != c.tb_off[c.n_items] || fread(c.ss, 1, c.ss_off[c.n_items], f) != c.ss_off[c.n_items] ||
+      fread(c.want_ok, 1, c.n_items, f) != c.n_items) return 2;
+  fclose(f);
+  bftkv_gpu_ctx* ctx = NULL;
+  if (bftkv_gpu_init(0, &ctx)) { fprintf(stderr, "no GPU\n"); return 1; }
+  if (bftkv_gpu_keyring_set(ctx, keys, n_keys)) { fprintf(stderr, "keyring: %s\n", bftkv_gpu_last_error(ctx)); return 1; }
+  bftkv_gpu_qc qc = {qn[0], qn[1], qn[2], qn[3], ids, n_keys};
+  int qh = -1;
+  if (bftkv_gpu_quorum_create(ctx, &qc, 1, &qh)) return 1;
+  bftkv_gpu_batcher* b = bftkv_gpu_batcher_create(ctx, max_items, max_wait);
+  const int sweep[] = {1, 8, 64, 256, 1024};
+  printf("{\"max_items\": %u, \"max_wait_us\": %u, \"writes\": %u, \"replicas\": %u, \"runs\": [", max_items, max_wait, c.n_items, n_keys);
+  for (unsigned s = 0; s < sizeof sweep / sizeof sweep[0]; ++s) {
+    const int T = sweep[s];
+    volatile int stop = 0;
+    worker* ws = calloc((size_t)T, sizeof *ws);
+    pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
+    for (int t = 0; t < T; ++t) {
+      ws[t].b = b; ws[t].qh = qh; ws[t].c = &c; ws[t].tid = t; ws[t].n_threads = T; ws[t].stop = &stop;
+      ws[t].lat_cap = 200000 / (uint64_t)T + 64; ws[t].lat = malloc(8 * ws[t].lat_cap);
+      pthread_create(&th[t], NULL, run, &ws[t]);
+    }
+    const double t0 = now_s();
+    struct timespec nap = {2, 0};
+    nanosleep(&nap, NULL);
+    stop = 1;
+    for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+    const double dt = now_s() - t0;
+    uint64_t calls = 0, wrong = 0, nl = 0;
+    for (int t = 0; t < T; ++t) { calls += ws[t].calls; wrong += ws[t].wrong; nl += ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; }
+    double* all = malloc(8 * (nl + 1));
+    uint64_t k = 0;
+    for (int t = 0; t < T; ++t) { uint64_t m = ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; memcpy(all + k, ws[t].lat, 8 * m); k += m; }
+    qsort(all, nl, 8, cmp_d);
+    uint64_t st[4] = {0, 0, 0, 0};
+    bftkv_gpu_batcher_stats(b, st);
+    printf("%s{\"threads\": %d, \"verify_calls_per_s\": %.0f, \"wrong\": %llu, \"latency_ms\": {\"p50\": %.3f, \"p99\": %.3f, \"max\": %.3f}, "
+           "\"calls_total\": %llu, \"batches_total\": %llu, \"largest_batch\": %llu}",
+           s ? ", " : "", T, calls / dt, (unsigned long long)wrong, nl ? all[nl / 2] * 1e3 : 0.0, nl ? all[(uint64_t)(nl * 0.99)] * 1e3 : 0.0,
+           nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2]);
+    fflush(stdout);
+    for (int t = 0; t < T; ++t) free(ws[t].lat);
+    free(ws); free(th); free(all);
+  }
+  printf("]}\n");
+  bftkv_gpu_batcher_destroy(b);
+  bftkv_gpu_destroy(ctx);
+  return 0;
+}
