@@ -299,13 +299,13 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   const size_t tr = total ? total : 1;
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
   HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
-  HIPCHK(c, c->r.ensure(sizeof(uint32_t) * MONT_N * tr));
+  HIPCHK(c, c->r.ensure(sizeof(uint32_t) * EM_LOW_LIMBS * tr));   // low limbs of s^e mod n: k_rsa_modexp -> k_rsa_compare
   HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? MONT_TPI_BIG * MONT_L3072 : MONT_N) * tr));
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
   HIPCHK(c, c->pk_list3072.ensure(c->have_rsa3072 ? sizeof(uint32_t) * tr : 16));
   HIPCHK(c, c->pk_list4096.ensure(c->have_rsa4096 ? sizeof(uint32_t) * tr : 16));
-  if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * MONT_TPI_BIG * MONT_L3072 * tr));
-  if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * MONT_TPI_BIG * MONT_L4096 * tr));
+  if (c->have_rsa3072) HIPCHK(c, c->r3072.ensure(sizeof(uint32_t) * EM_LOW_LIMBS * tr));
+  if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * EM_LOW_LIMBS * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
   // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
@@ -388,16 +388,15 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
                        d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
                        c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
-  const dim3 cg((total * 4 + 255) / 256);
-  const dim3 cg8(((uint64_t)total * MONT_TPI_BIG + 255) / 256);
+  const dim3 cg(((uint64_t)total * CMP_LANES + 255) / 256);
   auto launch_compare = [&](const uint32_t* start) {
-    hipLaunchKernelGGL((k_rsa_compare<MONT_L, MONT_TPI>), cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    hipLaunchKernelGGL(k_rsa_compare, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->r.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa3072)
-      hipLaunchKernelGGL((k_rsa_compare<MONT_L3072, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+      hipLaunchKernelGGL(k_rsa_compare, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
                          cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->digests.as<uint32_t>());
     if (c->have_rsa4096)
-      hipLaunchKernelGGL((k_rsa_compare<MONT_L4096, MONT_TPI_BIG>), cg8, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+      hipLaunchKernelGGL(k_rsa_compare, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->digests.as<uint32_t>());
   };
   // DSA signatures (if any): u1 depends on the digest, so the table multiplications run after the join; the

@@ -852,12 +852,31 @@ constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
 
 enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
 
-// r = s^e mod n (+ possibly n) for every queued signature; canonical radix-2^28 limbs to r_limbs.
+// EMSA-PKCS1-v1_5 splits at byte EM_LOW_BYTES: below it sit the digest, its DigestInfo prefix and the 00 separator (at most
+// 64 + 19 + 1 bytes, SHA-512) plus FF padding, above it only padding and the 00 01 top, a pattern of the modulus' byte
+// length alone.  k_rsa_modexp checks the upper part while the limbs of s^e mod n are still in registers and hands
+// k_rsa_compare the low EM_LOW_LIMBS limbs (96 instead of 304 bytes per signature, written once and read once).
+constexpr int EM_LOW_BYTES = 84;
+constexpr int EM_LOW_LIMBS = EM_LOW_BYTES * 8 / MONT_W;     // 24: 84 bytes are exactly 24 limbs of 28 bits
+static_assert(EM_LOW_LIMBS * MONT_W == EM_LOW_BYTES * 8, "the EM split must fall on a limb boundary");
+constexpr uint32_t EM_HEAD_BAD = 0xFFFFFFFFu;               // no canonical limb: marks a residue whose upper part is not padding
+
+// Limb gi (>= EM_LOW_LIMBS) of 00 01 FF .. FF for a modulus of kbytes bytes: ones from bit 8*EM_LOW_BYTES up to and
+// including bit 8*(kbytes-2), the 01 byte.
+__device__ __forceinline__ uint32_t em_head_limb(uint32_t gi, uint32_t kbytes) {
+  const int32_t top = 8 * ((int32_t)kbytes - 2), lo = (int32_t)gi * MONT_W;
+  if (top < lo) return 0u;
+  if (top >= lo + MONT_W - 1) return MONT_MASK;
+  return (1u << (top - lo + 1)) - 1u;
+}
+
+// r = s^e mod n for every queued signature: the upper limbs checked against the EMSA padding here, the low EM_LOW_LIMBS
+// limbs (canonical radix 2^28) to r_low for k_rsa_compare.
 template <int L, int TPI>   // limbs per lane x lanes per number: 19x4 (<= 2048-bit moduli), 14x8 (<= 3072), 19x8 (<= 4096)
-__global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
+__global__ void __launch_bounds__(RSA_BLOCK, 3) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                           const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
                                                           const uint32_t* __restrict__ pk_start_ptr,
-                                                          KeyTableDev kt, uint32_t* __restrict__ r_limbs,
+                                                          KeyTableDev kt, uint32_t* __restrict__ r_low,
                                                           uint32_t* __restrict__ xr_scratch, uint64_t* __restrict__ clk) {
   constexpr int NL = TPI * L;
   constexpr int GROUPS = RSA_BLOCK / TPI;      // numbers per block
@@ -899,6 +918,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
   }
   const uint32_t n0inv = kt.n0inv[key];
   const uint32_t e = kt.rsa_e[key];
+  const uint32_t kbytes = (kt.mod_bits[key] + 7) >> 3;
   // x-shortcut: the last multiplication of an odd exponent uses plain x instead of xR, which also
   // leaves the Montgomery domain.  Only when x < 2^(8k) so that the result stays below n(1+2^-79).
   const uint32_t cls = (e << 1) | (((e & 1u) && e > 1u && !(rec.flags & 1u)) ? 1u : 0u);
@@ -951,29 +971,55 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_rsa_modexp(const uint8_t* __restr
       --bitpos;
       kind = (bitpos >= 0) ? OP_SQR : OP_MUL1;
     }
+    // y = t or t + n for the residue t = s^e mod n, and t + n only when t < n * 2^-63: the last product is by 1 (y < n + 1)
+    // or by the plain value x < 2^(8k) (y < n(1 + 2^(8k+1)/R), R = 2^2128 / 2^3136 / 2^4256).  An encoded message is at
+    // least 2^(8k-16) > n * 2^-16, so such a t is no valid signature and neither is y >= n: comparing y itself with the
+    // encoding gives the verdict of comparing t, without a final subtraction.
     canonicalize<L, TPI>(y, qlane);
-    if (live && active) {
-      uint32_t* out = r_limbs + (uint64_t)pi * NL + qlane * L;
+    if (e_u == 0) {                            // x^0 = 1
 #pragma unroll
-      for (int k = 0; k < L; ++k) out[k] = (e_u == 0) ? ((qlane == 0 && k == 0) ? 1u : 0u) : y[k];   // x^0 = 1
+      for (int k = 0; k < L; ++k) y[k] = (qlane == 0 && k == 0) ? 1u : 0u;
     }
+    uint32_t head = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const uint32_t gi = (uint32_t)qlane * L + k;
+      if (gi >= (uint32_t)EM_LOW_LIMBS) head |= y[k] ^ em_head_limb(gi, kbytes);
+    }
+    head = grp_or<TPI>(head);
+    // the low limbs leave through the group's LDS slice (free now): each of the group's first four lanes stores six
+    // consecutive limbs, so a wave writes one contiguous run
+    if (head != 0 && qlane == 0) y[0] = EM_HEAD_BAD;
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = y[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (live && active && qlane < 4) {
+      uint32_t* out = r_low + (uint64_t)pi * EM_LOW_LIMBS + qlane * (EM_LOW_LIMBS / 4);
+      const uint32_t* src = a_rd + qlane * (EM_LOW_LIMBS / 4);
+#pragma unroll
+      for (int k = 0; k < EM_LOW_LIMBS / 4; ++k) out[k] = src[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     todo &= ~__builtin_amdgcn_ballot_w64(live);
   }
   if (stamp && *pk_start_ptr == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-// EMSA-PKCS1-v1_5(digest) == r, or == r - n (r is only reduced below n(1+2^-79)); TPI lanes per signature.
-template <int L, int TPI>
+// Low EM_LOW_LIMBS limbs of EMSA-PKCS1-v1_5(digest) == those of s^e mod n (k_rsa_modexp has checked everything above
+// them); four lanes per signature, six limbs each, whatever the modulus size.
+constexpr int CMP_LANES = 4;
+constexpr int CMP_L = EM_LOW_LIMBS / CMP_LANES;
+static_assert(CMP_L * CMP_LANES == EM_LOW_LIMBS, "the low limbs divide over the quad");
 __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, const uint32_t* __restrict__ pk_list,
                                                      const uint32_t* __restrict__ pk_count_ptr, const uint32_t* __restrict__ pk_start_ptr,
                                                      KeyTableDev kt,
-                                                     const uint32_t* __restrict__ r_limbs, const uint32_t* __restrict__ digests) {
-  constexpr int NL = TPI * L;
-  constexpr int GROUPS = 256 / TPI;
+                                                     const uint32_t* __restrict__ r_low, const uint32_t* __restrict__ digests) {
+  constexpr int GROUPS = 256 / CMP_LANES;
   const uint32_t count = *pk_count_ptr, start = *pk_start_ptr;
-  const uint32_t gq = start + (blockIdx.x * blockDim.x + threadIdx.x) / TPI;
-  const int qlane = threadIdx.x % TPI;
-  if (start + (blockIdx.x * blockDim.x) / TPI >= count) return;
+  const uint32_t q0 = start + blockIdx.x * GROUPS;
+  if (q0 >= count) return;
+  const uint32_t gq = q0 + threadIdx.x / CMP_LANES;
+  const int qlane = threadIdx.x % CMP_LANES;
   const bool active = gq < count;
   const uint32_t pi = active ? gq : (count - 1);
   const uint32_t ri = pk_list[pi];
@@ -984,17 +1030,17 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   const HashInfo hi = hash_info(rec.hash_id);
   const uint32_t hlen = hi.dlen, plen = hi.plen, tl = hlen + plen;
   // EM as little-endian 32-bit words, least significant first: [ digest | DigestInfo prefix | 00 ] (the variable tail,
-  // tl+1 bytes, staged in LDS by the quad), then FF words, then the 00 01 top.  Each lane builds the 18-word window its
-  // 19 limbs live in, shifts it to a limb boundary once, and slices limbs at compile-time offsets -- ~10 instructions
-  // per limb instead of five branchy byte look-ups.
+  // tl+1 bytes, staged in LDS by the quad), then FF words, then -- only under a very short modulus -- the 00 01 top.
+  // Each lane builds the 7-word window its six limbs live in, shifts it to a limb boundary once, and slices limbs at
+  // compile-time offsets.
   constexpr int EM_TAIL_W = 24;   // >= (64 + 19 + 1) / 4
   __shared__ uint32_t tail_sh[GROUPS * EM_TAIL_W];
-  uint32_t* tail = tail_sh + (threadIdx.x / TPI) * EM_TAIL_W;
+  uint32_t* tail = tail_sh + (threadIdx.x / CMP_LANES) * EM_TAIL_W;
   const uint32_t* dgw = digests + (uint64_t)ri * 16;
   const uint32_t hw = hlen >> 2;            // every supported digest length is a multiple of 4
 #pragma unroll
-  for (int t = 0; t < EM_TAIL_W / TPI; ++t) {
-    const uint32_t w = (uint32_t)qlane * (EM_TAIL_W / TPI) + t;
+  for (int t = 0; t < EM_TAIL_W / CMP_LANES; ++t) {
+    const uint32_t w = (uint32_t)qlane * (EM_TAIL_W / CMP_LANES) + t;
     uint32_t v = 0;
     if (w < hw) v = __builtin_bswap32(dgw[hw - 1 - w]);
     else {
@@ -1009,61 +1055,44 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   auto em_word = [&](uint32_t w) -> uint32_t {
     if (4 * w + 3 <= tl) return tail[w];
-    if (4 * w > tl && 4 * w + 3 < kbytes - 2) return 0xFFFFFFFFu;
-    uint32_t v = 0;                          // a word straddling a boundary (the 00 01 top; never the tail for SHA-1/2)
+    if (4 * w > tl && 4 * w + 3 + 2 < kbytes) return 0xFFFFFFFFu;
+    uint32_t v = 0;                          // a word straddling a boundary
 #pragma unroll
     for (uint32_t bq = 0; bq < 4; ++bq) {
       const uint32_t i = 4 * w + bq;
       uint32_t byte;
       if (i <= tl) byte = (tail[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-      else if (i < kbytes - 2) byte = 0xFF;
-      else byte = (i == kbytes - 2) ? 1u : 0u;
+      else if (i + 2 < kbytes) byte = 0xFF;
+      else byte = (i + 2 == kbytes) ? 1u : 0u;
       v |= byte << (8 * bq);
     }
     return v;
   };
-  constexpr int NW = (L * MONT_W + 31) / 32 + 1;
-  const uint32_t bit0 = (uint32_t)qlane * L * MONT_W, w0 = bit0 >> 5, s0 = bit0 & 31u;
+  constexpr int NW = (CMP_L * MONT_W + 31) / 32 + 1;
+  const uint32_t bit0 = (uint32_t)qlane * CMP_L * MONT_W, w0 = bit0 >> 5, s0 = bit0 & 31u;
   uint32_t Wd[NW + 1], Wn[NW];
 #pragma unroll
   for (int i = 0; i <= NW; ++i) Wd[i] = em_word(w0 + i);
 #pragma unroll
   for (int i = 0; i < NW; ++i) Wn[i] = __builtin_amdgcn_alignbit(Wd[i + 1], Wd[i], s0);
-  uint32_t em[L], r[L];
-  // r: the block's 64 results are one contiguous run of the work list -- fetch it with fully coalesced dword loads into
-  // LDS (a lane-per-limb-slice read straight from global touches 64 cache lines per instruction)
-  __shared__ uint32_t r_sh[GROUPS * NL];
+  // r: the block's 64 results are one contiguous run of the work list -- fetched with fully coalesced dword loads into LDS
+  __shared__ uint32_t r_sh[GROUPS * EM_LOW_LIMBS];
   {
-    const uint32_t q0 = start + (blockIdx.x * blockDim.x) / TPI;
-    const uint32_t n_valid = min((uint32_t)GROUPS, count - q0) * NL;
-    const uint32_t* src = r_limbs + (uint64_t)q0 * NL;
-    for (uint32_t t = threadIdx.x; t < GROUPS * NL; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
+    const uint32_t n_valid = min((uint32_t)GROUPS, count - q0) * EM_LOW_LIMBS;
+    const uint32_t* src = r_low + (uint64_t)q0 * EM_LOW_LIMBS;
+    for (uint32_t t = threadIdx.x; t < GROUPS * EM_LOW_LIMBS; t += 256) r_sh[t] = t < n_valid ? src[t] : 0u;
     __syncthreads();
   }
-  const uint32_t* rp = r_sh + ((threadIdx.x / TPI) * NL + qlane * L);
+  const uint32_t* rp = r_sh + (threadIdx.x / CMP_LANES) * EM_LOW_LIMBS + qlane * CMP_L;
   uint32_t diff = 0;
 #pragma unroll
-  for (int k = 0; k < L; ++k) {
-    constexpr int dummy = 0; (void)dummy;
+  for (int k = 0; k < CMP_L; ++k) {
     const int bit = MONT_W * k, wi = bit >> 5, sh = bit & 31;
-    em[k] = (sh == 0 ? Wn[wi] : __builtin_amdgcn_alignbit(Wn[wi + 1], Wn[wi], sh)) & MONT_MASK;
-    r[k] = rp[k];
-    diff |= em[k] ^ r[k];
+    const uint32_t em = (sh == 0 ? Wn[wi] : __builtin_amdgcn_alignbit(Wn[wi + 1], Wn[wi], sh)) & MONT_MASK;
+    diff |= em ^ rp[k];                     // EM_HEAD_BAD in limb 0 (upper part not padding) never matches a masked limb
   }
-  diff = grp_or<TPI>(diff);
-  bool ok = (diff == 0);
-  if (__any(!ok)) {
-    const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-    uint32_t diff2 = 0;
-#pragma unroll
-    for (int k = 0; k < L; ++k) em[k] += np[k];
-    canonicalize<L, TPI>(em, qlane);
-#pragma unroll
-    for (int k = 0; k < L; ++k) diff2 |= em[k] ^ r[k];
-    diff2 = grp_or<TPI>(diff2);
-    ok = ok || (diff2 == 0);
-  }
-  if (active && pending && qlane == 0) recs[ri].status = ok ? ST_OK : ST_BAD_SIG;
+  diff = quad_or(diff);
+  if (active && pending && qlane == 0) recs[ri].status = (diff == 0) ? ST_OK : ST_BAD_SIG;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ constexpr int DPP_QUAD_SWAP2 = 0x4E;           // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_SHL1 = 0x101;            // lane i <- lane i+1 within a row of 16, 0 past the end
 
 __device__ __forceinline__ uint32_t dpp_quad_bcast0(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_BCAST0, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_BCAST0, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t dpp_quad_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_SHR1, 0xF, 0xF, false);
@@ -106,6 +106,8 @@ __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_l
   // A column receives up to 2N = 2*TPI*L products of < 2^56: up to 255 of them fit 64 bits (76 and 112 limbs); beyond
   // that (152 limbs) the live columns are carry-normalised at every block boundary.
   constexpr bool NORM = 2 * TPI * L > 255;
+  uint32_t mask_v;   // the limb mask in a VGPR: lets the Montgomery factor's mask carry the quad broadcast (v_and_b32_dpp)
+  asm("v_mov_b32 %0, 0xfffffff" : "=v"(mask_v));
   uint64_t Q[2 * L - 1];
 #pragma unroll
   for (int k = 0; k < L + (NORM ? 1 : 0); ++k) Q[k] = 0;
@@ -125,23 +127,19 @@ __device__ __forceinline__ void mont_mul(uint32_t (&out)[L], const uint32_t* a_l
         else Q[r + k] = mad64(av, b[k], Q[r + k]);
       }
       // Montgomery factor from quad lane 0's column r
-      uint32_t m = ((uint32_t)Q[r] * n0inv) & MONT_MASK;
-      m = grp_bcast0<TPI>(m, qlane);
+      const uint32_t m = grp_bcast0<TPI>((uint32_t)Q[r] * n0inv, qlane) & mask_v;
 #pragma unroll
       for (int k = 0; k < L; ++k) Q[r + k] = mad64(m, n[k], Q[r + k]);
-      // retire column r: push its carry into column r+1 (value-preserving in every lane;
-      // in quad lane 0 the low 28 bits are zero by construction, so the column dies)
+      // retire column r: push its carry into column r+1.  What stays behind is the column's low 28 bits (zero in quad
+      // lane 0 by construction); the mask is applied where they are next read, the window shift below.
       Q[r + 1] += Q[r] >> MONT_W;
-      Q[r] &= MONT_MASK;
     }
     // window slid by L columns = one lane: re-align.  new Q[k] = own Q[L+k] + next lane's Q[k]
     // (quad lane 3 reads the next quad's lane 0, whose low columns are all zero; the last lane of
     //  a DPP row reads 0 through bound_ctrl).
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-      uint32_t lo = dpp_row_shl1((uint32_t)Q[k]);
-      uint32_t hi = dpp_row_shl1((uint32_t)(Q[k] >> 32));
-      uint64_t nx = ((uint64_t)hi << 32) | lo;
+      const uint64_t nx = dpp_row_shl1((uint32_t)Q[k]) & mask_v;   // the retired column's low 28 bits: v_and_b32_dpp
       Q[k] = (k < L - 1) ? Q[L + k] + nx : nx;
     }
     if (NORM) {
