@@ -52,12 +52,32 @@ struct SubpacketState {
   bool too_deep = false;      // an embedded signature nested deeper than this parser goes: outcome not claimed (fence)
   uint64_t issuer = 0;
 };
-// subpacket area walk; returns false on structural/unsupported error
-template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* p, uint32_t len, bool hashed, SubpacketState& st);
+// The parsers below read a packet body through a byte view B: a plain pointer, or WinBytes -- the head of the body
+// staged in this lane's LDS window by one round of wide loads (k_parse_body*), the rest still in global memory.  A
+// thread-per-packet parse straight from memory is ~40 dependent byte loads, each touching 64 different cache lines per
+// wave instruction; the signature header they walk is the first 30-60 bytes of the packet.
+constexpr uint32_t PARSE_WIN = 64;              // bytes staged per packet
+constexpr uint32_t PARSE_WIN_STRIDE = 68;       // LDS bytes per lane: 17 dwords, so the lanes' windows start in different banks
+typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;   // typed so that reads are ds_read_u8, not flat loads
+struct WinBytes {
+  const uint8_t* g;     // the bytes in global memory
+  lds_bytes_t l;        // the same bytes [0, n) in LDS
+  uint32_t n;
+  __device__ __forceinline__ uint8_t operator[](uint32_t i) const { return i < n ? l[i] : g[i]; }
+  __device__ __forceinline__ WinBytes operator+(uint32_t d) const {
+    return d < n ? WinBytes{g + d, l + d, n - d} : WinBytes{g + d, l, 0u};
+  }
+};
 
-template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, uint32_t blen, SigRec& rec, SubpacketState& st) {
+__host__ __device__ __forceinline__ const uint8_t* raw_bytes(const uint8_t* p) { return p; }
+__device__ __forceinline__ const uint8_t* raw_bytes(const WinBytes& w) { return w.g; }
+
+// subpacket area walk; returns false on structural/unsupported error
+template <int DEPTH, class B = const uint8_t*>
+__host__ __device__ __forceinline__ bool parse_subpackets_t(B p, uint32_t len, bool hashed, SubpacketState& st);
+
+template <int DEPTH, class B = const uint8_t*>
+__host__ __device__ __forceinline__ bool parse_sig_body_t(B body, uint32_t blen, SigRec& rec, SubpacketState& st) {
   if (blen < 1) return false;
   if (body[0] != 4) return false;  // v3 handled by the caller, others unsupported
   if (blen < 6) return false;
@@ -71,14 +91,14 @@ __host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, u
   uint32_t hl = ((uint32_t)body[4] << 8) | body[5];
   if (6 + hl > blen) return false;
   rec.hashed_len = (uint16_t)hl;
-  if (!parse_subpackets_t<DEPTH>(body + 6, hl, true, st)) return false;
+  if (!parse_subpackets_t<DEPTH, B>(body + 6u, hl, true, st)) return false;
   if (!st.have_ctime) return false;
   uint32_t p = 6 + hl;
   if (p + 2 > blen) return false;
   uint32_t ul = ((uint32_t)body[p] << 8) | body[p + 1];
   p += 2;
   if (p + ul > blen) return false;
-  if (!parse_subpackets_t<DEPTH>(body + p, ul, false, st)) return false;
+  if (!parse_subpackets_t<DEPTH, B>(body + p, ul, false, st)) return false;
   p += ul;
   if (p + 2 > blen) return false;
   rec.hash_tag[0] = body[p];
@@ -100,8 +120,8 @@ __host__ __device__ __forceinline__ bool parse_sig_body_t(const uint8_t* body, u
   return true;
 }
 
-template <int DEPTH>
-__host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, uint32_t len, bool hashed, SubpacketState& st) {
+template <int DEPTH, class B>
+__host__ __device__ __forceinline__ bool parse_subpackets_t(B a, uint32_t len, bool hashed, SubpacketState& st) {
   uint32_t p = 0;
   while (p < len) {
     uint32_t b = a[p], ln;
@@ -117,7 +137,7 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
     if (ln == 0) return false;
     uint32_t typ = a[p] & 0x7F;
     bool critical = (a[p] & 0x80) != 0;
-    const uint8_t* body = a + p + 1;
+    const B body = a + (p + 1);
     uint32_t bl = ln - 1;
     p += ln;
     switch (typ) {
@@ -154,7 +174,7 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
         if constexpr (DEPTH >= 2) { st.too_deep = true; return false; }   // bounded nesting
         else {
           SigRec tmp; SubpacketState inner;
-          const bool ok = parse_sig_body_t<DEPTH + 1>(body, bl, tmp, inner);
+          const bool ok = parse_sig_body_t<DEPTH + 1>(raw_bytes(body), bl, tmp, inner);   // rare: straight from memory
           if (inner.too_deep) st.too_deep = true;
           if (!ok) return false;
           if (tmp.sig_type != 0x19) return false;           // "cross-signature has unexpected type"
@@ -168,10 +188,11 @@ __host__ __device__ __forceinline__ bool parse_subpackets_t(const uint8_t* a, ui
   return true;
 }
 
-__host__ __device__ __forceinline__ bool parse_sig_body(const uint8_t* body, uint32_t blen, SigRec& rec, bool& have_issuer,
+template <class B = const uint8_t*>
+__host__ __device__ __forceinline__ bool parse_sig_body(B body, uint32_t blen, SigRec& rec, bool& have_issuer,
                                                         uint64_t& issuer, bool* too_deep = nullptr) {
   SubpacketState st;
-  const bool ok = parse_sig_body_t<0>(body, blen, rec, st);
+  const bool ok = parse_sig_body_t<0, B>(body, blen, rec, st);
   have_issuer = st.have_issuer;
   issuer = st.issuer;
   if (too_deep) *too_deep = st.too_deep;
@@ -182,7 +203,8 @@ __host__ __device__ __forceinline__ bool parse_sig_body(const uint8_t* body, uin
 // creation time, 8-octet issuer key id, public-key and hash algorithm, 16-bit hash tag, MPIs.  The hashed material is the
 // 5 bytes type || creation time (body[2..7)) with NO trailer -- rec.hashed_len stays 0 and SIGF_V3 tells the digest kernels.
 constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2;
-__host__ __device__ __forceinline__ bool parse_sig_body_v3(const uint8_t* body, uint32_t blen, SigRec& rec, uint64_t& issuer) {
+template <class B = const uint8_t*>
+__host__ __device__ __forceinline__ bool parse_sig_body_v3(B body, uint32_t blen, SigRec& rec, uint64_t& issuer) {
   if (blen < 1 || body[0] < 2 || body[0] > 3) return false;      // "signature packet version"
   if (blen < 19) return false;
   if (body[1] != 5) return false;                                 // "invalid hashed material length"
@@ -406,7 +428,8 @@ struct ParseArgs {
   uint32_t defer_queue;        // two-phase calls: k_plan decides which records join the work lists
 };
 
-__device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev& kt, uint32_t ri, uint32_t item) {
+// `win`: this lane's PARSE_WIN_STRIDE bytes of LDS.
+__device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev& kt, uint32_t ri, uint32_t item, uint32_t* win) {
   const uint8_t* __restrict__ sig_blob = a.sig_blob; const uint64_t* __restrict__ sig_off = a.sig_off;
   const uint32_t* __restrict__ rec_base = a.rec_base; const uint32_t* __restrict__ counts = a.counts;
   const WalkEnt* __restrict__ scratch = a.scratch; SigRec* __restrict__ recs = a.recs;
@@ -429,7 +452,19 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     rec = recs[ri];                                  // written by the sequential k_walk<true>
     if (rec.status != ST_PENDING_PARSE) return;
   }
-  const uint8_t* body = sig_blob + rec.body_off;
+  // the head of the body: four 16-byte loads per lane (never past the end of the blob), parked in LDS
+  const uint8_t* gbody = sig_blob + rec.body_off;
+  const uint64_t room = sig_off[a.n_items] - rec.body_off;
+  const uint32_t nwin = (room < PARSE_WIN ? (uint32_t)room : PARSE_WIN) & ~15u;
+#pragma unroll
+  for (uint32_t j = 0; j < PARSE_WIN / 16; ++j) {
+    if (16 * j < nwin) {
+      uint32_t v[4];
+      __builtin_memcpy(v, gbody + 16 * j, 16);
+      win[4 * j] = v[0]; win[4 * j + 1] = v[1]; win[4 * j + 2] = v[2]; win[4 * j + 3] = v[3];
+    }
+  }
+  const WinBytes body{gbody, (lds_bytes_t)win, nwin};
   uint8_t st;
   int q_kind = -1;             // public-key work list this record joins (decided below, queued at the end)
   // fence: the packet has a shape on which this library does not claim the reference's outcome (DESIGN.md "fenced inputs");
@@ -494,7 +529,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
           const uint32_t mod_bits = kt.mod_bits[slot];
           const uint32_t kbytes = (mod_bits + 7) >> 3;
           const uint32_t nb = (rec.mpi_bits[0] + 7u) >> 3;
-          const uint8_t* mp = body + rec.mpi_off[0];
+          const WinBytes mp = body + (uint32_t)rec.mpi_off[0];
           uint32_t lead = 0;
           while (lead < nb && mp[lead] == 0) ++lead;
           const uint32_t vbytes = nb - lead;
@@ -546,7 +581,8 @@ __global__ void __launch_bounds__(256) k_parse_body(ParseArgs a, KeyTableDev kt)
     const uint32_t mid = (lo + hi) >> 1;
     if (a.rec_base[mid] <= ri) lo = mid; else hi = mid;
   }
-  parse_one(a, kt, ri, lo);
+  __shared__ uint32_t win_sh[256 * (PARSE_WIN_STRIDE / 4)];
+  parse_one(a, kt, ri, lo, win_sh + threadIdx.x * (PARSE_WIN_STRIDE / 4));
 }
 
 // Item-major grid (block per item): collective signatures carry tens of packets per item, the block's lanes read one
@@ -555,7 +591,8 @@ constexpr int PARSE_ITEM_BLOCK = 128;
 __global__ void __launch_bounds__(PARSE_ITEM_BLOCK) k_parse_body_items(ParseArgs a, KeyTableDev kt) {
   const uint32_t item = blockIdx.x;
   const uint32_t cnt = a.counts[item], base = a.rec_base[item];
-  for (uint32_t j = threadIdx.x; j < cnt; j += PARSE_ITEM_BLOCK) parse_one(a, kt, base + j, item);
+  __shared__ uint32_t win_sh[PARSE_ITEM_BLOCK * (PARSE_WIN_STRIDE / 4)];
+  for (uint32_t j = threadIdx.x; j < cnt; j += PARSE_ITEM_BLOCK) parse_one(a, kt, base + j, item, win_sh + threadIdx.x * (PARSE_WIN_STRIDE / 4));
 }
 
 // PGPSignature.Signers (crypto_pgp.go:373-390): parse-only walk, issuers looked up among PRIMARY
