@@ -44,7 +44,7 @@ DSA_BYTES = 99                 # per DSA-2048/256 signature veri
 # limb MACs actually executed (mont28.h): a general Montgomery product = 76x76 (a*b) + 76x76 (m*n) = 11,552; a squaring forms
 # only the triangles of a*a: 4 lanes x (4 x 190 + 1,444) = 8,816.  e = 65537: 16 squarings + 2 products.
 MACS_PER_RSA_VERIFY = 16 * 8816 + 2 * 11552
-MACS_PER_DSA_VERIFY = 34 * 11552           # 16-bit windows: <= 32 table multiplications + entering and leaving the Montgomery domain
+MACS_PER_DSA_VERIFY = 31 * 11552           # 16-bit windows: 32 table entries, the first taken as is, the last stored in plain form
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -70,7 +70,8 @@ struct KeyTableDev {
   const uint32_t* dsa_tab;    // [n_keys][2][76] g*R, y*R mod p (Montgomery form): seeds of the fixed-base tables
   // Fixed-base window tables, resident in HBM for as long as the key is known (k_dsa_build_comb):
   //   dsa_comb[slot][base in {g, y}][window w][digit d-1][76] = base^(d * 2^(wbits*w)) * R mod p,  d = 1 .. 2^wbits - 1
-  // so g^u1 * y^u2 is at most 2 * 256/wbits table multiplications and no squarings.  The slot ends with
+  // so g^u1 * y^u2 is at most 2 * 256/wbits - 1 table multiplications and no squarings (the entries of the window multiplied
+  // by last, dsa_plain_window, are stored without the factor R: that product leaves the Montgomery domain).  The slot ends with
   //   q_pow28[76][10] = 2^(28 j) mod q as radix-2^28 limbs, which folds v (mod p) down to v mod q.
   const uint32_t* dsa_slot;   // [n_keys] table slot of a DSA key (0xFFFFFFFF otherwise)
   const uint32_t* dsa_comb;
@@ -82,6 +83,8 @@ constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits) {
 constexpr uint32_t DSA_QPOW_WORDS = 76 * 10;
 // ... followed by the mod-q Montgomery constants: 2^512 mod q (8 words), -q^-1 mod 2^32 (1 word), 3 words padding
 constexpr uint32_t DSA_QTAIL_WORDS = DSA_QPOW_WORDS + 12;
+// the (base, window) whose entries are stored in plain instead of Montgomery form: the one k_dsa_modexp multiplies by last
+constexpr bool dsa_plain_window(uint32_t base, uint32_t w, uint32_t nwin) { return base == 1u && w == nwin - 1u; }
 constexpr uint64_t dsa_slot_stride(uint32_t wbits) { return dsa_comb_limbs_per_key(wbits) + DSA_QTAIL_WORDS; }
 
 constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;

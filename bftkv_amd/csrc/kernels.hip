@@ -1263,16 +1263,29 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, co
     }
   }
   uint32_t* out = comb + (uint64_t)new_slots[which] * dsa_slot_stride(wbits) + ((uint64_t)(base * nwin + w) * nent) * MONT_N + qlane * L;
-#pragma unroll
-  for (int k = 0; k < L; ++k) a_lds[k] = y[k];       // a = B for the whole chain
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // The window k_dsa_modexp multiplies by LAST (base 1, top window) is stored in plain form, B^d instead of B^d R: that
+  // product then leaves the Montgomery domain by itself.  One more product per entry here, for the waves that hold such a quad.
+  const bool plain = dsa_plain_window(base, w, nwin);
+  const bool any_plain = __any(plain);
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t d = d0 + j;                        // entry index d - 1 holds B^d
+    if (any_plain) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      mont_mul(t, a_rd, b, n, n0inv, qlane);          // B^d R * 1 * R^-1
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      canonicalize(t, qlane);
+    }
     if (active && d >= 1) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) out[(uint64_t)(d - 1) * MONT_N + k] = b[k];
+      for (int k = 0; k < L; ++k) out[(uint64_t)(d - 1) * MONT_N + k] = plain ? t[k] : b[k];
     }
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = y[k];     // a = B for the chain
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     mont_mul(t, a_rd, b, n, n0inv, qlane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int k = 0; k < L; ++k) b[k] = t[k];
   }
@@ -1312,45 +1325,69 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   const uint32_t* a_rd = a_sh + quad * MONT_N;
   uint32_t n[L], b[L], y[L], t[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
   const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
   const uint32_t* slot_base = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(wbits);
   const uint32_t* tab = slot_base + qlane * L;
 #pragma unroll
-  for (int k = 0; k < L; ++k) { n[k] = np[k]; b[k] = rp[k]; a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; }
+  for (int k = 0; k < L; ++k) n[k] = np[k];
   const uint32_t n0inv = kt.n0inv[key];
   const uint32_t* up = dsa_u + (uint64_t)di * DSA_U_WORDS;
   const bool live = active && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  mont_mul(y, a_rd, b, n, n0inv, qlane);     // y = R mod p (Montgomery one)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (uint32_t step = 0; step < 2u * nwin; ++step) {
-    const uint32_t base = step & 1u, w = step >> 1;
-    const uint32_t bitpos = w * wbits;
-    const uint32_t d = live ? ((up[base * 8 + (bitpos >> 5)] >> (bitpos & 31)) & nent) : 0u;
-    if (__any(d != 0)) {
-      const uint32_t* tp = tab + ((uint64_t)(base * nwin + w) * nent + (d ? d - 1 : 0)) * MONT_N;
+  auto digit = [&](uint32_t step) -> uint32_t {
+    const uint32_t bitpos = (step >> 1) * wbits;
+    return live ? ((up[(step & 1u) * 8 + (bitpos >> 5)] >> (bitpos & 31)) & nent) : 0u;
+  };
+  auto entry = [&](uint32_t step, uint32_t d) -> const uint32_t* {
+    return tab + ((uint64_t)((step & 1u) * nwin + (step >> 1)) * nent + (d ? d - 1 : 0)) * MONT_N;
+  };
+  // The chain is 2*nwin - 1 products at most (31 for 16-bit windows): a signature's first non-zero digit just takes its
+  // table entry as the starting value, and the last window's entries are stored in plain form (k_dsa_build_comb) so that
+  // the product by them also leaves the Montgomery domain.  One multiplier call site; a wave skips a step no lane needs.
+  const uint32_t last = 2u * nwin - 1u;
+  bool started = false;
 #pragma unroll
-      for (int k = 0; k < L; ++k) { a_lds[k] = tp[k]; b[k] = y[k]; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      mont_mul(t, a_rd, b, n, n0inv, qlane);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (d) {
+  for (int k = 0; k < L; ++k) y[k] = 0;
+  for (uint32_t step = 0; step <= last; ++step) {
+    const uint32_t d = digit(step);
+    const bool need = (step == last) || d != 0;      // the last product always happens: a zero digit multiplies by the plain 1
+    if (!__any(need)) continue;
+    const uint32_t* tp = entry(step, d);
 #pragma unroll
-        for (int k = 0; k < L; ++k) y[k] = t[k];
+    for (int k = 0; k < L; ++k) a_lds[k] = tp[k];    // a zero digit reads entry 1 and (but for the last step) drops the product
+    if (step == last && __any(d == 0)) {
+      if (d == 0) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
       }
     }
-  }
-  // leave the Montgomery domain; the result is <= p and equals p only for 0
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (__any(need && started)) {
 #pragma unroll
-  for (int k = 0; k < L; ++k) { a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; b[k] = y[k]; }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  mont_mul(t, a_rd, b, n, n0inv, qlane);
+      for (int k = 0; k < L; ++k) b[k] = y[k];
+      mont_mul(t, a_rd, b, n, n0inv, qlane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (__any(need && !started)) {                   // first non-zero digit of some signature: the entry is its starting value
+      if (need) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) y[k] = started ? t[k] : a_lds[k];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (need) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) y[k] = t[k];
+    }
+    started = started || need;
+  }
+  // y = g^u1 y^u2 mod p, possibly + p (mont_mul leaves values below p(1 + 2^-79)): the mod-q fold below needs the residue
+#pragma unroll
+  for (int k = 0; k < L; ++k) t[k] = y[k];
   canonicalize(t, qlane);
+  reduce_once(t, n, qlane);
   uint32_t diff = 0;
 #pragma unroll
-  for (int k = 0; k < L; ++k) diff |= t[k] ^ n[k];
-  diff = quad_or(diff);                      // 0: v == p, i.e. v = 0, and r > 0 can never match
+  for (int k = 0; k < L; ++k) diff |= t[k];
+  diff = quad_or(diff);                      // 0: v = 0, and r > 0 can never match
   // v mod q: sum_j v_j * (2^(28 j) mod q) over 10 radix-2^28 columns (76 terms of < 2^56 each)
   uint64_t col[10];
 #pragma unroll

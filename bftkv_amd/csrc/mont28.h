@@ -191,4 +191,41 @@ __device__ __forceinline__ void canonicalize(uint32_t (&x)[L], int qlane) {
   }
 }
 
+// y -= n when y >= n (y, n canonical; y < 2n): the exact residue of a value mont_mul left below n(1 + 2^-79).
+// The top lane of the group compares its limbs first; only a wave holding a candidate (the top limbs of y not below those
+// of n: about 2^-50 per number for a 2048-bit modulus) runs the subtraction, whose borrow hops lane to lane like
+// canonicalize's carry.
+template <int L, int TPI = MONT_TPI>
+__device__ __forceinline__ void reduce_once(uint32_t (&y)[L], const uint32_t (&n)[L], int qlane) {
+  uint32_t ge = 1;
+#pragma unroll
+  for (int k = 0; k < L; ++k) ge = (y[k] > n[k]) ? 1u : ((y[k] < n[k]) ? 0u : ge);
+  if (!__any(ge != 0 && qlane == TPI - 1)) return;
+  uint32_t d[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) d[k] = y[k] - n[k];            // two's complement, |.| < 2^28
+  int32_t cout = 0, top = 0;
+#pragma unroll
+  for (int step = 0; step < TPI; ++step) {
+    int32_t c = (int32_t)grp_shr1<TPI>((uint32_t)cout);
+    if (qlane == 0) c = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const int32_t v = (int32_t)d[k] + c;
+      d[k] = (uint32_t)v & MONT_MASK;
+      c = v >> MONT_W;                                        // arithmetic shift: -1 = borrow
+    }
+    cout = c;
+    top += c;                                                 // borrows that left this lane, over all steps
+  }
+  // the group's verdict is its top lane's: no borrow out of it <=> y >= n
+  uint32_t keep = (top == 0) ? 1u : 0u;
+  if constexpr (TPI == 4) keep = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)keep, 0xFF, 0xF, 0xF, true);   // quad_perm:[3,3,3,3]
+  else keep = (uint32_t)__shfl((int)keep, (int)((threadIdx.x & 63u) | (uint32_t)(TPI - 1)));
+  if (keep) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) y[k] = d[k];
+  }
+}
+
 }  // namespace bftkv
