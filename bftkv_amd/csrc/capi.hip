@@ -104,9 +104,11 @@ struct bftkv_gpu_ctx {
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
   uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
+  uint32_t multiexp_lanes = 0;        // experiment knob (BFTKV_MULTIEXP_LANES = 4 | 8): lanes per number in k_multiexp, 0 = by call size
+  uint32_t n_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
-  std::map<std::string, std::array<DevBuf, 3>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
+  std::map<std::string, std::array<DevBuf, 4>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
   uint32_t* d_mail = nullptr;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
@@ -702,6 +704,8 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
       hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
   if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
+  if (const char* e = getenv("BFTKV_MULTIEXP_LANES")) c->multiexp_lanes = (uint32_t)atoi(e);
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus; }
   *out = c;
   return BFTKV_OK;
 }

@@ -14,8 +14,9 @@ namespace bftkv {
 
 struct ModTab {               // per distinct modulus, built on the host (hostbn::mont_setup)
   const uint32_t* n_limbs;    // [n_mods][76]
-  const uint32_t* r2_limbs;   // [n_mods][76]
+  const uint32_t* r2_limbs;   // [n_mods][76]  (2^2128)^2 mod n: 4 lanes x 19 limbs
   const uint32_t* n0inv;      // [n_mods]
+  const uint32_t* r2w_limbs;  // [n_mods][80]  (2^2240)^2 mod n: 8 lanes x 10 limbs (k_multiexp's form for calls that do not fill the chip)
 };
 
 #define QUAD_SETUP()                                                        \
@@ -226,30 +227,50 @@ constexpr int MULTIEXP_WIN = 4, MULTIEXP_ENT = 15;
 // The whole schedule -- table build, squarings, table multiplications, leaving the Montgomery domain -- runs through ONE
 // loop with two multiplier call sites (general and squaring): six inlined copies of mont_mul cost 239 VGPRs (two waves per
 // SIMD); this form allows three.
+//
+// <L, TPI>: 19 limbs x 4 lanes per number (R = 2^2128) when the call fills the chip, 10 limbs x 8 lanes (R = 2^2240, its
+// own R^2 column of the ModTab) when it does not: twice the waves, each half as long.  Rows in memory are MONT_N limbs
+// either way; the 8-lane form reads zeros past them and stores nothing there (every value is below 2p < 2^2049).
+constexpr int MULTI_L8 = 10, MULTI_TPI8 = 8;
+constexpr int MONT_N_WIDE = MULTI_L8 * MULTI_TPI8;     // 80 limbs: row length of ModTab::r2w_limbs
+template <int L, int TPI>
 __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
                                                         const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
                                                         const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][15][76]*/,
-                                                        uint32_t* __restrict__ out_limbs, uint32_t idx_div) {
-  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
-  QUAD_SETUP();
+                                                        uint32_t* __restrict__ out_limbs, uint32_t idx_div, uint32_t exp_windows) {
+  constexpr int NL = L * TPI, GROUPS = RSA_BLOCK / TPI;
+  static_assert(NL >= MONT_N, "a group holds a whole row");
+  __shared__ uint32_t a_sh[GROUPS * NL];
+  const uint32_t grp = threadIdx.x / TPI;
+  const int qlane = threadIdx.x % TPI;
+  const uint32_t gq = blockIdx.x * GROUPS + grp;
+  const bool active = gq < n_ops;
+  const uint32_t op = active ? gq : (n_ops - 1);
+  uint32_t* a_lds = a_sh + grp * NL + qlane * L;
+  const uint32_t* a_rd = a_sh + grp * NL;
+  // limb k of this lane in a MONT_N-limb row of memory
+  auto ld = [&](const uint32_t* row, int k) -> uint32_t { const int gi = qlane * L + k; return (NL == MONT_N || gi < MONT_N) ? row[gi] : 0u; };
+  auto st = [&](uint32_t* row, int k, uint32_t v) { const int gi = qlane * L + k; if (NL == MONT_N || gi < MONT_N) row[gi] = v; };
   const uint32_t mi = mod_idx[op / idx_div];
   uint32_t n[L], y[L], t[L];          // the register operand of every product is y (R^2 is loaded into it where needed)
-  const uint32_t* r2p = mt.r2_limbs + (uint64_t)mi * MONT_N + qlane * L;
+  const uint32_t* r2p = (TPI == MONT_TPI ? mt.r2_limbs + (uint64_t)mi * MONT_N : mt.r2w_limbs + (uint64_t)mi * MONT_N_WIDE) + qlane * L;
+  const uint32_t* nrow = mt.n_limbs + (uint64_t)mi * MONT_N;
 #pragma unroll
-  for (int k = 0; k < L; ++k) n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k];
+  for (int k = 0; k < L; ++k) n[k] = ld(nrow, k);
   const uint32_t n0inv = mt.n0inv[mi];
   // wave-uniform program counter
   enum : int { P_TO_MONT = 0, P_POWERS, P_ONE, P_SQR, P_TABMUL, P_LEAVE, P_DONE };
-  int phase = P_TO_MONT, w = 280 / MULTIEXP_WIN - 1, sq = 0;
+  int phase = P_TO_MONT, w = (int)exp_windows - 1, sq = 0;
   uint32_t j = 0, d = 0;           // base index / table digit (P_POWERS: entry being built)
-  uint32_t dig = 0;                // this quad's digit in P_TABMUL
+  uint32_t dig = 0;                // this group's digit in P_TABMUL
   while (phase != P_DONE) {
     const uint64_t sj = (uint64_t)op * k_bases + j;
-    uint32_t* tab = scratch + sj * MULTIEXP_ENT * MONT_N + qlane * L;
+    uint32_t* tab = scratch + sj * MULTIEXP_ENT * MONT_N;
     // ---- operands: a through LDS, b in registers
     if (phase == P_TO_MONT) {                       // b_j * R
+      const uint32_t* brow = base_limbs + sj * MONT_N;
 #pragma unroll
-      for (int k = 0; k < L; ++k) { a_lds[k] = base_limbs[sj * MONT_N + qlane * L + k]; y[k] = r2p[k]; }
+      for (int k = 0; k < L; ++k) { a_lds[k] = ld(brow, k); y[k] = r2p[k]; }
     } else if (phase == P_POWERS) {                 // b^(d+1) = b^d * b; a = b_j stays in LDS, y = the previous power
     } else if (phase == P_ONE) {                    // Montgomery one = mont(1, R^2)
 #pragma unroll
@@ -258,25 +279,25 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = y[k];
     } else if (phase == P_TABMUL) {
-      const uint32_t* row = scratch + (sj * MULTIEXP_ENT + (dig ? dig - 1 : 0)) * MONT_N + qlane * L;
+      const uint32_t* row = scratch + (sj * MULTIEXP_ENT + (dig ? dig - 1 : 0)) * MONT_N;
 #pragma unroll
-      for (int k = 0; k < L; ++k) a_lds[k] = row[k];
+      for (int k = 0; k < L; ++k) a_lds[k] = ld(row, k);
     } else {                                        // P_LEAVE: mont(y, 1)
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (phase == P_SQR) mont_mul<MONT_L, MONT_TPI, true>(t, a_rd, y, n, n0inv, qlane);
-    else mont_mul(t, a_rd, y, n, n0inv, qlane);
+    if (phase == P_SQR) mont_mul<L, TPI, true>(t, a_rd, y, n, n0inv, qlane);
+    else mont_mul<L, TPI, false>(t, a_rd, y, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // ---- results and next step (scalar control flow)
     if (phase == P_TO_MONT) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) { y[k] = t[k]; a_lds[k] = t[k]; if (active) tab[k] = t[k]; }      // a = b_j R for the powers
+      for (int k = 0; k < L; ++k) { y[k] = t[k]; a_lds[k] = t[k]; if (active) st(tab, k, t[k]); }      // a = b_j R for the powers
       d = 1; phase = P_POWERS;
     } else if (phase == P_POWERS) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) { y[k] = t[k]; if (active) tab[(uint64_t)d * MONT_N + k] = t[k]; }
+      for (int k = 0; k < L; ++k) { y[k] = t[k]; if (active) st(tab + (uint64_t)d * MONT_N, k, t[k]); }
       if (++d == MULTIEXP_ENT) {
         if (++j == k_bases) { j = 0; phase = P_ONE; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }   // own table rows are read back below
         else phase = P_TO_MONT;
@@ -301,8 +322,17 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
       }
     }
   }
-  canonicalize(t, qlane);
-  if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
+  canonicalize<L, TPI>(t, qlane);
+  // t <= p after mont(., 1); t == p only for 0
+  uint32_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < L; ++k) diff |= t[k] ^ n[k];
+  diff = grp_or<TPI>(diff);
+  if (active) {
+    uint32_t* orow = out_limbs + (uint64_t)op * MONT_N;
+#pragma unroll
+    for (int k = 0; k < L; ++k) st(orow, k, (diff == 0) ? 0u : t[k]);
+  }
 }
 
 // thread per op: out = in^-1 mod q (numbers as 76-limb radix-2^28, q <= 256 bits, odd); status |= 1 when no inverse

@@ -72,7 +72,16 @@ def test_lagrange_combine_sss_and_calculate_s(gpu_ctx):
     assert got[0] == secret
 
 
-def test_dsa_calculate_r(gpu_ctx):
+@pytest.mark.parametrize("lanes", (4, 8))
+def test_dsa_calculate_r(lanes):
+    """CalculateR through both forms of k_multiexp: 4 lanes x 19 limbs (R = 2^2128) and 8 lanes x 10 limbs (R = 2^2240, picked by
+    default for calls of at most one wave per SIMD)."""
+    from bftkv_amd import Context
+    os.environ["BFTKV_MULTIEXP_LANES"] = str(lanes)        # read when a context is created
+    try:
+        gpu_ctx = Context(0)
+    finally:
+        del os.environ["BFTKV_MULTIEXP_LANES"]
     g_ = KAT["dsa_group"]
     p, q, g = int(g_["p"], 16), int(g_["q"], 16), int(g_["g"], 16)
     rng = np.random.default_rng(8)
@@ -91,6 +100,7 @@ def test_dsa_calculate_r(gpu_ctx):
         assert want[-1] == pow(g, pow(kk, -1, q), p) % q
     got, st = gpu_ctx.dsa_calculate_r(xs, ri, vi, [(p, q)], [0] * len(xs))
     assert list(st) == [0] * len(xs) and got == want
+    gpu_ctx.close()
 
 
 def test_sss_distribute_and_round_trip(gpu_ctx):
