@@ -341,7 +341,7 @@ def measured_traffic(cfg, kernel):
     made by tools/profile_bench.sh + tools/summarize_profile.py: separate rocprofv3 --pmc passes over this same command,
     gfx950 FETCH_SIZE correction applied).  None when no summary is present."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_cfg%d_pmc_summary.json" % cfg)))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg%d_pmc_summary.json" % cfg)))
     if not cands and cfg == 2:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v?_pmc_summary.json")))
     if not cands:
@@ -488,7 +488,8 @@ def bench_cfg2(args, D):
             "verdicts_match_construction": bool(((err == 0) == want_ok).all()),
             "allgather": {"calls_in_timed_region": args.steps, "bytes_per_rank": (items + 7) // 8, "rows_consistent": gather_ok,
                           "via": "bftkv_gpu_allgather_errs_dev (library RCCL, verifier stream)"},
-            "kernel_ms": {"k_rsa_modexp": rsa_ms, "hash_stream": float(np.mean(timed_hash)), "step_device_span": float(np.mean(timed_total)),
+            "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_rsa_modexp_min_max": [float(np.min(timed_rsa)), float(np.max(timed_rsa))],
+                          "hash_stream": float(np.mean(timed_hash)), "step_device_span": float(np.mean(timed_total)),
                           "measured": "HIP events of the %d timed steps (%d in flight)" % (len(timed_rsa), V.n_ctx),
                           "isolated_call": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]}},
             "roofline": roofline(2, "k_rsa_modexp", alg_bytes, rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"),
