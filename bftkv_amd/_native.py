@@ -37,7 +37,7 @@ EXPORTS = [
     "bftkv_gpu_collective_verify", "bftkv_gpu_collective_verify_dev", "bftkv_gpu_sync",
     "bftkv_gpu_signature_verify", "bftkv_gpu_last_statuses", "bftkv_gpu_last_counters",
     "bftkv_gpu_signers", "bftkv_gpu_quorum_tally", "bftkv_gpu_modexp", "bftkv_gpu_last_timing",
-    "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r",
+    "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r", "bftkv_gpu_selftest_reduce",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
@@ -365,6 +365,16 @@ class Context:
         st = np.zeros(len(values) + 8, dtype=np.uint8)
         self._check(self.lib.bftkv_gpu_modinv(self.h, len(values), _ptr(v), nbytes, _ptr(mi), len(moduli), _ptr(m), _ptr(out), _ptr(st)), "modinv")
         return [int.from_bytes(out[i].tobytes(), "big") for i in range(len(values))], st[:len(values)]
+
+    def selftest_reduce(self, values, moduli, mod_idx, lanes: int, nbytes: int = 256):
+        """values[i] - m when values[i] >= m else values[i] (values < 2m): the kernels' conditional subtraction on its own."""
+        v = _ints_to_be(values, nbytes)
+        m = _ints_to_be(moduli, nbytes)
+        mi = np.ascontiguousarray(mod_idx, dtype=np.uint32)
+        out = np.zeros((len(values), nbytes), dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_selftest_reduce(self.h, len(values), _ptr(v), nbytes, _ptr(mi), len(moduli), _ptr(m), lanes, _ptr(out)),
+                    "selftest_reduce")
+        return [int.from_bytes(out[i].tobytes(), "big") for i in range(len(values))]
 
     def modexp_ops(self, base: np.ndarray, mod_idx: np.ndarray, mods: np.ndarray, exps: np.ndarray) -> np.ndarray:
         """out[i] = base[i] ^ exps[i] mod mods[mod_idx[i]] (one exponent per operation: CalculatePartialR, dsa.go:27-31)."""

@@ -1,18 +1,19 @@
 // Montgomery arithmetic for 2048/3072/4096-bit moduli on CDNA4 (gfx950) -- device code.
 //
-// Design (see DESIGN.md "k_rsa"):
-//   * radix 2^28 limbs, N = 4L limbs with L = 19 / 28 / 37 limbs per lane for moduli up to 2048 / 3072 / 4096
-//     bits (R = 2^(28N) > 4n, so values stay < 2n with NO conditional subtraction between multiplications);
-//   * 4 lanes (one DPP quad) per big number, 16 numbers per wave64;
-//   * lazy carries: every limb product is ONE v_mad_u64_u32 into a 64-bit column accumulator
-//     (152 products of < 2^56.6 fit in 64 bits) -- measured on MI355X v_mad_u64_u32 issues at the
-//     same rate as a plain 32-bit VALU op (tools/microbench), so carry handling, not the
-//     multiplier, would otherwise dominate;
-//   * row-wise (operand-scanning) Montgomery with a sliding window of 2L-1 columns per lane;
-//     after L rows the window has slid by exactly one lane and is re-aligned with DPP row_shl:1;
-//   * the broadcast operand a_i is read from LDS (same address across the quad = broadcast),
-//     the per-row Montgomery factor m is computed by quad lane 0 and broadcast with DPP quad_perm.
-// No MFMA: this is integer/modular work.
+// Design:
+//   * radix 2^28 limbs, L limbs per lane, TPI lanes per number: 19 x 4 (<= 2048-bit moduli, R = 2^2128), 14 x 8 (<= 3072,
+//     R = 2^3136), 19 x 8 (<= 4096, R = 2^4256), 10 x 8 (k_multiexp's form for small calls, R = 2^2240); R > 4n, so values
+//     stay < 2n with NO conditional subtraction between multiplications;
+//   * lazy carries: every limb product is ONE v_mad_u64_u32 into a 64-bit column accumulator (152 products of < 2^56.6 fit
+//     in 64 bits).  Measured on MI355X (tools/microbench): a wave64 v_mad_u64_u32 holds a SIMD's issue port for 4.64 cycles,
+//     a 64-bit add or shift for ~4.3, a plain 32-bit op for 2.3 -- the multiplier is barely dearer than a carry, so the loop
+//     is written to issue as few non-MAC instructions as possible (5 per row, 2 per shifted column);
+//   * row-wise (operand-scanning) Montgomery with a sliding window of 2L-1 columns per lane; after L rows the window has
+//     slid by exactly one lane and is re-aligned with DPP row_shl:1;
+//   * the broadcast operand a_i is read from LDS (same address across the group = broadcast), the per-row Montgomery
+//     factor m is computed by group lane 0 and broadcast with DPP quad_perm, the limb mask riding on that move;
+//   * squarings form one triangle of every limb-product block (mont_mul<.., SQR = true>).
+// No MFMA: this is integer/modular work (DESIGN.md section 9 for the arithmetic of that decision).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -335,6 +335,36 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t
   }
 }
 
+// Diagnostic (bftkv_gpu_selftest_reduce): out = v - m when v >= m, else v, for v < 2m -- reduce_once of mont28.h on its own, so
+// that the subtraction path (taken by about one value in 2^50 on the verify path) is exercised on chosen inputs.
+template <int L, int TPI>
+__global__ void __launch_bounds__(RSA_BLOCK) k_reduce_once(uint32_t n_ops, const uint32_t* __restrict__ v_limbs, const uint32_t* __restrict__ mod_idx,
+                                                           ModTab mt, uint32_t* __restrict__ out_limbs) {
+  constexpr int GROUPS = RSA_BLOCK / TPI;
+  const uint32_t grp = threadIdx.x / TPI;
+  const int qlane = threadIdx.x % TPI;
+  const uint32_t gq = blockIdx.x * GROUPS + grp;
+  const bool active = gq < n_ops;
+  const uint32_t op = active ? gq : (n_ops - 1);
+  const uint32_t* nrow = mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N;
+  const uint32_t* vrow = v_limbs + (uint64_t)op * MONT_N;
+  uint32_t n[L], y[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    const int gi = qlane * L + k;
+    n[k] = gi < MONT_N ? nrow[gi] : 0u;
+    y[k] = gi < MONT_N ? vrow[gi] : 0u;
+  }
+  reduce_once<L, TPI>(y, n, qlane);
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const int gi = qlane * L + k;
+      if (gi < MONT_N) out_limbs[(uint64_t)op * MONT_N + gi] = y[k];
+    }
+  }
+}
+
 // thread per op: out = in^-1 mod q (numbers as 76-limb radix-2^28, q <= 256 bits, odd); status |= 1 when no inverse
 __device__ __forceinline__ U256 u256_from_limbs(const uint32_t* l) {
   U256 r = u256_zero();

@@ -273,6 +273,12 @@ int bftkv_gpu_sss_distribute(bftkv_gpu_ctx* ctx, uint32_t n_polys, uint32_t n_sh
 int bftkv_gpu_modinv(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx, uint32_t n_mods,
                      const uint8_t* mods, uint8_t* out, uint8_t* status_out);
 
+/* Diagnostic: out[op] = values[op] - m when values[op] >= m, else values[op], for values < 2m (same width as m), through the
+ * conditional subtraction the kernels use where a residue must be exact (the DSA tail; lanes = 4 | 8 lanes per number).  On the
+ * verify path that subtraction is taken by about one value in 2^50, so the tests drive it here with chosen inputs. */
+int bftkv_gpu_selftest_reduce(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx,
+                              uint32_t n_mods, const uint8_t* mods, uint32_t lanes, uint8_t* out);
+
 /* The same five with the PER-OPERATION arrays (factors / xs / ys / ri / vi / coeffs / values / mod_idx / outputs / status)
  * already resident in HBM and the results left there: asynchronous on the context's stream until bftkv_gpu_sync.
  * mods / p / q stay HOST pointers (a few hundred bytes per distinct modulus, cached per context by value); mod_idx /

@@ -218,3 +218,27 @@ def test_partial_r_is_a_per_operation_exponent(gpu_ctx):
     exps = np.frombuffer(b"".join(x.to_bytes(20, "big") for x in a), dtype=np.uint8).reshape(n, 20).copy()
     out = gpu_ctx.modexp_ops(base, np.zeros(n, dtype=np.uint32), mods, exps)
     assert [int.from_bytes(out[i].tobytes(), "big") for i in range(n)] == [int.from_bytes(T.calculate_partial_r(g, x, p), "big") for x in a]
+
+
+@pytest.mark.parametrize("lanes", (4, 8))
+def test_conditional_subtraction_on_chosen_inputs(gpu_ctx, lanes):
+    """reduce_once (mont28.h): v - m for v >= m, v otherwise, v < 2m.  The verify path takes the subtraction for about one
+    value in 2^50 (only when the top limbs of v reach those of m), so it is driven here: values around m and 2m, borrows that
+    cross every lane boundary (limb runs of zeros), moduli whose top lane is empty (1024 bits: every value takes the path)."""
+    rng = np.random.default_rng(77)
+    mods, vals, idx = [], [], []
+    for bits in (2047, 2047, 1024, 1536, 600):
+        m = int.from_bytes(rng.bytes(256), "big") >> (2048 - bits) | (1 << (bits - 1)) | 1
+        mi = len(mods)
+        mods.append(m)
+        cases = [0, 1, m - 1, m, m + 1, 2 * m - 1, m >> 1, m + (m >> 1)]
+        for sh in (28 * 19, 28 * 38, 28 * 57, 28 * 10, 28 * 40, 28 * 70, 1000, 531):   # lane boundaries of both forms
+            if (1 << sh) < m:
+                cases += [m + (1 << sh) - 1, m + (1 << sh), m - (1 << sh), (m >> sh << sh), (m >> sh << sh) + m - 1]
+        cases += [int.from_bytes(rng.bytes(256), "big") % (2 * m) for _ in range(40)]
+        for v in cases:
+            if 0 <= v < 2 * m:
+                vals.append(v); idx.append(mi)
+    got = gpu_ctx.selftest_reduce(vals, mods, idx, lanes)
+    for v, i, g in zip(vals, idx, got):
+        assert g == (v - mods[i] if v >= mods[i] else v), (lanes, mods[i].bit_length(), hex(v)[:20])
