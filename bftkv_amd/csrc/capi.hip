@@ -7,8 +7,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <limits.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <memory>
 #include <functional>
 #include <map>
 #include <chrono>
