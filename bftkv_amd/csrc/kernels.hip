@@ -3,15 +3,16 @@
 //   k_walk<COUNT|FILL>    wave per item: speculative walk of the OpenPGP packet HEADERS of the signature stream
 //                         (x/crypto packet.Read framing) -> one event per packet (scratch row, or SigRec when the row is full)
 //   k_scan_counts         exclusive scan of per-item event counts; the total also goes to a pinned host mailbox
-//   k_parse_body[_items]  per packet: Signature.parse (subpackets, MPIs), KeysByIdUsage lookup (bisection), every
-//                         check that does not need the digest; queues public-key work (RSA by size class, DSA)
+//   k_parse_body[_items]  per packet: Signature.parse (subpackets, MPIs) over an LDS window of the packet head,
+//                         KeysByIdUsage lookup (bisection), every check that does not need the digest; names the work list
+//   k_plan<1|2>           two-phase queueing of the public-key work up to the reference's early exit
 //   k_sha256_mid          SHA-256 midstate of every item's signed payload, computed ONCE per item
 //                         (the reference re-hashes the whole payload per signature,
 //                          crypto/pgp/crypto_pgp.go:490); k_hash_mid_other: SHA-1/224/384/512 on demand
 //   k_digest_sha256/other per signature: finish the hash with the hash suffix, hash-tag check
-//   k_rsa_modexp<L>       s^e mod n by Montgomery ladder, 4 lanes per signature (mont28.h);
-//                         runs CONCURRENTLY with the hash kernels (separate HIP stream)
-//   k_rsa_compare<L>      EMSA-PKCS1-v1_5 from the digest, compare with s^e mod n
+//   k_rsa_modexp<L,TPI>   s^e mod n by Montgomery ladder, 4 (8) lanes per signature (mont28.h), EMSA padding above the
+//                         low 84 bytes checked in place; runs CONCURRENTLY with the hash kernels (separate HIP stream)
+//   k_rsa_compare         low 84 bytes of EMSA-PKCS1-v1_5 from the digest against those of s^e mod n
 //   k_dsa_inv/_mul/_modexp  dsa.Verify: s^-1 mod q and u2 on a third stream, u1 after the digests, g^u1 y^u2 mod p
 //                         from HBM-resident fixed-base window tables (k_dsa_build_comb), v mod q == r in place
 //   k_modexp              generic b^x mod n (corpus signing, threshold-RSA partial signatures)
@@ -1302,7 +1303,7 @@ __device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
 }
 
 // v = g^u1 * y^u2 mod p from the per-key fixed-base tables: one table multiplication per non-zero
-// window digit of u1 and u2 (<= 2 * 256/wbits), no squarings.  A table row is 304 B read straight from
+// window digit of u1 and u2 but the first (<= 2 * 256/wbits - 1), no squarings.  A table row is 304 B read straight from
 // HBM/MALL into the quad's LDS slot; a wave skips a (window, base) step when all 16 digits are zero.
 // The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each quad lane
 // folds its 19 limbs, the quad adds up, 35 shift-subtract steps finish), then (v mod q) == r.
