@@ -112,6 +112,7 @@ struct bftkv_gpu_ctx {
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
   uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
   uint32_t multiexp_lanes = 0;        // experiment knob (BFTKV_MULTIEXP_LANES = 4 | 8): lanes per number in k_multiexp, 0 = by call size
+  uint32_t dsa_inv_mode = 0;          // experiment knob (BFTKV_DSA_INV = single | batched): 1 / 2, 0 = by batch shape
   uint32_t n_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
@@ -347,10 +348,23 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_plan<1>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
+  // s^-1 mod q: one extended GCD per run of signatures under one key (k_dsa_inv_batched) when the batch gives every DSA key
+  // enough of them -- a thread's 16 sorted entries then hold one or two runs; with fewer signatures than that per key the
+  // runs shrink towards one entry and a thread would walk up to 16 GCDs in sequence -- else one per signature (k_dsa_inv)
+  const size_t n_slots = c->dsa_comb_slot.size();
+  const bool inv_batched = c->dsa_inv_mode ? c->dsa_inv_mode == 2
+                                           : (n_slots <= 256 && (uint64_t)total >= 64ull * (n_slots ? n_slots : 1) && total >= 8192);
+  auto launch_dsa_inv = [&](hipStream_t st, const uint32_t* start) {
+    if (inv_batched && n_slots <= (size_t)INV_MAX_SLOTS)
+      hipLaunchKernelGGL(k_dsa_inv_batched, dim3((total + INV_TILE - 1) / INV_TILE), dim3(INV_BLOCK), 0, st, d_ss, c->recs.as<SigRec>(),
+                         c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, st, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
+                         c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>());
+  };
   if (total && c->have_dsa_keys) {
     HIPCHK(c, hipStreamWaitEvent(c->stream_d, c->ev[1], 0));
-    hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, c->stream_d, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                       c->pk_count.as<uint32_t>(), start0, c->kt, c->dsa_u.as<uint32_t>());
+    launch_dsa_inv(c->stream_d, start0);
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream_d));
   }
   auto hash_stream_work = [&]() -> int {
@@ -433,9 +447,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pl.verdict = c->o_verdict.as<uint8_t>();
     hipLaunchKernelGGL(k_plan<2>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
     const uint32_t* const start1 = cnt_p + 8;
-    if (c->have_dsa_keys)
-      hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, s, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start1,
-                         c->kt, c->dsa_u.as<uint32_t>());
+    if (c->have_dsa_keys) launch_dsa_inv(s, start1);
     launch_modexp(start1);
     launch_compare(start1);
     if (c->have_dsa_keys) launch_dsa(start1);
@@ -712,6 +724,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
   if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_LANES")) c->multiexp_lanes = (uint32_t)atoi(e);
+  if (const char* e = getenv("BFTKV_DSA_INV")) c->dsa_inv_mode = !strcmp(e, "batched") ? 2u : !strcmp(e, "single") ? 1u : 0u;
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus; }
   *out = c;
   return BFTKV_OK;

@@ -1169,6 +1169,138 @@ __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_
   for (int i = 0; i < 8; ++i) { o[i] = w.w[i]; o[8 + i] = u2.w[i]; o[16 + i] = r.w[i]; }
 }
 
+// The same rows by Montgomery's trick.  Signatures under one key share q, so a run of them needs ONE extended GCD (65,000
+// instructions per signature in k_dsa_inv -- 5.3 G per cfg-3 step, three quarters of what the RSA modexp beside it issues)
+// and six 256-bit Montgomery products each: prefix products forward, the inverse of the whole product, then backward
+// w_i = inv * prefix_(i-1), inv *= s_i.  Grouping is tile-local: a block counting-sorts the table slots of its 4096 work-list
+// entries in LDS (no global pass), then every thread takes 16 consecutive entries of the sorted order -- one run, or two
+// where a key boundary falls inside.  The prefix products and the Montgomery forms of the s_i wait in the entries' own
+// dsa_u rows.  A product that has no inverse (composite q and an s sharing a factor with it) sends its run through the
+// per-signature routine, so the verdicts stay those of math/big.ModInverse.  Chosen by the host for batches with enough
+// signatures per DSA key (run_pipeline); rows written are identical to k_dsa_inv's.
+constexpr int INV_BLOCK = 256, INV_PER_THREAD = 16, INV_TILE = INV_BLOCK * INV_PER_THREAD, INV_MAX_SLOTS = 4096;
+__global__ void __launch_bounds__(INV_BLOCK) k_dsa_inv_batched(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
+                                                               const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
+                                                               const uint32_t* __restrict__ pk_start,
+                                                               KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/) {
+  __shared__ uint32_t bins[INV_MAX_SLOTS];
+  __shared__ uint32_t tsum[INV_BLOCK];
+  __shared__ uint16_t order[INV_TILE], slot_of[INV_TILE];
+  const uint32_t count = pk_count[1], start = pk_start[1];
+  const uint32_t tile0 = start + blockIdx.x * INV_TILE;
+  if (tile0 >= count) return;
+  const uint32_t n = min((uint32_t)INV_TILE, count - tile0);
+  const uint32_t t = threadIdx.x;
+  // ---- counting sort of the tile's entries by table slot
+#pragma unroll
+  for (int j = 0; j < INV_MAX_SLOTS / INV_BLOCK; ++j) bins[t + INV_BLOCK * j] = 0;
+  __syncthreads();
+  for (int j = 0; j < INV_PER_THREAD; ++j) {
+    const uint32_t e = t + INV_BLOCK * j;
+    if (e < n) {
+      const uint32_t sl = kt.dsa_slot[(uint32_t)recs[dsa_list[tile0 + e]].key_slot] & (INV_MAX_SLOTS - 1);
+      slot_of[e] = (uint16_t)sl;
+      atomicAdd(&bins[sl], 1u);
+    }
+  }
+  __syncthreads();
+  constexpr int BPT = INV_MAX_SLOTS / INV_BLOCK;      // bins per thread
+  uint32_t loc[BPT], sum = 0;
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) { loc[j] = sum; sum += bins[BPT * t + j]; }
+  tsum[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < INV_BLOCK; off <<= 1) {
+    const uint32_t v = t >= off ? tsum[t - off] : 0u;
+    __syncthreads();
+    tsum[t] += v;
+    __syncthreads();
+  }
+  const uint32_t base = tsum[t] - sum;
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) bins[BPT * t + j] = base + loc[j];
+  __syncthreads();
+  for (int j = 0; j < INV_PER_THREAD; ++j) {
+    const uint32_t e = t + INV_BLOCK * j;
+    if (e < n) order[atomicAdd(&bins[slot_of[e]], 1u)] = (uint16_t)e;
+  }
+  __syncthreads();
+  // ---- runs of one slot inside this thread's 16 sorted entries
+  uint32_t pos = INV_PER_THREAD * t;
+  const uint32_t end = min(pos + INV_PER_THREAD, n);
+  U256 one = u256_zero();
+  one.w[0] = 1;
+  while (pos < end) {
+    const uint32_t sl = slot_of[order[pos]];
+    uint32_t re = pos + 1;
+    while (re < end && slot_of[order[re]] == sl) ++re;
+    const uint32_t key = (uint32_t)recs[dsa_list[tile0 + order[pos]]].key_slot;
+    U256 q, r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
+    const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
+    const uint32_t q0inv = qc[8];
+    const bool q_ok = (kt.q_bits[key] & 7u) == 0;
+    uint32_t valid = 0;          // bit i: entry pos + i passed the range checks
+    U256 P = one;                // product of the valid s so far, Montgomery form
+    for (uint32_t i = pos; i < re; ++i) {
+      const uint32_t di = tile0 + order[i], ri = dsa_list[di];
+      const uint8_t* body = sig_blob + recs[ri].body_off;
+      U256 r, s_;
+      bool ok = u256_from_be(body + recs[ri].mpi_off[0], (recs[ri].mpi_bits[0] + 7u) >> 3, r);
+      ok = u256_from_be(body + recs[ri].mpi_off[1], (recs[ri].mpi_bits[1] + 7u) >> 3, s_) && ok;
+      ok = ok && q_ok && !u256_is_zero(r) && u256_cmp(r, q) < 0 && !u256_is_zero(s_) && u256_cmp(s_, q) < 0;   // 0 < r, s < q
+      uint32_t* o = dsa_u + (uint64_t)di * DSA_U_WORDS;
+      U256 st = u256_zero(), pw = u256_zero();
+      if (ok) {
+        st = u256_montmul(s_, r2, q, q0inv);
+        P = valid ? u256_montmul(P, st, q, q0inv) : st;
+        pw = P;
+        valid |= 1u << (i - pos);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { o[k] = pw.w[k]; o[8 + k] = st.w[k]; o[16 + k] = r.w[k]; }
+    }
+    if (valid) {
+      U256 inv;
+      const bool inv_ok = u256_modinv_odd(u256_montmul(P, one, q, q0inv), q, inv);
+      U256 I = u256_montmul(inv, r2, q, q0inv);      // (product of the s)^-1, Montgomery form
+      for (uint32_t i = re; i-- > pos;) {
+        if (!((valid >> (i - pos)) & 1u)) continue;
+        uint32_t* o = dsa_u + (uint64_t)(tile0 + order[i]) * DSA_U_WORDS;
+        U256 st, r, w, u2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { st.w[k] = o[8 + k]; r.w[k] = o[16 + k]; }
+        if (inv_ok) {
+          const uint32_t below = valid & ((1u << (i - pos)) - 1u);      // valid entries before this one
+          U256 wt = I;
+          if (below) {
+            const uint32_t pv = pos + (31u - (uint32_t)__builtin_clz(below));
+            const uint32_t* op = dsa_u + (uint64_t)(tile0 + order[pv]) * DSA_U_WORDS;
+            U256 Pp;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Pp.w[k] = op[k];
+            wt = u256_montmul(I, Pp, q, q0inv);
+          }
+          I = u256_montmul(I, st, q, q0inv);
+          w = u256_montmul(wt, one, q, q0inv);
+          u2 = u256_montmul(wt, r, q, q0inv);
+        } else {
+          // no inverse for the product: this signature on its own
+          const bool ok1 = u256_modinv_odd(u256_montmul(st, one, q, q0inv), q, w);
+          if (ok1) u2 = u256_mulmod_mont(w, r, q, q0inv, r2);
+          else { w = u256_zero(); u2 = u256_zero(); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = w.w[k]; o[8 + k] = u2.w[k]; }
+      }
+    }
+    pos = re;
+  }
+}
+
 // After the digests: u1 = z*w mod q replaces w in the row; refused signatures get their final status here.
 __global__ void __launch_bounds__(64) k_dsa_mul(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
                                                 const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,

@@ -947,3 +947,77 @@ def test_mixed_modulus_sizes_2048_3072_4096(gpu_ctx):
     finally:
         gpu_ctx.set_early_exit(True)
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_dsa_batched_inversion_gives_the_per_signature_rows():
+    """k_dsa_inv_batched (one extended GCD per run of signatures under a key, Montgomery's trick) against k_dsa_inv (one per
+    signature) and the oracle: runs of every length up to a tile's, keys whose signatures are few (runs of one), range-check
+    failures inside a run (r = 0, s = 0, r >= q, s >= q: dsa.Verify refuses before inverting) and corrupted values."""
+    import os
+    import hashlib
+    from bftkv_amd import Context
+    from corpus.keys import DRBG
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(9, dsa_fraction=1.0)
+    kr = H.oracle_keyring(cl)
+    q = H.clique_quorum(cl)
+    rng = np.random.default_rng(31)
+    srng = DRBG("dsa-batched")
+
+    def dsa_packet(kp, tbs, r=None, s=None):
+        prefix = cb.sig_prefix(0x00, kp.algo, cb._hashed_area(kp.key_id))
+        digest = hashlib.sha256(tbs + cb.hash_suffix(prefix)).digest()
+        pkt = cb.make_sig_packet(kp, prefix, digest, srng)
+        if r is None and s is None:
+            return pkt
+        body = bytearray(pkt[3:] if pkt[1] >= 192 else pkt[2:])
+        p = len(prefix) + 4                          # unhashed length (2) + hash tag (2)
+        mp = []
+        for _ in range(2):
+            nb = (int.from_bytes(body[p:p + 2], "big") + 7) // 8
+            mp.append(int.from_bytes(body[p + 2:p + 2 + nb], "big")); p += 2 + nb
+        r_, s_ = (mp[0] if r is None else r), (mp[1] if s is None else s)
+        enc = b"".join(cb.go_mpi_bytes(v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")) for v in (r_, s_))
+        nbody = bytes(body[:len(prefix) + 4]) + enc
+        return cb._hdr(2, len(nbody)) + nbody
+
+    tbs_l, ss_l = [], []
+    for i in range(700):
+        tbs = rng.bytes(int(rng.integers(1, 80)))
+        # replicas 0..2 sign nearly every item (long runs), 3..5 about one in eight, 6..8 a handful of items (runs of one)
+        who = [j for j in range(9) if (j < 3 and rng.random() < 0.95) or (3 <= j < 6 and rng.random() < 0.125) or (j >= 6 and i % 97 == j)]
+        parts = []
+        for j in rng.permutation(who):
+            kp = cl.replicas[int(j)]
+            m = int(rng.integers(0, 40))
+            if m == 0: parts.append(dsa_packet(kp, tbs, r=0))
+            elif m == 1: parts.append(dsa_packet(kp, tbs, s=0))
+            elif m == 2: parts.append(dsa_packet(kp, tbs, r=kp.q))
+            elif m == 3: parts.append(dsa_packet(kp, tbs, s=kp.q + 5))
+            elif m == 4: parts.append(dsa_packet(kp, tbs, s=int(rng.integers(1, 1 << 62))))
+            else: parts.append(dsa_packet(kp, tbs))
+        tbs_l.append(tbs); ss_l.append(b"".join(parts))
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    got = {}
+    for mode in ("single", "batched"):
+        os.environ["BFTKV_DSA_INV"] = mode
+        try:
+            ctx = Context(0)
+        finally:
+            del os.environ["BFTKV_DSA_INV"]
+        ctx.set_early_exit(False)
+        ctx.keyring_set(H.abi_keys(kr))
+        qh = ctx.quorum_create(H.abi_qcs(q))
+        err, nver, _ = ctx.collective_verify(qh, tb, to, sb, so)
+        st, st_item = ctx.last_statuses()
+        got[mode] = (err.copy(), nver.copy(), st.copy(), st_item.copy())
+        ctx.close()
+    for a, b in zip(got["single"], got["batched"]):
+        assert (a == b).all()
+    err, nver, st, st_item = got["batched"]
+    assert (st == 0).sum() > 1000 and (st != 0).sum() > 100
+    for i in range(0, 700, 23):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
+        assert list(st[st_item == i])[:len(r.statuses)] == r.statuses and (err[i] == 0) == (r.err is None), i
