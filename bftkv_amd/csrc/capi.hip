@@ -348,19 +348,20 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_plan<1>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
-  // s^-1 mod q: one extended GCD per run of signatures under one key (k_dsa_inv_batched) when the batch gives every DSA key
-  // enough of them -- a thread's 16 sorted entries then hold one or two runs; with fewer signatures than that per key the
-  // runs shrink towards one entry and a thread would walk up to 16 GCDs in sequence -- else one per signature (k_dsa_inv)
+  // s^-1 mod q: one extended GCD per run of signatures under one key (k_dsa_inv_batched) when the DSA work list gives every
+  // key of the ring enough of them (64 on average, 4096 in all: a thread's 16 sorted entries then hold one or two runs), else
+  // one per signature (k_dsa_inv).  The list length lives on the device, so both kernels are enqueued and one of them returns
+  // at once.
   const size_t n_slots = c->dsa_comb_slot.size();
-  const bool inv_batched = c->dsa_inv_mode ? c->dsa_inv_mode == 2
-                                           : (n_slots <= 256 && (uint64_t)total >= 64ull * (n_slots ? n_slots : 1) && total >= 8192);
+  const uint32_t inv_batch_min = c->dsa_inv_mode == 1 || n_slots > (c->dsa_inv_mode == 2 ? (size_t)INV_MAX_SLOTS : 256) ? 0xFFFFFFFFu
+                                 : c->dsa_inv_mode == 2 ? 0u : (uint32_t)std::max<size_t>(4096, 64 * n_slots);
   auto launch_dsa_inv = [&](hipStream_t st, const uint32_t* start) {
-    if (inv_batched && n_slots <= (size_t)INV_MAX_SLOTS)
+    if (inv_batch_min != 0xFFFFFFFFu)
       hipLaunchKernelGGL(k_dsa_inv_batched, dim3((total + INV_TILE - 1) / INV_TILE), dim3(INV_BLOCK), 0, st, d_ss, c->recs.as<SigRec>(),
-                         c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>());
-    else
+                         c->dsa_list.as<uint32_t>(), c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>(), inv_batch_min);
+    if (inv_batch_min != 0u)
       hipLaunchKernelGGL(k_dsa_inv, dim3((total + 63) / 64), dim3(64), 0, st, d_ss, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
-                         c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>());
+                         c->pk_count.as<uint32_t>(), start, c->kt, c->dsa_u.as<uint32_t>(), inv_batch_min);
   };
   if (total && c->have_dsa_keys) {
     HIPCHK(c, hipStreamWaitEvent(c->stream_d, c->ev[1], 0));

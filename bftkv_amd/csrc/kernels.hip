@@ -1142,7 +1142,8 @@ constexpr int DSA_U_WORDS = 24;
 __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
                                                 const uint32_t* __restrict__ pk_start,
-                                                KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/) {
+                                                KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/, uint32_t batch_min) {
+  if (pk_count[1] - pk_start[1] >= batch_min) return;     // enough DSA signatures for k_dsa_inv_batched: that one runs
   const uint32_t di = pk_start[1] + blockIdx.x * blockDim.x + threadIdx.x;
   if (di >= pk_count[1]) return;
   const uint32_t ri = dsa_list[di];
@@ -1176,13 +1177,15 @@ __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_
 // entries in LDS (no global pass), then every thread takes 16 consecutive entries of the sorted order -- one run, or two
 // where a key boundary falls inside.  The prefix products and the Montgomery forms of the s_i wait in the entries' own
 // dsa_u rows.  A product that has no inverse (composite q and an s sharing a factor with it) sends its run through the
-// per-signature routine, so the verdicts stay those of math/big.ModInverse.  Chosen by the host for batches with enough
-// signatures per DSA key (run_pipeline); rows written are identical to k_dsa_inv's.
+// per-signature routine, so the verdicts stay those of math/big.ModInverse.  Both kernels are launched and the DSA work-list
+// length, known on the device only, decides which of them runs (batch_min, run_pipeline): with few signatures per key the
+// runs shrink towards one entry and a thread would walk up to 16 GCDs in sequence.  Rows written are identical to k_dsa_inv's.
 constexpr int INV_BLOCK = 256, INV_PER_THREAD = 16, INV_TILE = INV_BLOCK * INV_PER_THREAD, INV_MAX_SLOTS = 4096;
 __global__ void __launch_bounds__(INV_BLOCK) k_dsa_inv_batched(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                                const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
                                                                const uint32_t* __restrict__ pk_start,
-                                                               KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/) {
+                                                               KeyTableDev kt, uint32_t* __restrict__ dsa_u /*[n][24]*/, uint32_t batch_min) {
+  if (pk_count[1] - pk_start[1] < batch_min) return;      // too few DSA signatures per key to form runs: k_dsa_inv runs
   __shared__ uint32_t bins[INV_MAX_SLOTS];
   __shared__ uint32_t tsum[INV_BLOCK];
   __shared__ uint16_t order[INV_TILE], slot_of[INV_TILE];
