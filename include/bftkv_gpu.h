@@ -176,8 +176,10 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
 /* ---- micro-batching of concurrent single calls ---------------------------------------------------- */
 /* The reference verifies ONE message per call, concurrently from one goroutine per HTTP request
  * (transport/http/http.go:85,143 -> protocol/server.go:562-620).  A batcher turns such calls into device batches:
- * each call blocks until its batch -- closed after max_items calls or max_wait_us microseconds, whichever comes
- * first -- has been verified.  Thread-safe; buffers are only read for the duration of the call.
+ * each call blocks until its batch has been verified.  A batch is taken when max_items calls wait, when as many wait as
+ * the worker has just seen at once (the previous batch plus the queue behind it: a lone caller is answered immediately), or
+ * max_wait_us microseconds after its first call, whichever comes first; calls that arrive while a batch runs are taken
+ * together behind it.  Thread-safe; buffers are only read for the duration of the call.
  * FAIL-CLOSED: the status byte is written on every path and is a failure (invalid signature / insufficient signatures /
  * read error) whenever the return code is not 0 -- a caller that only looks at the status can never read "verified" out
  * of an infrastructure error (allocation failure, stopped batcher, bad handle). */

@@ -48,7 +48,7 @@ func New(device int) *crypto.Crypto {
 	if rc := C.bftkv_gpu_init(C.int(device), &g.ctx); rc != 0 {
 		panic(errNoDevice)
 	}
-	// 256 calls or 200 us, whichever comes first (INTEGRATION.md section 2)
+	// at most 256 calls per batch, at most 200 us of waiting for company (INTEGRATION.md section 2)
 	g.batcher = C.bftkv_gpu_batcher_create(g.ctx, 256, 200)
 	if g.batcher == nil {
 		panic("pgpgpu: bftkv_gpu_batcher_create failed")
