@@ -64,6 +64,36 @@ def v3(kp, payload, sig_type=0):
     return cb._hdr(2, len(body)) + body
 
 
+def dsa_v4(kp, payload, rng, *, hash_id=8, r_add=0, s_add=0, r_set=None, s_set=None, lead_zero=False):
+    hashed = CT + iss(kp)
+    prefix = bytes([4, 0, kp.algo, hash_id]) + struct.pack(">H", len(hashed)) + hashed
+    digest = HASHES[hash_id](payload + cb.hash_suffix(prefix)).digest()
+    r, s = cb._dsa_sign(kp, digest, rng)            # z = leftmost min(len(digest), bytes(q)) bytes, as dsa.Verify takes it
+    r = (r + r_add) if r_set is None else r_set
+    s = (s + s_add) if s_set is None else s_set
+    enc = b""
+    for v in (r, s):
+        b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+        enc += (struct.pack(">H", 8 * len(b) + 8) + b"\x00" + b) if lead_zero else cb.go_mpi_bytes(b)
+    body = prefix + b"\x00\x00" + digest[:2] + enc
+    return cb._hdr(2, len(body)) + body
+
+
+def dsa_cases(kd, rng):
+    pl = b"negative-vector payload\n with a line ending"
+    return [
+        ("dsa-control-good", dsa_v4(kd, pl, rng), True, "DSA-2048/256 over SHA-256 as DetachSign emits it"),
+        ("dsa-r-zero", dsa_v4(kd, pl, rng, r_set=0), True, "FIPS 186: 0 < r < q"),
+        ("dsa-s-zero", dsa_v4(kd, pl, rng, s_set=0), True, "FIPS 186: 0 < s < q"),
+        ("dsa-r-plus-q", dsa_v4(kd, pl, rng, r_add=kd.q), True, "r >= q: equal mod q, must be refused before any arithmetic"),
+        ("dsa-s-plus-q", dsa_v4(kd, pl, rng, s_add=kd.q), True, "s >= q"),
+        ("dsa-leading-zero-mpis", dsa_v4(kd, pl, rng, lead_zero=True), False, "same values, non-canonical encoding"),
+        ("dsa-sha512-truncated", dsa_v4(kd, pl, rng, hash_id=10), True, "hash longer than q: leftmost 256 bits (FIPS 186-3 4.6)"),
+        ("dsa-sha1-shorter-than-q", dsa_v4(kd, pl, rng, hash_id=2), False, "160-bit hash under a 256-bit q: gpg demands >= 256 bits, dsa.Verify takes what it gets"),
+        ("dsa-wrong-payload", dsa_v4(kd, pl + b"!", rng), True, "signature over other bytes"),
+    ]
+
+
 def cases(kp, other):
     pl = b"negative-vector payload\n with a line ending"
     inner19 = cb.sig_prefix(0x19, other.algo, CT + iss(other)) + b"\x00\x00\xab\xcd" + cb.go_mpi_bytes(b"\x5a" * 256)
@@ -103,15 +133,17 @@ def gpg(home, *args, inp=None):
 def main():
     cl = cb.make_cluster(4, n_outsiders=1)
     kp, other = cl.replicas[0], cl.replicas[1]
+    kd = [r for r in cb.make_cluster(4, dsa_fraction=0.5, n_outsiders=1).replicas if r.algo == cb.PK_DSA][0]
     home = tempfile.mkdtemp(prefix="gnupg")
     os.chmod(home, 0o700)
     out = {"gpg_version": subprocess.run(["gpg", "--version"], stdout=subprocess.PIPE).stdout.decode().splitlines()[0], "vectors": []}
     try:
-        ring = b"".join(r.entity for r in cl.replicas)
+        ring = b"".join(r.entity for r in cl.replicas) + kd.entity
         imp = gpg(home, "--import", inp=ring)
         out["pubring"] = ring.hex()
         out["import_rc"] = imp.returncode
         pl, cs = cases(kp, other)
+        cs = cs + dsa_cases(kd, DRBG("negative-dsa"))
         out["payload"] = pl.hex()
         for name, sig, strict, note in cs:
             with open(os.path.join(home, "pl"), "wb") as f:
