@@ -550,17 +550,21 @@ def bench_cfg3(args, D):
     reply_t = rc.write_t[rc.reply_write]
     winners = [None]
 
+    # replies grouped by variable once (they do not change from step to step); each step only brings new error bytes
+    order = np.argsort(rc.reply_var, kind="stable")
+    roff = np.zeros(n_vars + 1, dtype=np.uint64)
+    roff[1:] = np.cumsum(np.bincount(rc.reply_var, minlength=n_vars), dtype=np.uint64)
+    peers_s = np.ascontiguousarray(rc.reply_peer[order]).astype(np.uint64, copy=False)
+    ts_s = np.ascontiguousarray(reply_t[order]).astype(np.uint64, copy=False)
+    vb_s = np.ascontiguousarray(vals[rc.reply_write[order]].reshape(-1))
+    vo_s = np.arange(n_replies + 1, dtype=np.uint64) * np.uint64(vlen)
+    in_order = bool((order == np.arange(n_replies)).all())
+
     def tally(err):
         """Client.Read's fold over the replies whose <x,v,t,sig,ss> verified (protocol/client.go:181-205) through the host
-        mirror (bftkv_host_max_timestamped_value); replies that fail verification are dropped as failures."""
-        ok = err == 0
-        cnt = np.bincount(rc.reply_var[ok], minlength=n_vars)
-        roff = np.zeros(n_vars + 1, dtype=np.uint64)
-        roff[1:] = np.cumsum(cnt, dtype=np.uint64)
-        peers = np.ascontiguousarray(rc.reply_peer[ok]); ts = np.ascontiguousarray(reply_t[ok])
-        vb = np.ascontiguousarray(vals[rc.reply_write[ok]].reshape(-1))
-        vo = (np.arange(len(peers) + 1, dtype=np.uint64) * vlen)
-        return HM.max_timestamped_value_raw(q_read, n_vars, peers, ts, vb, vo, roff)
+        mirror (bftkv_host_max_timestamped_value_masked): replies that fail verification are dropped as failures."""
+        e = np.ascontiguousarray(err if in_order else err[order], dtype=np.uint8)
+        return HM.max_timestamped_value_masked(q_read, n_vars, peers_s, ts_s, vb_s, vo_s, roff, e)
 
     def run(k):
         for i in range(k):
@@ -619,8 +623,9 @@ def bench_cfg3(args, D):
                 want.append(col.max_timestamped_value(rs, qo))
             t_tally = time.perf_counter() - t_c0
             got = []
-            okg = np.nonzero(err == 0)[0]
-            first = np.concatenate([[0], np.cumsum(np.bincount(rc.reply_var[err == 0], minlength=n_vars))])
+            acc_s = err[order] == 0                                   # winners index the accepted replies in variable order
+            okg = order[np.nonzero(acc_s)[0]]
+            first = np.concatenate([[0], np.cumsum(np.bincount(rc.reply_var[order][acc_s], minlength=n_vars))])
             for j in range(n_vars):
                 r = okg[first[j] + win[j]] if win[j] >= 0 else -1
                 got.append(None if r < 0 else (rc.write_value[rc.reply_write[r]], int(reply_t[r])))

@@ -42,7 +42,7 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_from_qcs", "bftkv_host_quorum_free", "bftkv_host_quorum_n_qcs", "bftkv_host_quorum_qc",
     "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
-    "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
+    "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_max_timestamped_value_masked", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
@@ -87,6 +87,7 @@ def _lib():
         lib.bftkv_host_collect_signatures.argtypes = [vp, vp, C.c_uint32, vp, vp, C.POINTER(_Reply), vp, vp, C.c_uint64, vp, vp, vp]
         lib.bftkv_host_server_write_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_max_timestamped_value.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        lib.bftkv_host_max_timestamped_value_masked.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
         lib.bftkv_host_vote_fold.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.bftkv_host_certs_parse.restype = vp
         lib.bftkv_host_certs_parse.argtypes = [C.c_char_p, C.c_uint64]
@@ -486,6 +487,20 @@ def max_timestamped_value_raw(q: Quorum, n_reads: int, peers: np.ndarray, ts: np
                                                  read_off.ctypes.data, out.ctypes.data)
     if rc:
         raise RuntimeError("max_timestamped_value: %d" % rc)
+    return out[:n_reads]
+
+
+def max_timestamped_value_masked(q: Quorum, n_reads: int, peers: np.ndarray, ts: np.ndarray, value_blob: np.ndarray, value_off: np.ndarray,
+                                 read_off: np.ndarray, reply_err: np.ndarray) -> np.ndarray:
+    """bftkv_host_max_timestamped_value_masked: the fold over ALL replies with the verifier's error byte per reply (arrays
+    prepared once, reply_err from each batch); same answers as max_timestamped_value_raw over the accepted replies."""
+    out = np.zeros(max(1, n_reads), dtype=np.int64)
+    for a, dt in ((peers, np.uint64), (ts, np.uint64), (value_blob, np.uint8), (value_off, np.uint64), (read_off, np.uint64), (reply_err, np.uint8)):
+        assert a.dtype == dt and a.flags["C_CONTIGUOUS"]
+    rc = _lib().bftkv_host_max_timestamped_value_masked(q.h, n_reads, peers.ctypes.data, ts.ctypes.data, value_blob.ctypes.data,
+                                                        value_off.ctypes.data, read_off.ctypes.data, reply_err.ctypes.data, out.ctypes.data)
+    if rc:
+        raise RuntimeError("max_timestamped_value_masked: %d" % rc)
     return out[:n_reads]
 
 

@@ -201,6 +201,12 @@ int bftkv_host_emsa_encode(int hash_id, const uint8_t* digest, uint32_t digest_l
 int bftkv_host_max_timestamped_value(const bftkv_quorum* q, uint32_t n_reads, const uint64_t* peer_ids, const uint64_t* ts,
                                      const uint8_t* value_blob, const uint64_t* value_off, const uint64_t* reply_off,
                                      int64_t* value_idx_out);
+/* The same fold over ALL replies received with the verifier's error byte per reply (bftkv_gpu_collective_verify's err_out):
+ * replies with reply_err[i] != 0 are dropped as Client.Read drops failures, and value_idx_out counts the accepted replies of
+ * the read only -- identical to filtering the arrays first, without the caller rebuilding them per batch. */
+int bftkv_host_max_timestamped_value_masked(const bftkv_quorum* q, uint32_t n_reads, const uint64_t* peer_ids, const uint64_t* ts,
+                                            const uint8_t* value_blob, const uint64_t* value_off, const uint64_t* reply_off,
+                                            const uint8_t* reply_err, int64_t* value_idx_out);
 
 /* Framing half of the transport message check (crypto_pgp.go:453-471 -> openpgp.ReadMessage / readSignedMessage), no
  * GPU and no keyring involved: walks [one-pass signature] [literal data] [signature] of ONE already-decrypted message.

@@ -196,6 +196,23 @@ def test_max_timestamped_value_matches_oracle(H):
     for r, g in zip(reads, got):
         assert g == col.max_timestamped_value(r, oq)
     assert any(g is not None for g in got) and any(g is None for g in got)
+    # the masked form: ALL replies plus an error byte per reply gives what filtering the accepted ones first gives
+    flat = [rep for r in reads for rep in r]
+    n = len(flat)
+    err = (rng.random(n) < 0.3).astype(np.uint8)
+    peers = np.array([p for p, _, _ in flat], dtype=np.uint64); ts = np.array([t for _, t, _ in flat], dtype=np.uint64)
+    vo = np.zeros(n + 1, dtype=np.uint64); vo[1:] = np.cumsum([len(v) for _, _, v in flat], dtype=np.uint64)
+    vb = np.frombuffer(b"".join(v for _, _, v in flat) + b"\0", dtype=np.uint8).copy()
+    ro = np.zeros(len(reads) + 1, dtype=np.uint64); ro[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    idx = H.max_timestamped_value_masked(hq, len(reads), peers, ts, vb, vo, ro, err)
+    pos = 0
+    for r, k in zip(reads, idx):
+        kept = [rep for j, rep in enumerate(r) if err[pos + j] == 0]
+        pos += len(r)
+        want = col.max_timestamped_value(kept, oq)
+        assert (k < 0) == (want is None)
+        if want is not None:
+            assert (kept[int(k)][2], kept[int(k)][1]) == want
 
 
 def test_certificate_parse_matches_oracle(H):
