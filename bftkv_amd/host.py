@@ -35,6 +35,22 @@ class _Reply(C.Structure):
     _fields_ = [("peer_id", C.c_uint64), ("err", C.c_int32), ("data", C.c_void_p), ("data_len", C.c_uint64)]
 
 
+class SigParse(C.Structure):
+    """bftkv_sig_parse (include/bftkv_host.h): what the kernels' signature parser keeps of one packet body."""
+    _fields_ = [("parsed", C.c_uint8), ("too_deep", C.c_uint8), ("version", C.c_uint8), ("sig_type", C.c_uint8), ("pk_algo", C.c_uint8),
+                ("hash_id", C.c_uint8), ("have_issuer", C.c_uint8), ("n_mpi", C.c_uint8), ("hash_tag", C.c_uint8 * 2),
+                ("hashed_len", C.c_uint16), ("mpi_bits", C.c_uint16 * 2), ("mpi_off", C.c_uint32 * 2), ("issuer", C.c_uint64)]
+
+
+def parse_signature(body: bytes) -> SigParse:
+    """bftkv_host_parse_signature: the verifier's Signature.parse / SignatureV3.parse on one packet body, on the host."""
+    out = SigParse()
+    rc = _lib().bftkv_host_parse_signature(body, len(body), C.byref(out))
+    if rc:
+        raise RuntimeError("parse_signature: %d" % rc)
+    return out
+
+
 HOST_EXPORTS = [
     "bftkv_host_packet_serialize", "bftkv_host_packet_parse", "bftkv_host_packet_tbs", "bftkv_host_packet_tbss",
     "bftkv_host_graph_new", "bftkv_host_graph_free", "bftkv_host_graph_add_node", "bftkv_host_graph_set_self",
@@ -46,6 +62,7 @@ HOST_EXPORTS = [
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
+    "bftkv_host_parse_signature",
 ]
 
 _ready = False
@@ -88,6 +105,7 @@ def _lib():
         lib.bftkv_host_server_write_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_max_timestamped_value.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         lib.bftkv_host_max_timestamped_value_masked.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+        lib.bftkv_host_parse_signature.argtypes = [C.c_char_p, C.c_uint32, vp]
         lib.bftkv_host_vote_fold.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.bftkv_host_certs_parse.restype = vp
         lib.bftkv_host_certs_parse.argtypes = [C.c_char_p, C.c_uint64]

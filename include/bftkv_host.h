@@ -191,6 +191,19 @@ int bftkv_host_server_register_verify(bftkv_gpu_ctx* ctx, bftkv_quorum* q_auth, 
 int bftkv_host_equivocation_signers(bftkv_gpu_ctx* ctx, uint32_t n_values, const uint32_t* group, const uint8_t* ss_blob,
                                     const uint64_t* ss_off, uint64_t* ids_out, uint32_t cap, uint32_t* n_out);
 
+/* Diagnostic: Signature.parse / SignatureV3.parse as the verifier's kernels restate it (the same code, run on the host over
+ * one signature packet BODY), so that a CPU-only test can fuzz the parser against the oracle.  parsed = 0: a parse error
+ * (too_deep = 1: an embedded signature nested deeper than the parser goes -- a fenced shape, no claim). */
+typedef struct {
+  uint8_t parsed, too_deep, version, sig_type, pk_algo, hash_id, have_issuer, n_mpi;
+  uint8_t hash_tag[2];
+  uint16_t hashed_len;
+  uint16_t mpi_bits[2];
+  uint32_t mpi_off[2];
+  uint64_t issuer;
+} bftkv_sig_parse;
+int bftkv_host_parse_signature(const uint8_t* body, uint32_t len, bftkv_sig_parse* out);
+
 /* emsaEncode (crypto/threshold/rsa/rsa.go:356-378): 00 01 FF.. 00 prefix digest, emlen = ceil(bits(N)/8);
  * hash_id is the OpenPGP hash id (2, 8, 9, 10, 11).  BFTKV_E_INVALID when padlen < 3 (crypto.ErrInvalidInput). */
 int bftkv_host_emsa_encode(int hash_id, const uint8_t* digest, uint32_t digest_len, uint32_t n_bits, uint8_t* em_out, uint32_t cap);

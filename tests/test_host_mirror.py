@@ -338,3 +338,72 @@ def test_message_framing_matches_oracle(H):
     assert got[0] == om.MSG_NOT_SIGNED and got[1] == got[2] == om.MSG_SIGNATURE_ERROR and got[3] == 0xFF
     assert got[4] == got[5] == got[6] == got[7] == got[8] == got[9] == om.MSG_READ_ERROR
     assert got[10] == got[11] == got[12] == om.MSG_UNSUPPORTED and got[13] == got[14] == got[15] == 0xFF
+
+
+def test_signature_parser_fuzz_against_the_oracle(H):
+    """The signature-body parser the KERNELS run (parse_sig_body_t / parse_sig_body_v3 of kernels.hip, the same template code
+    over a plain pointer) through bftkv_host_parse_signature, against oracle.openpgp on valid RSA / DSA / SignatureV3 bodies
+    with random bytes of the header, the subpacket areas and the MPI length fields overwritten, bodies cut short, and
+    hand-made subpacket areas (long lengths, critical bits, embedded signatures, creation time in the wrong area)."""
+    import struct
+    from corpus import build as cb
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp
+    rng = np.random.default_rng(2024)
+    srng = DRBG("parser-fuzz")
+    cl = cb.make_cluster(4, dsa_fraction=0.5)
+    ct = b"\x05\x02" + struct.pack(">I", cb.CREATION_TIME)
+
+    def sub(typ, body, critical=False, long=0):
+        n = len(body) + 1
+        ln = (bytes([255]) + struct.pack(">I", n)) if long == 2 else (bytes([192 + ((n - 192) >> 8), (n - 192) & 0xFF]) if n >= 192 else bytes([n]))
+        return ln + bytes([typ | (0x80 if critical else 0)]) + body
+
+    seeds = []
+    for kp in cl.replicas:
+        pkt = cb.detach_sign(kp, b"payload", srng)
+        seeds.append(pkt[3:] if pkt[1] >= 192 else pkt[2:])
+        iss = sub(16, struct.pack(">Q", kp.key_id))
+        inner = seeds[-1]
+        for hashed, unhashed in ((ct + iss, b""), (ct, iss), (iss, ct), (ct + iss + sub(32, inner), b""), (ct + iss, sub(32, inner) + sub(32, inner)),
+                                 (ct + sub(101, b"x", critical=True) + iss, b""), (ct + sub(20, b"y" * 200) + iss, b""), (ct + sub(16, iss[2:], long=2), b""),
+                                 (ct + iss + sub(2, b"\0\0\0\1"), sub(3, b"zz")), (ct + sub(27, b""), iss), (ct + sub(25, b"\1") + sub(9, b"\0\0\0\x09"), iss)):
+            body = bytes([4, 0, kp.algo, 8]) + struct.pack(">H", len(hashed)) + hashed + struct.pack(">H", len(unhashed)) + unhashed + b"\xab\xcd"
+            body += inner[len(inner) - (258 if kp.algo == cb.PK_RSA else 0):] if kp.algo == cb.PK_RSA else cb.go_mpi_bytes(b"\x11" * 32) * 2
+            seeds.append(body)
+        # SignatureV3 shape (RFC 4880 5.2.2)
+        seeds.append(bytes([3, 5, 0]) + struct.pack(">I", cb.CREATION_TIME) + struct.pack(">Q", kp.key_id) + bytes([kp.algo, 8]) + b"\x12\x34" +
+                     (cb.go_mpi_bytes(b"\x22" * 256) if kp.algo == cb.PK_RSA else cb.go_mpi_bytes(b"\x33" * 32) * 2))
+    n_ok = n_err = 0
+    for it in range(30000):
+        b = bytearray(seeds[int(rng.integers(0, len(seeds)))])
+        mode = it % 5
+        if mode >= 1:
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, min(len(b), 96)))
+                b[pos] = int(rng.choice([0, 1, 2, 3, 4, 5, 16, 32, 0x7F, 0x80, 191, 192, 223, 224, 254, 255])) if rng.random() < 0.5 else int(rng.integers(0, 256))
+        if mode == 4 and len(b) > 2:
+            b = b[:int(rng.integers(0, len(b)))]
+        body = bytes(b)
+        got = H.parse_signature(body)
+        try:
+            want = pgp.parse_signature_v3_body(body) if (body and body[0] < 4) else pgp.parse_signature_body(body)
+        except Exception as e:                     # StructuralError / UnsupportedError / truncation: Signature.parse fails
+            want = None
+            if isinstance(e, RecursionError):
+                continue
+        if got.too_deep:
+            continue                               # fenced shape: the device parser stops at depth 2
+        assert bool(got.parsed) == (want is not None), (it, body.hex()[:160], got.parsed)
+        if want is None:
+            n_err += 1
+            continue
+        n_ok += 1
+        assert (got.sig_type, got.pk_algo, got.hash_id, bytes(got.hash_tag)) == (want.sig_type, want.pk_algo, want.hash_id, want.hash_tag), it
+        assert bool(got.have_issuer) == (want.issuer is not None) and (want.issuer is None or got.issuer == want.issuer), it
+        if body[0] >= 4:
+            assert got.hashed_len == len(want.hash_suffix) - 12, it
+        assert got.n_mpi == len(want.mpis), it
+        for k, (bits, val) in enumerate(want.mpis):
+            assert got.mpi_bits[k] == bits and body[got.mpi_off[k]:got.mpi_off[k] + (bits + 7) // 8] == val, (it, k)
+    assert n_ok > 7000 and n_err > 7000
