@@ -51,6 +51,17 @@ def parse_signature(body: bytes) -> SigParse:
     return out
 
 
+def walk_stream(data: bytes, cap: int = 4096):
+    """bftkv_host_walk_stream: (status, body offset, body length) of every packet event of one stream, by the kernels' walk."""
+    st = np.zeros(cap, dtype=np.uint8); bo = np.zeros(cap, dtype=np.uint64); bl = np.zeros(cap, dtype=np.uint32)
+    n = C.c_uint32(0)
+    rc = _lib().bftkv_host_walk_stream(data, len(data), cap, st.ctypes.data, bo.ctypes.data, bl.ctypes.data, C.byref(n))
+    if rc:
+        raise RuntimeError("walk_stream: %d" % rc)
+    k = min(int(n.value), cap)
+    return [(int(st[i]), int(bo[i]), int(bl[i])) for i in range(k)], int(n.value)
+
+
 HOST_EXPORTS = [
     "bftkv_host_packet_serialize", "bftkv_host_packet_parse", "bftkv_host_packet_tbs", "bftkv_host_packet_tbss",
     "bftkv_host_graph_new", "bftkv_host_graph_free", "bftkv_host_graph_add_node", "bftkv_host_graph_set_self",
@@ -62,7 +73,7 @@ HOST_EXPORTS = [
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
-    "bftkv_host_parse_signature",
+    "bftkv_host_parse_signature", "bftkv_host_walk_stream",
 ]
 
 _ready = False
@@ -106,6 +117,7 @@ def _lib():
         lib.bftkv_host_max_timestamped_value.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         lib.bftkv_host_max_timestamped_value_masked.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
         lib.bftkv_host_parse_signature.argtypes = [C.c_char_p, C.c_uint32, vp]
+        lib.bftkv_host_walk_stream.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, vp, vp, vp, vp]
         lib.bftkv_host_vote_fold.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.bftkv_host_certs_parse.restype = vp
         lib.bftkv_host_certs_parse.argtypes = [C.c_char_p, C.c_uint64]

@@ -204,6 +204,12 @@ typedef struct {
 } bftkv_sig_parse;
 int bftkv_host_parse_signature(const uint8_t* body, uint32_t len, bftkv_sig_parse* out);
 
+/* Diagnostic: packet.Read framing as the kernels restate it (walk_step), over one stream on the host: per packet event its
+ * status (99 = a signature packet located, Signature.parse still to come; else a final BFTKV_ST_* status), body offset and
+ * length; *n_out = number of events (may exceed cap).  Unknown packet types raise no event (Reader.Next skips them). */
+int bftkv_host_walk_stream(const uint8_t* data, uint64_t len, uint32_t cap, uint8_t* status_out, uint64_t* body_off_out,
+                           uint32_t* body_len_out, uint32_t* n_out);
+
 /* emsaEncode (crypto/threshold/rsa/rsa.go:356-378): 00 01 FF.. 00 prefix digest, emlen = ceil(bits(N)/8);
  * hash_id is the OpenPGP hash id (2, 8, 9, 10, 11).  BFTKV_E_INVALID when padlen < 3 (crypto.ErrInvalidInput). */
 int bftkv_host_emsa_encode(int hash_id, const uint8_t* digest, uint32_t digest_len, uint32_t n_bits, uint8_t* em_out, uint32_t cap);

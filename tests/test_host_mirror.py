@@ -407,3 +407,75 @@ def test_signature_parser_fuzz_against_the_oracle(H):
         for k, (bits, val) in enumerate(want.mpis):
             assert got.mpi_bits[k] == bits and body[got.mpi_off[k]:got.mpi_off[k] + (bits + 7) // 8] == val, (it, k)
     assert n_ok > 7000 and n_err > 7000
+
+
+def test_packet_walk_fuzz_against_the_oracle(H):
+    """The packet framing the KERNELS walk (walk_step of kernels.hip) through bftkv_host_walk_stream against the oracle's
+    packet.Read restatement (oracle.openpgp.next_packet): random streams of packets in every header format, unknown and
+    non-signature types, partial / indeterminate lengths, stray bytes and truncations, then random byte mutations on top."""
+    from oracle import openpgp as pgp
+    rng = np.random.default_rng(99)
+
+    def hdr(tag, ln, fmt):
+        if fmt == 0:
+            if ln < 192: return bytes([0xC0 | tag, ln])
+            if ln < 8384: return bytes([0xC0 | tag, ((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+            return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+        if fmt == 1: return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+        if fmt == 2 and tag < 16 and ln < 256: return bytes([0x80 | (tag << 2), ln])
+        if fmt == 3 and tag < 16 and ln < 65536: return bytes([0x80 | (tag << 2) | 1]) + ln.to_bytes(2, "big")
+        if fmt == 4 and tag < 16: return bytes([0x80 | (tag << 2) | 3])                  # indeterminate length
+        if fmt == 5: return bytes([0xC0 | tag, 224 + int(rng.integers(0, 31))])           # partial body length
+        if tag < 16: return bytes([0x80 | (tag << 2) | 2]) + ln.to_bytes(4, "big")
+        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+
+    def oracle_events(data):
+        ev, pos = [], 0
+        while True:
+            try:
+                pkt = pgp.next_packet(data, pos)
+            except EOFError:
+                return ev
+            except pgp.StructuralError as e:
+                ev.append((pgp.ST_PARSE_ERROR, None, None)); pos = e.consumed
+                continue
+            except pgp.UnsupportedError as e:
+                ev.append((pgp.ST_UNSUPPORTED, None, None)); pos = e.consumed
+                continue
+            except pgp._Truncated:
+                ev.append((pgp.ST_PARSE_ERROR, None, None))
+                return ev
+            start = pkt.end - len(pkt.body)
+            pos = pkt.end
+            if pkt.tag == 2:
+                ev.append((99, start, len(pkt.body)))
+            elif pkt.tag in pgp._KNOWN_TAGS:
+                ev.append((pgp.ST_NOT_SIGNATURE, start, len(pkt.body)))
+
+    n_events = n_err = 0
+    for it in range(10000):
+        parts = []
+        for _ in range(int(rng.integers(0, 14))):
+            tag = int(rng.choice([2, 2, 2, 13, 11, 6, 14, 20, 40, 63, 1, 9, 17, 10, 12, 15]))
+            ln = int(rng.choice([0, 1, 5, 191, 192, 300, 287, 8383, 8384, 20000])) if rng.random() < 0.3 else int(rng.integers(0, 400))
+            fmt = int(rng.integers(0, 7)) if rng.random() < 0.9 else int(rng.integers(4, 6))
+            parts.append(hdr(tag, ln, fmt) + rng.bytes(ln))
+            if rng.random() < 0.05:
+                parts.append(bytes([int(rng.integers(0, 128))]))                          # a byte without the tag MSB
+        data = bytearray(b"".join(parts))
+        if it % 3 == 1 and len(data) > 1:
+            data = data[:int(rng.integers(1, len(data)))]
+        if it % 4 == 2 and len(data):
+            for _ in range(int(rng.integers(1, 4))):
+                data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+        data = bytes(data)
+        got, n = H.walk_stream(data)
+        want = oracle_events(data)
+        assert n == len(want), (it, n, len(want), data[:64].hex())
+        for g, w in zip(got, want):
+            assert g[0] == w[0], (it, g, w)
+            if w[1] is not None:
+                assert (g[1], g[2]) == (w[1], w[2]), (it, g, w)
+            n_err += w[1] is None
+        n_events += len(want)
+    assert n_events > 12000 and n_err > 3000
