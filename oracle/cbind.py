@@ -12,8 +12,8 @@ LIB = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "c", "oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "c", f) for f in ("oracle.c", "threshold.c", "Makefile")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c")])
     return LIB
 
@@ -84,3 +84,54 @@ class COracle:
         nt = self.lib.oracle_trace_item(self.h, tbs, len(tbs), ss, len(ss), tr.ctypes.data_as(C.c_void_p), len(tr),
                                         C.byref(nver), C.byref(err))
         return list(tr[:nt]), nver.value, err.value
+
+
+class CThreshold:
+    """oracle/c/threshold.c: the reference's share-combine arithmetic on OpenSSL bignums, threads over operations."""
+
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(LIB)
+        V = C.c_void_p
+        self.lib.oracle_rsa_combine.argtypes = [C.c_uint32, C.c_uint32, V, C.c_uint32, V, V, C.c_int]
+        self.lib.oracle_lagrange_combine.argtypes = [C.c_uint32, C.c_uint32, V, V, C.c_uint32, V, V, V, C.c_int]
+        self.lib.oracle_dsa_calculate_r.argtypes = [C.c_uint32, C.c_uint32, V, V, C.c_uint32, V, C.c_uint32, V, V, V, V, C.c_int]
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    @staticmethod
+    def _be(vals, nbytes):
+        return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "big") for v in vals), dtype=np.uint8).copy()
+
+    def rsa_combine(self, factors_be, k, nbytes, mod, n_threads=1):
+        """factors_be: uint8 [n][k][nbytes] -> uint8 [n][nbytes]"""
+        f = np.ascontiguousarray(factors_be, dtype=np.uint8)
+        n = f.size // (k * nbytes)
+        out = np.zeros((n, nbytes), dtype=np.uint8)
+        m = self._be([mod], nbytes)
+        self.lib.oracle_rsa_combine(n, k, self._p(f), nbytes, self._p(m), self._p(out), n_threads)
+        return out
+
+    def lagrange_combine(self, xs, ys_be, nbytes, mod, n_threads=1):
+        xs = np.ascontiguousarray(xs, dtype=np.int32)
+        n, k = xs.shape
+        y = np.ascontiguousarray(ys_be, dtype=np.uint8)
+        out = np.zeros((n, nbytes), dtype=np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        m = self._be([mod], nbytes)
+        self.lib.oracle_lagrange_combine(n, k, self._p(xs), self._p(y), nbytes, self._p(m), self._p(out), self._p(st), n_threads)
+        return out, st
+
+    def dsa_calculate_r(self, xs, ri_be, pbytes, vi_be, qbytes, p, q, n_threads=1):
+        xs = np.ascontiguousarray(xs, dtype=np.int32)
+        n, k = xs.shape
+        ri = np.ascontiguousarray(ri_be, dtype=np.uint8)
+        vi = np.ascontiguousarray(vi_be, dtype=np.uint8)
+        out = np.zeros((n, qbytes), dtype=np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        pb, qb = self._be([p], pbytes), self._be([q], qbytes)
+        self.lib.oracle_dsa_calculate_r(n, k, self._p(xs), self._p(ri), pbytes, self._p(vi), qbytes, self._p(pb), self._p(qb),
+                                        self._p(out), self._p(st), n_threads)
+        return out, st

@@ -326,6 +326,33 @@ def test_full_size_properties_cfg2(gpu_ctx, exit_mode):
     gpu_ctx.quorum_destroy(qh)
 
 
+def test_cfg2_full_size_identity_against_the_c_oracle(gpu_ctx):
+    """BASELINE configs[1] at FULL size -- 64 replicas, 10,000 RSA-2048 signed writes, the bench's seed and mutation mix --
+    compared write by write with the reference-shaped CPU path (oracle/c/oracle.c): error byte, exit count, and the number of
+    public-key operations the reference performs (bench.py's `value` counts exactly those)."""
+    import os
+    from oracle.cbind import COracle
+    import bench
+    cl = cb.make_cluster(64)
+    mods, exps = cb.signer_tables(cl)
+    signer = lambda em, ki: gpu_ctx.modexp(em, ki.astype(np.uint32), mods, exps)
+    c = cb.make_write_corpus(cl, 10000, seed=cb.MASTER_SEED, batch_signer=signer, with_client_sig=True)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    err, nver, verdict = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    st, st_item = gpu_ctx.last_statuses()
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    cerr, cnver, ops = co.collective_verify(c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off, n_threads=max(1, min(32, os.cpu_count() or 1)))
+    assert (cerr == err).all() and (cnver == nver).all()
+    assert len(st) == c.n_sigs and bench.reference_pubkey_ops(st, st_item, err, nver, c.n_items) == ops
+    assert 400000 < ops <= gpu_ctx.last_counters()["pubkey_ops"] < c.n_sigs
+    assert (err == 0).sum() > 9000 and (err == 2).sum() > 50
+    gpu_ctx.quorum_destroy(qh)
+
+
 def test_rccl_allgather_entry_points_single_rank(gpu_ctx):
     """bftkv_gpu_comm_* / bftkv_gpu_allgather_verdicts: librccl loads, a 1-rank communicator gathers by copying.
     (The box has one GPU; the N>1 exchange is covered by tests/test_dist_gloo.py and bench.py --gpus N.)"""

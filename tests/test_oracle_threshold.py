@@ -72,3 +72,64 @@ def test_threshold_dsa_relations_on_the_reference_group():
     assert T.calculate_r(rs, p, q) == pow(g, pow(kk, -1, q), p) % q
     assert T.format_dsa(5, 7, q) == (5).to_bytes(20, "big") + (7).to_bytes(20, "big")
     assert T.os2i(bytes(range(1, 33)), q) == int.from_bytes(bytes(range(1, 21)), "big")
+
+
+def test_c_port_reproduces_the_reference_answers_and_the_python_oracle():
+    """oracle/c/threshold.c (bench.py's cfg-5 cpu_baseline) on the reference's own known answers -- TestCombine's
+    signature, TestSSS's secret, CalculateR == g^(k^-1) on the fixed group -- and on random inputs against oracle/threshold.py."""
+    from oracle.cbind import CThreshold
+    ct = CThreshold()
+    be = CThreshold._be
+    toi = lambda row: int.from_bytes(row.tobytes(), "big")
+    rng = np.random.default_rng(5)
+    # RSA: TestCombine
+    r = KAT["rsa"]
+    n, d = int(r["n"], 16), int(r["d"], 16)
+    m = T.emsa_encode("sha256", hashlib.sha256(r["tbs"].encode()).digest(), n)
+    rnd = [int.from_bytes(rng.bytes(2 * 256 + 1), "big") % (1 << (2 * d.bit_length())) for _ in range(9)]
+    psigs = [T.partial_sign(m, x, n) for x in T.split_key(d, 10, rnd)]
+    out = ct.rsa_combine(be(psigs, 256), 10, 256, n, n_threads=1)
+    assert out[0].tobytes().hex() == r["sha256_pkcs1v15_sig"]
+    # SSS: TestSSS
+    s = KAT["sss"]
+    pb, secret = int(s["pb"], 16), int.from_bytes(s["secret"].encode(), "big")
+    shares = T.distribute(secret, s["n"], s["k"], pb, [int.from_bytes(rng.bytes(256), "big") % pb for _ in range(s["k"] - 1)])
+    picks = [[shares[i] for i in rng.choice(s["n"], size=s["k"], replace=False)] for _ in range(6)]
+    xs = np.array([[x for x, _ in p] for p in picks], dtype=np.int32)
+    out, st = ct.lagrange_combine(xs, be([y for p in picks for _, y in p], 256), 256, pb, n_threads=3)
+    assert not st.any() and all(toi(out[i]) == secret for i in range(len(picks)))
+    # threshold DSA on the reference's group: calculateS and CalculateR
+    g_ = KAT["dsa_group"]
+    p, q, g = int(g_["p"], 16), int(g_["q"], 16), int(g_["g"], 16)
+    nn, t = 10, 4
+    rq = lambda: int.from_bytes(rng.bytes(40), "big") % q
+    kk, aa = rq(), rq()
+    ks = T.distribute(kk, nn, t, q, [rq() for _ in range(t - 1)])
+    as_ = T.distribute(aa, nn, t, q, [rq() for _ in range(t - 1)])
+    zs = T.distribute(0, nn, 2 * t, q, [rq() for _ in range(2 * t - 1)])
+    pick = [int(i) for i in rng.choice(nn, size=2 * t, replace=False)]
+    qb = (q.bit_length() + 7) // 8
+    xs = np.array([[ks[i][0] for i in pick]], dtype=np.int32)
+    out, st = ct.lagrange_combine(xs, be([(ks[i][1] * as_[i][1] + zs[i][1]) % q for i in pick], qb), qb, q)
+    assert not st.any() and toi(out[0]) == (kk * aa) % q
+    ri = [pow(g, as_[i][1], p) for i in pick]
+    vi = [(ks[i][1] * as_[i][1] + zs[i][1]) % q for i in pick]
+    out, st = ct.dsa_calculate_r(xs, be(ri, 256), 256, be(vi, qb), qb, p, q)
+    assert not st.any() and toi(out[0]) == pow(g, pow(kk, -1, q), p) % q
+    # random residues (the bench's corpus shape) against the Python oracle, several threads
+    from corpus import build as cb
+    k0 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keys_dsa2048.json")))["keys"][0]
+    as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
+    tc = cb.make_threshold_corpus(24, n, pb, as_int(k0["p"]), as_int(k0["q"]), seed=99)
+    flat = lambda rows: [v for r_ in rows for v in r_]
+    got = ct.rsa_combine(be(flat(tc.rsa_factors), 256), 10, 256, tc.rsa_n, n_threads=4)
+    assert all(toi(got[i]) == T.calculate_signature(tc.rsa_factors[i], tc.rsa_n) for i in range(24))
+    got, st = ct.lagrange_combine(tc.s_xs, be(flat(tc.s_ys), 32), 32, tc.dsa_q, n_threads=4)
+    assert all(toi(got[i]) == T.calculate_s(list(zip([int(v) for v in tc.s_xs[i]], tc.s_ys[i])), tc.dsa_q) for i in range(24))
+    got, st = ct.dsa_calculate_r(tc.r_xs, be(flat(tc.r_ri), 256), 256, be(flat(tc.r_vi), 32), 32, tc.dsa_p, tc.dsa_q, n_threads=4)
+    for i in range(24):
+        try:
+            want = T.calculate_r([(int(tc.r_xs[i][j]), tc.r_ri[i][j].to_bytes(256, "big"), tc.r_vi[i][j]) for j in range(8)], tc.dsa_p, tc.dsa_q)
+            assert st[i] == 0 and toi(got[i]) == want
+        except ValueError:
+            assert st[i] == 1
