@@ -43,6 +43,7 @@ EXPORTS = [
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
+    "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times",
 ]
 
 _lib = None
@@ -85,12 +86,16 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_stream.argtypes = [vp]
     lib.bftkv_gpu_batcher_create.argtypes = [vp, u32, u32]
     lib.bftkv_gpu_batcher_create.restype = vp
+    lib.bftkv_gpu_batcher_create_lanes.argtypes = [vp, u32, u32, u32]
+    lib.bftkv_gpu_batcher_create_lanes.restype = vp
+    lib.bftkv_gpu_ctx_fork.argtypes = [vp, C.POINTER(vp)]
     lib.bftkv_gpu_batcher_destroy.argtypes = [vp]
     lib.bftkv_gpu_batcher_destroy.restype = None
     lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p]
     lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p, u8p]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.bftkv_gpu_batcher_times.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
     lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_comm_unique_id.argtypes = [u8p]
@@ -108,7 +113,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_modinv_dev.argtypes = lib.bftkv_gpu_modinv.argtypes
     for name in EXPORTS:
         if name not in ("bftkv_gpu_destroy", "bftkv_gpu_last_error", "bftkv_gpu_error_string", "bftkv_gpu_stream",
-                        "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy"):
+                        "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_destroy"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -138,6 +143,15 @@ class Context:
         if self.h:
             self.lib.bftkv_gpu_destroy(self.h)
             self.h = None
+
+    def fork(self) -> "Context":
+        """bftkv_gpu_ctx_fork: a context with its own streams and arena over this one's key table and quorums
+        (verify calls only; close it before its root)."""
+        h = C.c_void_p()
+        self._check(self.lib.bftkv_gpu_ctx_fork(self.h, C.byref(h)), "ctx_fork")
+        f = Context.__new__(Context)
+        f.lib, f.h, f._keep, f.root = self.lib, h, [], self
+        return f
 
     def __del__(self):
         try:
@@ -399,12 +413,12 @@ class Context:
 class Batcher:
     """bftkv_gpu_batcher: blocking one-message calls from many threads, aggregated into device batches."""
 
-    def __init__(self, ctx: Context, max_items: int = 256, max_wait_us: int = 200):
+    def __init__(self, ctx: Context, max_items: int = 256, max_wait_us: int = 200, n_lanes: int = 0):
         self.ctx = ctx
         self.lib = ctx.lib
-        self.h = C.c_void_p(self.lib.bftkv_gpu_batcher_create(ctx.h, max_items, max_wait_us))
+        self.h = C.c_void_p(self.lib.bftkv_gpu_batcher_create_lanes(ctx.h, max_items, max_wait_us, n_lanes))
         if not self.h:
-            raise NativeError("bftkv_gpu_batcher_create failed")
+            raise NativeError("bftkv_gpu_batcher_create_lanes failed")
 
     def close(self):
         if self.h:
@@ -450,7 +464,7 @@ class Batcher:
     def stats(self):
         st = (C.c_uint64 * 4)()
         self.lib.bftkv_gpu_batcher_stats(self.h, st)
-        return {"calls": st[0], "batches": st[1], "max_batch": st[2]}
+        return {"calls": st[0], "batches": st[1], "max_batch": st[2], "lanes": st[3]}
 
 
 def _ints_to_be(vals, nbytes: int) -> np.ndarray:

@@ -21,11 +21,13 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <string>
 #include <vector>
 
 #include "host_bignum.h"
+#include "host_sha256.h"
 #include "kernels.hip"
 #include "threshold_kernels.hip"
 
@@ -124,6 +126,24 @@ struct bftkv_gpu_ctx {
   bool have_timing = false;
   void* rccl_comm = nullptr;   // ncclComm_t
   int n_ranks = 1, rank = 0;
+
+  // Forked verifier contexts (bftkv_gpu_ctx_fork): own streams, arena, events and mailbox -- several device calls in flight at
+  // once -- over the ROOT's resident key table, DSA tables and quorum descriptors.  A fork holds root->kt_rw SHARED for the
+  // length of a device call; whatever changes the key table or the quorums (root only) holds it exclusively, i.e. waits until
+  // the forks' calls in flight have drained and keeps new ones out.  A fork never takes the root's `mu`.
+  bftkv_gpu_ctx* root = nullptr;            // null: this context is a root
+  std::shared_mutex kt_rw;                  // root
+  std::atomic<int> kt_writers{0};           // root: writers waiting or inside (forks stand back: pthread rwlocks prefer readers)
+  std::atomic<int> n_forks{0};              // root: live forks (bftkv_gpu_destroy of the root refuses while > 0)
+  uint64_t quorum_gen = 0;                  // root: bumped by quorum_create / quorum_destroy
+  uint64_t seen_keyring_gen = ~0ull, seen_quorum_gen = ~0ull;   // fork: what its copies reflect
+  size_t n_dsa_slots = 0;                   // fork: root->dsa_comb_slot.size() at the last refresh
+  int kt_read_depth = 0;                    // fork: nesting of KtRead (under the fork's own lock)
+  // staged small calls (the micro-batcher): one pinned staging buffer in, results written by the last kernel straight into
+  // mapped host memory, completion = h_mail[1] reaching the call's sequence number
+  DevBuf in_pack;
+  uint8_t* h_out = nullptr; uint8_t* d_out = nullptr; size_t out_cap = 0;
+  uint32_t out_seq = 0;
 };
 
 void rccl_release(bftkv_gpu_ctx* c);
@@ -132,6 +152,29 @@ extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, con
                                          uint8_t* fenced_out = nullptr);
 
 namespace {
+
+int fork_refresh(bftkv_gpu_ctx* c);
+
+// Exclusive access to the key table / quorum descriptors of a root context (see bftkv_gpu_ctx::root).
+struct KtWrite {
+  bftkv_gpu_ctx* c;
+  explicit KtWrite(bftkv_gpu_ctx* c_) : c(c_) { c->kt_writers.fetch_add(1); c->kt_rw.lock(); }
+  ~KtWrite() { c->kt_rw.unlock(); c->kt_writers.fetch_sub(1); }
+};
+// Shared access for the length of one device call of a FORK (a no-op on a root: its calls and its writers are serialised by
+// the context lock); brings the fork's copies of the key-table view and the quorum descriptors up to date first.
+// Constructed with the fork's own lock held; nests (the entry points call one another).
+struct KtRead {
+  bftkv_gpu_ctx *c, *r;
+  int rc = 0;
+  explicit KtRead(bftkv_gpu_ctx* c_) : c(c_), r(c_->root) {
+    if (!r || c->kt_read_depth++ > 0) return;
+    while (r->kt_writers.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    r->kt_rw.lock_shared();
+    rc = fork_refresh(c);
+  }
+  ~KtRead() { if (r && --c->kt_read_depth == 0) r->kt_rw.unlock_shared(); }
+};
 
 // live contexts: lets long-lived host objects (bftkv_quorum) notice that their context is gone
 std::mutex g_live_mu;
@@ -252,7 +295,15 @@ __global__ void __launch_bounds__(256) k_tally_ids(const uint64_t* __restrict__ 
 int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const uint64_t* d_tbs_off,
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
-                 const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0) {
+                 const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0,
+                 const uint32_t* d_mid_in = nullptr, const uint64_t* d_tbs_prefix = nullptr, uint32_t staged_cap = 0) {
+  // staged_cap (staged small calls): the arena and the grids are sized for that many packet events up front and the
+  // kernels read the real count from the device -- no host round trip in mid-pipeline; a call with more events turns
+  // itself into an empty one (k_scan_counts) and is run again through the ordinary path by its caller.
+  // d_mid_in / d_tbs_prefix (the micro-batcher, whose callers absorb the whole blocks of their payload on their own threads):
+  // SHA-256 midstates [n_items][8] and the byte counts behind them; d_tbs then holds only the < 64 bytes after each.  No
+  // payload hashing on the device; a signature that asks for another hash stays ST_PENDING_HASH (the caller re-submits
+  // such an item with its payload: k_fenced_out's rehash bit).
   // plan_q (CollectiveSignature.Verify with the early exit enabled): public-key work is queued in two phases by k_plan
   // instead of by the parse -- see kernels.hip "two-phase planning".
   // upload_tbs (host-buffer entry point): the signed payloads are still in host memory.  Only the hash stream reads them,
@@ -279,18 +330,18 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
   HIPCHK(c, hipEventRecord(c->ev[5], sh));
-  if (!upload_tbs)
+  if (!upload_tbs && !d_mid_in)
     hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>(), walk_cap);
   constexpr uint32_t MAIL_EMPTY = 0xFFFFFFFFu;
-  if (c->h_mail) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
+  if (c->h_mail && !staged_cap) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
-                     c->total.as<uint32_t>(), c->d_mail);
-  HIPCHK(c, hipMemsetAsync(c->pk_count.p, 0, 96, s));
-  HIPCHK(c, hipMemsetAsync(c->hash_mask.p, 0, sizeof(uint32_t) * (size_t)n_items, s));
-  uint32_t total = MAIL_EMPTY;
-  if (c->h_mail) {
+                     c->total.as<uint32_t>(), staged_cap ? (uint32_t*)nullptr : c->d_mail, c->pk_count.as<uint32_t>(), c->hash_mask.as<uint32_t>(),
+                     staged_cap);
+  uint32_t total = staged_cap ? staged_cap : MAIL_EMPTY;      // staged: the upper bound; the kernels read the count from c->total
+  const uint32_t* const n_recs_dev = staged_cap ? c->total.as<uint32_t>() : nullptr;
+  if (c->h_mail && !staged_cap) {
     // spin on the mailbox (a few microseconds after the scan retires); give up after 20 ms and synchronise
     const auto t_spin = std::chrono::steady_clock::now();
     for (uint32_t it = 0;; ++it) {
@@ -304,7 +355,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
   }
-  c->last_total = total;
+  c->last_total = staged_cap ? 0u : total;      // (per-packet diagnostics are not kept for staged calls)
   c->last_items = n_items;
   const size_t tr = total ? total : 1;
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
@@ -329,7 +380,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pa.pk_count = c->pk_count.as<uint32_t>(); pa.dsa_list = c->dsa_list.as<uint32_t>(); pa.item_hash_mask = c->hash_mask.as<uint32_t>();
     pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
     pa.defer_queue = plan_q ? 1u : 0u;
-    if ((uint64_t)total >= 128ull * n_items)     // very long items (n = 256 cliques: 171+ packets): block per item, no bisection
+    pa.n_recs_dev = n_recs_dev;
+    if (!staged_cap && (uint64_t)total >= 128ull * n_items)     // very long items (n = 256 cliques: 171+ packets): block per item, no bisection
                                                  // (measured at 53 packets per item: 237 us item-major vs 210 us record-major)
       hipLaunchKernelGGL(k_parse_body_items, dim3(n_items), dim3(PARSE_ITEM_BLOCK), 0, s, pa, c->kt);
     else
@@ -352,7 +404,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // key of the ring enough of them (64 on average, 4096 in all: a thread's 16 sorted entries then hold one or two runs), else
   // one per signature (k_dsa_inv).  The list length lives on the device, so both kernels are enqueued and one of them returns
   // at once.
-  const size_t n_slots = c->dsa_comb_slot.size();
+  const size_t n_slots = c->root ? c->n_dsa_slots : c->dsa_comb_slot.size();
   const uint32_t inv_batch_min = c->dsa_inv_mode == 1 || n_slots > (c->dsa_inv_mode == 2 ? (size_t)INV_MAX_SLOTS : 256) ? 0xFFFFFFFFu
                                  : c->dsa_inv_mode == 2 ? 0u : (uint32_t)std::max<size_t>(4096, 64 * n_slots);
   auto launch_dsa_inv = [&](hipStream_t st, const uint32_t* start) {
@@ -373,10 +425,12 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
     if (total) {
       // other hashes: a no-op grid unless some signature asked for them
-      hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
-                         c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
-      hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(),
-                         c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, c->digests.as<uint32_t>());
+      if (!d_mid_in)
+        hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
+                           c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
+      hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss,
+                         d_mid_in ? d_mid_in : c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
+                         c->digests.as<uint32_t>(), d_tbs_prefix, n_recs_dev);
     }
     HIPCHK(c, hipEventRecord(c->ev[6], sh));
     return 0;
@@ -408,7 +462,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // digests of the hashes other than SHA-256: on the MAIN stream, after the modexp.  Normally there are none and the kernel
   // exits on a device-side flag; at its 203 VGPRs it cannot co-schedule beside k_rsa_modexp, and on the hash stream it sat
   // there until the modexp drained (1.7 ms per step in the trace) holding back the join.
-  if (total)
+  if (total && !d_mid_in)
     hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
                        d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
                        c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
@@ -603,6 +657,8 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
 // Builds and uploads the device key table from c->ring (the node keyring, in getKeyring() order) followed by
 // c->certs (entities that only exist inside request certificates, reachable through VerifyWithCertificate).
 int upload_key_table(bftkv_gpu_ctx* c) {
+  if (c->root) return fail(c, BFTKV_E_STATE, "a forked context cannot change the key table (use its root)");
+  KtWrite kw(c);      // the forks' calls in flight drain first; new ones wait
   std::vector<uint64_t> key_id, entity_ids;
   std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
   std::vector<uint8_t> algo, flags;
@@ -692,6 +748,36 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   return 0;
 }
 
+// A fork's view of its root (caller holds root->kt_rw shared): the key-table descriptor and the host-side id vectors by
+// value, the quorum descriptors by value with the fork's own membership tables (built on demand, keyed to the generation).
+int fork_refresh(bftkv_gpu_ctx* c) {
+  bftkv_gpu_ctx* r = c->root;
+  if (c->seen_keyring_gen != r->keyring_gen) {
+    c->kt = r->kt;
+    c->n_keys = r->n_keys; c->n_entities = r->n_entities; c->n_ring_entities = r->n_ring_entities;
+    c->have_dsa_keys = r->have_dsa_keys; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096;
+    c->h_key_id = r->h_key_id; c->h_entity_id = r->h_entity_id; c->h_key_entity = r->h_key_entity; c->h_key_flags = r->h_key_flags;
+    c->n_dsa_slots = r->dsa_comb_slot.size(); c->dsa_wbits = r->dsa_wbits;
+    c->keyring_gen = r->keyring_gen;          // the fork's membership tables follow the root's generations
+    c->seen_keyring_gen = r->keyring_gen;
+  }
+  c->early_exit = r->early_exit;
+  if (c->seen_quorum_gen != r->quorum_gen) {
+    for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
+    c->quorums.clear();
+    c->quorums.resize(r->quorums.size());
+    for (size_t i = 0; i < r->quorums.size(); ++i) {
+      const QuorumHost& s = r->quorums[i];
+      QuorumHost& d = c->quorums[i];
+      d.live = s.live; d.n_qcs = s.n_qcs; d.nodes = s.nodes;
+      for (int k = 0; k < MAX_QC; ++k) { d.f[k] = s.f[k]; d.mn[k] = s.mn[k]; d.thr[k] = s.thr[k]; d.suff[k] = s.suff[k]; }
+      d.keyring_gen = ~0ull;
+    }
+    c->seen_quorum_gen = r->quorum_gen;
+  }
+  return 0;
+}
+
 // offsets must start at 0 and be non-decreasing: they become device-side read ranges
 int check_offsets(bftkv_gpu_ctx* c, const uint64_t* off, uint32_t n, const char* what) {
   if (off[0] != 0) return fail(c, BFTKV_E_INVALID, what);
@@ -718,6 +804,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   c->device = device_ordinal;
   if (hipHostMalloc((void**)&c->h_mail, 64, hipHostMallocMapped) == hipSuccess) {
     if (hipHostGetDevicePointer((void**)&c->d_mail, c->h_mail, 0) != hipSuccess) { (void)hipHostFree(c->h_mail); c->h_mail = nullptr; c->d_mail = nullptr; }
+    else memset(c->h_mail, 0, 64);
   } else c->h_mail = nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess ||
@@ -731,8 +818,26 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   return BFTKV_OK;
 }
 
+int bftkv_gpu_ctx_fork(bftkv_gpu_ctx* root, bftkv_gpu_ctx** out) {
+  if (!root || !out) return BFTKV_E_INVALID;
+  if (root->root) return fail(root, BFTKV_E_INVALID, "fork of a fork");
+  bftkv_gpu_ctx* c = nullptr;
+  int rc = bftkv_gpu_init(root->device, &c);
+  if (rc) return rc;
+  c->root = root;
+  c->early_exit = root->early_exit;
+  c->dsa_inv_mode = root->dsa_inv_mode;
+  root->n_forks.fetch_add(1);
+  *out = c;
+  return 0;
+}
+
 void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (!c) return;
+  if (!c->root && c->n_forks.load() > 0) {     // its forks read this context's key table: they go first
+    fprintf(stderr, "bftkv_gpu_destroy: context still has %d forked context(s); not destroyed\n", c->n_forks.load());
+    return;
+  }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     for (size_t i = 0; i < g_live.size(); ++i) if (g_live[i] == c) { g_live.erase(g_live.begin() + i); break; }
@@ -747,6 +852,9 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
+  c->in_pack.release();
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->root) c->root->n_forks.fetch_sub(1);
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
   for (auto& kv : c->modtab_cache) for (DevBuf& b : kv.second) b.release();
   if (c->h_mail) (void)hipHostFree(c->h_mail);
@@ -780,6 +888,8 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
 int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* c, int on) {
   if (!c) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "set on the root context; its forks follow");
+  KtWrite kw(c);
   c->early_exit = on != 0;
   return 0;
 }
@@ -794,6 +904,7 @@ int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32_t n_keys) {
   if (!c || (!keys && n_keys)) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "a forked context cannot change the key table (use its root)");
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<KeyEntry> ring;
   for (uint32_t i = 0; i < n_keys; ++i) {
@@ -822,6 +933,7 @@ int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t 
   if (!c || !out || (!qcs && n_qcs)) return BFTKV_E_INVALID;
   if (n_qcs > MAX_QC) return fail(c, BFTKV_E_UNSUPPORTED, "more than MAX_QC cliques in one quorum");
   ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "quorums are created on the root context; its forks see them");
   HIPCHK(c, hipSetDevice(c->device));
   QuorumHost q;
   q.live = true;
@@ -845,8 +957,10 @@ int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t 
   q.ids_off[MAX_QC] = (uint32_t)ids_words;   // remember where the offsets live
   int h = -1;
   for (size_t i = 0; i < c->quorums.size(); ++i) if (!c->quorums[i].live) { h = (int)i; break; }
+  KtWrite kw(c);
   if (h < 0) { c->quorums.emplace_back(); h = (int)c->quorums.size() - 1; }
   c->quorums[h] = std::move(q);
+  ++c->quorum_gen;
   *out = h;
   return 0;
 }
@@ -854,11 +968,14 @@ int bftkv_gpu_quorum_create(bftkv_gpu_ctx* c, const bftkv_gpu_qc* qcs, uint32_t 
 int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
   if (!c) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "quorums are destroyed on the root context");
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
+  KtWrite kw(c);
   c->quorums[quorum].member.release();
   c->quorums[quorum].ids.release();
   c->quorums[quorum] = QuorumHost();
+  ++c->quorum_gen;
   return 0;
 }
 
@@ -898,6 +1015,8 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_ite
                                     uint32_t* nver_out, uint8_t* verdict_out, uint8_t* fenced_out) {
   if (!c) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
+  KtRead kr(c);
+  if (kr.rc) return kr.rc;
   return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, nullptr, ss_len);
 }
 
@@ -907,6 +1026,8 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
   ctx_lock lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context
+  KtRead kr(c);
+  if (kr.rc) return kr.rc;
   HIPCHK(c, hipSetDevice(c->device));
   int rco;
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
@@ -946,6 +1067,8 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
 int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
                               const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class, uint8_t* fenced_out) {
   ctx_lock lk(c->mu);
+  KtRead kr(c);
+  if (kr.rc) return kr.rc;
   HIPCHK(c, hipSetDevice(c->device));
   int rco;
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, sig_off, n_items, "sig_off not monotone from 0")))
@@ -998,6 +1121,8 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t
   if (n_items == 0) return 0;
   std::vector<uint32_t> ce;
   ctx_lock lk(c->mu);      // entity indices resolved here stay valid until the pipeline has consumed them
+  KtRead kr(c);            // (shared locks nest: signature_verify_entities takes it again)
+  if (kr.rc) return kr.rc;
   if (cert_key_id) {
     ce.resize(n_items);
     for (uint32_t i = 0; i < n_items; ++i) {
@@ -1006,7 +1131,12 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t
       ce[i] = e;
     }
   }
-  return signature_verify_entities(c, n_items, tbs, tbs_off, sig, sig_off, cert_key_id ? ce.data() : nullptr, err_out, nullptr, fenced_out);
+  int rc = signature_verify_entities(c, n_items, tbs, tbs_off, sig, sig_off, cert_key_id ? ce.data() : nullptr, err_out, nullptr, fenced_out);
+  // a certificate whose entity the device table does not hold: the library cannot speak for the reference (which verifies
+  // against the certificate it is handed) -- reported as fenced, never as a verdict
+  if (!rc && fenced_out && cert_key_id)
+    for (uint32_t i = 0; i < n_items; ++i) if (ce[i] == 0xFFFFFFFEu) fenced_out[i] = 1;
+  return rc;
 }
 
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint32_t cap, uint32_t* n_out) {
@@ -1071,6 +1201,7 @@ int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* c, int quorum, uint32_t n_lists, const
   if (!c || (n_lists && (!list_off || !verdict_out))) return BFTKV_E_INVALID;
   if (n_lists == 0) return 0;
   ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "bftkv_gpu_quorum_tally runs on the root context");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
@@ -1099,6 +1230,8 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   // key ids only (getCertById, crypto_pgp.go:206-219).
   if (!c || (n_items && (!ss_off || !ids_off_out))) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
+  KtRead kr(c);
+  if (kr.rc) return kr.rc;
   HIPCHK(c, hipSetDevice(c->device));
   ids_off_out[0] = 0;
   if (n_items == 0) return 0;
@@ -1116,7 +1249,7 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
                      c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
-                     c->total.as<uint32_t>(), (uint32_t*)nullptr);
+                     c->total.as<uint32_t>(), (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
   uint32_t total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

@@ -427,6 +427,7 @@ struct ParseArgs {
   const uint8_t* msg_hash;     // per item, with msg_slot
   const uint8_t* item_flags;
   uint32_t defer_queue;        // two-phase calls: k_plan decides which records join the work lists
+  const uint32_t* n_recs_dev;  // staged calls: the record count lives on the device (n_recs is then the grid's upper bound)
 };
 
 // `win`: this lane's PARSE_WIN_STRIDE bytes of LDS.
@@ -575,7 +576,7 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
 // signatures, certificate checks, transport messages.
 __global__ void __launch_bounds__(256) k_parse_body(ParseArgs a, KeyTableDev kt) {
   const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ri >= a.n_recs) return;
+  if (ri >= (a.n_recs_dev ? *a.n_recs_dev : a.n_recs)) return;
   // which item does record ri belong to?  largest item with rec_base[item] <= ri (and a non-empty range)
   uint32_t lo = 0, hi = a.n_items;
   while (hi - lo > 1) {
@@ -635,9 +636,15 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
 // single-block exclusive scan (n up to a few million): each thread scans a contiguous chunk
 // `host_total` (optional) is a mapped, pinned host word: the host spins on it instead of paying an interrupt-driven
 // stream synchronisation for the one number it needs (arena and grid sizes) in the middle of the pipeline.
-__global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict__ counts, uint32_t n,
+// The kernel also clears what the parse accumulates into (the 24 work-list words, the per-item hash masks): two memset
+// launches fewer per call.
+// `cap` (staged small calls, which size their arena from the stream length instead of asking the host in mid-pipeline): a
+// call with more packet events than that becomes an EMPTY call -- every count zero, total[1] = the real total -- and the
+// caller runs it again through the ordinary entry point.
+__global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ counts, uint32_t n,
                                                       uint32_t* __restrict__ base, uint32_t* __restrict__ total,
-                                                      uint32_t* __restrict__ host_total) {
+                                                      uint32_t* __restrict__ host_total, uint32_t* __restrict__ pk_count /*[24] or null*/,
+                                                      uint32_t* __restrict__ item_hash_mask /*[n] or null*/, uint32_t cap) {
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
   uint32_t chunk = (n + 1023) / 1024;
@@ -645,6 +652,8 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict
   uint32_t s = 0;
   for (uint32_t i = lo; i < hi; ++i) s += counts[i];
   part[t] = s;
+  if (pk_count && t < 24) pk_count[t] = 0;
+  if (item_hash_mask) for (uint32_t i = lo; i < hi; ++i) item_hash_mask[i] = 0;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
     uint32_t v = (t >= off) ? part[t - off] : 0;
@@ -652,11 +661,17 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const uint32_t* __restrict
     part[t] += v;
     __syncthreads();
   }
+  const uint32_t all = part[1023];
+  if (cap && all > cap) {
+    for (uint32_t i = lo; i < hi; ++i) { base[i] = 0; counts[i] = 0; }
+    if (t == 1023) { total[0] = 0; total[1] = all; }
+    return;
+  }
   uint32_t run = (t == 0) ? 0 : part[t - 1];
   for (uint32_t i = lo; i < hi; ++i) { base[i] = run; run += counts[i]; }
   if (t == 1023) {
-    *total = part[1023];
-    if (host_total) { __hip_atomic_store(host_total, part[1023], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    total[0] = all; total[1] = 0;
+    if (host_total) { __hip_atomic_store(host_total, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
 
@@ -790,18 +805,21 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
                                             const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                             const uint64_t* __restrict__ mid64, uint32_t n_items,
                                             SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/,
-                                            uint32_t ri_in) {
+                                            uint32_t ri_in, const uint64_t* __restrict__ tbs_prefix = nullptr) {
   const uint32_t ri = ri_in;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
   if (rec.status != ST_PENDING_HASH) return;
   if ((rec.hash_id != HASH_SHA256) != OTHERS) return;
   const HashInfo hi = OTHERS ? hash_info(rec.hash_id) : HashInfo{32, 0, 32, 19};
-  const uint64_t tlen = tbs_off[rec.item + 1] - tbs_off[rec.item];
+  // tbs_prefix (callers that absorbed the whole blocks of their payload themselves, host_sha256.h): the blob holds only the
+  // < 64 bytes behind the midstate, tbs_prefix[item] bytes went before them
+  const uint64_t seg = tbs_off[rec.item + 1] - tbs_off[rec.item];
+  const uint64_t tlen = tbs_prefix ? tbs_prefix[rec.item] + seg : seg;
   const uint32_t bmask = (OTHERS && hi.family == 64) ? 127u : 63u;
   TailSrc ts;
-  ts.tail_len = (uint32_t)(tlen & bmask);
-  ts.tail = tbs_blob + tbs_off[rec.item] + (tlen - ts.tail_len);
+  ts.tail_len = tbs_prefix ? (uint32_t)seg : (uint32_t)(tlen & bmask);
+  ts.tail = tbs_blob + tbs_off[rec.item] + (seg - ts.tail_len);
   const bool v3 = (rec.flags & SIGF_V3) != 0;
   ts.body = sig_blob + rec.body_off + (v3 ? 2 : 0);
   ts.pre_len = v3 ? 5u : 6u + rec.hashed_len;
@@ -864,8 +882,10 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
 __global__ void __launch_bounds__(256) k_digest_sha256(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                        const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                        const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
-                                                       uint32_t n_recs, uint32_t* __restrict__ digests) {
-  digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, blockIdx.x * blockDim.x + threadIdx.x);
+                                                       uint32_t n_recs, uint32_t* __restrict__ digests,
+                                                       const uint64_t* __restrict__ tbs_prefix, const uint32_t* __restrict__ n_recs_dev) {
+  digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs_dev ? *n_recs_dev : n_recs, digests,
+                     blockIdx.x * blockDim.x + threadIdx.x, tbs_prefix);
 }
 // Every other hash (SHA-1 / 224 / 384 / 512).  Round 1 capped this kernel at 128 VGPRs so that its grid of immediate exits
 // could co-schedule beside k_rsa_modexp, at the price of 510 spilled VGPRs in the SHA-512 path; with the bounded grid
@@ -1853,15 +1873,37 @@ __global__ void k_plan_snapshot(uint32_t* __restrict__ pk_count) {
 }
 
 // per-item fence flag for the caller: the walk met a framing it does not follow, or the parse met a fenced packet shape
+// rehash_bits (calls that handed over SHA-256 midstates instead of payloads): bit 1 of out[i] = a signature of the item asks
+// for another hash, which needs the payload itself -- the caller submits the item again with its bytes
 __global__ void k_fenced_out(const uint8_t* __restrict__ item_flags, const uint32_t* __restrict__ item_hash_mask, uint32_t n,
-                             uint8_t* __restrict__ out) {
+                             uint8_t* __restrict__ out, uint32_t rehash_bits = 0) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = ((item_flags[i] & 4) || (item_hash_mask[i] & ITEM_FENCED)) ? 1 : 0;
+  if (i < n) out[i] = (((item_flags[i] & 4) || (item_hash_mask[i] & ITEM_FENCED)) ? 1 : 0) | ((item_hash_mask[i] & rehash_bits) ? 2 : 0);
 }
 
 __global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, uint8_t* __restrict__ e) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) e[i] = (v[i] & V_IS_SUFFICIENT) ? 0 : 2;   // BFTKV_ERR_NONE : BFTKV_ERR_INSUFFICIENT_SIGNATURES
+}
+
+// Last kernel of a staged small call (the micro-batcher): per item the error byte (from the verdict bits, or as it stands) and
+// the fenced / rehash flags, written straight into MAPPED HOST memory, then the call's sequence number into the mailbox
+// word the host spins on -- no device-to-host copy, no interrupt-driven stream synchronisation at the end of a call that
+// lasts ~0.1 ms.  One block: the flag is stored after every thread's result stores (block barrier, system-scope fence).
+__global__ void __launch_bounds__(256) k_finish_staged(const uint8_t* __restrict__ verdict_or_err, uint32_t from_verdict,
+                                                       const uint8_t* __restrict__ item_flags, const uint32_t* __restrict__ item_hash_mask,
+                                                       uint32_t n, uint32_t rehash_bits, uint8_t* __restrict__ host_out /*[2][n] + 8*/,
+                                                       uint32_t* __restrict__ host_flag, uint32_t seq,
+                                                       const uint32_t* __restrict__ total /*[0] packets, [1] overflow (k_scan_counts cap)*/) {
+  if (threadIdx.x < 8) host_out[2 * (size_t)n + threadIdx.x] = (uint8_t)(total[threadIdx.x >> 2] >> (8 * (threadIdx.x & 3)));
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint8_t v = verdict_or_err[i];
+    host_out[i] = from_verdict ? ((v & V_IS_SUFFICIENT) ? 0 : 2) : v;
+    host_out[n + i] = (((item_flags[i] & 4) || (item_hash_mask[i] & ITEM_FENCED)) ? 1 : 0) | ((item_hash_mask[i] & rehash_bits) ? 2 : 0);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // per-record status export (diagnostics / parity tests)

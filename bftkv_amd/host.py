@@ -73,7 +73,7 @@ HOST_EXPORTS = [
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
-    "bftkv_host_parse_signature", "bftkv_host_walk_stream",
+    "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_sha256",
 ]
 
 _ready = False
@@ -408,6 +408,18 @@ def quorum_cert_verify(ctx: _native.Context, q: "Quorum", cert: bytes):
     if rc:
         raise _native.NativeError("quorum_cert_verify failed: %d" % rc)
     return bool(ok[0]), [int(x) for x in ids[:n.value]]
+
+
+def sha256(data: bytes, mode: int = 0):
+    """bftkv_host_sha256: the compression the micro-batcher's callers run over their payloads (mode 0: SHA extensions when the
+    CPU has them, 1: portable).  Returns (digest, cpu_has_sha_extensions)."""
+    lib = _lib()
+    lib.bftkv_host_sha256.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p]
+    buf = C.create_string_buffer(32)
+    rc = lib.bftkv_host_sha256(data, len(data), mode, C.cast(buf, C.c_void_p))
+    if rc < 0:
+        raise ValueError("bftkv_host_sha256: %d" % rc)
+    return buf.raw, bool(rc)
 
 
 def emsa_encode(hash_id: int, digest: bytes, n_bits: int) -> bytes:

@@ -167,24 +167,41 @@ int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* ctx, int on);
 /* err_out[i] = BFTKV_ERR_NONE iff sig.Data holds >= 1 packet and every CheckDetachedSignature call
  * succeeds, else BFTKV_ERR_INVALID_SIGNATURE.  cert_key_id == NULL: keyring = the node keyring;
  * otherwise the keyring of item i is the single entity whose primary key id is cert_key_id[i]
- * (it must have been uploaded with bftkv_gpu_keyring_set; subkeys of that entity match too). */
+ * (subkeys of that entity match too).  The entity must be in the device table, i.e. have been uploaded with
+ * bftkv_gpu_keyring_set: the reference verifies against the certificate it is HANDED, the device only against what it
+ * holds, so an id that is not in the table comes back with fenced_out[i] = 1 (err_out[i] invalid-signature, fail-closed)
+ * and the caller takes the reference path; bftkv_host_server_sign_verify registers request certificates instead. */
 int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
                                const uint8_t* tbs_blob, const uint64_t* tbs_off,
                                const uint8_t* sig_blob, const uint64_t* sig_off,
                                const uint64_t* cert_key_id, uint8_t* err_out, uint8_t* fenced_out);
 
+/* ---- forked verifier contexts ------------------------------------------------------------------------ */
+/* A fork has its own streams, per-call arena and events -- several device calls in flight at once -- and reads the ROOT's
+ * resident key table, DSA tables and quorum handles (no copy: 64 DSA keys hold 41 GB of window tables).  It accepts the
+ * verify calls (collective / signature / message / signers); whatever changes the key table or the quorums
+ * (bftkv_gpu_keyring_set, bftkv_gpu_quorum_create / _destroy, the certificate sites of bftkv_host.h,
+ * bftkv_gpu_set_early_exit) is done on the root, waits there until the forks' calls in flight have drained, and is seen
+ * by every fork at its next call.  Destroy the forks before their root. */
+int bftkv_gpu_ctx_fork(bftkv_gpu_ctx* root, bftkv_gpu_ctx** fork_out);
+
 /* ---- micro-batching of concurrent single calls ---------------------------------------------------- */
 /* The reference verifies ONE message per call, concurrently from one goroutine per HTTP request
  * (transport/http/http.go:85,143 -> protocol/server.go:562-620).  A batcher turns such calls into device batches:
- * each call blocks until its batch has been verified.  A batch is taken when max_items calls wait, when as many wait as
- * the worker has just seen at once (the previous batch plus the queue behind it: a lone caller is answered immediately), or
- * max_wait_us microseconds after its first call, whichever comes first; calls that arrive while a batch runs are taken
- * together behind it.  Thread-safe; buffers are only read for the duration of the call.
+ * each call blocks until its batch has been verified.  There is no worker thread: the first caller into an empty batch
+ * leads it -- it takes a free LANE (a forked context; n_lanes of them, so that many batches are on the device at once),
+ * runs the device call on its own thread and wakes the callers that joined meanwhile; a lone caller crosses no thread at
+ * all.  While every lane is busy the callers pile up behind the waiting leader, at most max_items to a batch (the next
+ * caller then leads a new one).  Callers hash the whole blocks of their own payload on their own thread (SHA-256
+ * midstate, SHA extensions when the CPU has them) and the device finishes each signature's digest from there.
+ * max_wait_us is accepted for compatibility and unused: nobody waits for company.  n_lanes = 0 (and
+ * bftkv_gpu_batcher_create): $BFTKV_BATCHER_LANES or 4.  Thread-safe; buffers are only read for the duration of the call.
  * FAIL-CLOSED: the status byte is written on every path and is a failure (invalid signature / insufficient signatures /
  * read error) whenever the return code is not 0 -- a caller that only looks at the status can never read "verified" out
  * of an infrastructure error (allocation failure, stopped batcher, bad handle). */
 typedef struct bftkv_gpu_batcher bftkv_gpu_batcher;
 bftkv_gpu_batcher* bftkv_gpu_batcher_create(bftkv_gpu_ctx* ctx, uint32_t max_items, uint32_t max_wait_us);
+bftkv_gpu_batcher* bftkv_gpu_batcher_create_lanes(bftkv_gpu_ctx* ctx, uint32_t max_items, uint32_t max_wait_us, uint32_t n_lanes);
 void bftkv_gpu_batcher_destroy(bftkv_gpu_batcher* b);
 /* CollectiveSignature.Verify(tbs, ss, q) (crypto_pgp.go:485-500): *err_out = BFTKV_ERR_NONE / _INSUFFICIENT_SIGNATURES */
 int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const uint8_t* tbs, uint64_t tbs_len,
@@ -192,7 +209,7 @@ int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const 
 /* Signature.Verify / VerifyWithCertificate (crypto_pgp.go:319-344); cert_key_id NULL = node keyring */
 int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sig,
                                        uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out, uint8_t* fenced_out);
-/* stats[0] calls served, stats[1] device batches launched, stats[2] largest batch */
+/* stats[0] calls served, stats[1] device calls made, stats[2] largest batch, stats[3] lanes */
 /* One transport message (bftkv_gpu_message_verify for a single caller): blocks until its batch has run.  plain_out
  * receives the literal body (BFTKV_E_NOMEM if plain_cap is too small; msg_len always suffices), fname_out[256] the
  * file name. */
@@ -200,6 +217,9 @@ int bftkv_gpu_batcher_message_verify(bftkv_gpu_batcher* b, const uint8_t* msg, u
                                      uint64_t* signer_key_id_out, uint64_t* peer_id_out, uint8_t* plain_out, uint64_t plain_cap,
                                      uint64_t* plain_len_out, uint8_t* fname_out, uint8_t* fname_len_out);
 int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
+/* where the callers' time went, nanoseconds summed over all calls so far: [0] hashing their payloads, [1] leaders waiting
+ * for a lane, [2] leaders assembling batches, [3] leaders inside device calls */
+int bftkv_gpu_batcher_times(bftkv_gpu_batcher* b, uint64_t ns[4]);
 
 /* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* ctx, uint8_t* status_out, uint32_t* item_out, uint32_t cap, uint32_t* n_out);

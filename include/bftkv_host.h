@@ -239,6 +239,12 @@ int bftkv_host_message_frame(const uint8_t* msg, uint64_t len, uint8_t* framing_
                              uint8_t* plain_out, uint64_t plain_cap, uint64_t* plain_len_out, uint8_t* fname_out /*[256]*/,
                              uint8_t* fname_len_out, uint64_t* sig_off_out, uint64_t* sig_len_out);
 
+/* SHA-256 with the compression the micro-batcher's callers run over their own payload before they queue
+ * (bftkv_gpu_batcher_*: the device receives midstates; reference: the hash inside openpgp.CheckDetachedSignature,
+ * crypto/pgp/crypto_pgp.go:490).  mode 0: the fastest this CPU offers (SHA extensions when present), 1: the portable
+ * rounds.  Returns 1 when the CPU has the SHA extensions, 0 when not, < 0 on bad arguments. */
+int bftkv_host_sha256(const uint8_t* data, uint64_t len, int mode, uint8_t out[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,8 +23,9 @@ type CollectiveSignature struct {
 // protocol/client.go:165,470, api/api.go:130.
 func (cs *CollectiveSignature) Verify(tbs []byte, ss *packet.SignaturePacket, q quorum.Quorum) error {
 	h, err := cs.g.quorumHandle(q)
-	if err != nil {
-		return cs.inner.Verify(tbs, ss, q) // a quorum this package cannot describe: the reference path decides
+	if err != nil || !cs.keyring.fresh() {
+		// a quorum this package cannot describe, or a device table not known to equal the keyring: the reference decides
+		return cs.inner.Verify(tbs, ss, q)
 	}
 	var e, fenced C.uint8_t
 	rc := C.bftkv_gpu_batcher_collective_verify(cs.g.batcher, h, ptr(tbs), C.uint64_t(len(tbs)), ptr(ss.Data), C.uint64_t(len(ss.Data)), &e, &fenced)

@@ -30,6 +30,35 @@ type keyring struct {
 	mu      sync.Mutex
 	secring openpgp.EntityList
 	pubring openpgp.EntityList
+	// stale: the last upload failed, so the device table may differ from the rings (a REMOVED node could still verify
+	// there).  While it is set every verifying method goes to crypto/pgp; the next successful sync clears it.
+	stale bool
+}
+
+// fresh reports whether the device key table is known to equal getKeyring().
+func (k *keyring) fresh() bool {
+	k.mu.Lock()
+	defer k.mu.Unlock()
+	return !k.stale
+}
+
+// holds reports whether e IS one of the entities uploaded to the device (same object: Register stores the node's
+// *openpgp.Entity itself, crypto_pgp.go:142-160).  A certificate that only travels inside a request is a different object
+// even when its key id equals a keyring entity's, and its key material need not be the keyring's.
+func (k *keyring) holds(e *openpgp.Entity) bool {
+	k.mu.Lock()
+	defer k.mu.Unlock()
+	if k.stale {
+		return false
+	}
+	for _, ring := range []openpgp.EntityList{k.secring, k.pubring} {
+		for _, r := range ring {
+			if r == e {
+				return true
+			}
+		}
+	}
+	return false
 }
 
 func upsert(ring openpgp.EntityList, nodes []node.Node) openpgp.EntityList {
@@ -50,24 +79,26 @@ func upsert(ring openpgp.EntityList, nodes []node.Node) openpgp.EntityList {
 	return ring
 }
 
+// Register and Remove hold k.mu across the inner call AND the mirror update: a concurrent Register / Remove of one node
+// can then not leave the mirror and the PGPKeyring in different orders.
 func (k *keyring) Register(nodes []node.Node, priv bool, self bool) error {
+	k.mu.Lock()
+	defer k.mu.Unlock()
 	if err := k.inner.Register(nodes, priv, self); err != nil {
 		return err
 	}
-	k.mu.Lock()
-	defer k.mu.Unlock()
 	if priv {
 		k.secring = upsert(k.secring, nodes) // crypto_pgp.go:153-155
 	} else {
 		k.pubring = upsert(k.pubring, nodes) // crypto_pgp.go:156-158
 	}
-	return k.sync()
+	return k.syncLocked()
 }
 
 func (k *keyring) Remove(nodes []node.Node) {
-	k.inner.Remove(nodes)
 	k.mu.Lock()
 	defer k.mu.Unlock()
+	k.inner.Remove(nodes)
 	var kept openpgp.EntityList
 	for _, e := range k.pubring {
 		drop := false
@@ -81,7 +112,16 @@ func (k *keyring) Remove(nodes []node.Node) {
 		}
 	}
 	k.pubring = kept
-	_ = k.sync()
+	// Remove has no error to return (crypto.Keyring, crypto/crypto.go:35-41).  If the upload fails the revoked node's keys
+	// are still on the device: syncLocked marks the table stale and every Verify takes the reference path until an upload
+	// succeeds -- revocation must not fail open.
+	_ = k.syncLocked()
+}
+
+func (k *keyring) syncLocked() error {
+	err := k.sync()
+	k.stale = err != nil
+	return err
 }
 
 func (k *keyring) GetCertById(id uint64) node.Node { return k.inner.GetCertById(id) }

@@ -48,8 +48,8 @@ func New(device int) *crypto.Crypto {
 	if rc := C.bftkv_gpu_init(C.int(device), &g.ctx); rc != 0 {
 		panic(errNoDevice)
 	}
-	// at most 256 calls per batch, at most 200 us of waiting for company (INTEGRATION.md section 2)
-	g.batcher = C.bftkv_gpu_batcher_create(g.ctx, 256, 200)
+	// at most 256 calls per batch, 4 batches on the device at once (INTEGRATION.md section 2)
+	g.batcher = C.bftkv_gpu_batcher_create_lanes(g.ctx, 256, 0, 4)
 	if g.batcher == nil {
 		panic("pgpgpu: bftkv_gpu_batcher_create failed")
 	}
@@ -57,7 +57,7 @@ func New(device int) *crypto.Crypto {
 	c.Keyring = kr
 	// crypto/pgp's other objects were built around the original keyring by pgp.New(); they keep using it
 	// (same underlying *PGPKeyring), this wrapper only observes Register / Remove.
-	c.Signature = &Signature{g: g, inner: c.Signature}
+	c.Signature = &Signature{g: g, inner: c.Signature, keyring: kr}
 	c.CollectiveSignature = &CollectiveSignature{g: g, inner: c.CollectiveSignature, keyring: kr}
 	c.Message = &Message{g: g, inner: c.Message, keyring: kr}
 	return c

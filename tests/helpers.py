@@ -104,3 +104,10 @@ def random_framing_streams(cl, n_items, seed=77):
             data = data[:int(rng.integers(1, len(data)))]                               # truncated somewhere
         tbs_l.append(tbs); ss_l.append(data)
     return tbs_l, ss_l, hdr, srng
+
+
+def cat(parts):
+    """byte strings -> (blob, n+1 offsets) as the batched entry points take them"""
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    return np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)[:int(off[-1])].copy(), off

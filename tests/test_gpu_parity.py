@@ -127,6 +127,19 @@ def test_signature_verify_and_with_certificate(gpu_ctx):
         assert err[i] in (0, 1) and errc[i] in (0, 1)
         n_ok += want is None
     assert 5 < n_ok < 35
+    assert not gpu_ctx.last_fenced.any()
+    # a certificate whose entity the device table does not hold (server.go:199-207 hands over sig.Cert, normally a principal
+    # outside the node keyring): the library cannot speak for the reference there -- fenced, never a verdict
+    stranger = np.array([cl.outsiders[0].key_id ^ 0x55] * 40, dtype=np.uint64)
+    errs = gpu_ctx.signature_verify(tb, to, sb, so, cert_key_id=stranger)
+    assert (errs == 1).all() and gpu_ctx.last_fenced.all()
+    from bftkv_amd._native import Batcher
+    b = Batcher(gpu_ctx, max_items=8, n_lanes=1)
+    try:
+        assert b.signature_verify(tbs_l[0], sig_l[0], cert_key_id=int(stranger[0]), raw=True) == (0, 1, 1)
+        assert b.signature_verify(tbs_l[0], sig_l[0], cert_key_id=cl.client.key_id, raw=True) == (0, 0, 0)
+    finally:
+        b.close()
 
 
 def test_signers_parse_only(gpu_ctx):

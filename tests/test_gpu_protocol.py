@@ -277,9 +277,11 @@ def test_entity_verification_and_quorum_certificate(gpu_ctx):
     assert list(err) == [0, 0xFE, 0]      # bad_cert still passes the CODE's check: its certifier ids are only counted
 
 
-def test_micro_batcher_concurrent_single_calls(gpu_ctx):
+@pytest.mark.parametrize("n_lanes", [1, 4])
+def test_micro_batcher_concurrent_single_calls(gpu_ctx, n_lanes):
     """One CollectiveSignature.Verify per call from many threads (the reference's goroutine-per-request shape,
-    transport/http/http.go:85,143) -> device batches; every caller gets the oracle's answer."""
+    transport/http/http.go:85,143) -> device batches on n_lanes forked contexts at once; every caller gets the oracle's
+    answer."""
     import threading
     from bftkv_amd import Batcher
     cl = cb.make_cluster(4)
@@ -289,7 +291,7 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
     qh = gpu_ctx.quorum_create(H.abi_qcs(q))
     c = cb.make_write_corpus(cl, 96, mutation_rates={cb.MUT_ONE_SHORT: 0.3, cb.MUT_BAD_MPI: 0.2})
     want = [0 if H.oracle_collective(kr, q, c, i).err is None else 2 for i in range(c.n_items)]
-    b = Batcher(gpu_ctx, max_items=32, max_wait_us=20000)
+    b = Batcher(gpu_ctx, max_items=32, max_wait_us=20000, n_lanes=n_lanes)
     got = [None] * c.n_items
     sig_got = [None] * 16
     msg_got = [None] * 24
@@ -319,7 +321,8 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
     b.close()
     assert got == want and 0 < sum(g == 0 for g in got) < len(got)
     assert sig_got == [0 if i % 2 == 0 else 1 for i in range(16)]
-    assert st["calls"] == c.n_items + 16 + 24 and st["batches"] < st["calls"] / 2 and st["max_batch"] > 4
+    # (how the calls fall into batches depends on thread timing: a free lane is taken at once; only the bounds are asserted)
+    assert st["calls"] == c.n_items + 16 + 24 and st["lanes"] == n_lanes and st["max_batch"] <= 32
     import base64
     for i, (mst, signer, peer, plain, fname) in enumerate(msg_got):
         who = cl.replicas[i % 4] if i % 5 else cl.outsiders[0]
@@ -327,6 +330,129 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx):
         assert plain == b"body%d" % i and base64.standard_b64decode(fname) == b"nonce-%010d" % i
         assert signer == who.key_id and peer == (who.key_id if i % 5 else 0)
     gpu_ctx.quorum_destroy(qh)
+
+
+def test_forked_contexts_verify_over_the_roots_key_table(gpu_ctx):
+    """bftkv_gpu_ctx_fork: forks answer like their root, concurrently, follow the root's keyring and quorum changes, and
+    refuse to change either themselves."""
+    import threading
+    from bftkv_amd._native import NativeError
+    cl = cb.make_cluster(7, dsa_fraction=0.3)
+    kr = H.oracle_keyring(cl, include_client=True)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    c = cb.make_write_corpus(cl, 48, mutation_rates={cb.MUT_ONE_SHORT: 0.3, cb.MUT_BAD_MPI: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.1})
+    want = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    for i in range(c.n_items):
+        r = H.oracle_collective(kr, q, c, i)
+        assert (want[0][i] == 0) == (r.err is None) and want[1][i] == len(r.verified)
+    forks = [gpu_ctx.fork() for _ in range(3)]
+    out = [None] * len(forks)
+
+    def run(k):
+        res = []
+        for _ in range(4):
+            res.append(forks[k].collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off))
+        out[k] = res
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(len(forks))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    for res in out:
+        for e, nv, vd in res:
+            assert (e == want[0]).all() and (nv == want[1]).all() and (vd == want[2]).all()
+    with pytest.raises(NativeError):
+        forks[0].keyring_set(H.abi_keys(kr))
+    with pytest.raises(NativeError):
+        forks[0].quorum_create(H.abi_qcs(q))
+    # the root drops two replicas from its keyring: the forks see it at their next call
+    drop = {cl.replicas[0].key_id, cl.replicas[1].key_id}
+    kr2 = H.oracle_keyring(cl, include_client=True)
+    keys2 = [k for k in H.abi_keys(kr2) if k["entity_id"] not in drop]
+    gpu_ctx.keyring_set(keys2)
+    want2 = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    assert (want2[1] <= want[1]).all() and (want2[1] < want[1]).any()
+    got2 = forks[1].collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    assert (got2[0] == want2[0]).all() and (got2[1] == want2[1]).all()
+    # a quorum created on the root afterwards is usable on a fork; a destroyed one is not
+    qh2 = gpu_ctx.quorum_create(H.abi_qcs(q))
+    got3 = forks[2].collective_verify(qh2, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    assert (got3[0] == want2[0]).all()
+    gpu_ctx.quorum_destroy(qh2)
+    with pytest.raises(NativeError):
+        forks[2].collective_verify(qh2, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    for f in forks:
+        f.close()
+    gpu_ctx.quorum_destroy(qh)
+
+
+def test_micro_batcher_midstates_and_other_hashes(gpu_ctx):
+    """The batcher's callers hand over SHA-256 midstates of their payloads; a signature made with another hash sends its
+    item through the payload path.  The gpg fixtures (SHA-1 / 224 / 256 / 384 / 512, RSA and DSA) and payloads of every
+    length around the 64-byte block boundary, one call each, against the batched entry point."""
+    import json
+    import os
+    import threading
+    from bftkv_amd import Batcher
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
+    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B")):
+        ring = pgp.read_entities(bytes.fromhex(vec[ring_key]))
+        gpu_ctx.keyring_set(H.abi_keys(col.Keyring(keyring=ring)))
+        tbs_l = [bytes.fromhex(v["payload"]) for v in vec[group]]
+        sig_l = [bytes.fromhex(v["sig"]) for v in vec[group]]
+        tbs_l += [t + b"?" for t in tbs_l]
+        sig_l += sig_l
+        tb, to = H.cat(tbs_l)
+        sb, so = H.cat(sig_l)
+        want = list(gpu_ctx.signature_verify(tb, to, sb, so))
+        assert 0 in want and 1 in want
+        b = Batcher(gpu_ctx, max_items=16, n_lanes=2)
+        got = [None] * len(tbs_l)
+
+        def one(i):
+            got[i] = b.signature_verify(tbs_l[i], sig_l[i])
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(len(tbs_l))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        b.close()
+        assert got == want
+    # payload lengths 0 .. 200 (every residue of the block size, zero whole blocks, several whole blocks)
+    cl = cb.make_cluster(4)
+    kr = H.oracle_keyring(cl, include_client=True)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    b = Batcher(gpu_ctx, max_items=64, n_lanes=2)
+    try:
+        for ln in list(range(0, 200, 7)) + [63, 64, 65, 127, 128, 129, 8599, 8640]:
+            tbs = bytes((i * 31 + ln) & 0xFF for i in range(ln))
+            sig = cb.detach_sign(cl.replicas[ln % 4], tbs)
+            assert b.signature_verify(tbs, sig) == 0, ln
+            assert b.signature_verify(tbs + b"x", sig) == 1, ln
+        # more packet events than a staged call's arena is sized for (one event per stray byte): the call is run again through
+        # the ordinary entry point and answers like it
+        tbs = b"payload"
+        good = cb.detach_sign(cl.replicas[0], tbs)
+        for junk in (b"\x01" * 70000, good + b"\x01" * 70000, b"\xd4\x00" * 40000 + good):
+            tb, to = H.cat([tbs])
+            sb, so = H.cat([junk])
+            want = int(gpu_ctx.signature_verify(tb, to, sb, so)[0])
+            assert b.signature_verify(tbs, junk) == want
+        q = H.clique_quorum(cl)
+        qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+        ss = b"".join(cb.detach_sign(r, tbs) for r in cl.replicas)
+        for stream in (ss, b"\xd4\x00" * 50000 + ss, ss[:300] + b"\x01" * 60000):
+            tb, to = H.cat([tbs])
+            sb, so = H.cat([stream])
+            want = int(gpu_ctx.collective_verify(qh, tb, to, sb, so)[0][0])
+            assert b.collective_verify(qh, tbs, stream) == want
+        gpu_ctx.quorum_destroy(qh)
+    finally:
+        b.close()
 
 
 def test_audit_plain_storage_db(gpu_ctx, tmp_path):

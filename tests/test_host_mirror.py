@@ -479,3 +479,18 @@ def test_packet_walk_fuzz_against_the_oracle(H):
             n_err += w[1] is None
         n_events += len(want)
     assert n_events > 12000 and n_err > 3000
+
+
+def test_host_sha256_matches_hashlib_on_both_code_paths(H):
+    """The micro-batcher's callers hash their payloads with this compression (SHA extensions when the CPU has them, portable
+    rounds otherwise): every length around the block and padding boundaries, both paths, against hashlib."""
+    import hashlib
+    from corpus.keys import DRBG
+    rng = DRBG("host-sha256")
+    data = rng.bytes(70000)
+    lengths = list(range(0, 300)) + [511, 512, 513, 8599, 8600, 8640, 25100, 65535, 65536, 70000]
+    for ln in lengths:
+        want = hashlib.sha256(data[:ln]).digest()
+        for mode in (0, 1):
+            got, _ = H.sha256(data[:ln], mode)
+            assert got == want, (ln, mode)

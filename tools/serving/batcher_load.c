@@ -2,13 +2,14 @@
  * (bftkv_gpu_batcher_collective_verify) -- the shape of protocol.Server's goroutine-per-request handlers
  * (transport/http/http.go:85,143).  Prints throughput and per-call latency percentiles for a sweep of thread counts.
  *   gcc -O2 -std=gnu99 -I include tools/serving/batcher_load.c -L bftkv_amd -lbftkv_gpu -lpthread -Wl,-rpath,$PWD/bftkv_amd -o batcher_load
- *   ./batcher_load corpus.bin [max_items=256] [max_wait_us=200]
+ *   ./batcher_load corpus.bin [max_items=256] [max_wait_us=200] [lanes=0 (library default)] [threads,threads,...]
  * Not the bench line (bench.py measures resident batches); numbers feed DESIGN.md section 3.4. */
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/resource.h>
 #include "bftkv_gpu.h"
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -21,7 +22,7 @@ typedef struct {
 
 typedef struct {
   bftkv_gpu_batcher* b; int qh; const corpus* c; int tid, n_threads; double seconds; volatile int* stop;
-  uint64_t calls, wrong; double* lat; uint64_t lat_cap;
+  uint64_t calls, wrong; double* lat; uint64_t lat_cap, lat_skip;
 } worker;
 
 static void* run(void* p) {
@@ -35,7 +36,7 @@ static void* run(void* p) {
                                                  w->c->ss + w->c->ss_off[k], w->c->ss_off[k + 1] - w->c->ss_off[k], &err, &fenced);
     const double dt = now_s() - t0;
     if (rc != 0 || fenced || (err == 0) != (w->c->want_ok[k] != 0)) ++w->wrong;
-    if (w->calls < w->lat_cap) w->lat[w->calls] = dt;
+    if (w->calls < w->lat_cap) w->lat[w->calls] = dt;       /* (the warm-up's samples are dropped at the end) */
     ++w->calls;
     i += (uint32_t)w->n_threads;
   }
@@ -45,8 +46,15 @@ static void* run(void* p) {
 static int cmp_d(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s corpus.bin [max_items] [max_wait_us]\n", argv[0]); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: %s corpus.bin [max_items] [max_wait_us] [lanes] [threads,...]\n", argv[0]); return 2; }
   const uint32_t max_items = argc > 2 ? (uint32_t)atoi(argv[2]) : 256, max_wait = argc > 3 ? (uint32_t)atoi(argv[3]) : 200;
+  const uint32_t lanes = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
+  int sweep[16] = {1, 8, 64, 256, 1024};
+  unsigned n_sweep = 5;
+  if (argc > 5) {
+    n_sweep = 0;
+    for (char* tok = strtok(argv[5], ","); tok && n_sweep < 16; tok = strtok(NULL, ",")) sweep[n_sweep++] = atoi(tok);
+  }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror("corpus"); return 2; }
   uint32_t n_keys = 0;
@@ -74,37 +82,66 @@ int main(int argc, char** argv) {
   bftkv_gpu_qc qc = {qn[0], qn[1], qn[2], qn[3], ids, n_keys};
   int qh = -1;
   if (bftkv_gpu_quorum_create(ctx, &qc, 1, &qh)) return 1;
-  bftkv_gpu_batcher* b = bftkv_gpu_batcher_create(ctx, max_items, max_wait);
-  const int sweep[] = {1, 8, 64, 256, 1024};
-  printf("{\"max_items\": %u, \"max_wait_us\": %u, \"writes\": %u, \"replicas\": %u, \"runs\": [", max_items, max_wait, c.n_items, n_keys);
-  for (unsigned s = 0; s < sizeof sweep / sizeof sweep[0]; ++s) {
+  bftkv_gpu_batcher* b = bftkv_gpu_batcher_create_lanes(ctx, max_items, max_wait, lanes);
+  if (!b) { fprintf(stderr, "batcher: %s\n", bftkv_gpu_last_error(ctx)); return 1; }
+  uint64_t st0[4] = {0, 0, 0, 0};
+  bftkv_gpu_batcher_stats(b, st0);
+  printf("{\"max_items\": %u, \"lanes\": %llu, \"writes\": %u, \"replicas\": %u, \"runs\": [", max_items,
+         (unsigned long long)st0[3], c.n_items, n_keys);
+  for (unsigned s = 0; s < n_sweep; ++s) {
     const int T = sweep[s];
     volatile int stop = 0;
     worker* ws = calloc((size_t)T, sizeof *ws);
     pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
     for (int t = 0; t < T; ++t) {
       ws[t].b = b; ws[t].qh = qh; ws[t].c = &c; ws[t].tid = t; ws[t].n_threads = T; ws[t].stop = &stop;
-      ws[t].lat_cap = 200000 / (uint64_t)T + 64; ws[t].lat = malloc(8 * ws[t].lat_cap);
+      ws[t].lat_cap = 600000 / (uint64_t)T + 64; ws[t].lat = malloc(8 * ws[t].lat_cap);
       pthread_create(&th[t], NULL, run, &ws[t]);
     }
+    // warm-up (arenas and pinned buffers grow to this concurrency's batch sizes), then the measured window
+    struct timespec warm = {0, 700000000};
+    nanosleep(&warm, NULL);
+    uint64_t base_calls = 0;
+    for (int t = 0; t < T; ++t) { ws[t].lat_skip = ws[t].calls; base_calls += ws[t].calls; }
+    struct rusage ru0, ru1;
+    getrusage(RUSAGE_SELF, &ru0);
+    uint64_t tm0[4] = {0, 0, 0, 0}, tm1[4] = {0, 0, 0, 0}, stw[4] = {0, 0, 0, 0};
+    bftkv_gpu_batcher_times(b, tm0);
+    bftkv_gpu_batcher_stats(b, stw);
     const double t0 = now_s();
     struct timespec nap = {2, 0};
     nanosleep(&nap, NULL);
     stop = 1;
-    for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
     const double dt = now_s() - t0;
+    for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+    getrusage(RUSAGE_SELF, &ru1);
+    bftkv_gpu_batcher_times(b, tm1);
+    st0[0] = stw[0]; st0[1] = stw[1];
     uint64_t calls = 0, wrong = 0, nl = 0;
     for (int t = 0; t < T; ++t) { calls += ws[t].calls; wrong += ws[t].wrong; nl += ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; }
+    calls -= base_calls;
+    const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) +
+                         (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     double* all = malloc(8 * (nl + 1));
     uint64_t k = 0;
-    for (int t = 0; t < T; ++t) { uint64_t m = ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; memcpy(all + k, ws[t].lat, 8 * m); k += m; }
+    for (int t = 0; t < T; ++t) {
+      uint64_t m = ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap;
+      const uint64_t sk = ws[t].lat_skip < m ? ws[t].lat_skip : m;
+      memcpy(all + k, ws[t].lat + sk, 8 * (m - sk)); k += m - sk;
+    }
+    nl = k;
     qsort(all, nl, 8, cmp_d);
     uint64_t st[4] = {0, 0, 0, 0};
     bftkv_gpu_batcher_stats(b, st);
+    const uint64_t d_calls = st[0] - st0[0], d_batches = st[1] - st0[1];
+    st0[0] = st[0]; st0[1] = st[1];
     printf("%s{\"threads\": %d, \"verify_calls_per_s\": %.0f, \"wrong\": %llu, \"latency_ms\": {\"p50\": %.3f, \"p99\": %.3f, \"max\": %.3f}, "
-           "\"calls_total\": %llu, \"batches_total\": %llu, \"largest_batch\": %llu}",
+           "\"calls\": %llu, \"device_calls\": %llu, \"largest_batch_so_far\": %llu, \"cpu_cores_busy\": %.2f, "
+           "\"us_per_call\": {\"hash\": %.1f, \"assemble\": %.2f}, \"us_per_device_call\": {\"lane_wait\": %.1f, \"device\": %.1f}}",
            s ? ", " : "", T, calls / dt, (unsigned long long)wrong, nl ? all[nl / 2] * 1e3 : 0.0, nl ? all[(uint64_t)(nl * 0.99)] * 1e3 : 0.0,
-           nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2]);
+           nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)d_calls, (unsigned long long)d_batches, (unsigned long long)st[2], cpu_s / dt,
+           d_calls ? 1e-3 * (tm1[0] - tm0[0]) / d_calls : 0.0, d_calls ? 1e-3 * (tm1[2] - tm0[2]) / d_calls : 0.0,
+           d_batches ? 1e-3 * (tm1[1] - tm0[1]) / d_batches : 0.0, d_batches ? 1e-3 * (tm1[3] - tm0[3]) / d_batches : 0.0);
     fflush(stdout);
     for (int t = 0; t < T; ++t) free(ws[t].lat);
     free(ws); free(th); free(all);

@@ -35,3 +35,20 @@ for n in (1, 64, 256):
         spans.append(tm["total"]); parts.append(tm)
     p = {k: round(float(np.median([x[k] for x in parts])), 3) for k in parts[0]}
     print("items %4d  wall p50 %.3f ms  device span p50 %.3f ms  phases %s" % (n, np.median(walls) * 1e3, np.median(spans), p), flush=True)
+
+# the same writes, ONE per call through the micro-batcher from this one thread (no company: the lone-call latency)
+from bftkv_amd import Batcher  # noqa: E402
+b = Batcher(ctx, max_items=256, n_lanes=2)
+items = [(c.tbss(i), c.ss_data(i)) for i in range(64)]
+for t, s in items[:8]:
+    b.collective_verify(qh, t, s)
+walls = []
+for k in range(400):
+    t, s = items[k % 64]
+    t0 = time.perf_counter()
+    b.collective_verify(qh, t, s)
+    walls.append(time.perf_counter() - t0)
+b.close()
+w = np.array(walls) * 1e3
+print("batcher, one caller thread: wall p50 %.3f ms  p90 %.3f  min %.3f (includes ~5 us of ctypes and the payload's host-side SHA-256 chain)"
+      % (np.median(w), np.percentile(w, 90), w.min()), flush=True)
