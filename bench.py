@@ -160,6 +160,21 @@ class Dist:
                 self.dist.broadcast(u, src=0)
                 uid = u.cpu()
             cx.comm_init(self.world, self.rank, uid.numpy())
+        # before anything is timed: every rank's row of a gathered, rank-stamped buffer must be that rank's, on every context
+        # (bftkv_gpu_comm_selftest; collective).  A failure names the rank and RCCL's own error string and ends the run.
+        for k, cx in enumerate(ctxs):
+            try:
+                cx.comm_selftest(4096)
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("bench.py: rank %d of %d: exchange self-test failed on context %d: %s\n" % (self.rank, self.world, k, e))
+                raise
+        if self.world > 1:
+            path, pre = Context.comm_library()
+            seen = self.sum_ints([1])[0]
+            if seen != self.world:
+                raise RuntimeError("bench.py: %d ranks answered, world size %d" % (seen, self.world))
+            if self.rank == 0:
+                sys.stderr.write("bench.py: RCCL for the exchange step: %s (%s)\n" % (path, "already loaded by the process" if pre else "loaded by libbftkv_gpu"))
 
     def close(self):
         if self.dist:

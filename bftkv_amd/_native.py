@@ -43,7 +43,7 @@ EXPORTS = [
     "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
-    "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times",
+    "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
 ]
 
 _lib = None
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_comm_unique_id.argtypes = [u8p]
     lib.bftkv_gpu_comm_init.argtypes = [vp, C.c_int, C.c_int, u8p]
+    lib.bftkv_gpu_comm_library.argtypes = [C.c_char_p, u32, C.POINTER(C.c_int)]
+    lib.bftkv_gpu_comm_selftest.argtypes = [vp, u32, C.POINTER(u32)]
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
     lib.bftkv_gpu_set_early_exit.argtypes = [vp, C.c_int]
@@ -313,6 +315,21 @@ class Context:
 
     def comm_init(self, n_ranks: int, rank: int, uid: np.ndarray):
         self._check(self.lib.bftkv_gpu_comm_init(self.h, n_ranks, rank, _ptr(np.ascontiguousarray(uid, dtype=np.uint8))), "comm_init")
+
+    @staticmethod
+    def comm_library():
+        """(path of the librccl the library resolved, whether the process already held it)"""
+        buf = C.create_string_buffer(1024)
+        pre = C.c_int(0)
+        rc = load_library().bftkv_gpu_comm_library(buf, 1024, C.byref(pre))
+        if rc:
+            raise NativeError("bftkv_gpu_comm_library failed (%d): librccl not loadable" % rc)
+        return buf.value.decode(), bool(pre.value)
+
+    def comm_selftest(self, nbytes: int = 4096):
+        """Collective all-gather self-test on the verifier's stream; raises with the rank and RCCL's error string."""
+        bad = C.c_uint32(0)
+        self._check(self.lib.bftkv_gpu_comm_selftest(self.h, nbytes, C.byref(bad)), "comm_selftest")
 
     def allgather_verdicts(self, local_ptr: int, nbytes: int, out_ptr: int):
         self._check(self.lib.bftkv_gpu_allgather_verdicts(self.h, local_ptr, nbytes, out_ptr), "allgather_verdicts")

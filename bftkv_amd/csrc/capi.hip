@@ -9,6 +9,7 @@
 
 #include <limits.h>
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -144,6 +145,7 @@ struct bftkv_gpu_ctx {
   DevBuf in_pack;
   uint8_t* h_out = nullptr; uint8_t* d_out = nullptr; size_t out_cap = 0;
   uint32_t out_seq = 0;
+  uint32_t staged_spin_us = 50000;          // how long a staged call spins on its completion word before it blocks in the runtime (BFTKV_STAGED_SPIN_US)
 };
 
 void rccl_release(bftkv_gpu_ctx* c);
@@ -309,7 +311,13 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // upload_tbs (host-buffer entry point): the signed payloads are still in host memory.  Only the hash stream reads them,
   // so their copy is issued on that stream AFTER the modexp has been launched and runs beside it; the signature stream
   // (which the walk, the parse and the modexp need) was copied before the call.
-  hipStream_t s = c->stream, sh = c->stream_h;
+  // A staged small call keeps its hashing on the main stream: its digest kernel is a few microseconds, two cross-stream joins
+  // cost more than that, and a lane that occupies ONE hardware queue leaves the others to the other lanes (the runtime maps
+  // streams onto 4 queues by default: three streams per lane made four lanes run one after the other).
+  const bool one_stream = staged_cap != 0;
+  hipStream_t s = c->stream, sh = one_stream ? c->stream : c->stream_h;
+  auto rec = [&](int k, hipStream_t st) -> hipError_t { return one_stream ? hipSuccess : hipEventRecord(c->ev[k], st); };
+  auto join = [&](hipStream_t st, int k) -> hipError_t { return one_stream ? hipSuccess : hipStreamWaitEvent(st, c->ev[k], 0); };
   if (!c->ev[0]) for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
   HIPCHK(c, c->counts.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
@@ -326,10 +334,10 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                                        // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start),
                                        // [16..19] two uint64: clock stamps of k_rsa_modexp (bftkv_gpu_last_sclk_mhz)
   if (plan_q) HIPCHK(c, c->plan_cut.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
-  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  HIPCHK(c, rec(0, s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
-  HIPCHK(c, hipStreamWaitEvent(sh, c->ev[0], 0));
-  HIPCHK(c, hipEventRecord(c->ev[5], sh));
+  HIPCHK(c, join(sh, 0));
+  HIPCHK(c, rec(5, sh));
   if (!upload_tbs && !d_mid_in)
     hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
@@ -399,7 +407,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pl.margin = 1u + (uint32_t)min_suff / 64u;
     hipLaunchKernelGGL(k_plan<1>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
   }
-  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  const bool dsa_side = total && c->have_dsa_keys;
+  if (one_stream && dsa_side) HIPCHK(c, hipEventRecord(c->ev[1], s)); else HIPCHK(c, rec(1, s));
   // s^-1 mod q: one extended GCD per run of signatures under one key (k_dsa_inv_batched) when the DSA work list gives every
   // key of the ring enough of them (64 on average, 4096 in all: a thread's 16 sorted entries then hold one or two runs), else
   // one per signature (k_dsa_inv).  The list length lives on the device, so both kernels are enqueued and one of them returns
@@ -422,7 +431,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   }
   auto hash_stream_work = [&]() -> int {
   // hash stream: digests need the parsed records
-    HIPCHK(c, hipStreamWaitEvent(sh, c->ev[1], 0));
+    HIPCHK(c, join(sh, 1));
     if (total) {
       // other hashes: a no-op grid unless some signature asked for them
       if (!d_mid_in)
@@ -432,7 +441,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          d_mid_in ? d_mid_in : c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
                          c->digests.as<uint32_t>(), d_tbs_prefix, n_recs_dev);
     }
-    HIPCHK(c, hipEventRecord(c->ev[6], sh));
+    HIPCHK(c, rec(6, sh));
     return 0;
   };
   if (!upload_tbs) { int hrc = hash_stream_work(); if (hrc) return hrc; }
@@ -451,14 +460,14 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
   if (total) launch_modexp(start0);
-  HIPCHK(c, hipEventRecord(c->ev[2], s));
+  HIPCHK(c, rec(2, s));
   if (upload_tbs) {
     int hrc = (*upload_tbs)(sh);
     if (hrc) return hrc;
     hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
     if ((hrc = hash_stream_work())) return hrc;
   }
-  HIPCHK(c, hipStreamWaitEvent(s, c->ev[6], 0));
+  HIPCHK(c, join(s, 6));
   // digests of the hashes other than SHA-256: on the MAIN stream, after the modexp.  Normally there are none and the kernel
   // exits on a device-side flag; at its 203 VGPRs it cannot co-schedule beside k_rsa_modexp, and on the hash stream it sat
   // there until the modexp drained (1.7 ms per step in the trace) holding back the join.
@@ -487,7 +496,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                        c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
   };
   if (total) launch_compare(start0);
-  HIPCHK(c, hipEventRecord(c->ev[8], s));
+  HIPCHK(c, rec(8, s));
   if (total && c->have_dsa_keys) {
     HIPCHK(c, hipStreamWaitEvent(s, c->ev[7], 0));
     launch_dsa(start0);
@@ -507,7 +516,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     launch_compare(start1);
     if (c->have_dsa_keys) launch_dsa(start1);
   }
-  HIPCHK(c, hipEventRecord(c->ev[3], s));
+  HIPCHK(c, rec(3, s));
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -810,6 +819,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
       hipStreamCreateWithFlags(&c->stream_h, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
+  if (const char* e = getenv("BFTKV_STAGED_SPIN_US")) c->staged_spin_us = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_LANES")) c->multiexp_lanes = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_DSA_INV")) c->dsa_inv_mode = !strcmp(e, "batched") ? 2u : !strcmp(e, "single") ? 1u : 0u;

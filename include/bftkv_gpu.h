@@ -218,8 +218,9 @@ int bftkv_gpu_batcher_message_verify(bftkv_gpu_batcher* b, const uint8_t* msg, u
                                      uint64_t* plain_len_out, uint8_t* fname_out, uint8_t* fname_len_out);
 int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
 /* where the callers' time went, nanoseconds summed over all calls so far: [0] hashing their payloads, [1] leaders waiting
- * for a lane, [2] leaders assembling batches, [3] leaders inside device calls */
-int bftkv_gpu_batcher_times(bftkv_gpu_batcher* b, uint64_t ns[4]);
+ * for a lane, [2] leaders assembling batches, [3] leaders inside device calls, of which [4] enqueueing and [5] waiting
+ * for the results; [6] = device calls whose wait fell back to a stream synchronisation (a count) */
+int bftkv_gpu_batcher_times(bftkv_gpu_batcher* b, uint64_t ns[8]);
 
 /* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */
 int bftkv_gpu_last_statuses(bftkv_gpu_ctx* ctx, uint8_t* status_out, uint32_t* item_out, uint32_t cap, uint32_t* n_out);
@@ -257,6 +258,14 @@ int bftkv_gpu_modexp_ops(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* base
  * the caller (the Go shim: over its own transport).  librccl.so.1 is dlopen'ed on first use. */
 int bftkv_gpu_comm_unique_id(uint8_t uid_out[128]);
 int bftkv_gpu_comm_init(bftkv_gpu_ctx* ctx, int n_ranks, int rank, const uint8_t uid[128]);
+/* Which librccl the calls above go to, and whether the process already held it (ONE RCCL per process: an instance that
+ * torch.distributed or the host program loaded is reused, dlopen(RTLD_NOLOAD); only otherwise the system's is loaded). */
+int bftkv_gpu_comm_library(char* path_out, uint32_t cap, int* preloaded_out);
+/* Before the first exchange: every rank stamps nbytes with a pattern of its rank, all-gathers on the verifier's stream and
+ * checks every row on the device.  Collective: all ranks call it.  0 = every row is its rank's; otherwise
+ * bftkv_gpu_last_error names the rank, the wrong rows and RCCL's own error string.  BFTKV_FORCE_RCCL=1 in the environment
+ * makes a one-rank context build a real communicator, so the RCCL path can be exercised on a 1-GPU box. */
+int bftkv_gpu_comm_selftest(bftkv_gpu_ctx* ctx, uint32_t nbytes, uint32_t* bad_rows_out);
 /* local_bits: nbytes DEVICE bytes of this rank; all_bits_out: n_ranks*nbytes DEVICE bytes, rank-major. */
 int bftkv_gpu_allgather_verdicts(bftkv_gpu_ctx* ctx, const uint8_t* local_bits, uint64_t nbytes, uint8_t* all_bits_out);
 /* The exchange step of the path as ONE asynchronous call on the context's stream, to be issued right behind

@@ -1,0 +1,310 @@
+// Command genvectors pins this repository's oracle to the reference ITSELF.
+//
+// The build image of bftkv_amd has no Go toolchain, so its CPU oracle (oracle/*.py, oracle/c) restates
+// golang.org/x/crypto/openpgp from its published behaviour and is pinned against GnuPG only ("parity unpinned",
+// DESIGN.md section 5).  Anyone with Go closes that gap with this program: it runs the reference's own crypto/pgp and
+// quorum/wotqs -- with the x/crypto version go.mod:8 pins, v0.0.0-20191227163750-53104e6ec876 -- over the committed inputs
+// (tests/golden/reference_inputs.json, written by tests/golden/make_reference_inputs.py) and writes
+// tests/golden/reference_vectors.json, which tests/test_reference_vectors.py compares with the oracle, strictly.
+//
+//	cd $GOPATH/src/github.com/yahoo/bftkv            # the reference, with shim/patches/0001 applied (Cliques accessor)
+//	mkdir -p cmd/genvectors && cp <bftkv_amd>/shim/tools/genvectors/main.go cmd/genvectors/
+//	go run ./cmd/genvectors -in <bftkv_amd>/tests/golden/reference_inputs.json -out <bftkv_amd>/tests/golden/reference_vectors.json
+//
+// What is recorded, per input item:
+//
+//	calls      one entry per openpgp.CheckDetachedSignature call of the loops at crypto/pgp/crypto_pgp.go:319-330 and
+//	           :485-500: "ok:<signer key id>" or the error's class and text
+//	signature  crypto.Signature.Verify's error string ("" = nil)                              crypto_pgp.go:319-330
+//	collective crypto.CollectiveSignature.Verify's error string, ss.Completed, len(verified)   crypto_pgp.go:485-500
+//	predicates IsQuorum / IsThreshold / IsSufficient / Reject over the verified list           quorum/wotqs/wotqs.go:144-185
+//
+// and per cluster the cliques ChooseQuorum(AUTH) built from the certified ring (f, min, threshold, suff, node ids).
+//
+// Not compiled in the bftkv_amd repository.  Written against the reference at go.mod:8.
+package main
+
+import (
+	"bytes"
+	"encoding/hex"
+	"encoding/json"
+	"flag"
+	"fmt"
+	"io/ioutil"
+	"log"
+	"strings"
+
+	"golang.org/x/crypto/openpgp"
+	pgperrors "golang.org/x/crypto/openpgp/errors"
+
+	"github.com/yahoo/bftkv/crypto"
+	"github.com/yahoo/bftkv/crypto/pgp"
+	"github.com/yahoo/bftkv/node"
+	"github.com/yahoo/bftkv/node/graph"
+	"github.com/yahoo/bftkv/packet"
+	"github.com/yahoo/bftkv/quorum"
+	"github.com/yahoo/bftkv/quorum/wotqs"
+)
+
+type item struct {
+	Cluster string `json:"cluster,omitempty"`
+	Name    string `json:"name,omitempty"`
+	Ring    string `json:"ring,omitempty"`
+	Tbs     string `json:"tbs"`
+	Ss      string `json:"ss,omitempty"`
+	Sig     string `json:"sig,omitempty"`
+}
+
+type cluster struct {
+	Name      string   `json:"name"`
+	Pubring   string   `json:"pubring"`
+	Outsiders string   `json:"outsiders"`
+	Self      string   `json:"self"`
+	Members   []string `json:"members"`
+	Items     []item   `json:"items"`
+}
+
+type inputs struct {
+	Format   int               `json:"format"`
+	Clusters []cluster         `json:"clusters"`
+	Streams  []item            `json:"streams"`
+	Gpg      []item            `json:"gpg"`
+	Rings    map[string]string `json:"rings"`
+}
+
+type cliqueOut struct {
+	F, Min, Threshold, Suff int
+	Nodes                   []string
+}
+
+type itemOut struct {
+	Calls          []string `json:"calls"`
+	SignatureErr   string   `json:"signature"`
+	CollectiveErr  string   `json:"collective,omitempty"`
+	Completed      bool     `json:"completed,omitempty"`
+	NVerified      int      `json:"n_verified"`
+	IsQuorum       bool     `json:"is_quorum,omitempty"`
+	IsThreshold    bool     `json:"is_threshold,omitempty"`
+	IsSufficient   bool     `json:"is_sufficient,omitempty"`
+	Reject         bool     `json:"reject,omitempty"`
+	HasQuorumBlock bool     `json:"has_quorum"`
+}
+
+type clusterOut struct {
+	Name    string      `json:"name"`
+	Cliques []cliqueOut `json:"cliques"`
+	Items   []itemOut   `json:"items"`
+}
+
+type outputs struct {
+	Format   int          `json:"format"`
+	XCrypto  string       `json:"x_crypto"`
+	Clusters []clusterOut `json:"clusters"`
+	Streams  []itemOut    `json:"streams"`
+	Gpg      []itemOut    `json:"gpg"`
+}
+
+func unhex(s string) []byte {
+	b, err := hex.DecodeString(s)
+	if err != nil {
+		log.Fatalf("bad hex in the inputs: %v", err)
+	}
+	return b
+}
+
+// class names the error the way the oracle's status codes are grouped (oracle/openpgp.py): the TYPE decides, the text rides along
+func class(err error) string {
+	switch e := err.(type) {
+	case nil:
+		return "ok"
+	case pgperrors.SignatureError:
+		return "signature-error:" + string(e)
+	case pgperrors.StructuralError:
+		return "structural:" + string(e)
+	case pgperrors.UnsupportedError:
+		return "unsupported:" + string(e)
+	case pgperrors.UnknownPacketTypeError:
+		return fmt.Sprintf("unknown-packet-type:%d", int(e))
+	}
+	if err == pgperrors.ErrUnknownIssuer {
+		return "unknown-issuer"
+	}
+	return "error:" + err.Error()
+}
+
+func errString(err error) string {
+	if err == nil {
+		return ""
+	}
+	return err.Error()
+}
+
+// calls replays the loop of crypto_pgp.go:485-500 (which is also the loop of :319-330 up to its first error) and records
+// every CheckDetachedSignature result.
+func calls(keyring openpgp.EntityList, tbs, data []byte) (out []string, verified []uint64) {
+	r := bytes.NewReader(data)
+	for r.Len() > 0 {
+		signer, err := openpgp.CheckDetachedSignature(keyring, bytes.NewReader(tbs), r)
+		if err == nil {
+			out = append(out, fmt.Sprintf("ok:%016x", signer.PrimaryKey.KeyId))
+			verified = append(verified, signer.PrimaryKey.KeyId)
+		} else {
+			out = append(out, class(err))
+		}
+	}
+	return
+}
+
+func entityList(nodes []node.Node) openpgp.EntityList {
+	var l openpgp.EntityList
+	for _, n := range nodes {
+		l = append(l, n.Instance().(*openpgp.Entity))
+	}
+	return l
+}
+
+func nodesById(crypt *crypto.Crypto, ids []uint64) []node.Node {
+	var l []node.Node
+	for _, id := range ids {
+		if n := crypt.Keyring.GetCertById(id); n != nil {
+			l = append(l, n)
+		}
+	}
+	return l
+}
+
+func runItem(crypt *crypto.Crypto, ring openpgp.EntityList, q quorum.Quorum, tbs, data []byte) itemOut {
+	var o itemOut
+	var verified []uint64
+	o.Calls, verified = calls(ring, tbs, data)
+	sp := &packet.SignaturePacket{Type: packet.SignatureTypePGP, Data: data}
+	o.SignatureErr = errString(crypt.Signature.Verify(tbs, sp))
+	if q != nil {
+		o.HasQuorumBlock = true
+		ss := &packet.SignaturePacket{Type: packet.SignatureTypePGP, Data: data}
+		o.CollectiveErr = errString(crypt.CollectiveSignature.Verify(tbs, ss, q))
+		o.Completed = ss.Completed
+		// len(verified) when Verify returned: the prefix up to the first position where IsSufficient holds
+		var seen []node.Node
+		o.NVerified = len(verified)
+		for i, id := range verified {
+			seen = append(seen, nodesById(crypt, []uint64{id})...)
+			if q.IsSufficient(seen) {
+				o.NVerified = i + 1
+				break
+			}
+		}
+		all := nodesById(crypt, verified)
+		o.IsQuorum, o.IsThreshold, o.IsSufficient, o.Reject = q.IsQuorum(all), q.IsThreshold(all), q.IsSufficient(all), q.Reject(all)
+	} else {
+		o.NVerified = len(verified)
+	}
+	return o
+}
+
+// newCrypto: pgp.New() with the ring registered as the reference's daemon does at start-up (cmd/bftkv/main.go: the
+// pubring goes through Certificate.Parse and Keyring.Register(nodes, false, false)).
+func newCrypto(ring []byte) (*crypto.Crypto, []node.Node) {
+	crypt := pgp.New()
+	nodes, err := crypt.Certificate.Parse(ring)
+	if err != nil {
+		log.Fatalf("Certificate.Parse: %v", err)
+	}
+	if err := crypt.Keyring.Register(nodes, false, false); err != nil {
+		log.Fatalf("Keyring.Register: %v", err)
+	}
+	return crypt, nodes
+}
+
+func main() {
+	in := flag.String("in", "tests/golden/reference_inputs.json", "inputs written by tests/golden/make_reference_inputs.py")
+	out := flag.String("out", "tests/golden/reference_vectors.json", "where the reference's answers go")
+	flag.Parse()
+	raw, err := ioutil.ReadFile(*in)
+	if err != nil {
+		log.Fatal(err)
+	}
+	var inp inputs
+	if err := json.Unmarshal(raw, &inp); err != nil {
+		log.Fatal(err)
+	}
+	res := outputs{Format: 1, XCrypto: "golang.org/x/crypto v0.0.0-20191227163750-53104e6ec876 (go.mod:8)"}
+	byName := map[string]struct {
+		crypt *crypto.Crypto
+		ring  openpgp.EntityList
+		q     quorum.Quorum
+	}{}
+	for _, c := range inp.Clusters {
+		crypt, nodes := newCrypto(unhex(c.Pubring))
+		g := graph.New()
+		g.AddNodes(nodes)
+		var self []node.Node
+		for _, n := range nodes {
+			if fmt.Sprintf("%016x", n.Id()) == c.Self {
+				self = append(self, n)
+			}
+		}
+		g.SetSelfNodes(self)
+		q := wotqs.New(g).ChooseQuorum(quorum.AUTH)
+		co := clusterOut{Name: c.Name}
+		// shim/patches/0001: the per-clique numbers newQC computed
+		type cliquer interface{ Cliques() []wotqs.Clique }
+		if cq, ok := q.(cliquer); ok {
+			for _, k := range cq.Cliques() {
+				var ids []string
+				for _, n := range k.Nodes {
+					ids = append(ids, fmt.Sprintf("%016x", n.Id()))
+				}
+				co.Cliques = append(co.Cliques, cliqueOut{k.F, k.Min, k.Threshold, k.Suff, ids})
+			}
+		} else {
+			log.Printf("cluster %s: quorum has no Cliques() accessor -- apply shim/patches/0001-wotqs-export-cliques.patch", c.Name)
+		}
+		ring := entityList(nodes)
+		for _, it := range c.Items {
+			co.Items = append(co.Items, runItem(crypt, ring, q, unhex(it.Tbs), unhex(it.Ss)))
+		}
+		res.Clusters = append(res.Clusters, co)
+		byName[c.Name] = struct {
+			crypt *crypto.Crypto
+			ring  openpgp.EntityList
+			q     quorum.Quorum
+		}{crypt, ring, q}
+	}
+	for _, it := range inp.Streams {
+		c, ok := byName[it.Cluster]
+		if !ok {
+			log.Fatalf("stream names unknown cluster %q", it.Cluster)
+		}
+		res.Streams = append(res.Streams, runItem(c.crypt, c.ring, c.q, unhex(it.Tbs), unhex(it.Ss)))
+	}
+	rings := map[string]struct {
+		crypt *crypto.Crypto
+		ring  openpgp.EntityList
+	}{}
+	for _, it := range inp.Gpg {
+		r, ok := rings[it.Ring]
+		if !ok {
+			crypt, nodes := newCrypto(unhex(inp.Rings[it.Ring]))
+			r = struct {
+				crypt *crypto.Crypto
+				ring  openpgp.EntityList
+			}{crypt, entityList(nodes)}
+			rings[it.Ring] = r
+		}
+		o := runItem(r.crypt, r.ring, nil, unhex(it.Tbs), unhex(it.Sig))
+		res.Gpg = append(res.Gpg, o)
+	}
+	enc, err := json.MarshalIndent(res, "", " ")
+	if err != nil {
+		log.Fatal(err)
+	}
+	if err := ioutil.WriteFile(*out, enc, 0644); err != nil {
+		log.Fatal(err)
+	}
+	n := 0
+	for _, c := range res.Clusters {
+		n += len(c.Items)
+	}
+	log.Printf("wrote %s: %d cluster items, %d streams, %d gpg vectors (%s)", *out, n, len(res.Streams), len(res.Gpg), strings.Fields(res.XCrypto)[1])
+}

@@ -383,6 +383,42 @@ def test_rccl_allgather_entry_points_single_rank(gpu_ctx):
     assert torch.equal(D.allgather_verdicts(ok, 11), ok)
 
 
+def test_rccl_path_on_one_gpu_with_a_real_communicator(monkeypatch):
+    """The RCCL branch itself on the 1-GPU box: BFTKV_FORCE_RCCL makes a one-rank context build a REAL communicator
+    (ncclCommInitRank through the dlsym'd pointer with the 128-byte id by value), the self-test and the exchange step then go
+    through ncclAllGather on the verifier's stream.  torch is imported first, so the library must resolve the librccl the
+    process already holds (one RCCL per process) -- the same order bench.py --gpus N produces."""
+    import torch
+    from bftkv_amd import Context
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda:0")
+    path, pre = Context.comm_library()
+    assert "rccl" in path
+    import ctypes
+    already = any("librccl" in ln for ln in open("/proc/self/maps"))
+    assert already
+    monkeypatch.setenv("BFTKV_FORCE_RCCL", "1")
+    ctx = Context(0)
+    try:
+        ctx.comm_init(1, 0, Context.comm_unique_id())
+        ctx.comm_selftest(4096)
+        ctx.comm_selftest(1)
+        rng = np.random.default_rng(5)
+        for n in (1, 9, 1000, 125000):
+            err = rng.choice(np.array([0, 2], dtype=np.uint8), size=n)
+            d_err = torch.from_numpy(err).to("cuda:0")
+            out = torch.full(((n + 7) // 8,), 0xAA, dtype=torch.uint8, device="cuda:0")
+            ctx.allgather_errs_dev(d_err.data_ptr(), n, n, out.data_ptr())
+            ctx.sync()
+            want = np.packbits(np.concatenate([err == 0, np.zeros(((n + 7) // 8) * 8 - n, dtype=bool)]), bitorder="little")
+            assert out.cpu().numpy().tobytes() == want.tobytes()
+        # exactly one librccl mapped into the process
+        libs = {ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}
+        assert len(libs) == 1, libs
+    finally:
+        ctx.close()
+
+
 def test_exchange_step_on_the_verifier_stream(gpu_ctx):
     """bftkv_gpu_allgather_errs_dev: the err bytes of a verify call packed into the verdict bitmap on the device and gathered
     rank-major, asynchronously on the context's stream (one rank here: its row is the output)."""

@@ -1,0 +1,191 @@
+"""CPU: the oracle against the reference ITSELF -- strict once someone with a Go toolchain has run
+shim/tools/genvectors/main.go (the reference's crypto/pgp + quorum/wotqs with the x/crypto go.mod:8 pins) over
+tests/golden/reference_inputs.json and committed tests/golden/reference_vectors.json; skipped while that file is absent
+(this image has no Go, DESIGN.md section 5 "parity unpinned").  The replay half always runs, so the comparison code cannot rot."""
+import json
+import os
+
+import pytest
+
+from oracle import collective as col
+from oracle import openpgp as pgp
+from oracle import wotqs as W
+from oracle.packet import SignaturePacket
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INPUTS = os.path.join(GOLD, "reference_inputs.json")
+VECTORS = os.path.join(GOLD, "reference_vectors.json")
+
+# oracle status of a failed CheckDetachedSignature call -> what the reference's error (class:text, genvectors.class) must look
+# like.  The TYPE is asserted where x/crypto's type is certain, the text only where the oracle's status names one message.
+CLASS_OF = {
+    pgp.ST_UNKNOWN_ISSUER: lambda c: c == "unknown-issuer",
+    pgp.ST_PARSE_ERROR: lambda c: c.startswith(("structural:", "unsupported:", "error:")),
+    pgp.ST_NOT_SIGNATURE: lambda c: c.startswith("structural:"),
+    pgp.ST_NO_ISSUER: lambda c: c.startswith("structural:"),
+    pgp.ST_HASH_UNSUPPORTED: lambda c: c.startswith("unsupported:"),
+    pgp.ST_HASH_TAG: lambda c: c.startswith("signature-error:") and "hash tag" in c,
+    pgp.ST_ALGO_MISMATCH: lambda c: "different algorithms" in c,
+    pgp.ST_BAD_SIG: lambda c: c.startswith("signature-error:"),
+    pgp.ST_KEY_CANNOT_SIGN: lambda c: "cannot generate signatures" in c,
+    pgp.ST_UNSUPPORTED: lambda c: c.startswith(("unsupported:", "structural:", "error:")),
+}
+
+
+def replay(keyring, tbs, data):
+    """The loop of crypto_pgp.go:485-500 over the oracle: [(status, signer id or None)] per CheckDetachedSignature call."""
+    out, pos = [], 0
+    while len(data) - pos > 0:
+        r = pgp.check_detached_signature(keyring, tbs, data, pos)
+        pos = r.pos
+        out.append((r.status, r.signer.id if r.status == pgp.ST_OK else None))
+    return out
+
+
+def cluster_quorum(c):
+    """ChooseQuorum(AUTH) from the certified ring, as the reference's daemon builds it (graph.AddNodes over the pubring,
+    SetSelfNodes, wotqs.New(g).ChooseQuorum)."""
+    ents = pgp.read_entities(bytes.fromhex(c["pubring"]))
+    g = W.Graph()
+    g.add_nodes([(e.id, list(e.certifiers)) for e in ents])
+    g.set_self([int(c["self"], 16)])
+    return ents, W.Wot(g).choose_quorum(W.AUTH)
+
+
+def oracle_item(ents, q, tbs, data):
+    kr = col.Keyring(keyring=ents)
+    calls = replay(kr.get_keyring(), tbs, data)
+    sp = SignaturePacket(1, 0, False, data or None, None)
+    o = {"calls": calls, "signature": col.signature_verify(kr, tbs, sp)}
+    if q is not None:
+        r = col.collective_verify(kr, tbs, SignaturePacket(Type=1, Data=data or None), q)
+        allv = [s for st, s in calls if st == pgp.ST_OK]
+        o.update(collective=r.err, completed=r.completed, n_verified=len(r.verified), is_quorum=q.is_quorum(allv),
+                 is_threshold=q.is_threshold(allv), is_sufficient=q.is_sufficient(allv), reject=q.reject(allv))
+    return o
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return json.load(open(INPUTS))
+
+
+@pytest.fixture(scope="module")
+def replayed(inputs):
+    out = {"clusters": [], "streams": [], "gpg": []}
+    by_name = {}
+    for c in inputs["clusters"]:
+        ents, q = cluster_quorum(c)
+        by_name[c["name"]] = (ents, q)
+        out["clusters"].append({"name": c["name"], "q": q,
+                                "items": [oracle_item(ents, q, bytes.fromhex(i["tbs"]), bytes.fromhex(i["ss"])) for i in c["items"]]})
+    for s in inputs["streams"]:
+        ents, q = by_name[s["cluster"]]
+        out["streams"].append(oracle_item(ents, q, bytes.fromhex(s["tbs"]), bytes.fromhex(s["ss"])))
+    rings = {k: pgp.read_entities(bytes.fromhex(v)) for k, v in inputs["rings"].items()}
+    for v in inputs["gpg"]:
+        out["gpg"].append(oracle_item(rings[v["ring"]], None, bytes.fromhex(v["tbs"]), bytes.fromhex(v["sig"])))
+    return out
+
+
+def test_inputs_are_replayable_and_cover_both_outcomes(inputs, replayed):
+    """Always runs: every committed input goes through the oracle's replay, the clusters form the cliques their members name,
+    and the set holds accepted and refused items, every mutation class and several failure statuses."""
+    assert inputs["format"] == 1 and len(inputs["clusters"]) == 3 and len(inputs["gpg"]) > 100
+    statuses = set()
+    for c, cin in zip(replayed["clusters"], inputs["clusters"]):
+        q = c["q"]
+        assert len(q.qcs) == 1 and sorted(q.qcs[0].nodes) == sorted(int(m, 16) for m in cin["members"])
+        ok = [i["collective"] is None for i in c["items"]]
+        assert any(ok) and not all(ok)
+        for i in c["items"]:
+            statuses.update(st for st, _ in i["calls"])
+            assert i["completed"] == (i["collective"] is None)
+    assert {pgp.ST_OK, pgp.ST_UNKNOWN_ISSUER, pgp.ST_BAD_SIG, pgp.ST_HASH_TAG} <= statuses
+    stream_statuses = {st for s in replayed["streams"] for st, _ in s["calls"]}
+    assert pgp.ST_PARSE_ERROR in stream_statuses and pgp.ST_NOT_SIGNATURE in stream_statuses
+    good = [g["signature"] is None for g in replayed["gpg"]]
+    assert sum(good) > 40 and sum(not g for g in good) > 20
+
+
+def _same_item(tag, ours, ref):
+    assert len(ours["calls"]) == len(ref["calls"]), (tag, "number of CheckDetachedSignature calls", ours["calls"], ref["calls"])
+    for k, ((st, signer), rc) in enumerate(zip(ours["calls"], ref["calls"])):
+        if st == pgp.ST_OK:
+            assert rc == "ok:%016x" % signer, (tag, k, rc)
+        else:
+            assert not rc.startswith("ok:") and CLASS_OF[st](rc), (tag, k, st, rc)
+    assert (ours["signature"] is None) == (ref["signature"] == ""), (tag, "Signature.Verify", ref["signature"])
+    if ref["signature"]:
+        assert ref["signature"] == "crypto: invalid signature"
+    if ref.get("has_quorum"):
+        assert (ours["collective"] is None) == (ref.get("collective", "") == ""), (tag, "CollectiveSignature.Verify")
+        if ref.get("collective"):
+            assert ref["collective"] == "crypto: insufficient number of signatures"
+        assert ours["completed"] == ref.get("completed", False) and ours["n_verified"] == ref["n_verified"], tag
+        for k in ("is_quorum", "is_threshold", "is_sufficient", "reject"):
+            assert ours[k] == ref.get(k, False), (tag, k)
+
+
+def test_oracle_matches_the_reference_vectors(inputs, replayed):
+    if not os.path.exists(VECTORS):
+        pytest.skip("tests/golden/reference_vectors.json absent: run shim/tools/genvectors/main.go with a Go toolchain "
+                    "(x/crypto pinned by the reference's go.mod:8) to pin the oracle to the reference itself")
+    ref = json.load(open(VECTORS))
+    assert ref["format"] == 1 and "53104e6ec876" in ref["x_crypto"]
+    assert len(ref["clusters"]) == len(replayed["clusters"])
+    for ours, theirs, cin in zip(replayed["clusters"], ref["clusters"], inputs["clusters"]):
+        assert ours["name"] == theirs["name"] and len(theirs["items"]) == len(cin["items"])
+        # the cliques ChooseQuorum(AUTH) built: newQC's numbers and members (wotqs.go:36-70, graph.go:297-362)
+        assert len(theirs["cliques"]) == len(ours["q"].qcs)
+        for qc, k in zip(ours["q"].qcs, theirs["cliques"]):
+            assert (qc.f, qc.min, qc.threshold, qc.suff) == (k["F"], k["Min"], k["Threshold"], k["Suff"])
+            assert sorted(qc.nodes) == sorted(int(x, 16) for x in k["Nodes"])
+        for n, (a, b) in enumerate(zip(ours["items"], theirs["items"])):
+            _same_item("%s/%d" % (ours["name"], n), a, b)
+    assert len(ref["streams"]) == len(replayed["streams"]) and len(ref["gpg"]) == len(replayed["gpg"])
+    for n, (a, b) in enumerate(zip(replayed["streams"], ref["streams"])):
+        _same_item("stream/%d" % n, a, b)
+    for n, (a, b) in enumerate(zip(replayed["gpg"], ref["gpg"])):
+        _same_item("gpg/%s" % inputs["gpg"][n]["name"], a, b)
+
+
+REPRESENTATIVE = {
+    pgp.ST_UNKNOWN_ISSUER: "unknown-issuer", pgp.ST_PARSE_ERROR: "structural:parse", pgp.ST_NOT_SIGNATURE: "structural:non-signature packet found",
+    pgp.ST_NO_ISSUER: "structural:signature doesn't have an issuer", pgp.ST_HASH_UNSUPPORTED: "unsupported:hash",
+    pgp.ST_HASH_TAG: "signature-error:hash tag doesn't match", pgp.ST_ALGO_MISMATCH: "error:public key and signature use different algorithms",
+    pgp.ST_BAD_SIG: "signature-error:RSA verification failure", pgp.ST_KEY_CANNOT_SIGN: "error:public key cannot generate signatures",
+    pgp.ST_UNSUPPORTED: "unsupported:fenced",
+}
+
+
+def _as_reference_would_write(o):
+    ref = {"calls": ["ok:%016x" % s if st == pgp.ST_OK else REPRESENTATIVE[st] for st, s in o["calls"]],
+           "signature": "" if o["signature"] is None else "crypto: invalid signature", "n_verified": o.get("n_verified", 0)}
+    if "collective" in o:
+        ref.update(has_quorum=True, collective="" if o["collective"] is None else "crypto: insufficient number of signatures",
+                   completed=o["completed"], is_quorum=o["is_quorum"], is_threshold=o["is_threshold"], is_sufficient=o["is_sufficient"],
+                   reject=o["reject"])
+    return ref
+
+
+def test_comparison_accepts_the_oracles_own_answers_and_refuses_a_flipped_one(replayed):
+    """The strict comparison is exercised even while the reference's file is absent: fed the oracle's own answers in the
+    reference's format it passes, and any single flipped verdict, signer or count makes it fail."""
+    items = [i for c in replayed["clusters"] for i in c["items"]] + replayed["streams"] + replayed["gpg"]
+    for n, o in enumerate(items):
+        _same_item(n, o, _as_reference_would_write(o))
+    o = next(i for i in items if i.get("collective", 1) is None and len(i["calls"]) > 2)
+    for tamper in ("calls", "collective", "n_verified", "signature"):
+        ref = _as_reference_would_write(o)
+        if tamper == "calls":
+            k = next(k for k, c in enumerate(ref["calls"]) if c.startswith("ok:"))
+            ref["calls"][k] = "signature-error:RSA verification failure"
+        elif tamper == "collective":
+            ref["collective"] = "crypto: insufficient number of signatures"
+        elif tamper == "n_verified":
+            ref["n_verified"] += 1
+        else:
+            ref["signature"] = "" if ref["signature"] else "crypto: invalid signature"
+        with pytest.raises(AssertionError):
+            _same_item("tampered", o, ref)

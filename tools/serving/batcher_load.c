@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
     for (int t = 0; t < T; ++t) { ws[t].lat_skip = ws[t].calls; base_calls += ws[t].calls; }
     struct rusage ru0, ru1;
     getrusage(RUSAGE_SELF, &ru0);
-    uint64_t tm0[4] = {0, 0, 0, 0}, tm1[4] = {0, 0, 0, 0}, stw[4] = {0, 0, 0, 0};
+    uint64_t tm0[8] = {0}, tm1[8] = {0}, stw[4] = {0, 0, 0, 0};
     bftkv_gpu_batcher_times(b, tm0);
     bftkv_gpu_batcher_stats(b, stw);
     const double t0 = now_s();
@@ -120,8 +120,9 @@ int main(int argc, char** argv) {
     uint64_t calls = 0, wrong = 0, nl = 0;
     for (int t = 0; t < T; ++t) { calls += ws[t].calls; wrong += ws[t].wrong; nl += ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; }
     calls -= base_calls;
-    const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) +
-                         (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
+    const double usr_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec);
+    const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
+    const long csw = (ru1.ru_nvcsw - ru0.ru_nvcsw), icsw = (ru1.ru_nivcsw - ru0.ru_nivcsw);
     double* all = malloc(8 * (nl + 1));
     uint64_t k = 0;
     for (int t = 0; t < T; ++t) {
@@ -136,12 +137,17 @@ int main(int argc, char** argv) {
     const uint64_t d_calls = st[0] - st0[0], d_batches = st[1] - st0[1];
     st0[0] = st[0]; st0[1] = st[1];
     printf("%s{\"threads\": %d, \"verify_calls_per_s\": %.0f, \"wrong\": %llu, \"latency_ms\": {\"p50\": %.3f, \"p99\": %.3f, \"max\": %.3f}, "
-           "\"calls\": %llu, \"device_calls\": %llu, \"largest_batch_so_far\": %llu, \"cpu_cores_busy\": %.2f, "
-           "\"us_per_call\": {\"hash\": %.1f, \"assemble\": %.2f}, \"us_per_device_call\": {\"lane_wait\": %.1f, \"device\": %.1f}}",
+           "\"calls\": %llu, \"device_calls\": %llu, \"largest_batch_so_far\": %llu, \"cpu_cores_busy\": {\"user\": %.2f, \"sys\": %.2f}, "
+           "\"ctx_switches_per_call\": {\"voluntary\": %.2f, \"involuntary\": %.2f}, "
+           "\"us_per_call\": {\"hash\": %.1f, \"assemble\": %.2f}, \"us_per_device_call\": {\"lane_wait\": %.1f, \"device\": %.1f, \"enqueue\": %.1f, \"wait\": %.1f}, "
+           "\"sync_fallbacks\": %llu}",
            s ? ", " : "", T, calls / dt, (unsigned long long)wrong, nl ? all[nl / 2] * 1e3 : 0.0, nl ? all[(uint64_t)(nl * 0.99)] * 1e3 : 0.0,
-           nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)d_calls, (unsigned long long)d_batches, (unsigned long long)st[2], cpu_s / dt,
+           nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)d_calls, (unsigned long long)d_batches, (unsigned long long)st[2], usr_s / dt, sys_s / dt,
+           d_calls ? (double)csw / d_calls : 0.0, d_calls ? (double)icsw / d_calls : 0.0,
            d_calls ? 1e-3 * (tm1[0] - tm0[0]) / d_calls : 0.0, d_calls ? 1e-3 * (tm1[2] - tm0[2]) / d_calls : 0.0,
-           d_batches ? 1e-3 * (tm1[1] - tm0[1]) / d_batches : 0.0, d_batches ? 1e-3 * (tm1[3] - tm0[3]) / d_batches : 0.0);
+           d_batches ? 1e-3 * (tm1[1] - tm0[1]) / d_batches : 0.0, d_batches ? 1e-3 * (tm1[3] - tm0[3]) / d_batches : 0.0,
+           d_batches ? 1e-3 * (tm1[4] - tm0[4]) / d_batches : 0.0, d_batches ? 1e-3 * (tm1[5] - tm0[5]) / d_batches : 0.0,
+           (unsigned long long)(tm1[6] - tm0[6]));
     fflush(stdout);
     for (int t = 0; t < T; ++t) free(ws[t].lat);
     free(ws); free(th); free(all);
