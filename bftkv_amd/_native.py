@@ -44,6 +44,7 @@ EXPORTS = [
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
+    "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small",
 ]
 
 _lib = None
@@ -72,6 +73,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p, u8p]
     lib.bftkv_gpu_collective_verify_dev.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, C.c_uint64, u8p, vp, u8p, u8p]
+    lib.bftkv_gpu_collective_verify_small.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, u8p]
+    lib.bftkv_gpu_signature_verify_small.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p, u8p]
     lib.bftkv_gpu_sync.argtypes = [vp]
     lib.bftkv_gpu_signature_verify.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p, u8p]
     lib.bftkv_gpu_last_statuses.argtypes = [vp, u8p, vp, u32, C.POINTER(u32)]
@@ -241,10 +244,53 @@ class Context:
         nver = np.zeros(n, dtype=np.uint32)
         verdict = np.zeros(n, dtype=np.uint8)
         self.last_fenced = np.zeros(n, dtype=np.uint8)       # fenced_out of this call (see include/bftkv_gpu.h "fenced inputs")
+        small = self.collective_verify_small(quorum, tbs_blob, tbs_off, ss_blob, ss_off) if self._cross_check(n) else None
         self._check(self.lib.bftkv_gpu_collective_verify(self.h, quorum, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(ss_blob),
                                                          _ptr(ss_off), _ptr(err), _ptr(nver), _ptr(verdict), _ptr(self.last_fenced)),
                     "collective_verify")
+        self._compare_small("collective_verify", small, err, self.last_fenced)
         return err, nver, verdict
+
+    # The parity tests set check_small: every batched verify call is then ALSO made through the staged small-call route
+    # (bftkv_gpu_*_verify_small -- midstates from the host, one stream, 8-lane modexp, every packet verified) first, and the two
+    # answers must be identical item by item.
+    check_small = False
+
+    def _cross_check(self, n: int) -> bool:
+        return bool(self.check_small) and 0 < n <= 4096
+
+    @staticmethod
+    def _compare_small(what, small, err, fenced):
+        if small is None:
+            return
+        e2, f2 = small
+        if not (np.array_equal(e2, err) and np.array_equal(f2, fenced)):
+            bad = [int(i) for i in np.nonzero((e2 != err) | (f2 != fenced))[0][:8]]
+            raise NativeError("%s: the small-call route disagrees with the batched one at items %s: err %s vs %s, fenced %s vs %s"
+                              % (what, bad, e2[bad].tolist(), err[bad].tolist(), f2[bad].tolist(), fenced[bad].tolist()))
+
+    def collective_verify_small(self, quorum: int, tbs_blob, tbs_off, ss_blob, ss_off):
+        """bftkv_gpu_collective_verify_small: (err, fenced)."""
+        n = len(tbs_off) - 1
+        tbs_blob, ss_blob = _u8(tbs_blob), _u8(ss_blob)
+        tbs_off, ss_off = _u64(tbs_off), _u64(ss_off)
+        err = np.zeros(n, dtype=np.uint8)
+        fenced = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_collective_verify_small(self.h, quorum, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(ss_blob), _ptr(ss_off),
+                                                               _ptr(err), _ptr(fenced)), "collective_verify_small")
+        return err, fenced
+
+    def signature_verify_small(self, tbs_blob, tbs_off, sig_blob, sig_off, cert_key_id=None):
+        """bftkv_gpu_signature_verify_small: (err, fenced)."""
+        n = len(tbs_off) - 1
+        tbs_blob, sig_blob = _u8(tbs_blob), _u8(sig_blob)
+        tbs_off, sig_off = _u64(tbs_off), _u64(sig_off)
+        ck = None if cert_key_id is None else _u64(cert_key_id)
+        err = np.zeros(n, dtype=np.uint8)
+        fenced = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_signature_verify_small(self.h, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(sig_blob), _ptr(sig_off), _ptr(ck),
+                                                              _ptr(err), _ptr(fenced)), "signature_verify_small")
+        return err, fenced
 
     def collective_verify_dev(self, quorum: int, n_items: int, tbs_ptr: int, tbs_off_ptr: int, ss_ptr: int, ss_off_ptr: int,
                               ss_len: int, err_ptr: int, nver_ptr: int, verdict_ptr: int, fenced_ptr: int = 0):
@@ -261,8 +307,10 @@ class Context:
         ck = None if cert_key_id is None else _u64(cert_key_id)
         err = np.zeros(n, dtype=np.uint8)
         self.last_fenced = np.zeros(n, dtype=np.uint8)
+        small = self.signature_verify_small(tbs_blob, tbs_off, sig_blob, sig_off, cert_key_id) if self._cross_check(n) else None
         self._check(self.lib.bftkv_gpu_signature_verify(self.h, n, _ptr(tbs_blob), _ptr(tbs_off), _ptr(sig_blob), _ptr(sig_off),
                                                         _ptr(ck), _ptr(err), _ptr(self.last_fenced)), "signature_verify")
+        self._compare_small("signature_verify", small, err, self.last_fenced)
         return err
 
     def last_statuses(self):

@@ -55,7 +55,7 @@ struct KeyEntry {
   uint64_t key_id = 0, entity_id = 0;
   uint8_t algo = 0, flags = 0;
   uint32_t bits = 0, e = 0, n0 = 0, qbits = 0;
-  std::vector<uint32_t> nl, r2, qw, dtab, qpow;
+  std::vector<uint32_t> nl, r2, r2w, qw, dtab, qpow;    // r2w: R^2 mod n for the 80-limb form (<= 2048-bit RSA)
   std::string material;
   bool cert_only = false;
   int cert_group = -1;          // certificates: entries of one certificate share a group
@@ -99,6 +99,7 @@ struct bftkv_gpu_ctx {
   std::vector<KeyEntry> ring, certs;   // processed rows: node keyring, then certificate-only entities
   uint32_t n_ring_entities = 0;
   std::map<std::string, bool> cert_valid;   // certificate bytes -> openpgp.ReadEntity would accept it
+  DevBuf k_r2w;
   DevBuf k_id, k_entity, k_algo, k_flags, k_bits, k_e, k_n, k_r2, k_n0, k_q, k_qbits, k_dsatab, k_dsaslot, k_sorted_id, k_sorted_slot;
   // fixed-base DSA tables: built once per distinct key material, kept across key-table uploads
   DevBuf dsa_comb;
@@ -145,10 +146,12 @@ struct bftkv_gpu_ctx {
   DevBuf in_pack;
   uint8_t* h_out = nullptr; uint8_t* d_out = nullptr; size_t out_cap = 0;
   uint32_t out_seq = 0;
+  void* small_pin = nullptr;                // PinnedBuf[3] of bftkv_gpu_*_verify_small (batcher_capi.inc), created on first use
   uint32_t staged_spin_us = 50000;          // how long a staged call spins on its completion word before it blocks in the runtime (BFTKV_STAGED_SPIN_US)
 };
 
 void rccl_release(bftkv_gpu_ctx* c);
+void release_small_pin(bftkv_gpu_ctx* c);
 extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
                                          const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class = nullptr,
                                          uint8_t* fenced_out = nullptr);
@@ -369,7 +372,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
   HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
   HIPCHK(c, c->r.ensure(sizeof(uint32_t) * EM_LOW_LIMBS * tr));   // low limbs of s^e mod n: k_rsa_modexp -> k_rsa_compare
-  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? MONT_TPI_BIG * MONT_L3072 : MONT_N) * tr));
+  HIPCHK(c, c->xr.ensure(sizeof(uint32_t) * (c->have_rsa4096 ? MONT_NMAX : c->have_rsa3072 ? MONT_TPI_BIG * MONT_L3072 : 80) * tr));   // 80: the <10, 8> form
   HIPCHK(c, c->pk_list.ensure(sizeof(uint32_t) * tr));
   HIPCHK(c, c->pk_list3072.ensure(c->have_rsa3072 ? sizeof(uint32_t) * tr : 16));
   HIPCHK(c, c->pk_list4096.ensure(c->have_rsa4096 ? sizeof(uint32_t) * tr : 16));
@@ -448,7 +451,14 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
   const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
   const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
+  // A staged call with few signatures (no SIMD would get a second wave either way) spreads every <= 2048-bit number over
+  // eight lanes: 0.68x the instructions per wave, and such a call lasts as long as ONE wave's chain of 18 products.
+  const bool wide8 = staged_cap != 0 && ss_len / 256 <= 8192 && !getenv("BFTKV_NO_WIDE8");
   auto launch_modexp = [&](const uint32_t* start) {
+    if (wide8)
+      hipLaunchKernelGGL((k_rsa_modexp<10, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+                         cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
+    else
     hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
@@ -542,6 +552,7 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
   if (cert_only) e.flags |= KEYF_CERT_ONLY;
   e.bits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
   e.e = 0; e.n0 = 0; e.qbits = 0;
+  e.r2w.clear();
   e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(2 * MONT_N, 0); e.qpow.clear();
   if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
     if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
@@ -550,6 +561,12 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
     const int nlimbs = e.bits <= 2048 ? MONT_N : (e.bits <= 3072 ? MONT_TPI_BIG * MONT_L3072 : MONT_TPI_BIG * MONT_L4096);
     if (e.bits > 4096) e.bits = 0xFFFFFFFFu;                       // status ST_UNSUPPORTED for this key
     else if (!hostbn::mont_setup(k.n, k.n_len, nlimbs, e.nl.data(), e.r2.data(), &e.n0)) e.bits = 0xFFFFFFFFu;   // even / zero modulus
+    else if (e.bits <= 2048) {                                     // the 8-lane form of small calls: R = 2^2240
+      std::vector<uint32_t> nl80(80);
+      uint32_t n0b = 0;
+      e.r2w.assign(80, 0);
+      (void)hostbn::mont_setup(k.n, k.n_len, 80, nl80.data(), e.r2w.data(), &n0b);
+    }
   } else if (k.pk_algo == PK_DSA) {
     // n = p, e = q.  Montgomery domain mod p; g and y in Montgomery form seed the fixed-base tables.
     e.qbits = (uint32_t)hostbn::bit_length(k.e, k.e_len);
@@ -669,7 +686,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   if (c->root) return fail(c, BFTKV_E_STATE, "a forked context cannot change the key table (use its root)");
   KtWrite kw(c);      // the forks' calls in flight drain first; new ones wait
   std::vector<uint64_t> key_id, entity_ids;
-  std::vector<uint32_t> entity, bits, e32, nl, r2, n0, qw, qbits, dtab;
+  std::vector<uint32_t> entity, bits, e32, nl, r2, r2w, n0, qw, qbits, dtab;
   std::vector<uint8_t> algo, flags;
   std::vector<const KeyEntry*> rows;
   auto add = [&](const KeyEntry& e, bool own_entity) {
@@ -682,6 +699,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
     key_id.push_back(e.key_id); entity.push_back(ent); algo.push_back(e.algo); flags.push_back(e.flags);
     bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
     nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
+    r2w.insert(r2w.end(), e.r2w.begin(), e.r2w.end()); r2w.resize(key_id.size() * 80, 0);
     qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
     rows.push_back(&e);
     return ent;
@@ -697,6 +715,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
       key_id.push_back(e.key_id); entity.push_back(group_ent); algo.push_back(e.algo); flags.push_back(e.flags);
       bits.push_back(e.bits); e32.push_back(e.e); n0.push_back(e.n0); qbits.push_back(e.qbits);
       nl.insert(nl.end(), e.nl.begin(), e.nl.end()); r2.insert(r2.end(), e.r2.begin(), e.r2.end());
+      r2w.insert(r2w.end(), e.r2w.begin(), e.r2w.end()); r2w.resize(key_id.size() * 80, 0);
       qw.insert(qw.end(), e.qw.begin(), e.qw.end()); dtab.insert(dtab.end(), e.dtab.begin(), e.dtab.end());
       rows.push_back(&e);
     }
@@ -713,8 +732,9 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   if ((rc = upload(c, c->k_id, key_id)) || (rc = upload(c, c->k_entity, entity)) || (rc = upload(c, c->k_algo, algo)) ||
       (rc = upload(c, c->k_flags, flags)) || (rc = upload(c, c->k_bits, bits)) || (rc = upload(c, c->k_e, e32)) ||
       (rc = upload(c, c->k_n, nl)) || (rc = upload(c, c->k_r2, r2)) || (rc = upload(c, c->k_n0, n0)) ||
-      (rc = upload(c, c->k_q, qw)) || (rc = upload(c, c->k_qbits, qbits)) || (rc = upload(c, c->k_dsatab, dtab)))
+      (rc = upload(c, c->k_q, qw)) || (rc = upload(c, c->k_qbits, qbits)) || (rc = upload(c, c->k_dsatab, dtab)) || (rc = upload(c, c->k_r2w, r2w)))
     return rc;
+  c->kt.r2_limbs80 = c->k_r2w.as<uint32_t>();
   c->n_keys = (uint32_t)key_id.size();
   c->kt.n_keys = c->n_keys;
   c->kt.n_limbs = c->k_n.as<uint32_t>();
@@ -856,13 +876,14 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream_h);
   (void)hipStreamSynchronize(c->stream_d);
-  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot,
+  for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot, &c->k_r2w,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   c->in_pack.release();
+  release_small_pin(c);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->root) c->root->n_forks.fetch_sub(1);
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }

@@ -63,6 +63,7 @@ struct KeyTableDev {
   const uint32_t* rsa_e;      // [n_keys]
   const uint32_t* n_limbs;    // [n_keys][76] modulus (RSA n / DSA p), radix 2^28
   const uint32_t* r2_limbs;   // [n_keys][76] R^2 mod n
+  const uint32_t* r2_limbs80; // [n_keys][80] (2^2240)^2 mod n: the 8-lane form of k_rsa_modexp for small calls (<= 2048-bit RSA keys)
   const uint32_t* n0inv;      // [n_keys] -n^-1 mod 2^28
   // DSA keys only (zero otherwise)
   const uint32_t* q_words;    // [n_keys][8] subgroup order q, little-endian 32-bit words

@@ -962,7 +962,10 @@ __global__ void __launch_bounds__(RSA_BLOCK, 3) k_rsa_modexp(const uint8_t* __re
 
   uint32_t n[L], b[L], y[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  // <10, 8>: a <= 2048-bit modulus over eight lanes (80 limbs, R = 2^2240) -- 0.68x the instructions of <19, 4> per wave, the
+  // shorter chain for calls too small to fill the machine either way (run_pipeline picks it below ~8k signatures)
+  const uint32_t* rp = (L == 10 && TPI == 8) ? kt.r2_limbs80 + (uint64_t)key * 80 + qlane * L
+                                              : kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
   uint32_t* xrp = xr_scratch + (uint64_t)pi * NL + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) n[k] = np[k];

@@ -19,5 +19,7 @@ def gpu_ctx():
     import torch  # noqa: F401
     from bftkv_amd import Context
     ctx = Context(0)
+    # every batched verify call of the suite is also made through the small-call route and must agree (bftkv_amd/_native.py)
+    ctx.check_small = True
     yield ctx
     ctx.close()

@@ -399,7 +399,7 @@ def test_micro_batcher_midstates_and_other_hashes(gpu_ctx):
     from oracle import collective as col
     from oracle import openpgp as pgp
     vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
-    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B")):
+    for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B"), ("C_pubring", "C")):      # C: rsa3072 / rsa4096 beside rsa2048
         ring = pgp.read_entities(bytes.fromhex(vec[ring_key]))
         gpu_ctx.keyring_set(H.abi_keys(col.Keyring(keyring=ring)))
         tbs_l = [bytes.fromhex(v["payload"]) for v in vec[group]]
