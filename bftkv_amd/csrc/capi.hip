@@ -449,24 +449,24 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   };
   if (!upload_tbs) { int hrc = hash_stream_work(); if (hrc) return hrc; }
   // main stream: modular exponentiations (status bytes are only written by the hash stream meanwhile)
-  const dim3 qg((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-  const dim3 qg8((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
+  const dim3 qg((total + MODEXP_BLOCK / MONT_TPI - 1) / (MODEXP_BLOCK / MONT_TPI));
+  const dim3 qg8((total + MODEXP_BLOCK / MONT_TPI_BIG - 1) / (MODEXP_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
   // A staged call with few signatures (no SIMD would get a second wave either way) spreads every <= 2048-bit number over
   // eight lanes: 0.68x the instructions per wave, and such a call lasts as long as ONE wave's chain of 18 products.
   const bool wide8 = staged_cap != 0 && ss_len / 256 <= 8192 && !getenv("BFTKV_NO_WIDE8");
   auto launch_modexp = [&](const uint32_t* start) {
     if (wide8)
-      hipLaunchKernelGGL((k_rsa_modexp<10, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_modexp<10, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                          cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     else
-    hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
     if (c->have_rsa3072)
-      hipLaunchKernelGGL((k_rsa_modexp<MONT_L3072, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_modexp<MONT_L3072, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list3072.as<uint32_t>(),
                          cnt_p + 2, start + 2, c->kt, c->r3072.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
     if (c->have_rsa4096)
-      hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(RSA_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
+      hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
   if (total) launch_modexp(start0);

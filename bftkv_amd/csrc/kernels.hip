@@ -203,7 +203,7 @@ __host__ __device__ __forceinline__ bool parse_sig_body(B body, uint32_t blen, S
 // SignatureV3.parse (RFC 4880 5.2.2; x/crypto openpgp/packet/signature_v3.go): version 2 or 3, one octet "5", signature type,
 // creation time, 8-octet issuer key id, public-key and hash algorithm, 16-bit hash tag, MPIs.  The hashed material is the
 // 5 bytes type || creation time (body[2..7)) with NO trailer -- rec.hashed_len stays 0 and SIGF_V3 tells the digest kernels.
-constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2;
+constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2, SIGF_MORE_CANDIDATES = 4;   // MORE: other keys share the issuer id (k_candidates)
 template <class B = const uint8_t*>
 __host__ __device__ __forceinline__ bool parse_sig_body_v3(B body, uint32_t blen, SigRec& rec, uint64_t& issuer) {
   if (blen < 1 || body[0] < 2 || body[0] > 3) return false;      // "signature packet version"
@@ -415,6 +415,13 @@ __device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
   return false;
 }
 
+// KeysByIdUsage(id, KeyFlagSign) row filter: usable for signing (or, for certificate checks, for certification), inside the
+// keyring the call verifies against (the node keyring, or the single entity of VerifyWithCertificate).
+__device__ __forceinline__ bool key_is_candidate(const KeyTableDev& kt, uint32_t k, uint32_t only_ent, uint32_t cls) {
+  const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
+  return usable && (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent);
+}
+
 // Per packet: Signature.parse + KeysByIdUsage + every VerifySignature check that precedes the math.
 struct ParseArgs {
   const uint8_t* sig_blob; const uint64_t* sig_off; const uint32_t* rec_base; const uint32_t* counts; uint32_t n_items;
@@ -500,19 +507,24 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
           const uint32_t mid = (lo_i + hi_i) >> 1;
           if (kt.sorted_id[mid] < issuer) lo_i = mid + 1; else hi_i = mid;
         }
+        // CheckDetachedSignature tries every candidate in turn (VerifySignature: CanSign first, then the hash suffix is
+        // written into the SHARED hash, then tag, algorithm, arithmetic) and returns the first success or the last error.
+        // A candidate that cannot sign writes nothing, so the first one that CAN is the only one that ever sees the true
+        // digest: it takes the record through the pipeline.  What the candidates behind it do to the status of a record it
+        // did not verify is settled by k_candidates at the end (they see the suffix twice or more and cannot succeed).
+        int32_t first_any = -1;
         for (uint32_t i = lo_i; i < kt.n_keys && kt.sorted_id[i] == issuer; ++i) {
           const uint32_t k = kt.sorted_slot[i];
-          const bool usable = (kt.flags[k] & KEYF_USABLE_SIGN) || (cls != 0 && (kt.flags[k] & KEYF_CERT_CHECK_ONLY));
-          if (usable && (only_ent == 0xFFFFFFFFu ? !(kt.flags[k] & KEYF_CERT_ONLY) : kt.entity[k] == only_ent)) {
-            slot = (int32_t)k;
-            break;
-          }
+          if (!key_is_candidate(kt, k, only_ent, cls)) continue;
+          if (first_any < 0) first_any = (int32_t)k;
+          if (kt.flags[k] & KEYF_CAN_SIGN) { slot = (int32_t)k; break; }
         }
+        if (slot < 0) slot = first_any;          // nobody can sign: ST_KEY_CANNOT_SIGN below
       }
       rec.key_slot = slot;
       const HashInfo hi = hash_info(rec.hash_id);
       const uint32_t hlen = hi.dlen, plen = hi.plen;
-      if (slot >= 0 && (kt.flags[slot] & KEYF_AMBIGUOUS)) fence = true;    // several different keys under this 64-bit id
+      if (slot >= 0 && !msg_slot && (kt.flags[slot] & KEYF_AMBIGUOUS)) rec.flags |= SIGF_MORE_CANDIDATES;   // other keys under this 64-bit id
       if (slot < 0) st = ST_UNKNOWN_ISSUER;
       // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
@@ -773,18 +785,20 @@ struct TailSrc {
   const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
   const uint8_t* body; uint32_t pre_len;      // v4: first 6+hl bytes of the signature body; v3: type || creation time (5 bytes)
   uint32_t tr_len;                            // v4: the 6-byte trailer 04 FF len32; v3: none
+  uint32_t rep;                               // how often the hash suffix (pre || trailer) is written: 1, or j+1 for the
+                                              // j-th further candidate key of one issuer id (k_candidates)
 };
 __device__ __forceinline__ uint32_t tail_byte(const TailSrc& t, uint32_t j) {
   if (j < t.tail_len) return t.tail[j];
   j -= t.tail_len;
+  const uint32_t unit = t.pre_len + t.tr_len;
+  if (j >= unit * t.rep) return (j == unit * t.rep) ? 0x80 : 0;   // first byte after the message: the padding marker
+  if (t.rep > 1) j %= unit;
   if (j < t.pre_len) return t.body[j];
   j -= t.pre_len;
-  if (j < t.tr_len) {
-    if (j == 0) return 0x04;
-    if (j == 1) return 0xFF;
-    return (t.pre_len >> (8 * (5 - j))) & 0xFF;
-  }
-  return (j == t.tr_len) ? 0x80 : 0;   // first byte after the message: the padding marker
+  if (j == 0) return 0x04;
+  if (j == 1) return 0xFF;
+  return (t.pre_len >> (8 * (5 - j))) & 0xFF;
 }
 
 // value of a big-endian byte string as radix-2^28 limb j
@@ -805,12 +819,14 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
                                             const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                             const uint64_t* __restrict__ mid64, uint32_t n_items,
                                             SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/,
-                                            uint32_t ri_in, const uint64_t* __restrict__ tbs_prefix = nullptr) {
+                                            uint32_t ri_in, const uint64_t* __restrict__ tbs_prefix = nullptr, uint32_t rep = 1,
+                                            uint32_t* __restrict__ tag_only = nullptr) {
+  // tag_only (k_candidates): the top 16 bits of the digest with the hash suffix written `rep` times, nothing stored
   const uint32_t ri = ri_in;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
-  if (rec.status != ST_PENDING_HASH) return;
-  if ((rec.hash_id != HASH_SHA256) != OTHERS) return;
+  if (!tag_only && rec.status != ST_PENDING_HASH) return;
+  if (!tag_only && (rec.hash_id != HASH_SHA256) != OTHERS) return;
   const HashInfo hi = OTHERS ? hash_info(rec.hash_id) : HashInfo{32, 0, 32, 19};
   // tbs_prefix (callers that absorbed the whole blocks of their payload themselves, host_sha256.h): the blob holds only the
   // < 64 bytes behind the midstate, tbs_prefix[item] bytes went before them
@@ -824,9 +840,11 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   ts.body = sig_blob + rec.body_off + (v3 ? 2 : 0);
   ts.pre_len = v3 ? 5u : 6u + rec.hashed_len;
   ts.tr_len = v3 ? 0u : 6u;
-  const uint32_t rem = ts.tail_len + ts.pre_len + ts.tr_len;     // message bytes still to hash
-  const uint64_t bits = (tlen + ts.pre_len + ts.tr_len) * 8;
-  uint32_t* dg = digests + (uint64_t)ri * 16;
+  ts.rep = rep;
+  const uint32_t rem = ts.tail_len + (ts.pre_len + ts.tr_len) * rep;     // message bytes still to hash
+  const uint64_t bits = (tlen + (uint64_t)(ts.pre_len + ts.tr_len) * rep) * 8;
+  uint32_t dg_dummy[16];
+  uint32_t* dg = tag_only ? dg_dummy : digests + (uint64_t)ri * 16;
   uint32_t tag_hi;
   if (!OTHERS || hi.family == 32) {
     const uint32_t nblk = (rem + 9 + 63) >> 6;
@@ -872,6 +890,7 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   } else {
     tag_hi = 0;
   }
+  if (tag_only) { *tag_only = tag_hi >> 16; return; }
   // PublicKey.VerifySignature: hash tag first, then whatever k_parse_body determined
   uint8_t st;
   if ((uint8_t)(tag_hi >> 24) != rec.hash_tag[0] || (uint8_t)(tag_hi >> 16) != rec.hash_tag[1]) st = ST_HASH_TAG;
@@ -902,11 +921,66 @@ __global__ void __launch_bounds__(256) k_digest_other(const uint8_t* __restrict_
     digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, (uint32_t)ri);
 }
 
+// Several different keys under one 64-bit key id (ids are 64 bits of a SHA-1: a collision costs ~2^32 work, or nothing for
+// whoever generates both keys).  The reference asks every candidate in keyring order and returns the first success or the
+// LAST error (openpgp.CheckDetachedSignature).  Only the first candidate that can sign ever sees the true digest -- it went
+// through the pipeline as the record's key (parse_one).  Each later one finds the hash suffix written once more into the
+// shared hash (candidate j hashes payload || suffix x (j+1)), so its tag check fails, or -- once in 2^16 -- passes and the
+// arithmetic over a foreign digest fails; a candidate that cannot sign fails before it writes anything.  None of them can
+// turn a failure into a success, so verdicts and tallies stand as the pipeline left them; this kernel, launched only when
+// the key table holds such ids, settles the STATUS of the records their first candidate did not verify.
+__global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                   const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
+                                                   const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
+                                                   uint32_t n_recs, const uint32_t* __restrict__ n_recs_dev, const uint64_t* __restrict__ tbs_prefix,
+                                                   KeyTableDev kt, const uint32_t* __restrict__ cert_ent, const uint8_t* __restrict__ sig_class) {
+  const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nr = n_recs_dev ? *n_recs_dev : n_recs;
+  if (ri >= nr) return;
+  const SigRec rec = recs[ri];
+  if (!(rec.flags & SIGF_MORE_CANDIDATES)) return;
+  uint8_t st = rec.status;
+  // statuses the candidate loop produces; anything else was decided before the loop, is a success, or was never examined
+  if (!(st == ST_KEY_CANNOT_SIGN || st == ST_HASH_TAG || st == ST_ALGO_MISMATCH || st == ST_BAD_SIG)) return;
+  if (tbs_prefix && rec.hash_id != HASH_SHA256) return;      // staged call: the item is run again with its payload
+  const uint32_t slot = (uint32_t)rec.key_slot;
+  const uint64_t issuer = kt.key_id[slot];
+  const uint32_t only_ent = cert_ent ? cert_ent[rec.item] : 0xFFFFFFFFu;
+  const uint32_t cls = sig_class ? sig_class[rec.item] : 0;
+  uint32_t lo_i = 0, hi_i = kt.n_keys;
+  while (lo_i < hi_i) {
+    const uint32_t mid = (lo_i + hi_i) >> 1;
+    if (kt.sorted_id[mid] < issuer) lo_i = mid + 1; else hi_i = mid;
+  }
+  bool behind = false;
+  uint32_t writes = (kt.flags[slot] & KEYF_CAN_SIGN) ? 1u : 0u;
+  for (uint32_t i = lo_i; i < kt.n_keys && kt.sorted_id[i] == issuer; ++i) {
+    const uint32_t k = kt.sorted_slot[i];
+    if (!key_is_candidate(kt, k, only_ent, cls)) continue;
+    if (k == slot) { behind = true; continue; }
+    if (!behind) continue;                       // ahead of the record's key: could not sign, wrote nothing, error overwritten
+    if (!(kt.flags[k] & KEYF_CAN_SIGN)) { st = ST_KEY_CANNOT_SIGN; continue; }
+    ++writes;
+    uint32_t tag = 0;
+    if (rec.hash_id == HASH_SHA256) digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
+    else digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
+    if ((uint8_t)(tag >> 8) != rec.hash_tag[0] || (uint8_t)tag != rec.hash_tag[1]) st = ST_HASH_TAG;
+    else st = (kt.pk_algo[k] != rec.pk_algo) ? (uint8_t)ST_ALGO_MISMATCH : (uint8_t)ST_BAD_SIG;
+  }
+  recs[ri].status = st;
+}
+
 // ------------------------------------------------------------------------------------------------
 // RSA: 4 lanes per signature
 // ------------------------------------------------------------------------------------------------
 constexpr int RSA_BLOCK = 256;
 constexpr int QUADS_PER_BLOCK = RSA_BLOCK / MONT_TPI;
+// k_rsa_modexp's waves never meet (wavefront fences only), so its block size only decides how many waves must retire before
+// their CU slots are handed out again; measured variants: tools/ab.sh with -DBFTKV_MODEXP_BLOCK=64|128|256.
+#ifndef BFTKV_MODEXP_BLOCK
+#define BFTKV_MODEXP_BLOCK 256
+#endif
+constexpr int MODEXP_BLOCK = BFTKV_MODEXP_BLOCK;
 
 enum : int { OP_TO_MONT = 0, OP_SQR = 1, OP_MULX = 2, OP_MULP = 3, OP_MUL1 = 4 };
 
@@ -931,13 +1005,13 @@ __device__ __forceinline__ uint32_t em_head_limb(uint32_t gi, uint32_t kbytes) {
 // r = s^e mod n for every queued signature: the upper limbs checked against the EMSA padding here, the low EM_LOW_LIMBS
 // limbs (canonical radix 2^28) to r_low for k_rsa_compare.
 template <int L, int TPI>   // limbs per lane x lanes per number: 19x4 (<= 2048-bit moduli), 14x8 (<= 3072), 19x8 (<= 4096)
-__global__ void __launch_bounds__(RSA_BLOCK, 3) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
+__global__ void __launch_bounds__(MODEXP_BLOCK, 3) k_rsa_modexp(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                           const uint32_t* __restrict__ pk_list, const uint32_t* __restrict__ pk_count_ptr,
                                                           const uint32_t* __restrict__ pk_start_ptr,
                                                           KeyTableDev kt, uint32_t* __restrict__ r_low,
                                                           uint32_t* __restrict__ xr_scratch, uint64_t* __restrict__ clk) {
   constexpr int NL = TPI * L;
-  constexpr int GROUPS = RSA_BLOCK / TPI;      // numbers per block
+  constexpr int GROUPS = MODEXP_BLOCK / TPI;   // numbers per block
   // diagnostics: shader-clock ticks (s_memtime) and constant 100 MHz ticks (s_memrealtime) over the life of block 0's first
   // wave -- the clock the part actually ran this kernel at (bftkv_gpu_last_sclk_mhz); two scalar reads at each end
   const bool stamp = clk && blockIdx.x == 0 && threadIdx.x == 0;

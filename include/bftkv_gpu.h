@@ -210,7 +210,7 @@ int bftkv_gpu_signature_verify_small(bftkv_gpu_ctx* ctx, uint32_t n_items, const
  * caller then leads a new one).  Callers hash the whole blocks of their own payload on their own thread (SHA-256
  * midstate, SHA extensions when the CPU has them) and the device finishes each signature's digest from there.
  * max_wait_us is accepted for compatibility and unused: nobody waits for company.  n_lanes = 0 (and
- * bftkv_gpu_batcher_create): $BFTKV_BATCHER_LANES or 2.  Thread-safe; buffers are only read for the duration of the call.
+ * bftkv_gpu_batcher_create): $BFTKV_BATCHER_LANES or 3.  Thread-safe; buffers are only read for the duration of the call.
  * FAIL-CLOSED: the status byte is written on every path and is a failure (invalid signature / insufficient signatures /
  * read error) whenever the return code is not 0 -- a caller that only looks at the status can never read "verified" out
  * of an infrastructure error (allocation failure, stopped batcher, bad handle). */
