@@ -92,7 +92,7 @@ struct bftkv_gpu_ctx {
   // key table
   uint64_t keyring_gen = 0;
   uint32_t n_keys = 0, n_entities = 0;
-  bool have_dsa_keys = false, have_rsa3072 = false, have_rsa4096 = false;
+  bool have_dsa_keys = false, have_rsa3072 = false, have_rsa4096 = false, have_ambiguous = false;
   std::vector<uint64_t> h_key_id, h_entity_id;      // per key slot / per entity
   std::vector<uint32_t> h_key_entity;
   std::vector<uint8_t> h_key_flags;
@@ -110,6 +110,7 @@ struct bftkv_gpu_ctx {
   std::vector<QuorumHost> quorums;
 
   // per-call arena
+  DevBuf txt_mid32, txt_mid64, txt_tail, txt_len;     // text-mode hashing state (TextDev)
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
@@ -337,6 +338,14 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                                        // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start),
                                        // [16..19] two uint64: clock stamps of k_rsa_modexp (bftkv_gpu_last_sclk_mhz)
   if (plan_q) HIPCHK(c, c->plan_cut.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
+  TextDev txt{nullptr, nullptr, nullptr, nullptr};
+  if (!d_mid_in) {      // (a midstate-only call cannot hash text-mode signatures: their items come back marked for the ordinary path)
+    HIPCHK(c, c->txt_mid32.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));
+    HIPCHK(c, c->txt_mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));
+    HIPCHK(c, c->txt_tail.ensure((size_t)128 * 5 * n_items + 16));
+    HIPCHK(c, c->txt_len.ensure(sizeof(uint64_t) * 5 * (size_t)n_items + 16));
+    txt = TextDev{c->txt_mid32.as<uint32_t>(), c->txt_mid64.as<uint64_t>(), c->txt_tail.as<uint8_t>(), c->txt_len.as<uint64_t>()};
+  }
   HIPCHK(c, rec(0, s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, join(sh, 0));
@@ -437,9 +446,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     HIPCHK(c, join(sh, 1));
     if (total) {
       // other hashes: a no-op grid unless some signature asked for them
-      if (!d_mid_in)
+      if (!d_mid_in) {
         hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
                            c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
+        hipLaunchKernelGGL(k_hash_mid_text, dim3((n_items + 63) / 64, 5), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->hash_mask.as<uint32_t>(), txt);
+      }
       hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss,
                          d_mid_in ? d_mid_in : c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
                          c->digests.as<uint32_t>(), d_tbs_prefix, n_recs_dev);
@@ -484,7 +495,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (total && !d_mid_in)
     hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
                        d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
-                       c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4);
+                       c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4, txt);
   const dim3 cg(((uint64_t)total * CMP_LANES + 255) / 256);
   auto launch_compare = [&](const uint32_t* start) {
     hipLaunchKernelGGL(k_rsa_compare, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
@@ -526,6 +537,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     launch_compare(start1);
     if (c->have_dsa_keys) launch_dsa(start1);
   }
+  // several keys under one key id: what the candidates behind the first do to the status of a record it did not verify
+  // (never to a verdict: see the kernel)
+  if (total && c->have_ambiguous && !d_msg_slot)
+    hipLaunchKernelGGL(k_candidates, dim3((total + 63) / 64), dim3(64), 0, s, d_tbs, d_tbs_off, d_ss, d_mid_in ? d_mid_in : c->mid.as<uint32_t>(),
+                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, n_recs_dev, d_tbs_prefix, c->kt, d_cert_ent, d_sig_class, txt);
   HIPCHK(c, rec(3, s));
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -743,8 +759,9 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
   if ((rc = sync_dsa_tables(c, rows, algo, bits))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = false;
+  c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
   for (size_t i = 0; i < algo.size(); ++i) {
+    if (flags[i] & KEYF_AMBIGUOUS) c->have_ambiguous = true;
     if (algo[i] == PK_DSA) c->have_dsa_keys = true;
     if ((algo[i] == PK_RSA || algo[i] == PK_RSA_SIGN_ONLY) && bits[i] != 0xFFFFFFFFu) {
       if (bits[i] > 3072) c->have_rsa4096 = true; else if (bits[i] > 2048) c->have_rsa3072 = true;
@@ -784,7 +801,7 @@ int fork_refresh(bftkv_gpu_ctx* c) {
   if (c->seen_keyring_gen != r->keyring_gen) {
     c->kt = r->kt;
     c->n_keys = r->n_keys; c->n_entities = r->n_entities; c->n_ring_entities = r->n_ring_entities;
-    c->have_dsa_keys = r->have_dsa_keys; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096;
+    c->have_dsa_keys = r->have_dsa_keys; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096; c->have_ambiguous = r->have_ambiguous;
     c->h_key_id = r->h_key_id; c->h_entity_id = r->h_entity_id; c->h_key_entity = r->h_key_entity; c->h_key_flags = r->h_key_flags;
     c->n_dsa_slots = r->dsa_comb_slot.size(); c->dsa_wbits = r->dsa_wbits;
     c->keyring_gen = r->keyring_gen;          // the fork's membership tables follow the root's generations
@@ -879,7 +896,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot, &c->k_r2w,
                     &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
-                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut})
+                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut, &c->txt_mid32, &c->txt_mid64, &c->txt_tail, &c->txt_len})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   c->in_pack.release();

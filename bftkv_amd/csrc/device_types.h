@@ -98,8 +98,20 @@ constexpr uint8_t KEYF_CERT_CHECK_ONLY = 16;
 // another, different key of the keyring carries the same 64-bit key id: the reference tries every candidate (the second one
 // against a hash that has absorbed the suffix twice); the device takes the first and raises the item's fence flag
 constexpr uint8_t KEYF_AMBIGUOUS = 32;
-// per-item word item_hash_mask: bits 1..4 = midstates wanted besides SHA-256, bit 31 = the item met a fenced input shape
+// per-item word item_hash_mask: bits 1..4 = midstates wanted besides SHA-256, bits 8..12 = midstates wanted over the
+// CANONICAL TEXT form of the payload (text-mode signatures; SHA-256, 224, SHA-1, 512, 384), bit 31 = the item met a fenced
+// input shape
 constexpr uint32_t ITEM_FENCED = 0x80000000u;
+constexpr uint32_t ITEM_TEXT_SHIFT = 8, ITEM_NEEDS_PAYLOAD = 0x1F1Eu;   // NEEDS_PAYLOAD: any hashing a midstate-only call cannot do
+
+// Text-mode (signature type 0x01) hashing state per (hash, item): openpgp.NewCanonicalTextHash rewrites the line endings of
+// the signed data, so these signatures hash a different byte stream than the binary ones of the same item.
+struct TextDev {
+  uint32_t* mid32;      // [3][n_items][8]   SHA-256 | SHA-224 | SHA-1 state after the whole blocks of the canonical stream
+  uint64_t* mid64;      // [2][n_items][8]   SHA-512 | SHA-384
+  uint8_t* tail;        // [5][n_items][128] the bytes behind the last whole block
+  uint64_t* len;        // [5][n_items]      length of the canonical stream
+};
 
 // Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.
 constexpr int MAX_QC = 8;

@@ -203,7 +203,7 @@ __host__ __device__ __forceinline__ bool parse_sig_body(B body, uint32_t blen, S
 // SignatureV3.parse (RFC 4880 5.2.2; x/crypto openpgp/packet/signature_v3.go): version 2 or 3, one octet "5", signature type,
 // creation time, 8-octet issuer key id, public-key and hash algorithm, 16-bit hash tag, MPIs.  The hashed material is the
 // 5 bytes type || creation time (body[2..7)) with NO trailer -- rec.hashed_len stays 0 and SIGF_V3 tells the digest kernels.
-constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2, SIGF_MORE_CANDIDATES = 4;   // MORE: other keys share the issuer id (k_candidates)
+constexpr uint8_t SIGF_LONG_VALUE = 1, SIGF_V3 = 2, SIGF_MORE_CANDIDATES = 4, SIGF_TEXT = 8;   // MORE: other keys share the issuer id (k_candidates)
 template <class B = const uint8_t*>
 __host__ __device__ __forceinline__ bool parse_sig_body_v3(B body, uint32_t blen, SigRec& rec, uint64_t& issuer) {
   if (blen < 1 || body[0] < 2 || body[0] > 3) return false;      // "signature packet version"
@@ -529,13 +529,18 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
       // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
       // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
-      else if (!msg_slot && !sig_class_ok(cls, rec.sig_type)) { st = ST_HASH_UNSUPPORTED; fence = (cls == 0 && rec.sig_type == 0x01); }
+      else if (!msg_slot && !sig_class_ok(cls, rec.sig_type) && !(cls == 0 && rec.sig_type == 0x01)) st = ST_HASH_UNSUPPORTED;
       else if (hi.family == 0) { st = ST_HASH_UNSUPPORTED; fence = true; }                      // MD5 / RIPEMD-160
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {
         // everything below is only reached when the hash tag matches (k_digest decides)
         st = ST_PENDING_HASH;
-        if (rec.hash_id != HASH_SHA256) { atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot)); pk_count[4] = 1u; }
+        if (!msg_slot && cls == 0 && rec.sig_type == 0x01) {
+          // text mode: the signed data is hashed in canonical form (k_hash_mid_text), per item and hash on demand
+          rec.flags |= SIGF_TEXT;
+          atomicOr(&item_hash_mask[rec.item], 1u << (ITEM_TEXT_SHIFT + (hi.family == 64 ? 3 : 0) + hi.slot));
+          pk_count[4] = 1u;
+        } else if (rec.hash_id != HASH_SHA256) { atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot)); pk_count[4] = 1u; }
         if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
         else if ((rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) && sig_hash_id != rec.hash_id)
           rec.after_tag = ST_BAD_SIG;   // rsa.VerifyPKCS1v15(sig.Hash, digest of another algorithm): length mismatch
@@ -781,6 +786,65 @@ __global__ void __launch_bounds__(64) k_hash_mid_other(const uint8_t* __restrict
   }
 }
 
+// Canonical-text midstates (text-mode signatures, hashForSignature's NewCanonicalTextHash): thread per (hash, item), only for
+// the items whose signatures ask.  The payload is streamed byte by byte through x/crypto's two-state rewriter -- a '\n' that
+// does not follow a '\r' becomes "\r\n", the byte after a '\r' passes unchanged whatever it is -- into a block buffer.
+// Rare path: nothing here is tuned.
+__global__ void __launch_bounds__(64) k_hash_mid_text(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
+                                                      uint32_t n_items, const uint32_t* __restrict__ item_hash_mask, TextDev txt) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t which = blockIdx.y;   // 0 SHA-256, 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384
+  if (item >= n_items) return;
+  if (!((item_hash_mask[item] >> (ITEM_TEXT_SHIFT + which)) & 1u)) return;
+  const uint8_t* p = tbs_blob + tbs_off[item];
+  const uint64_t len = tbs_off[item + 1] - tbs_off[item];
+  const uint32_t B = which < 3 ? 64u : 128u;
+  uint32_t s32[8];
+  uint64_t s64[8];
+  if (which == 0) sha256_init(s32); else if (which == 1) sha224_init(s32); else if (which == 2) sha1_init(s32);
+  else if (which == 3) sha512_init(s64); else sha384_init(s64);
+  uint8_t buf[128];
+  uint32_t fill = 0;
+  uint64_t total = 0;
+  auto put = [&](uint8_t c) {
+    buf[fill++] = c;
+    ++total;
+    if (fill == B) {
+      if (which < 3) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)buf[4 * i] << 24) | ((uint32_t)buf[4 * i + 1] << 16) | ((uint32_t)buf[4 * i + 2] << 8) | buf[4 * i + 3];
+        if (which == 2) sha1_compress(s32, w); else sha256_compress(s32, w);
+      } else {
+        uint64_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          uint64_t v = 0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) v = (v << 8) | buf[8 * i + t];
+          w[i] = v;
+        }
+        sha512_compress(s64, w);
+      }
+      fill = 0;
+    }
+  };
+  int st = 0;
+  for (uint64_t i = 0; i < len; ++i) {
+    const uint8_t c = p[i];
+    if (st == 0) {
+      if (c == 0x0D) { st = 1; put(c); }
+      else if (c == 0x0A) { put(0x0D); put(0x0A); }
+      else put(c);
+    } else { st = 0; put(c); }
+  }
+  const uint64_t slot = (uint64_t)which * n_items + item;
+  if (which < 3) { for (int i = 0; i < 8; ++i) txt.mid32[slot * 8 + i] = s32[i]; }
+  else { for (int i = 0; i < 8; ++i) txt.mid64[((uint64_t)(which - 3) * n_items + item) * 8 + i] = s64[i]; }
+  for (uint32_t i = 0; i < fill; ++i) txt.tail[slot * 128 + i] = buf[i];
+  txt.len[slot] = total;
+}
+
 struct TailSrc {
   const uint8_t* tail; uint32_t tail_len;     // last (len % 64) bytes of the signed payload
   const uint8_t* body; uint32_t pre_len;      // v4: first 6+hl bytes of the signature body; v3: type || creation time (5 bytes)
@@ -820,22 +884,25 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
                                             const uint64_t* __restrict__ mid64, uint32_t n_items,
                                             SigRec* __restrict__ recs, uint32_t n_recs, uint32_t* __restrict__ digests /*[n_recs][16]*/,
                                             uint32_t ri_in, const uint64_t* __restrict__ tbs_prefix = nullptr, uint32_t rep = 1,
-                                            uint32_t* __restrict__ tag_only = nullptr) {
+                                            uint32_t* __restrict__ tag_only = nullptr, TextDev txt = TextDev{nullptr, nullptr, nullptr, nullptr}) {
   // tag_only (k_candidates): the top 16 bits of the digest with the hash suffix written `rep` times, nothing stored
   const uint32_t ri = ri_in;
   if (ri >= n_recs) return;
   const SigRec rec = recs[ri];
   if (!tag_only && rec.status != ST_PENDING_HASH) return;
-  if (!tag_only && (rec.hash_id != HASH_SHA256) != OTHERS) return;
+  const bool text = OTHERS && (rec.flags & SIGF_TEXT) != 0;      // (text-mode records of any hash take the OTHERS kernels)
+  if (!tag_only && ((rec.hash_id != HASH_SHA256) || (rec.flags & SIGF_TEXT) != 0) != OTHERS) return;
+  if (OTHERS && text && !txt.len) return;                          // a call without payloads: the item is run again with them
   const HashInfo hi = OTHERS ? hash_info(rec.hash_id) : HashInfo{32, 0, 32, 19};
   // tbs_prefix (callers that absorbed the whole blocks of their payload themselves, host_sha256.h): the blob holds only the
   // < 64 bytes behind the midstate, tbs_prefix[item] bytes went before them
   const uint64_t seg = tbs_off[rec.item + 1] - tbs_off[rec.item];
-  const uint64_t tlen = tbs_prefix ? tbs_prefix[rec.item] + seg : seg;
   const uint32_t bmask = (OTHERS && hi.family == 64) ? 127u : 63u;
+  const uint64_t tslot = ((uint64_t)((hi.family == 64 ? 3 : 0) + hi.slot)) * n_items + rec.item;     // text-mode state of (hash, item)
+  const uint64_t tlen = text ? txt.len[tslot] : (tbs_prefix ? tbs_prefix[rec.item] + seg : seg);
   TailSrc ts;
-  ts.tail_len = tbs_prefix ? (uint32_t)seg : (uint32_t)(tlen & bmask);
-  ts.tail = tbs_blob + tbs_off[rec.item] + (seg - ts.tail_len);
+  ts.tail_len = text ? (uint32_t)(tlen & bmask) : (tbs_prefix ? (uint32_t)seg : (uint32_t)(tlen & bmask));
+  ts.tail = text ? txt.tail + tslot * 128 : tbs_blob + tbs_off[rec.item] + (seg - ts.tail_len);
   const bool v3 = (rec.flags & SIGF_V3) != 0;
   ts.body = sig_blob + rec.body_off + (v3 ? 2 : 0);
   ts.pre_len = v3 ? 5u : 6u + rec.hashed_len;
@@ -849,7 +916,7 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   if (!OTHERS || hi.family == 32) {
     const uint32_t nblk = (rem + 9 + 63) >> 6;
     uint32_t s[8];
-    const uint32_t* m = mid32 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
+    const uint32_t* m = (text ? txt.mid32 : mid32) + ((uint64_t)hi.slot * n_items + rec.item) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = m[i];
     for (uint32_t blk = 0; blk < nblk; ++blk) {
@@ -868,7 +935,7 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   } else if (OTHERS) {
     const uint32_t nblk = (rem + 17 + 127) >> 7;
     uint64_t s[8];
-    const uint64_t* m = mid64 + ((uint64_t)hi.slot * n_items + rec.item) * 8;
+    const uint64_t* m = (text ? txt.mid64 : mid64) + ((uint64_t)hi.slot * n_items + rec.item) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = m[i];
     for (uint32_t blk = 0; blk < nblk; ++blk) {
@@ -913,12 +980,12 @@ __global__ void __launch_bounds__(256) k_digest_other(const uint8_t* __restrict_
                                                          const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                          const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                          uint32_t n_recs, uint32_t* __restrict__ digests,
-                                                         const uint32_t* __restrict__ any_other /*set by k_parse_body*/) {
-  if (*any_other == 0) return;        // every signature of the batch is SHA-256 (the path's default): nothing to read
+                                                         const uint32_t* __restrict__ any_other /*set by k_parse_body*/, TextDev txt) {
+  if (*any_other == 0) return;        // every signature of the batch is binary SHA-256 (the path's default): nothing to read
   // bounded grid (the host launches at most DIGEST_OTHER_MAX_BLOCKS blocks): normally this kernel has nothing to do, and a
   // grid of one block per 256 records -- 104k blocks for a cfg-4 batch -- spent 40 ms just being dispatched beside the modexp
   for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n_recs; ri += (uint64_t)gridDim.x * blockDim.x)
-    digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, (uint32_t)ri);
+    digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, n_recs, digests, (uint32_t)ri, nullptr, 1, nullptr, txt);
 }
 
 // Several different keys under one 64-bit key id (ids are 64 bits of a SHA-1: a collision costs ~2^32 work, or nothing for
@@ -933,7 +1000,8 @@ __global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ t
                                                    const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                    const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                    uint32_t n_recs, const uint32_t* __restrict__ n_recs_dev, const uint64_t* __restrict__ tbs_prefix,
-                                                   KeyTableDev kt, const uint32_t* __restrict__ cert_ent, const uint8_t* __restrict__ sig_class) {
+                                                   KeyTableDev kt, const uint32_t* __restrict__ cert_ent, const uint8_t* __restrict__ sig_class,
+                                                   TextDev txt) {
   const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nr = n_recs_dev ? *n_recs_dev : n_recs;
   if (ri >= nr) return;
@@ -942,7 +1010,7 @@ __global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ t
   uint8_t st = rec.status;
   // statuses the candidate loop produces; anything else was decided before the loop, is a success, or was never examined
   if (!(st == ST_KEY_CANNOT_SIGN || st == ST_HASH_TAG || st == ST_ALGO_MISMATCH || st == ST_BAD_SIG)) return;
-  if (tbs_prefix && rec.hash_id != HASH_SHA256) return;      // staged call: the item is run again with its payload
+  if (tbs_prefix && (rec.hash_id != HASH_SHA256 || (rec.flags & SIGF_TEXT))) return;      // staged call: the item is run again with its payload
   const uint32_t slot = (uint32_t)rec.key_slot;
   const uint64_t issuer = kt.key_id[slot];
   const uint32_t only_ent = cert_ent ? cert_ent[rec.item] : 0xFFFFFFFFu;
@@ -962,8 +1030,9 @@ __global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ t
     if (!(kt.flags[k] & KEYF_CAN_SIGN)) { st = ST_KEY_CANNOT_SIGN; continue; }
     ++writes;
     uint32_t tag = 0;
-    if (rec.hash_id == HASH_SHA256) digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
-    else digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
+    if (rec.hash_id == HASH_SHA256 && !(rec.flags & SIGF_TEXT))
+      digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
+    else digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag, txt);
     if ((uint8_t)(tag >> 8) != rec.hash_tag[0] || (uint8_t)tag != rec.hash_tag[1]) st = ST_HASH_TAG;
     else st = (kt.pk_algo[k] != rec.pk_algo) ? (uint8_t)ST_ALGO_MISMATCH : (uint8_t)ST_BAD_SIG;
   }

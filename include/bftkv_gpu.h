@@ -85,9 +85,10 @@ typedef struct {
 
 /* keys[] in keyring order (secring entities first, crypto_pgp.go:195-197).  Identical material
  * under one key id (the node's own key appears in both rings) is de-duplicated.  DIFFERENT keys
- * under one 64-bit id all stay in the table (ids can be made to collide with ~2^32 work; the
- * reference's KeysByIdUsage returns every candidate): a signature naming such an id is checked
- * against the first usable candidate and its item is reported through fenced_out. */
+ * under one 64-bit id all stay in the table (ids can be made to collide with ~2^32 work) and are
+ * asked in keyring order as openpgp.CheckDetachedSignature asks KeysByIdUsage's candidates: the first
+ * that can sign sees the true digest, every later one the hash suffix once more (x/crypto writes it
+ * into the shared hash per candidate), so the first success or the LAST candidate's error stands. */
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint32_t n_keys);
 
 /* DSA verification (Go crypto/dsa.Verify under packet.PublicKey.VerifySignature) multiplies from per-key
@@ -131,8 +132,7 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 /* ---- fenced inputs ------------------------------------------------------------------------------------
  * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs":
  * partial / indeterminate body lengths on signature packets, text-mode signatures, MD5 / RIPEMD-160, ECDSA,
- * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2, several different keys under
- * one key id).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
+ * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
  * shape -- its err_out is then NOT a statement about what the reference would decide, and the caller must run the
  * reference path for that item (the cgo shim calls the wrapped crypto/pgp implementation).  Items with
  * fenced_out[i] = 0 carry the reference's verdict.  None of the path's own writers produce a fenced shape. */

@@ -397,9 +397,23 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
     for (int i = 0; i < o->n_keys; ++i) if (o->keys[i].key_id == s.issuer && o->keys[i].usable_sign) { found = 1; break; }
     if (!found) { TRACE(ST_UNKNOWN_ISSUER); continue; }
     hctx hc;
-    if (s.sig_type != 0 || !h_init(&hc, s.hash_id)) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
-    /* the reference hashes the WHOLE payload again for every signature packet */
-    h_update(&hc, tbs, tbs_len);
+    if ((s.sig_type != 0 && s.sig_type != 1) || !h_init(&hc, s.hash_id)) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
+    /* the reference hashes the WHOLE payload again for every signature packet; text-mode (0x01) signatures through
+     * openpgp.NewCanonicalTextHash: a '\n' that does not follow a '\r' becomes "\r\n", the byte after a '\r' passes
+     * unchanged (the hash suffix below goes into the raw hash) */
+    if (s.sig_type == 0) h_update(&hc, tbs, tbs_len);
+    else {
+      int cs = 0;
+      size_t start = 0;
+      for (size_t i = 0; i < (size_t)tbs_len; ++i) {
+        const uint8_t ch = tbs[i];
+        if (cs == 0) {
+          if (ch == '\r') cs = 1;
+          else if (ch == '\n') { h_update(&hc, tbs + start, i - start); h_update(&hc, "\r\n", 2); start = i + 1; }
+        } else cs = 0;
+      }
+      h_update(&hc, tbs + start, (size_t)tbs_len - start);
+    }
     int st = ST_BAD_SIG;
     for (int i = 0; i < o->n_keys; ++i) {
       const okey* k = &o->keys[i];

@@ -430,20 +430,74 @@ def _gcd(a: int, b: int) -> int:
     return a
 
 
+class CanonicalTextHash:
+    """openpgp.NewCanonicalTextHash (x/crypto openpgp/canonical_text.go): what the SIGNED DATA of a text-mode (0x01)
+    signature passes through on its way into the hash -- a '\n' that does not follow a '\r' becomes "\r\n"; the byte after
+    a '\r' passes unchanged whatever it is (state 1 only resets), so "\r\r\n" comes out as "\r\r\r\n".  The state
+    carries across writes.  VerifySignature writes the hash suffix into the RAW hash behind it: ``raw_update``."""
+
+    def __init__(self, h, state=0):
+        self.h, self.s = h, state
+
+    def update(self, data: bytes):
+        out = bytearray()
+        for c in data:
+            if self.s == 0:
+                if c == 0x0D:
+                    self.s = 1
+                    out.append(c)
+                elif c == 0x0A:
+                    out += b"\r\n"
+                else:
+                    out.append(c)
+            else:
+                self.s = 0
+                out.append(c)
+        self.h.update(bytes(out))
+
+    def raw_update(self, data: bytes):
+        self.h.update(data)
+
+    def copy(self):
+        return CanonicalTextHash(self.h.copy(), self.s)
+
+    def digest(self):
+        return self.h.digest()
+
+
+class _BinaryHash:
+    """hashForSignature for binary (0x00) signatures: signed data and hash suffix go into the same hash."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def update(self, data: bytes):
+        self.h.update(data)
+
+    raw_update = update
+
+    def copy(self):
+        return _BinaryHash(self.h.copy())
+
+    def digest(self):
+        return self.h.digest()
+
+
 def hash_for_signature(hash_id: int, sig_type: int):
-    """hashForSignature: binary (0x00) hashes raw bytes; text (0x01) canonicalises line endings
-    (not produced on this path -> fenced as unsupported); others unsupported."""
+    """hashForSignature: binary (0x00) hashes raw bytes; text (0x01) canonicalises the line endings of the signed data
+    (CanonicalTextHash); other signature types are unsupported."""
     name = HASH_BY_ID.get(hash_id)
     if name is None or name in ("md5", "ripemd160"):
         # whether MD5 / RIPEMD-160 are linked into a bftkv binary cannot be established without the
         # x/crypto source: FENCED as unavailable (DESIGN.md), identically in oracle.c and the HIP path
         return None
-    if sig_type != 0x00:
+    if sig_type not in (0x00, 0x01):
         return None
     try:
-        return hashlib.new(name)
+        h = hashlib.new(name)
     except ValueError:
         return None
+    return CanonicalTextHash(h) if sig_type == 0x01 else _BinaryHash(h)
 
 
 def verify_signature(key: PublicKey, hash_id: int, digest: bytes, sig: Signature) -> int:
@@ -523,7 +577,7 @@ def check_detached_signature(keyring: List[Entity], signed: bytes, sigdata: byte
             if not key.can_sign():          # checked before the suffix is written
                 st = ST_KEY_CANNOT_SIGN
                 continue
-            h.update(sig.hash_suffix)
+            h.raw_update(sig.hash_suffix)
             st = verify_signature(key, sig.hash_id, h.copy().digest(), sig)
             if st == ST_OK:
                 per_packet.append(ST_OK)

@@ -142,6 +142,89 @@ def test_signature_verify_and_with_certificate(gpu_ctx):
         b.close()
 
 
+def test_text_mode_signatures(gpu_ctx, exit_mode):
+    """Signature type 0x01: the signed data is hashed in canonical-text form (openpgp.NewCanonicalTextHash -- k_hash_mid_text),
+    per item and hash only where a signature asks.  The gpg-judged vectors (every hash, RSA and DSA, the rewriter's corner
+    cases), then quorum signatures that mix text-mode and binary packets over one payload, random payloads full of CR / LF,
+    and payload lengths around the block boundaries -- verdicts, exit counts and statuses are the oracle's."""
+    import hashlib
+    import json
+    import os
+    import struct
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    tv = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_text_vectors.json")))
+    ring = pgp.read_entities(bytes.fromhex(tv["pubring"]))
+    kr = col.Keyring(keyring=ring)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    tbs_l = [bytes.fromhex(v["payload"]) for v in tv["vectors"]]
+    sig_l = [bytes.fromhex(v["sig"]) for v in tv["vectors"]]
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(sig_l)
+    err = gpu_ctx.signature_verify(tb, to, sb, so)
+    assert not gpu_ctx.last_fenced.any()
+    for v, e, t, s_ in zip(tv["vectors"], err, tbs_l, sig_l):
+        want = col.signature_verify(kr, t, SignaturePacket(1, 0, False, s_, None)) is None
+        assert (e == 0) == want, v["name"]
+        if v["strict"]:
+            assert (e == 0) == v["gpg_good"], v["name"]
+    # quorum signatures mixing text-mode and binary packets; payloads with CR / LF everywhere and of every length class
+    cl = cb.make_cluster(7, dsa_fraction=0.3)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    rng = np.random.default_rng(17)
+    from corpus.keys import DRBG
+    srng = DRBG("text-mode-gpu")
+    names = {8: "sha256", 10: "sha512", 2: "sha1", 9: "sha384", 11: "sha224"}
+
+    def text_sig(kp, payload, hash_id):
+        hashed = b"\x05\x02" + struct.pack(">I", cb.CREATION_TIME) + bytes([9, 16]) + struct.pack(">Q", kp.key_id)
+        prefix = bytes([4, 1, kp.algo, hash_id]) + struct.pack(">H", len(hashed)) + hashed
+        h = pgp.CanonicalTextHash(hashlib.new(names[hash_id]))
+        h.update(payload)
+        h.raw_update(cb.hash_suffix(prefix))
+        digest = h.digest()
+        if kp.algo == cb.PK_RSA:
+            t = pgp.HASH_PREFIXES[names[hash_id]] + digest
+            em = int.from_bytes(b"\x00\x01" + b"\xff" * (256 - len(t) - 3) + b"\x00" + t, "big")
+            mp = cb.go_mpi_bytes(kp.rsa_private(em).to_bytes(256, "big"))
+        else:
+            r, s2 = cb._dsa_sign(kp, digest, srng)
+            mp = b"".join(cb.go_mpi_bytes(v.to_bytes((v.bit_length() + 7) // 8, "big")) for v in (r, s2))
+        body = prefix + b"\x00\x00" + digest[:2] + mp
+        return cb._hdr(2, len(body)) + body
+    tbs_l, ss_l = [], []
+    alphabet = np.frombuffer(b"\r\n\r\nab \t", dtype=np.uint8)
+    for i, ln in enumerate([0, 1, 2, 61, 62, 63, 64, 65, 126, 127, 128, 129, 191, 200, 1000, 5000] + [int(x) for x in rng.integers(0, 400, 16)]):
+        payload = alphabet[rng.integers(0, len(alphabet), ln)].tobytes()
+        pkts = []
+        for k, kp in enumerate(cl.replicas):
+            mode = (i + k) % 4
+            if mode == 0:
+                pkts.append(cb.detach_sign(kp, payload, srng))                       # binary
+            else:
+                pkts.append(text_sig(kp, payload, (8, 10, 2, 9, 11)[(i + k) % 5]))
+        if i % 5 == 4:
+            payload = payload + b"\n"                                               # signed bytes differ: nothing verifies
+        tbs_l.append(payload); ss_l.append(b"".join(pkts))
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    assert not gpu_ctx.last_fenced.any()
+    n_ok = 0
+    for i in range(len(tbs_l)):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(Type=1, Data=ss_l[i]), q)
+        assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (i, len(tbs_l[i]), err[i], nver[i], r.err, r.statuses)
+        got = list(st[st_item == i])
+        assert got[:len(r.statuses)] == r.statuses, (i, got, r.statuses)
+        n_ok += r.err is None
+    assert 10 < n_ok < len(tbs_l)
+    gpu_ctx.quorum_destroy(qh)
+
+
 def test_signers_parse_only(gpu_ctx):
     """PGPSignature.Signers / PGPCollectiveSignature.Signers (crypto_pgp.go:373-390, 517-519)."""
     from oracle import collective as col
@@ -295,7 +378,7 @@ def test_negative_gpg_vectors_on_gpu(gpu_ctx):
     for v, e, f, s in zip(neg["vectors"], err, gpu_ctx.last_fenced, sigs):
         want = col.signature_verify(kr, payload, SignaturePacket(1, 0, False, s, None)) is None
         assert (e == 0) == want, v["name"]
-        assert f == (1 if v["name"] == "text-mode" else 0), v["name"]
+        assert f == 0, v["name"]          # (text mode is hashed natively since round 3: nothing among these is fenced)
         if v["strict"]:
             assert (e == 0) == v["gpg_good"], v["name"]
 
@@ -800,7 +883,6 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
     fenced_cases = {
         "partial-length": partial,
         "indeterminate-length": indeterminate,
-        "text-mode": cb._hdr(2, len(v4(sig_type=1))) + v4(sig_type=1),
         "md5": cb._hdr(2, len(v4(hash_id=1, h=hashlib.md5))) + v4(hash_id=1, h=hashlib.md5),
         "value-beyond-R": cb._hdr(2, len(v4(value=kp.rsa_private(5) + (1 << 2200)))) + v4(value=kp.rsa_private(5) + (1 << 2200)),
         "nesting-3": cb._hdr(2, len(deep)) + deep,
@@ -822,6 +904,8 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
         "unknown-packet-type": bytes([0xC0 | 60, 3]) + b"abc" + b"".join(good),
         "empty": b"",
         "non-0x00-type": cb._hdr(2, len(v4(sig_type=2))) + v4(sig_type=2),          # hashForSignature refuses it in the reference too
+        # text mode over a payload without line ends: the canonical form IS the payload, the signature verifies
+        "text-mode": cb._hdr(2, len(v4(sig_type=1))) + v4(sig_type=1) + good[1] + good[2] + good[3],
         "truncated": good[0][:100],
     }
     names = list(fenced_cases) + list(plain_cases)
@@ -844,28 +928,76 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
     gpu_ctx.quorum_destroy(qh)
 
 
-def test_two_keys_under_one_key_id(gpu_ctx):
-    """Key ids are 64 bits of a SHA-1: two different keys can be made to share one.  The keyring must load (round 1 refused
-    it, which let any peer that registers such a pair switch the verifier off); signatures naming the id are checked against
-    the first candidate and their items are fenced, everything else is untouched."""
-    cl = cb.make_cluster(4)
-    kr = H.oracle_keyring(cl)
-    keys = H.abi_keys(kr)
-    twin = dict(keys[1])
-    twin["key_id"] = keys[0]["key_id"]                 # replica 1's key material under replica 0's id, after the original
-    twin["entity_id"] = keys[1]["entity_id"]
-    gpu_ctx.keyring_set(keys + [twin])
-    qh = gpu_ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+def test_two_keys_under_one_key_id(gpu_ctx, exit_mode):
+    """Key ids are 64 bits of a SHA-1: two different keys can be made to share one.  The reference asks every candidate in
+    keyring order -- each through the SAME hash object, into which every VerifySignature that gets that far writes the hash
+    suffix again -- and returns the first success or the last error.  So: the first candidate that can sign is the only one
+    that can succeed; a genuine signer listed behind a twin that can sign is REFUSED (hash tag mismatch); a candidate that
+    cannot sign is passed over without harm.  Verdicts, exit counts and per-packet statuses are the oracle's; nothing is
+    fenced any more (round 2 fenced every item that named such an id)."""
+    import copy
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(5, dsa_fraction=0.0)
+    cld = cb.make_cluster(3, dsa_fraction=1.0, seed=cb.MASTER_SEED + 7)
+    base = H.oracle_keyring(cl).get_keyring()
+    id0 = cl.replicas[0].key_id
+
+    def twin_of(ent, algo=None):
+        t = copy.deepcopy(ent)
+        t.primary = copy.deepcopy(ent.primary)
+        t.primary.key_id = id0                       # another key's material under replica 0's id
+        if algo is not None:
+            t.primary.pk_algo = algo
+        return t
     tbs = b"collision"
     s = [cb.detach_sign(r, tbs) for r in cl.replicas]
-    ss_l = [s[0] + s[1] + s[2], s[1] + s[2] + s[3], s[3] + s[2] + s[0]]
-    tb, to = _cat([tbs] * 3)
-    sb, so = _cat(ss_l)
-    err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
-    assert list(gpu_ctx.last_fenced) == [1, 0, 1] and err[1] == 0 and nver[1] == 3
-    assert err[0] == 0 and err[2] == 0                  # the first candidate is the genuine key: it verifies
-    gpu_ctx.quorum_destroy(qh)
-    gpu_ctx.keyring_set(keys)
+    streams = [s[0] + s[1] + s[2] + s[3], s[1] + s[2] + s[3] + s[4], s[3] + s[0] + s[2] + s[1], s[0], s[4] + s[0] + s[0]]
+    # a packet whose 16-bit hash tag is that of the digest with the suffix written TWICE: the genuine key refuses it (tag), the
+    # twin behind it gets past the tag and fails on the algorithm (DSA twin) or on the arithmetic (RSA twin)
+    import hashlib
+    pk = bytearray(s[0])
+    hdr = 3 if pk[1] >= 192 else 2
+    hl = (pk[hdr + 4] << 8) | pk[hdr + 5]
+    suffix = cb.hash_suffix(bytes(pk[hdr:hdr + 6 + hl]))
+    pk[hdr + 6 + hl + 2:hdr + 6 + hl + 4] = hashlib.sha256(tbs + suffix + suffix).digest()[:2]
+    streams.append(bytes(pk) + s[1] + s[2] + s[3])
+    dsa_ent = pgp.read_entities(cld.replicas[0].entity)[0]
+    scenarios = {
+        "twin behind the genuine key": base + [twin_of(base[1])],
+        "DSA twin behind the genuine key": base + [twin_of(dsa_ent)],
+        "twin ahead of the genuine key": [twin_of(base[1])] + base,
+        "encrypt-only twin ahead": [twin_of(base[2], algo=2)] + base,
+        "DSA twin ahead": [twin_of(dsa_ent)] + base,
+        "two twins around the genuine key": [twin_of(base[2], algo=2)] + base[:1] + [twin_of(base[3])] + base[1:],
+        "only keys that cannot sign": [twin_of(base[2], algo=2), twin_of(base[3], algo=2)] + base[1:],
+    }
+    q = H.clique_quorum(cl)
+    seen = set()
+    for name, ring in scenarios.items():
+        kr = col.Keyring(keyring=ring)
+        gpu_ctx.keyring_set(H.abi_keys(kr))
+        qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+        tb, to = _cat([tbs] * len(streams))
+        sb, so = _cat(streams)
+        err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+        st, st_item = gpu_ctx.last_statuses()
+        assert not gpu_ctx.last_fenced.any(), name
+        for i, data in enumerate(streams):
+            r = col.collective_verify(kr, tbs, SignaturePacket(Type=1, Data=data), q)
+            assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (name, i, err[i], nver[i], r.err, r.verified)
+            got = list(st[st_item == i])
+            assert got[:len(r.statuses)] == r.statuses, (name, i, got, r.statuses)
+            seen.update(r.statuses)
+        # Signature.Verify over the same rings (every packet must verify: the last error decides)
+        sig_err = gpu_ctx.signature_verify(tb, to, sb, so)
+        for i, data in enumerate(streams):
+            want = col.signature_verify(kr, tbs, SignaturePacket(1, 0, False, data, None))
+            assert (sig_err[i] == 0) == (want is None), (name, i)
+        gpu_ctx.quorum_destroy(qh)
+    assert {0, 6, 7, 8, 9} <= seen      # ok, hash tag, algorithm mismatch, bad signature, key cannot sign: all were produced
+    gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
 
 
 def test_batcher_fails_closed(gpu_ctx):
