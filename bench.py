@@ -74,6 +74,7 @@ def parse_args(argv=None):
                     "(2 overlaps walk/parse and compare/tally of neighbouring steps with the modexp; then a launch's duration no "
                     "longer measures the kernel, so the default 1 keeps the roofline line meaningful)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serving", action="store_true", help="cfg 2: skip the one-Verify-per-call leg (tools/serving/batcher_load.c)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="after the timed region: keep running the same step, untimed for "
                     "the headline, for about this long (reported as `sustained`); an activity sampler with a period of seconds "
                     "otherwise never sees a timed region of tens of milliseconds.  0 disables")
@@ -472,6 +473,56 @@ def load_or_make(args, tag, rank, make):
     return d
 
 
+def serving_leg(args, cl, z, want_ok, n_writes=4096, threads="1,64,256", lanes=0):
+    """One CollectiveSignature.Verify per CALL from many caller threads through the micro-batcher -- the shape the reference
+    actually has (one goroutine per request, transport/http/http.go:85,143 -> protocol/server.go:562-620) -- measured by the
+    plain-C load generator tools/serving/batcher_load.c in its own process, on the first writes of this run's batch.  Reported
+    beside the headline (resident batches), never as `value`.  None when there is no C compiler or the tool fails."""
+    import shutil
+    import struct
+    import tempfile
+    if shutil.which("gcc") is None:
+        return None
+    from corpus import build as cb
+    n = min(n_writes, len(z["to"]) - 1)
+    tmp = tempfile.mkdtemp(prefix="bftkv_serving")
+    try:
+        exe = os.path.join(tmp, "batcher_load")
+        lib_dir = os.path.join(ROOT, "bftkv_amd")
+        cc = subprocess.run(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "serving", "batcher_load.c"),
+                             "-L", lib_dir, "-lbftkv_gpu", "-lpthread", "-Wl,-rpath," + lib_dir, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if cc.returncode != 0:
+            return {"error": "gcc: " + cc.stderr.decode(errors="replace")[-300:]}
+        f, mn, thr, suff = cb.quorum_numbers(cl.n)
+        path = os.path.join(tmp, "load.bin")
+        with open(path, "wb") as fh:
+            fh.write(struct.pack("<I", cl.n))
+            for r in cl.replicas:
+                fh.write(struct.pack("<Q", r.key_id) + r.n.to_bytes(256, "big") + r.e.to_bytes(4, "big"))
+            fh.write(struct.pack("<iiiiI", f, mn, thr, suff, n))
+            fh.write(z["to"][:n + 1].astype("<u8").tobytes() + z["so"][:n + 1].astype("<u8").tobytes())
+            fh.write(z["tb"][:int(z["to"][n])].tobytes() + z["sb"][:int(z["so"][n])].tobytes())
+            fh.write(want_ok[:n].astype(np.uint8).tobytes())
+        r = subprocess.run([exe, path, "256", "0", str(lanes), threads], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        if r.returncode != 0:
+            return {"error": "batcher_load rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        sigs_per_write = float(z["so"][n]) / n / 287.0
+        runs = [{"caller_threads": x["threads"], "verify_calls_per_s": x["verify_calls_per_s"],
+                 "signatures_per_s": x["verify_calls_per_s"] * float(np.mean(z["sig_count"][:n])) if "sig_count" in z else None,
+                 "latency_ms": x["latency_ms"], "wrong_answers": x["wrong"], "device_calls": x["device_calls"],
+                 "cpu_cores_busy": x["cpu_cores_busy"]} for x in d["runs"]]
+        return {"what": "one bftkv_gpu_batcher_collective_verify per call (one write, ~%.0f signature packets, %.1f KB payload) from N caller "
+                        "threads, plain-C load generator in its own process, 2 s per point after 0.7 s of warm-up; every answer checked "
+                        "against the corpus' constructed verdict" % (sigs_per_write, float(z["to"][n]) / n / 1e3),
+                "lanes": d["lanes"], "max_items_per_batch": d["max_items"], "writes": n, "runs": runs,
+                "usable_host_cores": effective_cores(), "tool": "tools/serving/batcher_load.c"}
+    except Exception as e:      # noqa: BLE001  (a side measurement must not take the bench line down)
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def write_corpus_arrays(c):
     return {"tb": c.tbss_blob, "to": c.tbss_off, "sb": c.ss_blob, "so": c.ss_off, "n_sigs": np.array(c.n_sigs),
             "expected_valid": c.expected_valid, "sig_count": c.sig_count}
@@ -574,6 +625,8 @@ def bench_cfg2(args, D):
             out["host_buffers"] = {"ms_per_step": min(hb) * 1e3, "verifies_per_sec": n_sigs / min(hb),
                                    "bytes_over_pcie": int(z["to"][-1]) + int(z["so"][-1]) + 16 * items,
                                    "note": "pageable host memory in, verdicts out; best of 3"}
+        if D.world == 1 and not args.no_serving:
+            out["serving"] = serving_leg(args, cl, z, want_ok)
         if D.world == 1 and not args.no_cpu_baseline:
             cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"])
             out["cpu_baseline"] = {

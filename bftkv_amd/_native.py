@@ -44,7 +44,7 @@ EXPORTS = [
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
-    "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small",
+    "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy",
 ]
 
 _lib = None
@@ -68,6 +68,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_error_string.restype = C.c_char_p
     lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
     lib.bftkv_gpu_set_dsa_window_bits.argtypes = [vp, u32]
+    lib.bftkv_gpu_set_hash_policy.argtypes = [vp, C.c_int, C.c_int]
     lib.bftkv_gpu_message_verify.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
@@ -148,6 +149,10 @@ class Context:
         if self.h:
             self.lib.bftkv_gpu_destroy(self.h)
             self.h = None
+
+    def set_hash_policy(self, hash_id: int, state: int):
+        """bftkv_gpu_set_hash_policy: MD5 (1) / RIPEMD-160 (3): 0 unknown (fenced), 1 available, 2 not available."""
+        self._check(self.lib.bftkv_gpu_set_hash_policy(self.h, hash_id, state), "set_hash_policy")
 
     def fork(self) -> "Context":
         """bftkv_gpu_ctx_fork: a context with its own streams and arena over this one's key table and quorums

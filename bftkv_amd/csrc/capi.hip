@@ -19,6 +19,7 @@
 #include <memory>
 #include <functional>
 #include <map>
+#include <set>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -61,6 +62,8 @@ struct KeyEntry {
   int cert_group = -1;          // certificates: entries of one certificate share a group
   uint32_t entity_index = 0;   // filled by upload_key_table
   std::string cert_digest;     // certificates: identity of the certificate bytes
+  uint64_t last_used = 0;      // certificates: the compound call (ctx->cert_clock) that last named this certificate
+  bool dsa_unslotted = false;  // certificates: a DSA key that found no table slot at the last upload (its signatures are fenced)
 };
 
 struct QuorumHost {
@@ -105,6 +108,10 @@ struct bftkv_gpu_ctx {
   DevBuf dsa_comb;
   uint32_t dsa_wbits = 8, dsa_wbits_pinned = 0;
   std::map<std::string, uint32_t> dsa_comb_slot;   // key material -> slot in dsa_comb
+  std::set<std::string> dsa_cert_materials;        // ... those of certificate-only keys (bounded, recycled: sync_dsa_tables)
+  uint64_t ring_epoch = 0, dsa_ring_epoch_seen = ~0ull;   // bftkv_gpu_keyring_set calls / the one the window width was chosen for
+  uint32_t dsa_wbits_want = 0;
+  uint64_t cert_clock = 0;     // compound calls over request certificates (host_capi.inc cert_cache_gc)
   KeyTableDev kt{};
 
   std::vector<QuorumHost> quorums;
@@ -331,7 +338,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // items with more events than the row holds take the sequential fill pass
   const uint32_t walk_cap = ss_len ? (uint32_t)std::min<uint64_t>(WALK_CAP_MAX, std::max<uint64_t>(WALK_CAP_MIN, ss_len / n_items / 48)) : 96u;
   HIPCHK(c, c->walk_scratch.ensure(sizeof(WalkEnt) * walk_cap * (size_t)n_items + 16));
-  HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 midstates
+  HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * N_MID32 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 | MD5 | RIPEMD-160 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
   HIPCHK(c, c->pk_count.ensure(96));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256,
@@ -340,10 +347,10 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (plan_q) HIPCHK(c, c->plan_cut.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
   TextDev txt{nullptr, nullptr, nullptr, nullptr};
   if (!d_mid_in) {      // (a midstate-only call cannot hash text-mode signatures: their items come back marked for the ordinary path)
-    HIPCHK(c, c->txt_mid32.ensure(sizeof(uint32_t) * 8 * 3 * (size_t)n_items + 16));
-    HIPCHK(c, c->txt_mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));
-    HIPCHK(c, c->txt_tail.ensure((size_t)128 * 5 * n_items + 16));
-    HIPCHK(c, c->txt_len.ensure(sizeof(uint64_t) * 5 * (size_t)n_items + 16));
+    HIPCHK(c, c->txt_mid32.ensure(sizeof(uint32_t) * 8 * N_MID32 * (size_t)n_items + 16));
+    HIPCHK(c, c->txt_mid64.ensure(sizeof(uint64_t) * 8 * N_MID64 * (size_t)n_items + 16));
+    HIPCHK(c, c->txt_tail.ensure((size_t)128 * N_HASHES * n_items + 16));
+    HIPCHK(c, c->txt_len.ensure(sizeof(uint64_t) * N_HASHES * (size_t)n_items + 16));
     txt = TextDev{c->txt_mid32.as<uint32_t>(), c->txt_mid64.as<uint64_t>(), c->txt_tail.as<uint8_t>(), c->txt_len.as<uint64_t>()};
   }
   HIPCHK(c, rec(0, s));
@@ -447,9 +454,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     if (total) {
       // other hashes: a no-op grid unless some signature asked for them
       if (!d_mid_in) {
-        hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, 4), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
+        hipLaunchKernelGGL(k_hash_mid_other, dim3((n_items + 63) / 64, N_HASHES - 1), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items,
                            c->hash_mask.as<uint32_t>(), c->mid.as<uint32_t>(), c->mid64.as<uint64_t>());
-        hipLaunchKernelGGL(k_hash_mid_text, dim3((n_items + 63) / 64, 5), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->hash_mask.as<uint32_t>(), txt);
+        hipLaunchKernelGGL(k_hash_mid_text, dim3((n_items + 63) / 64, N_HASHES), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->hash_mask.as<uint32_t>(), txt);
       }
       hipLaunchKernelGGL(k_digest_sha256, dim3((total + 255) / 256), dim3(256), 0, sh, d_tbs, d_tbs_off, d_ss,
                          d_mid_in ? d_mid_in : c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
@@ -626,18 +633,54 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
 // Fixed-base tables for the DSA rows of the table being uploaded.  A table depends only on (p, g, y), so it is
 // keyed by the row's key material and survives re-uploads (certificate batches re-upload the table per request).
 // Window width 8 while the slots fit 4096 keys (20 GB); a larger DSA population restarts the cache at width 4.
+// Certificate-only DSA keys (they arrive inside unauthenticated requests) get a bounded number of table slots -- 8 at the
+// 16-bit width (637 MB and a 2 ms build each), 1024 below -- recycled among themselves; a certificate key beyond that is marked
+// unsupported for this upload (its signatures are fenced: the reference path decides).  The window width follows the NODE
+// keyring's DSA population alone and is re-evaluated only when that keyring changes, so neither a flood of certificates nor
+// jitter in the free-memory reading can force the node keys' tables to be rebuilt.  `bits_changed`: rows were marked.
 int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, const std::vector<uint8_t>& algo,
-                    const std::vector<uint32_t>& bits) {
+                    std::vector<uint32_t>& bits, bool* bits_changed) {
   std::vector<uint32_t> slot(rows.size() ? rows.size() : 1, 0xFFFFFFFFu);
+  *bits_changed = false;
   auto assign = [&](std::vector<uint32_t>& new_slots, std::vector<uint32_t>& new_rows) {
     new_slots.clear(); new_rows.clear();
+    const size_t cert_cap = c->dsa_wbits == 16 ? 8 : 1024;
     for (size_t i = 0; i < rows.size(); ++i) {
       if (algo[i] != PK_DSA || bits[i] == 0xFFFFFFFFu) continue;
       auto it = c->dsa_comb_slot.find(rows[i]->material);
       if (it == c->dsa_comb_slot.end()) {
-        it = c->dsa_comb_slot.emplace(rows[i]->material, (uint32_t)c->dsa_comb_slot.size()).first;
+        uint32_t id = (uint32_t)c->dsa_comb_slot.size();
+        if (rows[i]->cert_only && c->dsa_cert_materials.size() >= cert_cap) {
+          // recycle the slot of a certificate key this upload does not hold
+          // ... a slot whose key is not in the table any more, or whose certificate the current compound call does not name
+          std::string victim;
+          if (rows[i]->last_used == c->cert_clock) {
+            for (const std::string& m : c->dsa_cert_materials) {
+              bool in_use = false;
+              for (size_t j = 0; j < rows.size() && !in_use; ++j)
+                in_use = algo[j] == PK_DSA && rows[j]->material == m && (!rows[j]->cert_only || rows[j]->last_used == c->cert_clock);
+              if (!in_use) { victim = m; break; }
+            }
+          }
+          if (victim.empty()) {
+            bits[i] = 0xFFFFFFFFu; *bits_changed = true;
+            const_cast<KeyEntry*>(rows[i])->dsa_unslotted = true;
+            continue;
+          }
+          for (size_t j = 0; j < rows.size(); ++j)       // whoever held the slot is fenced from now on
+            if (algo[j] == PK_DSA && rows[j]->material == victim) {
+              bits[j] = 0xFFFFFFFFu; slot[j] = 0xFFFFFFFFu; *bits_changed = true;
+              const_cast<KeyEntry*>(rows[j])->dsa_unslotted = true;
+            }
+          id = c->dsa_comb_slot[victim];
+          c->dsa_comb_slot.erase(victim);
+          c->dsa_cert_materials.erase(victim);
+        }
+        it = c->dsa_comb_slot.emplace(rows[i]->material, id).first;
+        if (rows[i]->cert_only) c->dsa_cert_materials.insert(rows[i]->material);
+        const_cast<KeyEntry*>(rows[i])->dsa_unslotted = false;
         new_slots.push_back(it->second); new_rows.push_back((uint32_t)i);
-      }
+      } else if (!rows[i]->cert_only) c->dsa_cert_materials.erase(rows[i]->material);      // (a certificate key that joined the node keyring)
       slot[i] = it->second;
     }
   };
@@ -656,13 +699,28 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
     }
     return n_keys > 4096 ? 4u : 8u;
   };
-  const uint32_t want_wbits = policy(c->dsa_comb_slot.size());
+  if (c->dsa_ring_epoch_seen != c->ring_epoch || c->dsa_wbits_want == 0) {      // the node keyring changed (or first upload)
+    size_t ring_dsa = 0;
+    for (size_t i = 0; i < rows.size(); ++i) ring_dsa += algo[i] == PK_DSA && bits[i] != 0xFFFFFFFFu && !rows[i]->cert_only;
+    c->dsa_wbits_want = policy(ring_dsa);
+    c->dsa_ring_epoch_seen = c->ring_epoch;
+  }
+  const uint32_t want_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : c->dsa_wbits_want;
   bool restart = false;
   if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256) {   // width change, or mostly stale: restart
     restart = true;
     c->dsa_comb_slot.clear();
-    c->dsa_wbits = policy(live);
+    c->dsa_cert_materials.clear();
+    c->dsa_wbits = want_wbits;
+    for (size_t i = 0; i < rows.size(); ++i) slot[i] = 0xFFFFFFFFu;
     assign(new_slots, new_rows);
+  }
+  if (getenv("BFTKV_DEBUG_DSA")) {
+    size_t n_cert_rows = 0, n_dsa = 0, n_fenced = 0;
+    for (size_t i = 0; i < rows.size(); ++i) { n_cert_rows += rows[i]->cert_only; n_dsa += algo[i] == PK_DSA; n_fenced += algo[i] == PK_DSA && bits[i] == 0xFFFFFFFFu; }
+    fprintf(stderr, "[dsa tables] rows %zu (cert %zu, dsa %zu, dsa without slot %zu) width %u want %u slots %zu cert-slots %zu new %zu restart %d clock %llu\n", rows.size(),
+            n_cert_rows, n_dsa, n_fenced, c->dsa_wbits, want_wbits, c->dsa_comb_slot.size(), c->dsa_cert_materials.size(), new_slots.size(), (int)restart,
+            (unsigned long long)c->cert_clock);
   }
   int rc;
   if ((rc = upload(c, c->k_dsaslot, slot))) return rc;
@@ -674,8 +732,9 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   if (need > c->dsa_comb.cap) {           // grow, keeping the tables already built
     DevBuf bigger;
     HIPCHK(c, bigger.ensure(need + need / 2));
-    const size_t keep = restart ? 0 : per_key * (c->dsa_comb_slot.size() - new_slots.size());
-    if (keep && c->dsa_comb.p && keep <= c->dsa_comb.cap) HIPCHK(c, hipMemcpyAsync(bigger.p, c->dsa_comb.p, keep, hipMemcpyDeviceToDevice, c->stream));
+    // every whole slot the old buffer holds (new and recycled slots are built below, in place)
+    const size_t keep = restart ? 0 : std::min(need, (c->dsa_comb.cap / per_key) * per_key);
+    if (keep && c->dsa_comb.p) HIPCHK(c, hipMemcpyAsync(bigger.p, c->dsa_comb.p, keep, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dsa_comb.release();
     c->dsa_comb = bigger;
@@ -757,7 +816,9 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->kt.r2_limbs = c->k_r2.as<uint32_t>();          // k_dsa_build_comb reads n, R^2, n0inv and the table seeds
   c->kt.n0inv = c->k_n0.as<uint32_t>();
   c->kt.dsa_tab = c->k_dsatab.as<uint32_t>();
-  if ((rc = sync_dsa_tables(c, rows, algo, bits))) return rc;
+  bool bits_changed = false;
+  if ((rc = sync_dsa_tables(c, rows, algo, bits, &bits_changed))) return rc;
+  if (bits_changed && (rc = upload(c, c->k_bits, bits))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
   for (size_t i = 0; i < algo.size(); ++i) {
@@ -942,6 +1003,17 @@ int bftkv_gpu_set_early_exit(bftkv_gpu_ctx* c, int on) {
   return 0;
 }
 
+int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* c, int hash_id, int state) {
+  if (!c || (hash_id != HASH_MD5 && hash_id != HASH_RIPEMD160) || state < 0 || state > 2) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "set on the root context; its forks follow");
+  KtWrite kw(c);
+  const int sh = hash_id == HASH_MD5 ? 0 : 2;
+  c->kt.hash_policy = (c->kt.hash_policy & ~(3u << sh)) | ((uint32_t)state << sh);
+  ++c->keyring_gen;       // the forks copy the key-table descriptor when the generation moves
+  return 0;
+}
+
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && bits != 4 && bits != 8 && bits != 16)) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
@@ -974,6 +1046,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   c->ring = std::move(ring);
   c->certs.clear();
   c->cert_valid.clear();
+  ++c->ring_epoch;
   return upload_key_table(c);
 }
 

@@ -77,6 +77,7 @@ struct KeyTableDev {
   const uint32_t* dsa_slot;   // [n_keys] table slot of a DSA key (0xFFFFFFFF otherwise)
   const uint32_t* dsa_comb;
   uint32_t dsa_wbits;         // 8 (4.96 MB per key) or 4 (0.58 MB per key, very large DSA keyrings)
+  uint32_t hash_policy;       // bits 0-1 MD5, bits 2-3 RIPEMD-160: 0 unknown (fenced), 1 available, 2 not available (bftkv_gpu_set_hash_policy)
 };
 constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits) {
   return 2ull * (256u / wbits) * ((1u << wbits) - 1u) * 76u;
@@ -98,19 +99,19 @@ constexpr uint8_t KEYF_CERT_CHECK_ONLY = 16;
 // another, different key of the keyring carries the same 64-bit key id: the reference tries every candidate (the second one
 // against a hash that has absorbed the suffix twice); the device takes the first and raises the item's fence flag
 constexpr uint8_t KEYF_AMBIGUOUS = 32;
-// per-item word item_hash_mask: bits 1..4 = midstates wanted besides SHA-256, bits 8..12 = midstates wanted over the
-// CANONICAL TEXT form of the payload (text-mode signatures; SHA-256, 224, SHA-1, 512, 384), bit 31 = the item met a fenced
-// input shape
+// per-item word item_hash_mask: bits 1..6 = midstates wanted besides SHA-256 (hash_info().idx: SHA-224, SHA-1, SHA-512,
+// SHA-384, MD5, RIPEMD-160), bits 8..14 = midstates wanted over the CANONICAL TEXT form of the payload (text-mode
+// signatures; bit 8 + idx, SHA-256 included), bit 31 = the item met a fenced input shape
 constexpr uint32_t ITEM_FENCED = 0x80000000u;
-constexpr uint32_t ITEM_TEXT_SHIFT = 8, ITEM_NEEDS_PAYLOAD = 0x1F1Eu;   // NEEDS_PAYLOAD: any hashing a midstate-only call cannot do
+constexpr uint32_t ITEM_TEXT_SHIFT = 8, ITEM_NEEDS_PAYLOAD = 0x7F7Eu;   // NEEDS_PAYLOAD: any hashing a midstate-only call cannot do
 
 // Text-mode (signature type 0x01) hashing state per (hash, item): openpgp.NewCanonicalTextHash rewrites the line endings of
 // the signed data, so these signatures hash a different byte stream than the binary ones of the same item.
 struct TextDev {
-  uint32_t* mid32;      // [3][n_items][8]   SHA-256 | SHA-224 | SHA-1 state after the whole blocks of the canonical stream
+  uint32_t* mid32;      // [5][n_items][8]   SHA-256 | SHA-224 | SHA-1 | MD5 | RIPEMD-160 state after the whole blocks of the canonical stream
   uint64_t* mid64;      // [2][n_items][8]   SHA-512 | SHA-384
-  uint8_t* tail;        // [5][n_items][128] the bytes behind the last whole block
-  uint64_t* len;        // [5][n_items]      length of the canonical stream
+  uint8_t* tail;        // [7][n_items][128] the bytes behind the last whole block, by hash_info().idx
+  uint64_t* len;        // [7][n_items]      length of the canonical stream
 };
 
 // Quorum (wotq) on the device: up to MAX_QC cliques, membership as a byte table over entities.

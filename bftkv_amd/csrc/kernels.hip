@@ -530,7 +530,14 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
       // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
       else if (!msg_slot && !sig_class_ok(cls, rec.sig_type) && !(cls == 0 && rec.sig_type == 0x01)) st = ST_HASH_UNSUPPORTED;
-      else if (hi.family == 0) { st = ST_HASH_UNSUPPORTED; fence = true; }                      // MD5 / RIPEMD-160
+      else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;                                          // no such hash id (parse refuses them earlier)
+      // MD5 / RIPEMD-160: hashForSignature fails with "hash not available" unless the binary links them -- a property of
+      // the deployment this library cannot see.  Policy per context (bftkv_gpu_set_hash_policy): 0 unknown => fenced,
+      // 1 available => verified like any other hash, 2 not available => the reference's error, no fence.
+      else if (hi.le && ((kt.hash_policy >> (hi.idx == 5 ? 0 : 2)) & 3u) != 1u) {
+        st = ST_HASH_UNSUPPORTED;
+        fence = ((kt.hash_policy >> (hi.idx == 5 ? 0 : 2)) & 3u) == 0u;
+      }
       else if (!(kt.flags[slot] & KEYF_CAN_SIGN)) st = ST_KEY_CANNOT_SIGN;  // checked before the hash is finished
       else {
         // everything below is only reached when the hash tag matches (k_digest decides)
@@ -538,9 +545,9 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
         if (!msg_slot && cls == 0 && rec.sig_type == 0x01) {
           // text mode: the signed data is hashed in canonical form (k_hash_mid_text), per item and hash on demand
           rec.flags |= SIGF_TEXT;
-          atomicOr(&item_hash_mask[rec.item], 1u << (ITEM_TEXT_SHIFT + (hi.family == 64 ? 3 : 0) + hi.slot));
+          atomicOr(&item_hash_mask[rec.item], 1u << (ITEM_TEXT_SHIFT + hi.idx));
           pk_count[4] = 1u;
-        } else if (rec.hash_id != HASH_SHA256) { atomicOr(&item_hash_mask[rec.item], 1u << ((hi.family == 64 ? 3 : 0) + hi.slot)); pk_count[4] = 1u; }
+        } else if (rec.hash_id != HASH_SHA256) { atomicOr(&item_hash_mask[rec.item], 1u << hi.idx); pk_count[4] = 1u; }
         if (kt.pk_algo[slot] != rec.pk_algo) rec.after_tag = ST_ALGO_MISMATCH;
         else if ((rec.pk_algo == PK_RSA || rec.pk_algo == PK_RSA_SIGN_ONLY) && sig_hash_id != rec.hash_id)
           rec.after_tag = ST_BAD_SIG;   // rsa.VerifyPKCS1v15(sig.Hash, digest of another algorithm): length mismatch
@@ -747,25 +754,33 @@ __global__ void __launch_bounds__(64) k_sha256_mid(const uint8_t* __restrict__ t
 }
 
 // Midstates of the other hashes, only for the items whose signatures ask for them
-// (item_hash_mask bits: 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384).  Thread per (algorithm, item).
+// (item_hash_mask bits: 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384, 5 MD5, 6 RIPEMD-160).  Thread per (algorithm, item).
+__device__ __forceinline__ void load_block_le(const uint8_t* p, uint32_t (&w)[16]) {
+  uint32_t t[17];
+  load_block_raw(p, t);
+  const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_alignbyte(t[i + 1], t[i], mis);
+}
 __global__ void __launch_bounds__(64) k_hash_mid_other(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                        uint32_t n_items, const uint32_t* __restrict__ item_hash_mask,
-                                                       uint32_t* __restrict__ mid32 /*[3][n][8]*/, uint64_t* __restrict__ mid64 /*[2][n][8]*/) {
+                                                       uint32_t* __restrict__ mid32 /*[5][n][8]*/, uint64_t* __restrict__ mid64 /*[2][n][8]*/) {
   const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t which = blockIdx.y;   // 0 SHA-224, 1 SHA-1, 2 SHA-512, 3 SHA-384
+  const uint32_t which = blockIdx.y;   // 0 SHA-224, 1 SHA-1, 2 SHA-512, 3 SHA-384, 4 MD5, 5 RIPEMD-160  (= hash_info().idx - 1)
   if (item >= n_items) return;
   if (!((item_hash_mask[item] >> (which + 1)) & 1u)) return;
   const uint8_t* p = tbs_blob + tbs_off[item];
   const uint64_t len = tbs_off[item + 1] - tbs_off[item];
-  if (which < 2) {
+  if (which < 2 || which >= 4) {
     uint32_t s[8];
-    if (which == 0) sha224_init(s); else sha1_init(s);
+    if (which == 0) sha224_init(s); else if (which == 1) sha1_init(s); else if (which == 4) md5_init(s); else ripemd160_init(s);
     for (uint64_t blk = 0; blk < (len >> 6); ++blk) {
       uint32_t w[16];
-      load_block_be(p + blk * 64, w);
-      if (which == 0) sha256_compress(s, w); else sha1_compress(s, w);
+      if (which >= 4) { load_block_le(p + blk * 64, w); if (which == 4) md5_compress(s, w); else ripemd160_compress(s, w); }
+      else { load_block_be(p + blk * 64, w); if (which == 0) sha256_compress(s, w); else sha1_compress(s, w); }
     }
-    uint32_t* o = mid32 + ((uint64_t)(which + 1) * n_items + item) * 8;
+    const uint32_t slot32 = which < 2 ? which + 1 : which - 1;      // 1 SHA-224, 2 SHA-1, 3 MD5, 4 RIPEMD-160
+    uint32_t* o = mid32 + ((uint64_t)slot32 * n_items + item) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = s[i];
   } else {
@@ -793,16 +808,17 @@ __global__ void __launch_bounds__(64) k_hash_mid_other(const uint8_t* __restrict
 __global__ void __launch_bounds__(64) k_hash_mid_text(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                       uint32_t n_items, const uint32_t* __restrict__ item_hash_mask, TextDev txt) {
   const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t which = blockIdx.y;   // 0 SHA-256, 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384
+  const uint32_t which = blockIdx.y;   // hash_info().idx: 0 SHA-256, 1 SHA-224, 2 SHA-1, 3 SHA-512, 4 SHA-384, 5 MD5, 6 RIPEMD-160
   if (item >= n_items) return;
   if (!((item_hash_mask[item] >> (ITEM_TEXT_SHIFT + which)) & 1u)) return;
   const uint8_t* p = tbs_blob + tbs_off[item];
   const uint64_t len = tbs_off[item + 1] - tbs_off[item];
-  const uint32_t B = which < 3 ? 64u : 128u;
+  const bool wide = which == 3 || which == 4;
+  const uint32_t B = wide ? 128u : 64u;
   uint32_t s32[8];
   uint64_t s64[8];
   if (which == 0) sha256_init(s32); else if (which == 1) sha224_init(s32); else if (which == 2) sha1_init(s32);
-  else if (which == 3) sha512_init(s64); else sha384_init(s64);
+  else if (which == 3) sha512_init(s64); else if (which == 4) sha384_init(s64); else if (which == 5) md5_init(s32); else ripemd160_init(s32);
   uint8_t buf[128];
   uint32_t fill = 0;
   uint64_t total = 0;
@@ -810,7 +826,12 @@ __global__ void __launch_bounds__(64) k_hash_mid_text(const uint8_t* __restrict_
     buf[fill++] = c;
     ++total;
     if (fill == B) {
-      if (which < 3) {
+      if (which >= 5) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = (uint32_t)buf[4 * i] | ((uint32_t)buf[4 * i + 1] << 8) | ((uint32_t)buf[4 * i + 2] << 16) | ((uint32_t)buf[4 * i + 3] << 24);
+        if (which == 5) md5_compress(s32, w); else ripemd160_compress(s32, w);
+      } else if (!wide) {
         uint32_t w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)buf[4 * i] << 24) | ((uint32_t)buf[4 * i + 1] << 16) | ((uint32_t)buf[4 * i + 2] << 8) | buf[4 * i + 3];
@@ -839,8 +860,10 @@ __global__ void __launch_bounds__(64) k_hash_mid_text(const uint8_t* __restrict_
     } else { st = 0; put(c); }
   }
   const uint64_t slot = (uint64_t)which * n_items + item;
-  if (which < 3) { for (int i = 0; i < 8; ++i) txt.mid32[slot * 8 + i] = s32[i]; }
-  else { for (int i = 0; i < 8; ++i) txt.mid64[((uint64_t)(which - 3) * n_items + item) * 8 + i] = s64[i]; }
+  if (!wide) {
+    const uint32_t slot32 = which < 3 ? which : which - 2;       // 0 SHA-256, 1 SHA-224, 2 SHA-1, 3 MD5, 4 RIPEMD-160
+    for (int i = 0; i < 8; ++i) txt.mid32[((uint64_t)slot32 * n_items + item) * 8 + i] = s32[i];
+  } else { for (int i = 0; i < 8; ++i) txt.mid64[((uint64_t)(which - 3) * n_items + item) * 8 + i] = s64[i]; }
   for (uint32_t i = 0; i < fill; ++i) txt.tail[slot * 128 + i] = buf[i];
   txt.len[slot] = total;
 }
@@ -898,7 +921,7 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
   // < 64 bytes behind the midstate, tbs_prefix[item] bytes went before them
   const uint64_t seg = tbs_off[rec.item + 1] - tbs_off[rec.item];
   const uint32_t bmask = (OTHERS && hi.family == 64) ? 127u : 63u;
-  const uint64_t tslot = ((uint64_t)((hi.family == 64 ? 3 : 0) + hi.slot)) * n_items + rec.item;     // text-mode state of (hash, item)
+  const uint64_t tslot = (uint64_t)hi.idx * n_items + rec.item;     // text-mode state of (hash, item)
   const uint64_t tlen = text ? txt.len[tslot] : (tbs_prefix ? tbs_prefix[rec.item] + seg : seg);
   TailSrc ts;
   ts.tail_len = text ? (uint32_t)(tlen & bmask) : (tbs_prefix ? (uint32_t)seg : (uint32_t)(tlen & bmask));
@@ -919,19 +942,24 @@ __device__ __forceinline__ void digest_body(const uint8_t* __restrict__ tbs_blob
     const uint32_t* m = (text ? txt.mid32 : mid32) + ((uint64_t)hi.slot * n_items + rec.item) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = m[i];
+    const bool le = OTHERS && hi.le;       // MD5 / RIPEMD-160: little-endian words and length
     for (uint32_t blk = 0; blk < nblk; ++blk) {
       uint32_t w[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         uint32_t j = blk * 64 + i * 4;
-        w[i] = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
+        const uint32_t be = (tail_byte(ts, j) << 24) | (tail_byte(ts, j + 1) << 16) | (tail_byte(ts, j + 2) << 8) | tail_byte(ts, j + 3);
+        w[i] = le ? __builtin_bswap32(be) : be;
       }
-      if (blk == nblk - 1) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
-      if (OTHERS && hi.slot == 2) sha1_compress(s, w); else sha256_compress(s, w);
+      if (blk == nblk - 1) { w[14] = le ? (uint32_t)bits : (uint32_t)(bits >> 32); w[15] = le ? (uint32_t)(bits >> 32) : (uint32_t)bits; }
+      if (OTHERS && hi.slot == 2) sha1_compress(s, w);
+      else if (OTHERS && hi.slot == 3) md5_compress(s, w);
+      else if (OTHERS && hi.slot == 4) ripemd160_compress(s, w);
+      else sha256_compress(s, w);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dg[i] = __builtin_bswap32(s[i]);
-    tag_hi = s[0];
+    for (int i = 0; i < 8; ++i) dg[i] = le ? s[i] : __builtin_bswap32(s[i]);
+    tag_hi = le ? __builtin_bswap32(s[0]) : s[0];
   } else if (OTHERS) {
     const uint32_t nblk = (rem + 17 + 127) >> 7;
     uint64_t s[8];

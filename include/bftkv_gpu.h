@@ -91,6 +91,14 @@ typedef struct {
  * into the shared hash per candidate), so the first success or the LAST candidate's error stands. */
 int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint32_t n_keys);
 
+/* MD5 (hash id 1) and RIPEMD-160 (3): openpgp's hashForSignature answers "hash not available" unless the BINARY links the
+ * package (crypto/md5, golang.org/x/crypto/ripemd160) -- a property of the deployment, not of the input.  state 0 (default):
+ * unknown, signatures naming the hash are fenced (the reference path decides); 1: available, they are hashed and verified
+ * natively like any other; 2: not available, they fail with the reference's unsupported-hash outcome and are NOT fenced.
+ * The Go shim sets it from crypto.MD5.Available() / crypto.RIPEMD160.Available() at start-up.  Transport
+ * messages that name these hashes stay BFTKV_MSG_UNSUPPORTED. */
+int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* ctx, int hash_id, int state);
+
 /* DSA verification (Go crypto/dsa.Verify under packet.PublicKey.VerifySignature) multiplies from per-key
  * fixed-base window tables kept in HBM: 16-bit windows cost 637 MB per key and <= 32 multiplications per
  * signature, 8-bit windows 4.96 MB and <= 64, 4-bit windows 0.58 MB and <= 128.  The default is 16 for up to
@@ -131,7 +139,8 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 
 /* ---- fenced inputs ------------------------------------------------------------------------------------
  * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs":
- * partial / indeterminate body lengths on signature packets, text-mode signatures, MD5 / RIPEMD-160, ECDSA,
+ * partial / indeterminate body lengths on signature packets, MD5 / RIPEMD-160 while their availability in the
+ * reference binary is unknown (bftkv_gpu_set_hash_policy), ECDSA,
  * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
  * shape -- its err_out is then NOT a statement about what the reference would decide, and the caller must run the
  * reference path for that item (the cgo shim calls the wrapped crypto/pgp implementation).  Items with

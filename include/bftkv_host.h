@@ -152,7 +152,9 @@ int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu
  * (classes 0x10 / 0x13 issued by the primary key, over 0x99 len key || 0xB4 len uid) and every subkey binding
  * (0x18, over 0x99 len key || 0x99 len subkey) with the entity's own primary key.  valid_out[e] = 1 iff the entity
  * has a signing-capable primary key, at least one validly self-signed identity, no invalid self-signature and a valid
- * binding for every subkey.  (The embedded cross-signature of signing subkeys is not checked: fenced.) */
+ * binding for every subkey; valid_out[e] = 2 when one of its checks met a fenced shape (e.g. a DSA certificate key beyond
+ * the bounded table slots of certificate keys): no verdict, nothing is remembered about the certificate.  (The embedded
+ * cross-signature of signing subkeys is not checked: fenced.) */
 int bftkv_host_certs_verify(bftkv_gpu_ctx* ctx, const uint8_t* cert, uint64_t len, uint8_t* valid_out, uint32_t cap, uint32_t* n_out);
 
 /* CheckQuorumCert as the paper states it (docs/tex/algo.tex:68-83; the code only counts certifier key ids,

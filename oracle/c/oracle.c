@@ -15,6 +15,8 @@
  * CheckDetachedSignature, PublicKey.VerifySignature; Go crypto/rsa.VerifyPKCS1v15, crypto/dsa.Verify).
  */
 #include <openssl/bn.h>
+#include <openssl/md5.h>
+#include <openssl/ripemd.h>
 #include <openssl/sha.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -228,11 +230,17 @@ static int parse_body_v3(const uint8_t* b, int n, psig* s) {
  * cache line, which serialises hundreds of worker threads. */
 typedef struct {
   int id;
-  union { SHA_CTX s1; SHA256_CTX s256; SHA512_CTX s512; } u;
+  union { SHA_CTX s1; SHA256_CTX s256; SHA512_CTX s512; MD5_CTX m5; RIPEMD160_CTX r160; } u;
 } hctx;
+/* MD5 / RIPEMD-160 are "available" in the reference only when its binary links them (oracle/openpgp.py HASH_POLICY):
+ * bit 0 MD5, bit 1 RIPEMD-160; default 0 = refused like an unsupported hash */
+static int g_weak_hashes = 0;
+void oracle_set_weak_hashes(int mask) { g_weak_hashes = mask; }
 static int h_init(hctx* h, int hash_id) {
   h->id = hash_id;
-  switch (hash_id) {   /* md5 / ripemd160: fenced as unavailable */
+  switch (hash_id) {
+    case 1: if (!(g_weak_hashes & 1)) return 0; MD5_Init(&h->u.m5); return 1;
+    case 3: if (!(g_weak_hashes & 2)) return 0; RIPEMD160_Init(&h->u.r160); return 1;
     case 2: SHA1_Init(&h->u.s1); return 1;
     case 8: SHA256_Init(&h->u.s256); return 1;
     case 9: SHA384_Init(&h->u.s512); return 1;
@@ -243,6 +251,8 @@ static int h_init(hctx* h, int hash_id) {
 }
 static void h_update(hctx* h, const void* p, size_t n) {
   switch (h->id) {
+    case 1: MD5_Update(&h->u.m5, p, n); break;
+    case 3: RIPEMD160_Update(&h->u.r160, p, n); break;
     case 2: SHA1_Update(&h->u.s1, p, n); break;
     case 8: SHA256_Update(&h->u.s256, p, n); break;
     case 9: SHA384_Update(&h->u.s512, p, n); break;
@@ -254,6 +264,8 @@ static void h_update(hctx* h, const void* p, size_t n) {
 static unsigned h_peek(const hctx* h, uint8_t* out) {
   hctx c = *h;
   switch (c.id) {
+    case 1: MD5_Final(out, &c.u.m5); return 16;
+    case 3: RIPEMD160_Final(out, &c.u.r160); return 20;
     case 2: SHA1_Final(out, &c.u.s1); return 20;
     case 8: SHA256_Final(out, &c.u.s256); return 32;
     case 9: SHA384_Final(out, &c.u.s512); return 48;
@@ -269,8 +281,13 @@ static const uint8_t PFX_SHA256[] = {0x30, 0x31, 0x30, 0x0d, 0x06, 0x09, 0x60, 0
 static const uint8_t PFX_SHA384[] = {0x30, 0x41, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x02, 0x05, 0x00, 0x04, 0x30};
 static const uint8_t PFX_SHA512[] = {0x30, 0x51, 0x30, 0x0d, 0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, 0x03, 0x05, 0x00, 0x04, 0x40};
 
+static const uint8_t PFX_MD5[] = {0x30, 0x20, 0x30, 0x0c, 0x06, 0x08, 0x2a, 0x86, 0x48, 0x86, 0xf7, 0x0d, 0x02, 0x05, 0x05, 0x00, 0x04, 0x10};
+/* Go's entry (crypto/threshold/rsa/rsa.go:353): ISO/IEC 10118-3 identifier, not gpg's TeleTrusT one */
+static const uint8_t PFX_RMD160[] = {0x30, 0x20, 0x30, 0x08, 0x06, 0x06, 0x28, 0xcf, 0x06, 0x03, 0x00, 0x31, 0x04, 0x14};
 static const uint8_t* prefix_for(int hash_id, int* len) {
   switch (hash_id) {
+    case 1: *len = sizeof PFX_MD5; return PFX_MD5;
+    case 3: *len = sizeof PFX_RMD160; return PFX_RMD160;
     case 2: *len = sizeof PFX_SHA1; return PFX_SHA1;
     case 8: *len = sizeof PFX_SHA256; return PFX_SHA256;
     case 9: *len = sizeof PFX_SHA384; return PFX_SHA384;

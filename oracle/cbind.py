@@ -35,6 +35,7 @@ class COracle:
         self.lib.oracle_collective_verify.restype = C.c_uint64
         self.lib.oracle_trace_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_void_p, C.c_int,
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        self.lib.oracle_set_weak_hashes.argtypes = [C.c_int]
         self.h = C.c_void_p(self.lib.oracle_new())
 
     def __del__(self):
@@ -42,6 +43,10 @@ class COracle:
             self.lib.oracle_free(self.h)
         except Exception:
             pass
+
+    def set_weak_hashes(self, md5: bool, ripemd160: bool):
+        """process-wide: are MD5 / RIPEMD-160 "available" in the modelled reference binary (oracle/openpgp.py HASH_POLICY)"""
+        self.lib.oracle_set_weak_hashes((1 if md5 else 0) | (2 if ripemd160 else 0))
 
     def set_keyring(self, keyring):
         """keyring: oracle.collective.Keyring"""

@@ -53,7 +53,10 @@ HASH_PREFIXES = {
     "sha256": bytes.fromhex("3031300d060960864801650304020105000420"),
     "sha384": bytes.fromhex("3041300d060960864801650304020205000430"),
     "sha512": bytes.fromhex("3051300d060960864801650304020305000440"),
-    "ripemd160": bytes.fromhex("3020300706052b240302010414"),
+    # Go's table (crypto/rsa/pkcs1v15.go; the reference carries a copy at crypto/threshold/rsa/rsa.go:345-354) names RIPEMD-160
+    # by its ISO/IEC 10118-3 identifier, not by the TeleTrusT one gpg writes: an RSA / RIPEMD-160 signature made by gpg does
+    # not verify under Go and vice versa (tests/golden/gpg_weak_hash_vectors.json)
+    "ripemd160": bytes.fromhex("30203008060628cf060300310414"),
 }
 
 
@@ -430,6 +433,90 @@ def _gcd(a: int, b: int) -> int:
     return a
 
 
+# MD5 / RIPEMD-160: hashForSignature returns "hash not available" unless the reference BINARY links the package.  That cannot
+# be read off the reference's sources here (x/crypto is not vendored), so it is a setting: None = unknown (the verifier fences
+# such signatures and this oracle refuses them), True = linked, False = not linked.  tests set it per case.
+HASH_POLICY = {"md5": None, "ripemd160": None}
+
+
+class _Ripemd160:
+    """RIPEMD-160 (hashlib of this image has none): the published algorithm, for the oracle only."""
+    _R1 = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 7, 4, 13, 1, 10, 6, 15, 3, 12, 0, 9, 5, 2, 14, 11, 8,
+           3, 10, 14, 4, 9, 15, 8, 1, 2, 7, 0, 6, 13, 11, 5, 12, 1, 9, 11, 10, 0, 8, 12, 4, 13, 3, 7, 15, 14, 5, 6, 2,
+           4, 0, 5, 9, 7, 12, 2, 10, 14, 1, 3, 8, 11, 6, 15, 13]
+    _R2 = [5, 14, 7, 0, 9, 2, 11, 4, 13, 6, 15, 8, 1, 10, 3, 12, 6, 11, 3, 7, 0, 13, 5, 10, 14, 15, 8, 12, 4, 9, 1, 2,
+           15, 5, 1, 3, 7, 14, 6, 9, 11, 8, 12, 2, 10, 0, 4, 13, 8, 6, 4, 1, 3, 11, 15, 0, 5, 12, 2, 13, 9, 7, 10, 14,
+           12, 15, 10, 4, 1, 5, 8, 7, 6, 2, 13, 14, 0, 3, 9, 11]
+    _S1 = [11, 14, 15, 12, 5, 8, 7, 9, 11, 13, 14, 15, 6, 7, 9, 8, 7, 6, 8, 13, 11, 9, 7, 15, 7, 12, 15, 9, 11, 7, 13, 12,
+           11, 13, 6, 7, 14, 9, 13, 15, 14, 8, 13, 6, 5, 12, 7, 5, 11, 12, 14, 15, 14, 15, 9, 8, 9, 14, 5, 6, 8, 6, 5, 12,
+           9, 15, 5, 11, 6, 8, 13, 12, 5, 12, 13, 14, 11, 8, 5, 6]
+    _S2 = [8, 9, 9, 11, 13, 15, 15, 5, 7, 7, 8, 11, 14, 14, 12, 6, 9, 13, 15, 7, 12, 8, 9, 11, 7, 7, 12, 7, 6, 15, 13, 11,
+           9, 7, 15, 11, 8, 6, 6, 14, 12, 13, 5, 14, 13, 13, 7, 5, 15, 5, 8, 11, 14, 14, 6, 14, 6, 9, 12, 9, 12, 5, 15, 8,
+           8, 5, 12, 9, 12, 5, 14, 6, 8, 13, 6, 5, 15, 13, 11, 11]
+    _K1 = [0x00000000, 0x5A827999, 0x6ED9EBA1, 0x8F1BBCDC, 0xA953FD4E]
+    _K2 = [0x50A28BE6, 0x5C4DD124, 0x6D703EF3, 0x7A6D76E9, 0x00000000]
+    digest_size = 20
+
+    def __init__(self, data: bytes = b""):
+        self.h = [0x67452301, 0xEFCDAB89, 0x98BADCFE, 0x10325476, 0xC3D2E1F0]
+        self.buf, self.n = b"", 0
+        if data:
+            self.update(data)
+
+    @staticmethod
+    def _f(j, x, y, z):
+        if j == 0: return x ^ y ^ z
+        if j == 1: return (x & y) | (~x & z)
+        if j == 2: return (x | ~y) ^ z
+        if j == 3: return (x & z) | (y & ~z)
+        return x ^ (y | ~z)
+
+    def _block(self, blk: bytes):
+        M = 0xFFFFFFFF
+        rol = lambda v, s: ((v << s) | (v >> (32 - s))) & M
+        w = struct.unpack("<16I", blk)
+        a1, b1, c1, d1, e1 = self.h
+        a2, b2, c2, d2, e2 = self.h
+        for i in range(80):
+            j = i >> 4
+            t = (rol((a1 + (self._f(j, b1, c1, d1) & M) + w[self._R1[i]] + self._K1[j]) & M, self._S1[i]) + e1) & M
+            a1, e1, d1, c1, b1 = e1, d1, rol(c1, 10), b1, t
+            t = (rol((a2 + (self._f(4 - j, b2, c2, d2) & M) + w[self._R2[i]] + self._K2[j]) & M, self._S2[i]) + e2) & M
+            a2, e2, d2, c2, b2 = e2, d2, rol(c2, 10), b2, t
+        h = self.h
+        t = (h[1] + c1 + d2) & M
+        self.h = [t, (h[2] + d1 + e2) & M, (h[3] + e1 + a2) & M, (h[4] + a1 + b2) & M, (h[0] + b1 + c2) & M]
+        self.h = [self.h[0], self.h[1], self.h[2], self.h[3], self.h[4]]
+
+    def update(self, data: bytes):
+        self.buf += data
+        self.n += len(data)
+        while len(self.buf) >= 64:
+            self._block(self.buf[:64])
+            self.buf = self.buf[64:]
+
+    def copy(self):
+        c = _Ripemd160()
+        c.h, c.buf, c.n = list(self.h), self.buf, self.n
+        return c
+
+    def digest(self) -> bytes:
+        c = self.copy()
+        pad = b"\x80" + b"\x00" * ((55 - c.n) % 64) + struct.pack("<Q", c.n * 8)
+        c.update(pad)
+        return struct.pack("<5I", *c.h)
+
+
+def new_hash(name: str):
+    """hashlib.new, with RIPEMD-160 supplied where OpenSSL 3's default provider has dropped it."""
+    if name == "ripemd160":
+        try:
+            return hashlib.new(name)
+        except ValueError:
+            return _Ripemd160()
+    return hashlib.new(name)
+
+
 class CanonicalTextHash:
     """openpgp.NewCanonicalTextHash (x/crypto openpgp/canonical_text.go): what the SIGNED DATA of a text-mode (0x01)
     signature passes through on its way into the hash -- a '\n' that does not follow a '\r' becomes "\r\n"; the byte after
@@ -487,14 +574,16 @@ def hash_for_signature(hash_id: int, sig_type: int):
     """hashForSignature: binary (0x00) hashes raw bytes; text (0x01) canonicalises the line endings of the signed data
     (CanonicalTextHash); other signature types are unsupported."""
     name = HASH_BY_ID.get(hash_id)
-    if name is None or name in ("md5", "ripemd160"):
-        # whether MD5 / RIPEMD-160 are linked into a bftkv binary cannot be established without the
-        # x/crypto source: FENCED as unavailable (DESIGN.md), identically in oracle.c and the HIP path
+    if name is None:
+        return None
+    if name in HASH_POLICY and HASH_POLICY[name] is not True:
+        # whether MD5 / RIPEMD-160 are linked into a bftkv binary cannot be established without the x/crypto source
+        # (HASH_POLICY above): unknown and "not linked" both refuse here; the verifier FENCES the unknown case
         return None
     if sig_type not in (0x00, 0x01):
         return None
     try:
-        h = hashlib.new(name)
+        h = new_hash(name)
     except ValueError:
         return None
     return CanonicalTextHash(h) if sig_type == 0x01 else _BinaryHash(h)

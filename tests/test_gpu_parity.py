@@ -225,6 +225,56 @@ def test_text_mode_signatures(gpu_ctx, exit_mode):
     gpu_ctx.quorum_destroy(qh)
 
 
+def test_md5_and_ripemd160_by_availability_policy(gpu_ctx):
+    """bftkv_gpu_set_hash_policy: unknown (default) => such signatures are FENCED; declared not available => the reference's
+    unsupported-hash failure, not fenced; declared available => hashed and verified natively (k_hash_mid_other / k_hash_mid_text,
+    little-endian compressions), RSA against Go's DigestInfo table.  Verdicts are the oracle's under the same policy; other
+    signatures of the same items are unaffected."""
+    import json
+    import os
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    wv = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_weak_hash_vectors.json")))
+    ring = pgp.read_entities(bytes.fromhex(wv["pubring"]))
+    kr = col.Keyring(keyring=ring)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    tbs_l = [bytes.fromhex(v["payload"]) for v in wv["vectors"]]
+    sig_l = [bytes.fromhex(v["sig"]) for v in wv["vectors"]]
+    # the same payloads signed with SHA-256 by the cluster's first key, appended as a second item set: untouched by the policy
+    cl = cb.make_cluster(4, n_outsiders=1)
+    extra = [cb.detach_sign(cl.replicas[0], t) for t in tbs_l[:3]]
+    tb, to = _cat(tbs_l + tbs_l[:3])
+    sb, so = _cat(sig_l + extra)
+    n = len(sig_l)
+    saved = dict(pgp.HASH_POLICY)
+    try:
+        for state, policy in ((0, None), (2, False), (1, True)):
+            gpu_ctx.set_hash_policy(1, state)
+            gpu_ctx.set_hash_policy(3, state)
+            pgp.HASH_POLICY.update(md5=policy, ripemd160=policy)
+            err = gpu_ctx.signature_verify(tb, to, sb, so)
+            fenced = gpu_ctx.last_fenced.copy()
+            assert (err[n:] == 0).all() and not fenced[n:].any()
+            for i, v in enumerate(wv["vectors"]):
+                want = col.signature_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, sig_l[i], None)) is None
+                assert fenced[i] == (1 if state == 0 else 0), (v["name"], state)
+                if not fenced[i]:
+                    assert (err[i] == 0) == want, (v["name"], state, err[i])
+            if state == 1:
+                assert (err[:n] == 0).sum() >= 7
+        # one hash available, the other unknown
+        gpu_ctx.set_hash_policy(1, 1)
+        gpu_ctx.set_hash_policy(3, 0)
+        err = gpu_ctx.signature_verify(tb, to, sb, so)
+        for i, v in enumerate(wv["vectors"]):
+            assert gpu_ctx.last_fenced[i] == (1 if "ripemd160" in v["name"] else 0), v["name"]
+    finally:
+        pgp.HASH_POLICY.update(saved)
+        gpu_ctx.set_hash_policy(1, 0)
+        gpu_ctx.set_hash_policy(3, 0)
+
+
 def test_signers_parse_only(gpu_ctx):
     """PGPSignature.Signers / PGPCollectiveSignature.Signers (crypto_pgp.go:373-390, 517-519)."""
     from oracle import collective as col

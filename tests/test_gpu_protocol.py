@@ -208,6 +208,60 @@ def test_server_sign_verify(gpu_ctx):
     gpu_ctx.quorum_destroy(qh)
 
 
+def test_dsa_certificates_from_requests_take_bounded_table_slots(gpu_ctx):
+    """Server.sign requests carry their principal's certificate (server.go:199-207).  A DSA certificate key needs fixed-base
+    window tables -- 637 MB and a table build at the 16-bit width -- so certificate-only DSA keys share a bounded, recycled set
+    of slots (8 at that width): 14 fresh DSA principals in one batch verify for the 8 that got slots, the others come back
+    FENCED (the reference path decides), and verify when they are sent again; the node keys' tables are never rebuilt and
+    the window width does not move."""
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp
+    cl, og, hg, host = _world(10)
+    me = cl.replicas[2].key_id
+    og.set_self([me])
+    hg.SetSelfNodes([me])
+    oq = W.Wot(og).choose_quorum(W.AUTH | W.CERT)
+    hq = host.wotqs.New(hg).ChooseQuorum(host.AUTH | host.CERT)
+    kr = H.oracle_keyring(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    mats = cb.load_keys("dsa2048", 34)[20:34]
+    certifiers = [r for r in cl.replicas if r.algo == cb.PK_RSA][:5]
+    users = []
+    for i, m in enumerate(mats):
+        u = cb.make_keypair(cb.PK_DSA, m, "d%02d <d%02d@bftkv.example>" % (i, i))
+        cb.build_entity(u, certifiers, DRBG("dsa-user-%d" % i))
+        users.append(u)
+    srng = DRBG("dsa-user-sigs")
+
+    def request(u, i, good=True):
+        x, v, t = b"key%03d" % i, b"value", i + 1
+        tbs = cb.serialize_tbs(x, v, t)
+        return opk.serialize(x, v, t, opk.SignaturePacket(1, 0, False, cb.detach_sign(u, tbs if good else tbs + b"!", srng), u.entity))
+    reqs = [request(u, i, good=(i % 5 != 4)) for i, u in enumerate(users)]
+    srv = host.Server(gpu_ctx)
+    err = list(srv.sign_verify(hq, reqs))
+    want = []
+    for r in reqs:
+        x, v, t, sig, ss, _ = opk.parse(r)
+        ent = pgp.read_entities(sig.Cert)[0]
+        if col.signature_verify_with_certificate(opk.tbs(r), sig, ent) is not None:
+            want.append(1)
+        else:
+            nodes = [c for c in ent.certifiers if kr.get_cert_by_id(c) is not None]
+            want.append(0 if oq.is_threshold(nodes) else 0xFD)
+    fenced = [i for i, e in enumerate(err) if e == 0xFC]
+    assert len(fenced) == len(users) - 8, err                     # 8 slots at the 16-bit width
+    assert all(err[i] == want[i] for i in range(len(users)) if i not in fenced), (err, want)
+    # the fenced ones again, alone: slots of certificate keys that are not in this batch are recycled
+    again = list(srv.sign_verify(hq, [reqs[i] for i in fenced]))
+    assert again == [want[i] for i in fenced], (again, [want[i] for i in fenced])
+    assert 0 in want and 1 in want
+    # and the whole batch once more: still 8 slots, whichever 8 hold them
+    err3 = list(srv.sign_verify(hq, reqs))
+    assert sum(e == 0xFC for e in err3) == len(users) - 8
+    assert all(e == w for e, w in zip(err3, want) if e != 0xFC)
+
+
 def test_equivocation_signers(gpu_ctx):
     """Client.revoke's tally (client.go:304-353): signers common to two different values at one timestamp."""
     cl, og, hg, host = _world(10)
