@@ -243,6 +243,7 @@ struct WalkStep {
   uint64_t body_off;
   uint32_t body_len;
   bool event;          // false: silently skipped (unknown packet type)
+  bool reads_to_end;   // known non-signature packet whose parser consumes the whole body (user id, user attribute, private key)
   uint8_t status;      // ST_PENDING_PARSE for signature packets, final otherwise
 };
 
@@ -252,6 +253,7 @@ template <typename HDR>
 __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, uint64_t end) {
   WalkStep r;
   r.event = true;
+  r.reads_to_end = false;
   r.status = ST_PARSE_ERROR;
   r.body_off = pos;
   r.body_len = 0;
@@ -287,7 +289,7 @@ __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, ui
   r.body_off = start;
   r.body_len = (uint32_t)ln;
   if (tag != 2) {
-    if (known_tag(tag)) r.status = ST_NOT_SIGNATURE;
+    if (known_tag(tag)) { r.status = ST_NOT_SIGNATURE; r.reads_to_end = tag == 13 || tag == 17 || tag == 5 || tag == 7; }
     else r.event = false;
     return r;
   }
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     const uint64_t p = pos + (uint64_t)lane * stride;
     const bool act = lane == 0 || (stride != 0 && p < end);
     WalkStep w;
-    w.next = ~0ull; w.body_off = 0; w.body_len = 0; w.event = false; w.status = ST_PARSE_ERROR;
+    w.next = ~0ull; w.body_off = 0; w.body_len = 0; w.event = false; w.reads_to_end = false; w.status = ST_PARSE_ERROR;
     if (act) w = walk_next_dev(sig_blob, p, end);
     const uint32_t pn_lo = __shfl_up((uint32_t)w.next, 1), pn_hi = __shfl_up((uint32_t)(w.next >> 32), 1);
     const bool link = act && (lane == 0 || (((uint64_t)pn_hi << 32) | pn_lo) == p);
@@ -360,7 +362,16 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     const bool conf = lane < n_conf;
     const uint64_t evm = __builtin_amdgcn_ballot_w64(conf && w.event);
     const uint32_t idx = n + (uint32_t)__builtin_popcountll(evm & ((1ull << lane) - 1ull));
-    if (conf && w.event && w.status == ST_UNSUPPORTED) unsup = true;
+    // Where the reference's reader stands AFTER a packet is part of the semantics (CollectiveSignature.Verify keeps calling
+    // CheckDetachedSignature on the same reader).  packet.Read drains a body on every error, and a signature body of up to
+    // 4096 bytes is drained by the bufio reader peekVersion wraps around it.  Two shapes leave the reader INSIDE the body:
+    // a known non-signature packet whose parser does not read to the end (literal data, compressed, encrypted, one-pass, key
+    // packets with trailing bytes ...: everything but user id / user attribute / private key, which end in ReadAll), and a
+    // signature body longer than the 4096-byte buffer.  What follows is then parsed out of the middle of that body -- not
+    // followed here: the item is fenced.
+    if (conf && w.event && (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end) ||
+                            (w.status == ST_PENDING_PARSE && w.body_len > 4096u)))
+      unsup = true;
     if (conf && w.event) {
       if (!FILL) {
         if (idx < WALK_CAP) {

@@ -1111,6 +1111,11 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx, exit_mode):
     sb, so = _cat(ss_l)
     err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
     st, st_item = gpu_ctx.last_statuses()
+    # fenced exactly where the reference's reader position after a packet depends on the packet type's parser (a literal-data
+    # or key packet among the signatures: oracle.openpgp.position_is_type_dependent); statuses still follow the oracle's walk
+    from oracle import openpgp as pgp
+    want_fenced = [1 if pgp.position_is_type_dependent(s_) else 0 for s_ in ss_l]
+    assert list(gpu_ctx.last_fenced) == want_fenced and 10 < sum(want_fenced) < len(ss_l) - 40
     n_long = 0
     r_big = col.collective_verify(kr, tbs_l[-1], SignaturePacket(1, 0, False, ss_l[-1], None), q)
     assert list(st[st_item == n_all - 1])[:len(r_big.statuses)] == r_big.statuses and (err[-1] == 0) == (r_big.err is None)
