@@ -44,7 +44,7 @@ EXPORTS = [
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
-    "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy",
+    "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
 ]
 
 _lib = None
@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_last_statuses.argtypes = [vp, u8p, vp, u32, C.POINTER(u32)]
     lib.bftkv_gpu_last_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_signers.argtypes = [vp, u32, u8p, u64p, u64p, u64p, C.c_uint64]
+    lib.bftkv_gpu_signers_fenced.argtypes = [vp, u32, u8p, u64p, u64p, u64p, C.c_uint64, u8p]
     lib.bftkv_gpu_quorum_tally.argtypes = [vp, C.c_int, u32, u64p, u64p, u8p]
     lib.bftkv_gpu_modexp.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u32, u8p]
     lib.bftkv_gpu_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
@@ -347,7 +348,8 @@ class Context:
         cap = max(1, int(len(ss_blob) // 12) + 1)
         ids = np.zeros(cap, dtype=np.uint64)
         off = np.zeros(n + 1, dtype=np.uint64)
-        self._check(self.lib.bftkv_gpu_signers(self.h, n, _ptr(ss_blob), _ptr(ss_off), _ptr(ids), _ptr(off), cap), "signers")
+        self.last_fenced = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_signers_fenced(self.h, n, _ptr(ss_blob), _ptr(ss_off), _ptr(ids), _ptr(off), cap, _ptr(self.last_fenced)), "signers")
         return ids[:int(off[n])], off
 
     def quorum_tally(self, quorum: int, ids, list_off):

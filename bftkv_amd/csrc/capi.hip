@@ -1347,6 +1347,11 @@ int bftkv_gpu_quorum_tally(bftkv_gpu_ctx* c, int quorum, uint32_t n_lists, const
 
 int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, const uint64_t* ss_off, uint64_t* ids_out,
                       uint64_t* ids_off_out, uint64_t cap) {
+  return bftkv_gpu_signers_fenced(c, n_items, ss, ss_off, ids_out, ids_off_out, cap, nullptr);
+}
+
+int bftkv_gpu_signers_fenced(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, const uint64_t* ss_off, uint64_t* ids_out,
+                             uint64_t* ids_off_out, uint64_t cap, uint8_t* fenced_out) {
   // parse-only walk: reuse the parse kernels with no hashing; issuers resolved against PRIMARY
   // key ids only (getCertById, crypto_pgp.go:206-219).
   if (!c || (n_items && (!ss_off || !ids_off_out))) return BFTKV_E_INVALID;
@@ -1367,8 +1372,10 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   HIPCHK(c, c->base.ensure(sizeof(uint32_t) * (n_items + 1)));
   HIPCHK(c, c->total.ensure(16));
   const uint32_t nb = (n_items + 63) / 64;
+  if (fenced_out) HIPCHK(c, c->o_fenced.ensure(n_items));
   hipLaunchKernelGGL(k_signers<false>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
-                     c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt);
+                     c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt, fenced_out ? c->o_fenced.as<uint8_t>() : (uint8_t*)nullptr);
+  if (fenced_out) HIPCHK(c, hipMemcpyAsync(fenced_out, c->o_fenced.p, n_items, hipMemcpyDeviceToHost, s));
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>(), (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
   uint32_t total = 0;
@@ -1377,7 +1384,7 @@ int bftkv_gpu_signers(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* ss, con
   if (total > cap) return fail(c, BFTKV_E_NOMEM, "ids_out too small");
   HIPCHK(c, c->ids_tmp.ensure(sizeof(uint64_t) * (total + 1)));
   hipLaunchKernelGGL(k_signers<true>, dim3(nb), dim3(64), 0, s, c->in_ss.as<uint8_t>(), c->in_ss_off.as<uint64_t>(), n_items,
-                     c->counts.as<uint32_t>(), c->base.as<uint32_t>(), c->ids_tmp.as<uint64_t>(), c->kt);
+                     c->counts.as<uint32_t>(), c->base.as<uint32_t>(), c->ids_tmp.as<uint64_t>(), c->kt, (uint8_t*)nullptr);
   std::vector<uint32_t> hb(n_items);
   HIPCHK(c, hipMemcpyAsync(hb.data(), c->base.p, sizeof(uint32_t) * n_items, hipMemcpyDeviceToHost, s));
   if (total && ids_out) HIPCHK(c, hipMemcpyAsync(ids_out, c->ids_tmp.p, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, s));

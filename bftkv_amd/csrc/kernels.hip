@@ -638,16 +638,23 @@ template <bool FILL>
 __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                                 uint32_t n_items, uint32_t* __restrict__ counts,
                                                 const uint32_t* __restrict__ out_base, uint64_t* __restrict__ ids_out,
-                                                KeyTableDev kt) {
+                                                KeyTableDev kt, uint8_t* __restrict__ fenced /*[n_items] or null; written by the counting pass*/) {
   uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= n_items) return;
   uint64_t pos = sig_off[item], end = sig_off[item + 1];
   uint32_t n = 0;
   uint32_t base = FILL ? out_base[item] : 0;
+  // fence: the walk met a shape on which this library does not follow the reference's reader (partial / indeterminate
+  // lengths; a packet after which the reader stands inside the body, see k_walk; a v4 signature without issuer, on which the
+  // reference dereferences nil) -- the caller takes the reference path for the item
+  bool fence = false;
   while (pos < end) {
     WalkStep w = walk_next_dev(sig_blob, pos, end);
     pos = w.next;
     if (!w.event) continue;                               // unknown packet type: skipped by Next
+    if (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end) ||
+        (w.status == ST_PENDING_PARSE && w.body_len > 4096u))
+      fence = true;
     if (w.status == ST_NOT_SIGNATURE) continue;           // other packet types fall through the type switch
     if (w.status != ST_PENDING_PARSE) break;              // framing error => Next returns err => loop ends
     const uint8_t* body = sig_blob + w.body_off;
@@ -656,7 +663,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
     bool have_issuer = false;
     uint64_t issuer = 0;
     if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer)) break;   // parse error => Next returns err
-    if (!have_issuer) break;                              // nil dereference in the reference: fenced
+    if (!have_issuer) { fence = true; break; }            // nil dereference in the reference: fenced
     for (uint32_t k = 0; k < kt.n_keys; ++k) {
       if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY) && !(kt.flags[k] & KEYF_CERT_ONLY)) {
         if (FILL) ids_out[base + n] = issuer;
@@ -665,7 +672,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
       }
     }
   }
-  if (!FILL) counts[item] = n;
+  if (!FILL) { counts[item] = n; if (fenced) fenced[item] = fence ? 1 : 0; }
 }
 
 // single-block exclusive scan (n up to a few million): each thread scans a contiguous chunk

@@ -256,6 +256,11 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* ctx, uint64_t counters[4]);
  * ids_off_out[n_items+1] delimits them.  cap = capacity of ids_out. */
 int bftkv_gpu_signers(bftkv_gpu_ctx* ctx, uint32_t n_items, const uint8_t* ss_blob, const uint64_t* ss_off,
                       uint64_t* ids_out, uint64_t* ids_off_out, uint64_t cap);
+/* same, with the per-item fence flag of the verify calls: fenced_out[i] = 1 when the stream holds a shape on which the
+ * walk does not follow the reference's reader (partial / indeterminate lengths, a packet that leaves the reader inside
+ * its body, a v4 signature without issuer -- on which the reference itself dereferences nil): take the reference path */
+int bftkv_gpu_signers_fenced(bftkv_gpu_ctx* ctx, uint32_t n_items, const uint8_t* ss_blob, const uint64_t* ss_off,
+                             uint64_t* ids_out, uint64_t* ids_off_out, uint64_t cap, uint8_t* fenced_out);
 
 /* ---- quorum predicates over node lists, batched (wotqs.go:144-193) ---------------------------- */
 /* verdict_out[i] = BFTKV_V_* bits for nodes = ids[list_off[i]..list_off[i+1]) (duplicates count

@@ -332,7 +332,7 @@ def next_packet(buf: bytes, pos: int) -> RawPacket:
 _READS_TO_END = {5, 7, 13, 17}
 
 
-def position_is_type_dependent(buf: bytes) -> bool:
+def position_is_type_dependent(buf: bytes, stop_at_error: bool = False) -> bool:
     """Does this signature stream contain a packet after which the reference's reader may stand INSIDE the packet body?
 
     packet.Read drains a body on every error and -- through the 4096-byte bufio reader peekVersion wraps around it -- a
@@ -348,6 +348,8 @@ def position_is_type_dependent(buf: bytes) -> bool:
         except UnsupportedError:
             return True
         except StructuralError as e:          # a stray byte: that call fails, the next one starts behind it
+            if stop_at_error:                 # (PGPSignature.Signers: the first error of Reader.Next ends the walk)
+                return False
             pos = e.consumed
             continue
         except (_Truncated, EOFError):

@@ -72,8 +72,9 @@ func signers(g *gpu, kr *keyring, ss *packet.SignaturePacket, fallback func(*pac
 	capIds := len(ss.Data)/12 + 1 // a signature packet is never shorter than 12 bytes
 	ids := make([]C.uint64_t, capIds)
 	var idsOff [2]C.uint64_t
-	if rc := C.bftkv_gpu_signers(g.ctx, 1, ptr(ss.Data), &off[0], &ids[0], &idsOff[0], C.uint64_t(capIds)); rc != 0 {
-		return fallback(ss)
+	var fenced C.uint8_t
+	if rc := C.bftkv_gpu_signers_fenced(g.ctx, 1, ptr(ss.Data), &off[0], &ids[0], &idsOff[0], C.uint64_t(capIds), &fenced); rc != 0 || fenced != 0 || !kr.fresh() {
+		return fallback(ss) // infrastructure error, a shape the walk does not follow, or a stale device table: crypto/pgp decides
 	}
 	var nodes []node.Node
 	for _, id := range ids[:int(idsOff[1])] {

@@ -20,6 +20,7 @@ package pgpgpu
 import "C"
 
 import (
+	gocrypto "crypto"
 	"errors"
 	"sync"
 	"unsafe"
@@ -53,6 +54,16 @@ func New(device int) *crypto.Crypto {
 	if g.batcher == nil {
 		panic("pgpgpu: bftkv_gpu_batcher_create failed")
 	}
+	// MD5 / RIPEMD-160: openpgp's hashForSignature refuses a hash this BINARY does not link ("hash not available").  Only
+	// the binary knows -- tell the library, which otherwise fences every signature naming them (bftkv_gpu_set_hash_policy).
+	avail := func(h gocrypto.Hash) C.int {
+		if h.Available() {
+			return 1
+		}
+		return 2
+	}
+	C.bftkv_gpu_set_hash_policy(g.ctx, 1, avail(gocrypto.MD5))
+	C.bftkv_gpu_set_hash_policy(g.ctx, 3, avail(gocrypto.RIPEMD160))
 	kr := &keyring{inner: c.Keyring, g: g}
 	c.Keyring = kr
 	// crypto/pgp's other objects were built around the original keyring by pgp.New(); they keep using it

@@ -26,6 +26,7 @@ package main
 
 import (
 	"bytes"
+	gocrypto "crypto"
 	"encoding/hex"
 	"encoding/json"
 	"flag"
@@ -99,6 +100,9 @@ type clusterOut struct {
 type outputs struct {
 	Format   int          `json:"format"`
 	XCrypto  string       `json:"x_crypto"`
+	// what this binary links: decides hashForSignature's "hash not available" (bftkv_gpu_set_hash_policy, oracle HASH_POLICY)
+	MD5Available       bool `json:"md5_available"`
+	RIPEMD160Available bool `json:"ripemd160_available"`
 	Clusters []clusterOut `json:"clusters"`
 	Streams  []itemOut    `json:"streams"`
 	Gpg      []itemOut    `json:"gpg"`
@@ -228,7 +232,8 @@ func main() {
 	if err := json.Unmarshal(raw, &inp); err != nil {
 		log.Fatal(err)
 	}
-	res := outputs{Format: 1, XCrypto: "golang.org/x/crypto v0.0.0-20191227163750-53104e6ec876 (go.mod:8)"}
+	res := outputs{Format: 1, XCrypto: "golang.org/x/crypto v0.0.0-20191227163750-53104e6ec876 (go.mod:8)",
+		MD5Available: gocrypto.MD5.Available(), RIPEMD160Available: gocrypto.RIPEMD160.Available()}
 	byName := map[string]struct {
 		crypt *crypto.Crypto
 		ring  openpgp.EntityList

@@ -1129,6 +1129,9 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx, exit_mode):
     assert n_long >= 8 and (err == 0).any() and (err != 0).any()
     # Signers (parse-only walk) over the same streams
     ids, off = gpu_ctx.signers(sb, so)
+    sf = gpu_ctx.last_fenced.copy()
+    # the same shapes raise the fence of the parse-only walk, as far as that walk gets (its first error ends it)
+    assert list(sf) == [1 if pgp.position_is_type_dependent(s_, stop_at_error=True) else 0 for s_ in ss_l]
     for i in range(0, 160, 9):
         want = col.signers(kr, SignaturePacket(1, 0, False, ss_l[i] or None, None))
         assert [int(x) for x in ids[int(off[i]):int(off[i + 1])]] == want, i
