@@ -122,6 +122,7 @@ struct bftkv_gpu_ctx {
   DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
+  DevBuf chunk_arena, chunk_ctr;    // linearised partial-length signature bodies (parse_one) and their counters (k_walk / k_scan_counts)
   uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
   uint32_t multiexp_lanes = 0;        // experiment knob (BFTKV_MULTIEXP_LANES = 4 | 8): lanes per number in k_multiexp, 0 = by call size
   uint32_t dsa_inv_mode = 0;          // experiment knob (BFTKV_DSA_INV = single | batched): 1 / 2, 0 = by batch shape
@@ -341,6 +342,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   HIPCHK(c, c->mid.ensure(sizeof(uint32_t) * 8 * N_MID32 * (size_t)n_items + 16));      // SHA-256 | SHA-224 | SHA-1 | MD5 | RIPEMD-160 midstates
   HIPCHK(c, c->mid64.ensure(sizeof(uint64_t) * 8 * 2 * (size_t)n_items + 16));   // SHA-512 | SHA-384
   HIPCHK(c, c->hash_mask.ensure(sizeof(uint32_t) * (size_t)n_items + 16));
+  // partial-length signature packets are linearised into this arena by the parse; the walk reports how much the call needs
+  // (mailbox word 2) and a staged call, which does not ask the host in mid-pipeline, lives with the minimum (beyond it: fenced)
+  constexpr size_t CHUNK_ARENA_MIN = 64u << 10;
+  if (!c->chunk_ctr.p) { HIPCHK(c, c->chunk_ctr.ensure(16)); HIPCHK(c, hipMemsetAsync(c->chunk_ctr.p, 0, 16, c->stream)); }
+  HIPCHK(c, c->chunk_arena.ensure(CHUNK_ARENA_MIN + (staged_cap ? 2 * (size_t)ss_len : 0)));
   HIPCHK(c, c->pk_count.ensure(96));   // [0..3] work-list lengths, [4] some signature uses a hash other than SHA-256,
                                        // [8..11] lengths after phase 1 (phase 2's start), [12..15] zeros (phase 1's start),
                                        // [16..19] two uint64: clock stamps of k_rsa_modexp (bftkv_gpu_last_sclk_mhz)
@@ -360,12 +366,13 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (!upload_tbs && !d_mid_in)
     hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
   hipLaunchKernelGGL(k_walk<false>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>(), walk_cap);
+                     (const uint32_t*)nullptr, (SigRec*)nullptr, c->item_flags.as<uint8_t>(), c->walk_scratch.as<WalkEnt>(), walk_cap,
+                     c->chunk_ctr.as<uint32_t>());
   constexpr uint32_t MAIL_EMPTY = 0xFFFFFFFFu;
   if (c->h_mail && !staged_cap) __atomic_store_n(&c->h_mail[0], MAIL_EMPTY, __ATOMIC_RELEASE);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
                      c->total.as<uint32_t>(), staged_cap ? (uint32_t*)nullptr : c->d_mail, c->pk_count.as<uint32_t>(), c->hash_mask.as<uint32_t>(),
-                     staged_cap);
+                     staged_cap, c->chunk_ctr.as<uint32_t>());
   uint32_t total = staged_cap ? staged_cap : MAIL_EMPTY;      // staged: the upper bound; the kernels read the count from c->total
   const uint32_t* const n_recs_dev = staged_cap ? c->total.as<uint32_t>() : nullptr;
   if (c->h_mail && !staged_cap) {
@@ -378,10 +385,13 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       __builtin_ia32_pause();
     }
   }
+  uint32_t chunk_units = (c->h_mail && !staged_cap && total != MAIL_EMPTY) ? c->h_mail[2] : 0u;
   if (total == MAIL_EMPTY) {
     HIPCHK(c, hipMemcpyAsync(&total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&chunk_units, c->chunk_ctr.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
   }
+  if (!staged_cap && (size_t)chunk_units * 16 > c->chunk_arena.cap) HIPCHK(c, c->chunk_arena.ensure((size_t)chunk_units * 16));
   c->last_total = staged_cap ? 0u : total;      // (per-packet diagnostics are not kept for staged calls)
   c->last_items = n_items;
   const size_t tr = total ? total : 1;
@@ -398,7 +408,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
   // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
-                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr, walk_cap);
+                     c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr, walk_cap, (uint32_t*)nullptr);
   if (total) {
     ParseArgs pa;
     pa.sig_blob = d_ss; pa.sig_off = d_ss_off; pa.rec_base = c->base.as<uint32_t>(); pa.counts = c->counts.as<uint32_t>(); pa.n_items = n_items;
@@ -408,6 +418,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
     pa.defer_queue = plan_q ? 1u : 0u;
     pa.n_recs_dev = n_recs_dev;
+    pa.chunk_arena = c->chunk_arena.as<uint8_t>(); pa.chunk_cap_units = (uint32_t)std::min<size_t>(c->chunk_arena.cap / 16, 0xFFFFFFF0u);
+    pa.chunk_bump = c->chunk_ctr.as<uint32_t>() + 1;
     if (!staged_cap && (uint64_t)total >= 128ull * n_items)     // very long items (n = 256 cliques: 171+ packets): block per item, no bisection
                                                  // (measured at 53 packets per item: 237 us item-major vs 210 us record-major)
       hipLaunchKernelGGL(k_parse_body_items, dim3(n_items), dim3(PARSE_ITEM_BLOCK), 0, s, pa, c->kt);
@@ -955,7 +967,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream_h);
   (void)hipStreamSynchronize(c->stream_d);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot, &c->k_r2w,
-                    &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
+                    &c->chunk_arena, &c->chunk_ctr, &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut, &c->txt_mid32, &c->txt_mid64, &c->txt_tail, &c->txt_len})
     b->release();
@@ -1377,7 +1389,7 @@ int bftkv_gpu_signers_fenced(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* 
                      c->counts.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr, c->kt, fenced_out ? c->o_fenced.as<uint8_t>() : (uint8_t*)nullptr);
   if (fenced_out) HIPCHK(c, hipMemcpyAsync(fenced_out, c->o_fenced.p, n_items, hipMemcpyDeviceToHost, s));
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->counts.as<uint32_t>(), n_items, c->base.as<uint32_t>(),
-                     c->total.as<uint32_t>(), (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                     c->total.as<uint32_t>(), (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
   uint32_t total = 0;
   HIPCHK(c, hipMemcpyAsync(&total, c->total.p, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

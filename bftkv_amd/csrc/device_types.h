@@ -20,6 +20,7 @@ enum SigStatus : uint8_t {
   ST_UNSUPPORTED = 10,
   ST_NOT_EXAMINED = 11,    // behind the early exit of CollectiveSignature.Verify: the reference never reads this packet
   // internal, never returned:
+  ST_PENDING_CHUNKED = 98, // signature packet with partial body lengths located: its chunks are linearised before the parse
   ST_PENDING_PARSE = 99,   // signature packet located, body not parsed yet
   ST_PENDING_HASH = 100,   // parsed, key found; digest not computed yet
   ST_PENDING_RSA = 101,    // digest + tag OK; waiting for the modexp

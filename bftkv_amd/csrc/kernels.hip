@@ -72,6 +72,8 @@ struct WinBytes {
 
 __host__ __device__ __forceinline__ const uint8_t* raw_bytes(const uint8_t* p) { return p; }
 __device__ __forceinline__ const uint8_t* raw_bytes(const WinBytes& w) { return w.g; }
+struct ChainBytes;
+__host__ __device__ inline ChainBytes raw_bytes(const ChainBytes& c);
 
 // subpacket area walk; returns false on structural/unsupported error
 template <int DEPTH, class B = const uint8_t*>
@@ -237,24 +239,157 @@ __host__ __device__ __forceinline__ bool parse_sig_body_v3(B body, uint32_t blen
   return true;
 }
 
-// One packet.Read framing step at stream position pos of [.., end): header only.
+// ------------------------------------------------------------------------------------------------
+// Packet bodies as x/crypto's readers deliver them (openpgp/packet/packet.go readHeader, readLength, spanReader,
+// partialLengthReader; the 4096-byte bufio.Reader of peekVersion).  PGPCollectiveSignature.Verify keeps ONE bytes.Reader
+// and calls CheckDetachedSignature on it again and again: what a packet consumes is what those readers pulled.
+//   definite length       spanReader: at most `length` bytes; a stream that ends early only matters to a parser that asks for more
+//   partial lengths       partialLengthReader: 2^k-byte chunks, each followed by the next length header, the last one definite
+//   indeterminate length  (old format, length type 3) the rest of the stream
+// A signature body that parses is NOT drained afterwards (the reader stays where bufio's last fetch ended); one that fails is.
+// ------------------------------------------------------------------------------------------------
+constexpr uint8_t BODY_DEFINITE = 0, BODY_PARTIAL = 1, BODY_INDETERMINATE = 2;
+constexpr uint32_t BUFIO_SIZE = 4096;
+
+// position of the next body byte in the item's stream, bytes left in the current chunk, another length header behind it?
+struct ChunkCursor { uint64_t pos; uint64_t rem; bool partial; };
+
+// partialLengthReader.Read's `for r.remaining == 0` loop: readLength at c.pos.  Returns false when the stream ends inside a
+// length header (c.pos = end); true with rem == 0 means the body is over (io.EOF).
+__host__ __device__ inline bool cursor_next_chunk(const uint8_t* base, ChunkCursor& c, uint64_t end) {
+  while (c.rem == 0) {
+    if (!c.partial) return true;
+    if (c.pos >= end) return false;
+    const uint32_t b = base[c.pos];
+    if (b < 192) { c.rem = b; c.pos += 1; c.partial = false; }
+    else if (b < 224) {
+      if (c.pos + 2 > end) { c.pos = end; return false; }
+      c.rem = ((uint64_t)(b - 192) << 8) + base[c.pos + 1] + 192; c.pos += 2; c.partial = false;
+    } else if (b == 255) {
+      if (c.pos + 5 > end) { c.pos = end; return false; }
+      c.rem = ((uint64_t)base[c.pos + 1] << 24) | ((uint64_t)base[c.pos + 2] << 16) | ((uint64_t)base[c.pos + 3] << 8) | base[c.pos + 4];
+      c.pos += 5; c.partial = false;
+    } else { c.rem = 1ull << (b & 31u); c.pos += 1; }
+  }
+  return true;
+}
+
+// Everything a chain of chunks can deliver: `avail` body bytes, the reader behind the last of them at `next`; truncated: the
+// stream ends inside a chunk or a length header (next = end).  gave_up: more than max_hops headers (speculating lanes of k_walk).
+struct BodyExtent { uint64_t next, avail; bool truncated, gave_up; };
+__host__ __device__ inline BodyExtent chain_extent(const uint8_t* base, ChunkCursor c, uint64_t end, uint32_t max_hops) {
+  BodyExtent e{end, 0, false, false};
+  for (uint32_t hop = 0;; ++hop) {
+    const uint64_t room = end - c.pos, take = c.rem < room ? c.rem : room;
+    e.avail += take; c.pos += take;
+    if (take < c.rem) { e.truncated = true; return e; }
+    c.rem = 0;
+    if (!c.partial) { e.next = c.pos; return e; }
+    if (hop >= max_hops) { e.gave_up = true; return e; }
+    if (!cursor_next_chunk(base, c, end)) { e.truncated = true; return e; }
+  }
+}
+
+// the deliverable bytes of a chain, one after the other, into dst[0, n)
+__host__ __device__ inline void chain_copy(const uint8_t* base, ChunkCursor c, uint64_t end, uint8_t* dst, uint64_t n) {
+  uint64_t done = 0;
+  while (done < n) {
+    if (c.rem == 0 && !cursor_next_chunk(base, c, end)) return;
+    if (c.rem == 0) return;
+    uint64_t take = c.rem < end - c.pos ? c.rem : end - c.pos;
+    if (take > n - done) take = n - done;
+    if (take == 0) return;
+    for (uint64_t i = 0; i < take; ++i) dst[done + i] = base[c.pos + i];
+    done += take; c.pos += take; c.rem -= take;
+  }
+}
+
+// Byte view of a chunked body for the parsers (k_signers, which has no arena to linearise into): byte i is found by walking
+// the chain from its start -- a rare shape, a handful of chunks.
+struct ChainBytes {
+  const uint8_t* base; ChunkCursor c0; uint64_t end; uint32_t skip;
+  __host__ __device__ inline uint8_t operator[](uint32_t i) const {
+    ChunkCursor c = c0;
+    uint64_t want = (uint64_t)skip + i;
+    for (;;) {
+      if (c.rem == 0 && (!cursor_next_chunk(base, c, end) || c.rem == 0)) return 0;
+      if (want < c.rem) return c.pos + want < end ? base[c.pos + want] : 0;
+      want -= c.rem; c.pos += c.rem; c.rem = 0;
+      if (c.pos >= end) return 0;
+    }
+  }
+  __host__ __device__ inline ChainBytes operator+(uint32_t d) const { return ChainBytes{base, c0, end, skip + d}; }
+};
+__host__ __device__ inline ChainBytes raw_bytes(const ChainBytes& c) { return c; }
+
+// bufio.Reader over the body readers, reduced to positions.  fetch(req) is ONE Read(req) of the underlying reader: never across
+// a chunk boundary, never more than the stream holds.
+struct FetchSim {
+  ChunkCursor c; uint64_t end; uint64_t buffered; bool dry;
+  __host__ __device__ inline uint64_t fetch(const uint8_t* base, uint64_t req) {
+    if (c.rem == 0 && !cursor_next_chunk(base, c, end)) { dry = true; return 0; }
+    uint64_t take = c.rem < end - c.pos ? c.rem : end - c.pos;
+    if (take > req) take = req;
+    if (take == 0) { dry = true; return 0; }
+    c.pos += take; c.rem -= take;
+    return take;
+  }
+  // readFull(r, n bytes) through bufio.Read: from the buffer while it holds something; an empty buffer is refilled by one
+  // Read(4096), or -- for a request of at least the buffer size -- bypassed by one Read straight into the caller's slice
+  __host__ __device__ inline void read_full(const uint8_t* base, uint64_t n) {
+    while (n > 0 && !dry) {
+      if (buffered == 0) {
+        if (n >= BUFIO_SIZE) { n -= fetch(base, n); continue; }
+        buffered = fetch(base, BUFIO_SIZE);
+        if (buffered == 0) return;
+      }
+      const uint64_t take = n < buffered ? n : buffered;
+      n -= take; buffered -= take;
+    }
+  }
+};
+
+// Where does the shared reader stand after packet.Read has PARSED this signature body?  Replays peekVersion's Peek(1) and the
+// reads of Signature.parse (1, 5, hashed area, 2, unhashed area, 2, then 2 + n per MPI) / SignatureV3.parse (1, 1, 5, 8, 2, 2,
+// MPIs); zero-length reads issue no Read call (io.ReadFull).
+__host__ __device__ inline uint64_t reader_position_after_parse(const uint8_t* base, ChunkCursor body, uint64_t end, const SigRec& rec, bool v3) {
+  FetchSim f{body, end, 0, false};
+  f.buffered = f.fetch(base, BUFIO_SIZE);
+  const int n_mpi = rec.mpi_bits[1] || rec.mpi_off[1] ? 2 : 1;
+  // (small reads that follow one another without an area between them cannot empty the buffer in mid-read differently when
+  // merged: bufio refills by the same Read(4096) either way -- so 1+1+5+8+2+2 is one read of 19, 1+5 one of 6)
+  if (v3) f.read_full(base, 19);
+  else {
+    const uint64_t hl = rec.hashed_len, ul = (uint64_t)rec.mpi_off[0] - hl - 12;
+    f.read_full(base, 6); f.read_full(base, hl); f.read_full(base, 2); f.read_full(base, ul); f.read_full(base, 2);
+  }
+  f.read_full(base, 2); f.read_full(base, ((uint64_t)rec.mpi_bits[0] + 7) >> 3);
+  if (n_mpi == 2) { f.read_full(base, 2); f.read_full(base, ((uint64_t)rec.mpi_bits[1] + 7) >> 3); }
+  return f.dry ? ~0ull : f.c.pos;
+}
+
+// One packet.Read framing step at stream position pos of [.., end).
 struct WalkStep {
-  uint64_t next;       // stream position after the packet
-  uint64_t body_off;
-  uint32_t body_len;
+  uint64_t next;       // stream position after the packet, ALL of its body taken (a drained or fully fetched body)
+  uint64_t body_off;   // first body byte (of the first chunk)
+  uint32_t body_len;   // body bytes the readers can deliver (a stream that ends early delivers fewer than announced)
   bool event;          // false: silently skipped (unknown packet type)
   bool reads_to_end;   // known non-signature packet whose parser consumes the whole body (user id, user attribute, private key)
-  uint8_t status;      // ST_PENDING_PARSE for signature packets, final otherwise
+  bool gave_up;        // a chain of chunks longer than this (speculating) caller follows: nothing decided
+  uint8_t status;      // ST_PENDING_PARSE / ST_PENDING_CHUNKED for signature packets, final otherwise
+  uint8_t kind;        // BODY_*
 };
 
 // `hdr(i)` yields stream byte pos+i (i < 6): straight from memory on the host / generic path, from registers on the
-// device fast path below.
+// device fast path below.  `base`: the stream itself, for the length headers between the chunks of a partial-length body.
 template <typename HDR>
-__host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, uint64_t end) {
+__host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, const uint8_t* base, uint64_t pos, uint64_t end, uint32_t max_hops) {
   WalkStep r;
   r.event = true;
   r.reads_to_end = false;
+  r.gave_up = false;
   r.status = ST_PARSE_ERROR;
+  r.kind = BODY_DEFINITE;
   r.body_off = pos;
   r.body_len = 0;
   uint32_t b0 = hdr(0);
@@ -264,12 +399,14 @@ __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, ui
   if ((b0 & 0x40) == 0) {
     tag = (b0 & 0x3F) >> 2;
     uint32_t lt = b0 & 3;
-    if (lt == 3) { r.next = end; r.status = ST_UNSUPPORTED; return r; }  // indeterminate length: fenced
-    uint32_t nb = 1u << lt;
-    if (pos + 1 + nb > end) { r.next = end; return r; }
-    ln = 0;
-    for (uint32_t i = 0; i < nb; ++i) ln = (ln << 8) | hdr(1 + i);
-    start = pos + 1 + nb;
+    if (lt == 3) { r.kind = BODY_INDETERMINATE; start = pos + 1; ln = end - start; }   // contents = the stream itself
+    else {
+      uint32_t nb = 1u << lt;
+      if (pos + 1 + nb > end) { r.next = end; return r; }
+      ln = 0;
+      for (uint32_t i = 0; i < nb; ++i) ln = (ln << 8) | hdr(1 + i);
+      start = pos + 1 + nb;
+    }
   } else {
     tag = b0 & 0x3F;
     if (pos + 1 >= end) { r.next = end; return r; }
@@ -282,29 +419,39 @@ __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, uint64_t pos, ui
       if (pos + 6 > end) { r.next = end; return r; }
       ln = ((uint64_t)hdr(2) << 24) | ((uint64_t)hdr(3) << 16) | ((uint64_t)hdr(4) << 8) | hdr(5);
       start = pos + 6;
-    } else { r.next = end; r.status = ST_UNSUPPORTED; return r; }  // partial body length: fenced
+    } else { r.kind = BODY_PARTIAL; ln = 1ull << (b1 & 31u); start = pos + 2; }
   }
-  if (start + ln > end) { r.next = end; return r; }  // truncated
-  r.next = start + ln;
+  uint64_t avail;
+  if (r.kind == BODY_PARTIAL) {
+    const BodyExtent e = chain_extent(base, ChunkCursor{start, ln, true}, end, max_hops);
+    if (e.gave_up) { r.gave_up = true; r.event = false; r.next = ~0ull; return r; }
+    avail = e.avail; r.next = e.next;
+  } else {
+    const uint64_t room = end - start;
+    avail = ln < room ? ln : room;            // the stream may end inside the body: only a parser that asks for more notices
+    r.next = start + avail;
+  }
   r.body_off = start;
-  r.body_len = (uint32_t)ln;
+  r.body_len = avail < 0xFFFFFFFFull ? (uint32_t)avail : 0xFFFFFFFFu;
   if (tag != 2) {
+    // unknown type: UnknownPacketTypeError, the body drained, Reader.Next goes on.  Known type: an event, "non signature packet"
     if (known_tag(tag)) { r.status = ST_NOT_SIGNATURE; r.reads_to_end = tag == 13 || tag == 17 || tag == 5 || tag == 7; }
     else r.event = false;
     return r;
   }
-  r.status = ST_PENDING_PARSE;
+  if (avail > 0xFFFFFF00ull) { r.status = ST_UNSUPPORTED; return r; }   // beyond the record's 32-bit fields: fenced
+  r.status = r.kind == BODY_PARTIAL ? ST_PENDING_CHUNKED : ST_PENDING_PARSE;
   return r;
 }
 
-__host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end) {
-  return walk_step([&](uint32_t i) -> uint32_t { return base[pos + i]; }, pos, end);
+__host__ __device__ __forceinline__ WalkStep walk_next(const uint8_t* base, uint64_t pos, uint64_t end, uint32_t max_hops = 0xFFFFFFFFu) {
+  return walk_step([&](uint32_t i) -> uint32_t { return base[pos + i]; }, base, pos, end, max_hops);
 }
 
 // Device walk: the whole header (<= 6 bytes) arrives with ONE memory round trip -- three independent aligned dword
 // loads and a funnel shift -- instead of up to three dependent byte loads; the per-item walk is a chain of ~53 such
 // steps and nothing but load latency.  Needs 12 readable bytes from the aligned address, else the byte path.
-__device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t pos, uint64_t end) {
+__device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t pos, uint64_t end, uint32_t max_hops = 0xFFFFFFFFu) {
   const uint64_t a = pos & ~3ull;
   if (a + 12 <= end && ((uintptr_t)base & 3u) == 0) {
     const uint32_t* wp = (const uint32_t*)(base + a);
@@ -312,9 +459,9 @@ __device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t 
     const uint32_t sh = (uint32_t)(pos & 3u) * 8u;
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);     // bytes pos .. pos+3
     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);     // bytes pos+4 .. pos+7
-    return walk_step([&](uint32_t i) -> uint32_t { return ((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4)))) & 0xFFu; }, pos, end);
+    return walk_step([&](uint32_t i) -> uint32_t { return ((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4)))) & 0xFFu; }, base, pos, end, max_hops);
   }
-  return walk_next(base, pos, end);
+  return walk_next(base, pos, end, max_hops);
 }
 
 // Per-item scratch of the counting pass: the first WALK_CAP packet events of an item as
@@ -324,7 +471,10 @@ __device__ __forceinline__ WalkStep walk_next_dev(const uint8_t* base, uint64_t 
 // (the row length is chosen per call by the host from the average stream length: WALK_CAP_MIN .. WALK_CAP_MAX)
 constexpr uint32_t WALK_CAP_MIN = 32, WALK_CAP_MAX = 320;
 constexpr uint32_t DIGEST_OTHER_MAX_BLOCKS = 4096;
-struct WalkEnt { uint32_t body_rel; uint32_t body_len_status; };   // len in the low 24 bits, status in the high 8
+struct WalkEnt { uint32_t body_rel; uint32_t body_len_status; };
+// linearisation arena for partial-length signature bodies: 16-byte units per body (one spare: the parse window reads whole
+// 16-byte granules behind the last byte)
+__host__ __device__ constexpr uint32_t chunk_arena_units(uint32_t body_len) { return (body_len + 15u) / 16u + 4u; }   // len in the low 24 bits, status in the high 8
 
 // One WAVE per item.  A packet stream is a chain -- the position of packet j+1 is known only after the header of
 // packet j -- and walking it one packet per memory round trip made this kernel pure latency (53 dependent misses per
@@ -336,7 +486,9 @@ template <bool FILL>
 __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blob, const uint64_t* __restrict__ sig_off,
                                              uint32_t n_items, uint32_t* __restrict__ counts,
                                              const uint32_t* __restrict__ rec_base, SigRec* __restrict__ recs,
-                                             uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch, uint32_t WALK_CAP) {
+                                             uint8_t* __restrict__ item_flags, WalkEnt* __restrict__ scratch, uint32_t WALK_CAP,
+                                             uint32_t* __restrict__ chunk_units /* counting pass: 16-byte units the parse will need to
+                                                                                   linearise partial-length signature bodies */) {
   const uint32_t item = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   if (item >= n_items) return;
@@ -348,30 +500,33 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
   uint64_t stride = 0;
   bool trailing_skip = false;   // silently skipped packet(s) after the last event
   bool force = false;           // an event that does not fit the scratch encoding: the fill pass must write this item
-  bool unsup = false;           // a framing this walk does not follow (partial / indeterminate length): the item is fenced
+  bool unsup = false;           // a packet after which this walk does not know where the reference's reader stands: the item is fenced
+  uint32_t units = 0;           // this lane's share of the item's linearisation arena
   while (pos < end) {
     const uint64_t p = pos + (uint64_t)lane * stride;
     const bool act = lane == 0 || (stride != 0 && p < end);
     WalkStep w;
-    w.next = ~0ull; w.body_off = 0; w.body_len = 0; w.event = false; w.reads_to_end = false; w.status = ST_PARSE_ERROR;
-    if (act) w = walk_next_dev(sig_blob, p, end);
+    w.next = ~0ull; w.body_off = 0; w.body_len = 0; w.event = false; w.reads_to_end = false; w.gave_up = false; w.status = ST_PARSE_ERROR;
+    w.kind = BODY_DEFINITE;
+    // (a speculating lane follows a chain of partial-length chunks for a few headers only: garbage positions can spell long
+    // chains; lane 0 stands on a true boundary and follows its packet to the end)
+    if (act) w = walk_next_dev(sig_blob, p, end, lane == 0 ? 0xFFFFFFFFu : 4u);
     const uint32_t pn_lo = __shfl_up((uint32_t)w.next, 1), pn_hi = __shfl_up((uint32_t)(w.next >> 32), 1);
-    const bool link = act && (lane == 0 || (((uint64_t)pn_hi << 32) | pn_lo) == p);
+    const bool link = act && !w.gave_up && (lane == 0 || (((uint64_t)pn_hi << 32) | pn_lo) == p);
     const uint64_t broken = __builtin_amdgcn_ballot_w64(!link);
     const uint32_t n_conf = broken ? (uint32_t)__builtin_ctzll(broken) : 64u;   // >= 1: lane 0 always links
     const bool conf = lane < n_conf;
     const uint64_t evm = __builtin_amdgcn_ballot_w64(conf && w.event);
     const uint32_t idx = n + (uint32_t)__builtin_popcountll(evm & ((1ull << lane) - 1ull));
     // Where the reference's reader stands AFTER a packet is part of the semantics (CollectiveSignature.Verify keeps calling
-    // CheckDetachedSignature on the same reader).  packet.Read drains a body on every error, and a signature body of up to
-    // 4096 bytes is drained by the bufio reader peekVersion wraps around it.  Two shapes leave the reader INSIDE the body:
-    // a known non-signature packet whose parser does not read to the end (literal data, compressed, encrypted, one-pass, key
-    // packets with trailing bytes ...: everything but user id / user attribute / private key, which end in ReadAll), and a
-    // signature body longer than the 4096-byte buffer.  What follows is then parsed out of the middle of that body -- not
-    // followed here: the item is fenced.
-    if (conf && w.event && (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end) ||
-                            (w.status == ST_PENDING_PARSE && w.body_len > 4096u)))
+    // CheckDetachedSignature on the same reader).  packet.Read drains a body on every error.  On success nothing is drained: a
+    // known non-signature packet whose parser does not read to the end (literal data, compressed, encrypted, one-pass, key
+    // packets with trailing bytes ...: everything but user id / user attribute / private key, which end in ReadAll) leaves the
+    // reader INSIDE the body, and what follows is parsed out of the middle of it -- not followed here: the item is fenced.
+    // (Signature packets: the parse decides, from what bufio fetched -- parse_one.)
+    if (conf && w.event && (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end)))
       unsup = true;
+    if (!FILL && conf && w.event && w.status == ST_PENDING_CHUNKED) units += chunk_arena_units(w.body_len);
     if (conf && w.event) {
       if (!FILL) {
         if (idx < WALK_CAP) {
@@ -403,6 +558,10 @@ __global__ void __launch_bounds__(64) k_walk(const uint8_t* __restrict__ sig_blo
     const bool any_force = __builtin_amdgcn_ballot_w64(force) != 0;
     const bool any_unsup = __builtin_amdgcn_ballot_w64(unsup) != 0;
     if (lane == 0) { counts[item] = n; item_flags[item] = (trailing_skip ? 1 : 0) | (any_force ? 2 : 0) | (any_unsup ? 4 : 0); }
+    if (__builtin_amdgcn_ballot_w64(units != 0)) {      // rare: a partial-length signature packet in this item
+      for (int d = 32; d >= 1; d >>= 1) units += __shfl_down(units, d);
+      if (lane == 0 && chunk_units) atomicAdd(chunk_units, units);
+    }
   }
 }
 
@@ -446,6 +605,9 @@ struct ParseArgs {
   const uint8_t* item_flags;
   uint32_t defer_queue;        // two-phase calls: k_plan decides which records join the work lists
   const uint32_t* n_recs_dev;  // staged calls: the record count lives on the device (n_recs is then the grid's upper bound)
+  // partial-length signature bodies are linearised here before they are parsed (the kernels downstream read a body as
+  // sig_blob + body_off + i): 16-byte units handed out by an atomic bump; no room => the packet is not claimed (fence)
+  uint8_t* chunk_arena; uint32_t chunk_cap_units; uint32_t* chunk_bump;
 };
 
 // `win`: this lane's PARSE_WIN_STRIDE bytes of LDS.
@@ -467,14 +629,35 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     rec.hashed_len = 0; rec.hash_tag[0] = rec.hash_tag[1] = 0;
     rec.pk_algo = rec.hash_id = rec.sig_type = 0; rec.status = (uint8_t)(e.body_len_status >> 24);
     rec.after_tag = 0; rec.flags = 0; rec.q_kind1 = rec.queued = 0; rec.pk_idx = 0xFFFFFFFFu;
-    if (rec.status != ST_PENDING_PARSE) { recs[ri] = rec; return; }
+    if (rec.status != ST_PENDING_PARSE && rec.status != ST_PENDING_CHUNKED) { recs[ri] = rec; return; }
   } else {
     rec = recs[ri];                                  // written by the sequential k_walk<true>
-    if (rec.status != ST_PENDING_PARSE) return;
+    if (rec.status != ST_PENDING_PARSE && rec.status != ST_PENDING_CHUNKED) return;
+  }
+  // the body as the reference's readers see it in the item's stream: one span, or a chain of partial-length chunks
+  const uint64_t item_end = sig_off[item + 1];
+  const bool chunked = rec.status == ST_PENDING_CHUNKED;
+  ChunkCursor body_cur{rec.body_off, rec.body_len, false};
+  uint64_t body_next = rec.body_off + rec.body_len;
+  if (chunked) {
+    body_cur = ChunkCursor{rec.body_off, 1ull << (sig_blob[rec.body_off - 1] & 31u), true};      // the first chunk's length octet
+    body_next = chain_extent(sig_blob, body_cur, item_end, 0xFFFFFFFFu).next;
+    const uint32_t units = chunk_arena_units(rec.body_len);
+    const uint32_t at = a.chunk_arena ? atomicAdd(a.chunk_bump, units) : 0xFFFFFFFFu;
+    if (!a.chunk_arena || at > a.chunk_cap_units || units > a.chunk_cap_units - at) {
+      rec.status = ST_UNSUPPORTED;                   // nowhere to linearise it: not claimed
+      atomicOr(&item_hash_mask[item], ITEM_FENCED);
+      recs[ri] = rec;
+      return;
+    }
+    uint8_t* const lin = a.chunk_arena + 16ull * at;
+    chain_copy(sig_blob, body_cur, item_end, lin, rec.body_len);
+    rec.body_off = (uint64_t)((uintptr_t)lin - (uintptr_t)sig_blob);   // addressed like every other body: sig_blob + body_off
+    rec.status = ST_PENDING_PARSE;
   }
   // the head of the body: four 16-byte loads per lane (never past the end of the blob), parked in LDS
   const uint8_t* gbody = sig_blob + rec.body_off;
-  const uint64_t room = sig_off[a.n_items] - rec.body_off;
+  const uint64_t room = chunked ? PARSE_WIN : sig_off[a.n_items] - rec.body_off;   // (a linearised body has 64 spare bytes behind it)
   const uint32_t nwin = (room < PARSE_WIN ? (uint32_t)room : PARSE_WIN) & ~15u;
 #pragma unroll
   for (uint32_t j = 0; j < PARSE_WIN / 16; ++j) {
@@ -498,6 +681,11 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     bool parsed;
     if (v3) { parsed = parse_sig_body_v3(body, rec.body_len, rec, issuer); have_issuer = parsed; }
     else parsed = parse_sig_body(body, rec.body_len, rec, have_issuer, issuer, &too_deep);
+    // A body that parses is not drained: the shared reader stays where bufio's last fetch ended.  Short of the packet's end (a
+    // body beyond the 4096-byte buffer, unread chunks, bytes behind an indeterminate-length signature) the next call parses
+    // packets out of the middle of this one -- not followed: fenced.  (One span of <= 4096 bytes is taken by the first fetch.)
+    if (parsed && (chunked || rec.body_len > BUFIO_SIZE) && reader_position_after_parse(sig_blob, body_cur, item_end, rec, v3) != body_next)
+      fence = true;
     if (!parsed) { st = ST_PARSE_ERROR; fence = too_deep; }
     else if (!have_issuer && !msg_slot) st = ST_NO_ISSUER;
     else {
@@ -652,17 +840,29 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
     WalkStep w = walk_next_dev(sig_blob, pos, end);
     pos = w.next;
     if (!w.event) continue;                               // unknown packet type: skipped by Next
-    if (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end) ||
-        (w.status == ST_PENDING_PARSE && w.body_len > 4096u))
-      fence = true;
+    if (w.status == ST_UNSUPPORTED || (w.status == ST_NOT_SIGNATURE && !w.reads_to_end)) fence = true;
     if (w.status == ST_NOT_SIGNATURE) continue;           // other packet types fall through the type switch
-    if (w.status != ST_PENDING_PARSE) break;              // framing error => Next returns err => loop ends
-    const uint8_t* body = sig_blob + w.body_off;
-    if (w.body_len >= 1 && body[0] < 4) continue;         // SignatureV3 is a different Go type
+    if (w.status != ST_PENDING_PARSE && w.status != ST_PENDING_CHUNKED) break;   // framing error => Next returns err => loop ends
     SigRec tmp;
-    bool have_issuer = false;
+    bool have_issuer = false, too_deep = false, parsed, v3;
     uint64_t issuer = 0;
-    if (!parse_sig_body(body, w.body_len, tmp, have_issuer, issuer)) break;   // parse error => Next returns err
+    ChunkCursor cur{w.body_off, w.body_len, false};
+    if (w.status == ST_PENDING_CHUNKED) {
+      // partial body lengths: parsed through a view that walks the chunks (no arena in this parse-only kernel)
+      cur = ChunkCursor{w.body_off, 1ull << (sig_blob[w.body_off - 1] & 31u), true};
+      const ChainBytes body{sig_blob, cur, end, 0u};
+      v3 = w.body_len >= 1 && body[0] < 4;
+      parsed = v3 ? parse_sig_body_v3(body, w.body_len, tmp, issuer) : parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, &too_deep);
+    } else {
+      const uint8_t* body = sig_blob + w.body_off;
+      v3 = w.body_len >= 1 && body[0] < 4;
+      parsed = v3 ? parse_sig_body_v3(body, w.body_len, tmp, issuer) : parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, &too_deep);
+    }
+    if (!parsed) { fence |= too_deep; break; }            // parse error => Next returns err (the body drained)
+    // parsed: the reader stays where bufio's last fetch ended (parse_one) -- short of the packet's end: not followed
+    if ((w.status == ST_PENDING_CHUNKED || w.body_len > BUFIO_SIZE) && reader_position_after_parse(sig_blob, cur, end, tmp, v3) != w.next)
+      fence = true;
+    if (v3) continue;                                     // SignatureV3 is a different Go type: no case of the switch
     if (!have_issuer) { fence = true; break; }            // nil dereference in the reference: fenced
     for (uint32_t k = 0; k < kt.n_keys; ++k) {
       if (kt.key_id[k] == issuer && (kt.flags[k] & KEYF_PRIMARY) && !(kt.flags[k] & KEYF_CERT_ONLY)) {
@@ -686,7 +886,9 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
 __global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ counts, uint32_t n,
                                                       uint32_t* __restrict__ base, uint32_t* __restrict__ total,
                                                       uint32_t* __restrict__ host_total, uint32_t* __restrict__ pk_count /*[24] or null*/,
-                                                      uint32_t* __restrict__ item_hash_mask /*[n] or null*/, uint32_t cap) {
+                                                      uint32_t* __restrict__ item_hash_mask /*[n] or null*/, uint32_t cap,
+                                                      uint32_t* __restrict__ chunk_ctr /*[4] or null: [0] arena units the walk asked
+                                                        for (zeroed here for the next call), [1] the parse's bump, [2] copy of [0]*/) {
   __shared__ uint32_t part[1024];
   uint32_t t = threadIdx.x;
   uint32_t chunk = (n + 1023) / 1024;
@@ -706,14 +908,19 @@ __global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ cou
   const uint32_t all = part[1023];
   if (cap && all > cap) {
     for (uint32_t i = lo; i < hi; ++i) { base[i] = 0; counts[i] = 0; }
-    if (t == 1023) { total[0] = 0; total[1] = all; }
+    if (t == 1023) { total[0] = 0; total[1] = all; if (chunk_ctr) { chunk_ctr[0] = 0; chunk_ctr[1] = 0; chunk_ctr[2] = 0; } }
     return;
   }
   uint32_t run = (t == 0) ? 0 : part[t - 1];
   for (uint32_t i = lo; i < hi; ++i) { base[i] = run; run += counts[i]; }
   if (t == 1023) {
     total[0] = all; total[1] = 0;
-    if (host_total) { __hip_atomic_store(host_total, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    uint32_t units = 0;
+    if (chunk_ctr) { units = chunk_ctr[0]; chunk_ctr[0] = 0; chunk_ctr[1] = 0; chunk_ctr[2] = units; }
+    if (host_total) {
+      host_total[2] = units;      // (ahead of the release below: the host reads it after the packet count)
+      __hip_atomic_store(host_total, all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

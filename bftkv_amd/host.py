@@ -51,6 +51,16 @@ def parse_signature(body: bytes) -> SigParse:
     return out
 
 
+def scan_stream(data: bytes, cap: int = 4096):
+    """bftkv_host_scan_stream: (statuses of the packet events, fence flag) of one signature stream, by the kernels' walk + parse."""
+    st = np.zeros(cap, dtype=np.uint8)
+    n, f = C.c_uint32(0), C.c_uint8(0)
+    rc = _lib().bftkv_host_scan_stream(data, len(data), cap, st.ctypes.data, C.byref(n), C.byref(f))
+    if rc:
+        raise RuntimeError("scan_stream: %d" % rc)
+    return [int(x) for x in st[:min(n.value, cap)]], n.value, bool(f.value)
+
+
 def walk_stream(data: bytes, cap: int = 4096):
     """bftkv_host_walk_stream: (status, body offset, body length) of every packet event of one stream, by the kernels' walk."""
     st = np.zeros(cap, dtype=np.uint8); bo = np.zeros(cap, dtype=np.uint64); bl = np.zeros(cap, dtype=np.uint32)
@@ -73,7 +83,7 @@ HOST_EXPORTS = [
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
-    "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_sha256",
+    "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256",
 ]
 
 _ready = False
@@ -118,6 +128,7 @@ def _lib():
         lib.bftkv_host_max_timestamped_value_masked.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
         lib.bftkv_host_parse_signature.argtypes = [C.c_char_p, C.c_uint32, vp]
         lib.bftkv_host_walk_stream.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, vp, vp, vp, vp]
+        lib.bftkv_host_scan_stream.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_vote_fold.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.bftkv_host_certs_parse.restype = vp
         lib.bftkv_host_certs_parse.argtypes = [C.c_char_p, C.c_uint64]

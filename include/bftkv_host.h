@@ -211,6 +211,12 @@ int bftkv_host_parse_signature(const uint8_t* body, uint32_t len, bftkv_sig_pars
  * length; *n_out = number of events (may exceed cap).  Unknown packet types raise no event (Reader.Next skips them). */
 int bftkv_host_walk_stream(const uint8_t* data, uint64_t len, uint32_t cap, uint8_t* status_out, uint64_t* body_off_out,
                            uint32_t* body_len_out, uint32_t* n_out);
+/* Diagnostic: what the kernels decide about one signature stream before any key or hash is involved (framing, partial-length
+ * bodies linearised, Signature.parse / SignatureV3.parse, where the reference's reader stands after each parsed signature), on
+ * the host through the same code.  status_out[i]: BFTKV_ST_NOT_SIGNATURE, BFTKV_ST_PARSE_ERROR, BFTKV_ST_UNSUPPORTED, or 99 for a
+ * signature body that parsed; *fenced_out: the stream holds a packet after which the reference's reader is not followed.
+ * (crypto/pgp/crypto_pgp.go:486-498 -> x/crypto openpgp/packet.Read) */
+int bftkv_host_scan_stream(const uint8_t* data, uint64_t len, uint32_t cap, uint8_t* status_out, uint32_t* n_out, uint8_t* fenced_out);
 
 /* emsaEncode (crypto/threshold/rsa/rsa.go:356-378): 00 01 FF.. 00 prefix digest, emlen = ceil(bits(N)/8);
  * hash_id is the OpenPGP hash id (2, 8, 9, 10, 11).  BFTKV_E_INVALID when padlen < 3 (crypto.ErrInvalidInput). */

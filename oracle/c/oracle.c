@@ -363,58 +363,204 @@ done:
 
 static int known_tag(int tag) { return tag < 32 && ((0x00066BFEu >> tag) & 1u); }
 
+/* ---- the signature stream as x/crypto READS it (oracle/openpgp.py B.1b is the commented twin of this) --------------------
+ * Reader objects with Go's Read contract, err: 0 none, 1 io.EOF, 2 io.ErrUnexpectedEOF.  Only packets off the common shape
+ * (definite length, body inside the stream, <= 4096 bytes) come through here. */
+typedef struct { const uint8_t* d; uint64_t pos, end; } bstream;                       /* bytes.Reader */
+static uint64_t bs_read(bstream* s, uint8_t* out, uint64_t k, int* err) {
+  *err = 0;
+  if (s->pos >= s->end) { *err = 1; return 0; }
+  uint64_t n = s->end - s->pos < k ? s->end - s->pos : k;
+  if (out) memcpy(out, s->d + s->pos, n);
+  s->pos += n;
+  return n;
+}
+static int bs_read_full(bstream* s, uint8_t* out, uint64_t k) {                        /* packet.readFull: any shortfall is an error */
+  int err;
+  uint64_t got = 0;
+  while (got < k) { uint64_t n = bs_read(s, out + got, k - got, &err); got += n; if (err) return 2; }
+  return 0;
+}
+/* packet.readLength */
+static int read_length(bstream* s, uint64_t* len, int* partial) {
+  uint8_t b[4];
+  *partial = 0;
+  if (bs_read_full(s, b, 1)) return 2;
+  if (b[0] < 192) { *len = b[0]; return 0; }
+  if (b[0] < 224) { const uint64_t hi = (uint64_t)(b[0] - 192) << 8; if (bs_read_full(s, b, 1)) return 2; *len = hi + b[0] + 192; return 0; }
+  if (b[0] < 255) { *len = 1ull << (b[0] & 0x1F); *partial = 1; return 0; }
+  if (bs_read_full(s, b, 4)) return 2;
+  *len = ((uint64_t)b[0] << 24) | ((uint64_t)b[1] << 16) | ((uint64_t)b[2] << 8) | b[3];
+  return 0;
+}
+/* spanReader (kind 0), partialLengthReader (1), the bare stream of an indeterminate-length packet (2) */
+typedef struct { int kind; bstream* s; uint64_t rem; int partial; } body_rd;
+static uint64_t body_read(body_rd* r, uint8_t* out, uint64_t k, int* err) {
+  if (r->kind == 2) return bs_read(r->s, out, k, err);
+  if (r->kind == 0) {
+    if (r->rem == 0) { *err = 1; return 0; }
+    const uint64_t n = bs_read(r->s, out, k < r->rem ? k : r->rem, err);
+    r->rem -= n;
+    if (r->rem > 0 && *err == 1) *err = 2;
+    return n;
+  }
+  while (r->rem == 0) {
+    if (!r->partial) { *err = 1; return 0; }
+    if (read_length(r->s, &r->rem, &r->partial)) { *err = 2; return 0; }
+  }
+  const uint64_t want = k < r->rem ? k : r->rem;
+  const uint64_t n = bs_read(r->s, out, want, err);
+  r->rem -= n;
+  if (n < want && *err == 1) *err = 2;
+  return n;
+}
+static void consume_all(body_rd* r) {                                                  /* packet.consumeAll */
+  int err;
+  do { body_read(r, NULL, 1024, &err); } while (!err);
+}
+/* bufio.Reader, 4096 bytes: Peek(1) and Read */
+typedef struct { body_rd* rd; uint8_t buf[4096]; uint32_t r, w; int err; } bufio_rd;
+static int bufio_take_err(bufio_rd* b) { const int e = b->err; b->err = 0; return e; }
+static int bufio_peek1(bufio_rd* b, uint8_t* v) {
+  while (b->r == b->w && !b->err) {
+    b->r = b->w = 0;
+    b->w = (uint32_t)body_read(b->rd, b->buf, sizeof b->buf, &b->err);                 /* fill(): our readers never return (0, nil) */
+  }
+  if (b->r < b->w) { *v = b->buf[b->r]; return 0; }
+  return bufio_take_err(b);
+}
+static uint64_t bufio_read(bufio_rd* b, uint8_t* out, uint64_t k, int* err) {
+  *err = 0;
+  if (b->r == b->w) {
+    if (b->err) { *err = bufio_take_err(b); return 0; }
+    if (k >= sizeof b->buf) {                                                          /* large read, empty buffer: no copy */
+      const uint64_t n = body_read(b->rd, out, k, &b->err);
+      *err = bufio_take_err(b);
+      return n;
+    }
+    b->r = b->w = 0;
+    const uint64_t n = body_read(b->rd, b->buf, sizeof b->buf, &b->err);
+    if (n == 0) { *err = bufio_take_err(b); return 0; }
+    b->w = (uint32_t)n;
+  }
+  uint64_t n = b->w - b->r < k ? b->w - b->r : k;
+  if (out) memcpy(out, b->buf + b->r, n);
+  b->r += (uint32_t)n;
+  return n;
+}
+static int bufio_read_full(bufio_rd* b, uint64_t k) {                                  /* readFull(r, make([]byte, k)); data discarded */
+  uint64_t got = 0;
+  int err = 0;
+  uint8_t* sink = k ? malloc(k) : NULL;       /* a real destination: the large-read path copies straight into it */
+  while (got < k && !err) got += bufio_read(b, sink + got, k - got, &err);
+  free(sink);
+  return got < k;
+}
+
+/* One signature packet off the common shape.  `rd` is positioned on the first body byte.  The body is parsed from a linear copy
+ * of what the readers can deliver; when it parses, the reads Signature.parse / SignatureV3.parse would issue are replayed through
+ * a real bufio over the real readers, which leaves the shared stream where the reference leaves it; when it does not, the body
+ * is drained.  Returns 1 when parsed (*lin is then the caller's to free: psig points into it). */
+static int read_signature_general(body_rd* rd, psig* s, uint8_t** lin) {
+  bstream probe_s = *rd->s;
+  body_rd probe = *rd;
+  probe.s = &probe_s;
+  uint64_t cap = 4096, n = 0;
+  uint8_t* buf = malloc(cap);
+  for (;;) {
+    int err;
+    if (n == cap) { cap *= 2; buf = realloc(buf, cap); }
+    n += body_read(&probe, buf + n, cap - n, &err);
+    if (err) break;
+  }
+  *lin = buf;
+  const int parsed = n > 0x7FFFFFFF ? 0 : ((n >= 1 && buf[0] < 4) ? parse_body_v3(buf, (int)n, s) : parse_body(buf, (int)n, s, 0));
+  bufio_rd* b = calloc(1, sizeof *b);
+  b->rd = rd;
+  uint8_t ver;
+  if (bufio_peek1(b, &ver)) { free(b); free(buf); *lin = NULL; return 0; }             /* empty body: Peek fails, nothing to drain */
+  if (!parsed) {
+    int err;
+    do { bufio_read(b, NULL, 1024, &err); } while (!err);                              /* consumeAll(contents) -- contents is the bufio */
+    free(b); free(buf); *lin = NULL;
+    return 0;
+  }
+  int bad = 0;
+  if (s->v3) {
+    const uint64_t reads[6] = {1, 1, 5, 8, 2, 2};
+    for (int i = 0; i < 6; ++i) bad |= bufio_read_full(b, reads[i]);
+  } else {
+    const uint64_t hl = (uint64_t)s->prefix_len - 6;
+    const uint64_t ul = (uint64_t)(s->mpi[0] - buf) - 6 - hl - 2 - 2 - 2;
+    const uint64_t reads[6] = {1, 5, hl, 2, ul, 2};
+    for (int i = 0; i < 6; ++i) bad |= bufio_read_full(b, reads[i]);
+  }
+  for (int i = 0; i < 2 && s->mpi[i]; ++i) { bad |= bufio_read_full(b, 2); bad |= bufio_read_full(b, (uint64_t)s->mpi_len[i]); }
+  free(b);
+  if (bad) { fprintf(stderr, "oracle: replay of a parsed signature ran dry\n"); abort(); }
+  return 1;
+}
+
 /* One openpgp.CheckDetachedSignature(keyring, signed, sigstream@pos) call (B.3).
  * Returns the call's status; *signer = entity id on ST_OK; *pos advanced; per-packet statuses
  * appended to trace (if non-NULL). */
 static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sd, uint64_t end, uint64_t* pos,
                           uint64_t* signer, uint8_t* trace, int* ntrace, int cap, BN_CTX* ctx, uint64_t* n_pk_ops) {
 #define TRACE(st) do { if (trace && *ntrace < cap) trace[(*ntrace)++] = (uint8_t)(st); } while (0)
+  uint8_t* lin = NULL;       /* linear copy of a signature body that did not lie in the stream in one piece */
+#define RETURN(st) do { free(lin); return (st); } while (0)
   for (;;) {
-    uint64_t p = *pos;
-    if (p >= end) return ST_UNKNOWN_ISSUER;   /* io.EOF => ErrUnknownIssuer */
-    int b0 = sd[p];
-    if (!(b0 & 0x80)) { *pos = p + 1; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-    int tag; uint64_t start, ln;
+    free(lin); lin = NULL;
+    bstream bs = {sd, *pos, end};
+    uint8_t b0;
+    if (bs.pos >= end) RETURN(ST_UNKNOWN_ISSUER);   /* io.EOF => ErrUnknownIssuer */
+    b0 = sd[bs.pos++];
+    if (!(b0 & 0x80)) { *pos = bs.pos; TRACE(ST_PARSE_ERROR); RETURN(ST_PARSE_ERROR); }
+    int tag;
+    body_rd rd = {0, &bs, 0, 0};
     if (!(b0 & 0x40)) {
       tag = (b0 & 0x3F) >> 2;
-      int lt = b0 & 3;
-      if (lt == 3) { *pos = end; TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
-      int nb = 1 << lt;
-      if (p + 1 + nb > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-      ln = 0;
-      for (int i = 0; i < nb; ++i) ln = (ln << 8) | sd[p + 1 + i];
-      start = p + 1 + nb;
+      const int lt = b0 & 3;
+      if (lt == 3) rd.kind = 2;
+      else {
+        uint8_t lb[4];
+        if (bs_read_full(&bs, lb, 1u << lt)) { *pos = bs.pos; TRACE(ST_PARSE_ERROR); RETURN(ST_PARSE_ERROR); }
+        for (int i = 0; i < (1 << lt); ++i) rd.rem = (rd.rem << 8) | lb[i];
+      }
     } else {
       tag = b0 & 0x3F;
-      if (p + 1 >= end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-      int b1 = sd[p + 1];
-      if (b1 < 192) { ln = b1; start = p + 2; }
-      else if (b1 < 224) {
-        if (p + 2 >= end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-        ln = ((uint64_t)(b1 - 192) << 8) + sd[p + 2] + 192; start = p + 3;
-      } else if (b1 == 255) {
-        if (p + 6 > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-        ln = ((uint64_t)sd[p + 2] << 24) | ((uint64_t)sd[p + 3] << 16) | ((uint64_t)sd[p + 4] << 8) | sd[p + 5];
-        start = p + 6;
-      } else { *pos = end; TRACE(ST_UNSUPPORTED); return ST_UNSUPPORTED; }
+      if (read_length(&bs, &rd.rem, &rd.partial)) { *pos = bs.pos; TRACE(ST_PARSE_ERROR); RETURN(ST_PARSE_ERROR); }
+      if (rd.partial) rd.kind = 1;
     }
-    if (start + ln > end) { *pos = end; TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-    *pos = start + ln;
     if (tag != 2) {
-      if (known_tag(tag)) { TRACE(ST_NOT_SIGNATURE); return ST_NOT_SIGNATURE; }
+      /* unknown type: UnknownPacketTypeError, body drained, Next goes on.  Known type: parsed by code this restatement does not
+       * follow (whole body taken; the verifier fences the types whose parser can stop early) */
+      consume_all(&rd);
+      *pos = bs.pos;
+      if (known_tag(tag)) { TRACE(ST_NOT_SIGNATURE); RETURN(ST_NOT_SIGNATURE); }
       continue;
     }
     psig s;
-    /* packet.Read peeks the version: < 4 => SignatureV3, else Signature */
-    const int parsed = (ln >= 1 && sd[start] < 4) ? parse_body_v3(sd + start, (int)ln, &s) : parse_body(sd + start, (int)ln, &s, 0);
-    if (!parsed) { TRACE(ST_PARSE_ERROR); return ST_PARSE_ERROR; }
-    if (!s.have_issuer) { TRACE(ST_NO_ISSUER); return ST_NO_ISSUER; }
+    int parsed;
+    if (rd.kind == 0 && rd.rem <= 4096 && rd.rem <= end - bs.pos) {
+      /* the common shape: the body lies in the stream in one piece and bufio's first fetch takes all of it, so the reader
+       * stands behind the packet whatever the parse says */
+      const uint64_t start = bs.pos, ln = rd.rem;
+      *pos = start + ln;
+      /* packet.Read peeks the version: < 4 => SignatureV3, else Signature */
+      parsed = (ln >= 1 && sd[start] < 4) ? parse_body_v3(sd + start, (int)ln, &s) : parse_body(sd + start, (int)ln, &s, 0);
+    } else {
+      parsed = read_signature_general(&rd, &s, &lin);
+      *pos = bs.pos;
+    }
+    if (!parsed) { TRACE(ST_PARSE_ERROR); RETURN(ST_PARSE_ERROR); }
+    if (!s.have_issuer) { TRACE(ST_NO_ISSUER); RETURN(ST_NO_ISSUER); }
     /* KeysByIdUsage(issuer, KeyFlagSign) */
     int found = 0;
     for (int i = 0; i < o->n_keys; ++i) if (o->keys[i].key_id == s.issuer && o->keys[i].usable_sign) { found = 1; break; }
     if (!found) { TRACE(ST_UNKNOWN_ISSUER); continue; }
     hctx hc;
-    if ((s.sig_type != 0 && s.sig_type != 1) || !h_init(&hc, s.hash_id)) { TRACE(ST_HASH_UNSUPPORTED); return ST_HASH_UNSUPPORTED; }
+    if ((s.sig_type != 0 && s.sig_type != 1) || !h_init(&hc, s.hash_id)) { TRACE(ST_HASH_UNSUPPORTED); RETURN(ST_HASH_UNSUPPORTED); }
     /* the reference hashes the WHOLE payload again for every signature packet; text-mode (0x01) signatures through
      * openpgp.NewCanonicalTextHash: a '\n' that does not follow a '\r' becomes "\r\n", the byte after a '\r' passes
      * unchanged (the hash suffix below goes into the raw hash) */
@@ -451,12 +597,13 @@ static int check_detached(const oracle* o, const uint8_t* tbs, uint64_t tbs_len,
         int sub = (BN_num_bits(k->q) + 7) / 8;
         ok = dsa_verify(k, dg, (int)dl > sub ? sub : (int)dl, s.mpi[0], s.mpi_len[0], s.mpi[1], s.mpi_len[1], ctx);
       } else { st = ST_UNSUPPORTED; continue; }
-      if (ok) { *signer = k->entity_id; TRACE(ST_OK); return ST_OK; }
+      if (ok) { *signer = k->entity_id; TRACE(ST_OK); RETURN(ST_OK); }
       st = ST_BAD_SIG;
     }
     TRACE(st);
-    return st;
+    RETURN(st);
   }
+#undef RETURN
 #undef TRACE
 }
 

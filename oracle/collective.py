@@ -75,19 +75,15 @@ def signers(kr: Keyring, sig: SignaturePacket) -> List[int]:
     data = sig.Data or b""
     pos = 0
     while True:
-        try:
-            pkt = pgp.next_packet(data, pos)
-        except Exception:
-            break
-        pos = pkt.end
-        if pkt.tag != 2:
+        pkt = pgp.packet_read_stream(data, pos)
+        pos = pkt.pos
+        if pkt.kind in ("eof", "error", "sig_error"):
+            break     # any error of Reader.Next (io.EOF included) ends the walk
+        if pkt.kind != "sig":
             continue  # unknown types are skipped by Next; other known types fall through the type switch
-        if len(pkt.body) >= 1 and pkt.body[0] < 4:
+        s = pkt.sig
+        if s.version < 4:
             continue  # SignatureV3 is a different Go type: not matched by the switch
-        try:
-            s = pgp.parse_signature_body(pkt.body)
-        except Exception:
-            break
         if s.issuer is None:
             break
         e = kr.get_cert_by_id(s.issuer)

@@ -300,6 +300,293 @@ def parse_signature_v3_body(body: bytes) -> Signature:
     return sig
 
 
+# ------------------------------------------------------------------------------------------------
+# B.1b  The signature stream as x/crypto READS it: reader objects, not byte ranges
+#
+# PGPCollectiveSignature.Verify hands ONE bytes.Reader to CheckDetachedSignature again and again (crypto_pgp.go:486-498); what a
+# call consumes is whatever the readers stacked on top of it pulled: packet.readHeader's spanReader (definite lengths) or
+# partialLengthReader (new-format partial lengths) or the bare stream (old-format indeterminate length), and -- for signature
+# packets -- the 4096-byte bufio.Reader that peekVersion wraps around them.  A body that parses is NOT drained afterwards; a body
+# that fails is (consumeAll).  Consequences the byte-range view above cannot express, all restated literally here:
+#   * a signature whose declared length runs past the end of the stream still verifies when the signature itself is complete;
+#   * partial-length and indeterminate-length signature packets parse like any other;
+#   * after a SUCCESSFUL parse the shared reader stands where bufio's last fetch ended, which can be short of the packet's end
+#     (bodies over 4096 bytes, unread chunks): the next call then parses packets out of the middle of this one.
+# Go's Read contract is kept as (data, err) pairs: err is None, "EOF" (io.EOF) or "UEOF" (io.ErrUnexpectedEOF).
+# (golang.org/x/crypto v0.0.0-20191227163750-53104e6ec876 openpgp/packet/packet.go, reader.go; Go's bufio and io -- sources absent
+# here: restated from their documented behaviour, pinned by shim/tools/genvectors when someone runs it.)
+# ------------------------------------------------------------------------------------------------
+class _ByteStream:
+    """bytes.Reader: Read returns what is there, (0, io.EOF) once nothing is."""
+    def __init__(self, buf: bytes, pos: int = 0):
+        self.buf, self.pos = buf, pos
+
+    def read(self, n: int):
+        if self.pos >= len(self.buf):
+            return b"", "EOF"
+        d = self.buf[self.pos:self.pos + n]
+        self.pos += len(d)
+        return d, None
+
+
+def _io_read_full(r, n: int):
+    """io.ReadFull: no Read call at all for an empty buffer; io.EOF only when nothing was read."""
+    out = b""
+    err = None
+    while len(out) < n and err is None:
+        d, err = r.read(n - len(out))
+        out += d
+    if len(out) >= n:
+        return out, None
+    if out and err == "EOF":
+        err = "UEOF"
+    return out, err
+
+
+def _read_full(r, n: int):
+    """packet.readFull: io.ReadFull with io.EOF turned into io.ErrUnexpectedEOF."""
+    d, err = _io_read_full(r, n)
+    return d, ("UEOF" if err == "EOF" else err)
+
+
+class _SpanReader:
+    """packet.spanReader: at most n bytes of r; the stream ending early is io.ErrUnexpectedEOF."""
+    def __init__(self, r, n: int):
+        self.r, self.n = r, n
+
+    def read(self, k: int):
+        if self.n <= 0:
+            return b"", "EOF"
+        d, err = self.r.read(min(k, self.n))
+        self.n -= len(d)
+        if self.n > 0 and err == "EOF":
+            err = "UEOF"
+        return d, err
+
+
+def _read_length(r):
+    """packet.readLength (RFC 4880 4.2.2): (length, is_partial, err)."""
+    b, err = _read_full(r, 1)
+    if err:
+        return 0, False, err
+    b0 = b[0]
+    if b0 < 192:
+        return b0, False, None
+    if b0 < 224:
+        b, err = _read_full(r, 1)
+        if err:
+            return 0, False, err
+        return ((b0 - 192) << 8) + b[0] + 192, False, None
+    if b0 < 255:
+        return 1 << (b0 & 0x1F), True, None
+    b, err = _read_full(r, 4)
+    if err:
+        return 0, False, err
+    return int.from_bytes(b, "big"), False, None
+
+
+class _PartialLengthReader:
+    """packet.partialLengthReader: chunk after chunk, each announced by its own length header."""
+    def __init__(self, r, remaining: int):
+        self.r, self.remaining, self.is_partial = r, remaining, True
+
+    def read(self, k: int):
+        while self.remaining == 0:
+            if not self.is_partial:
+                return b"", "EOF"
+            self.remaining, self.is_partial, err = _read_length(self.r)
+            if err:
+                return b"", err
+        want = min(k, self.remaining)
+        d, err = self.r.read(want)
+        self.remaining -= len(d)
+        if len(d) < want and err == "EOF":
+            err = "UEOF"
+        return d, err
+
+
+class _Bufio:
+    """bufio.Reader (default size 4096) as far as Peek(1) and Read go."""
+    SIZE = 4096
+
+    def __init__(self, rd):
+        self.rd, self.buf, self.err = rd, b"", None
+
+    def _read_err(self):
+        e, self.err = self.err, None
+        return e
+
+    def peek1(self):
+        while not self.buf and self.err is None:
+            for _ in range(100):                      # fill(): one Read, repeated only while it returns (0, nil)
+                d, err = self.rd.read(self.SIZE)
+                self.buf += d
+                if err is not None:
+                    self.err = err
+                    break
+                if d:
+                    break
+            else:
+                self.err = "NOPROGRESS"
+        if self.buf:
+            return self.buf[:1], None
+        return b"", self._read_err()
+
+    def read(self, n: int):
+        if n == 0:
+            return b"", (None if self.buf else self._read_err())
+        if not self.buf:
+            if self.err is not None:
+                return b"", self._read_err()
+            if n >= self.SIZE:                        # large read, empty buffer: straight into the caller's slice
+                d, self.err = self.rd.read(n)
+                return d, self._read_err()
+            d, self.err = self.rd.read(self.SIZE)     # one read, not fill()
+            if not d:
+                return b"", self._read_err()
+            self.buf = d
+        out, self.buf = self.buf[:n], self.buf[n:]
+        return out, None
+
+
+def _consume_all(r) -> None:
+    """packet.consumeAll: 1024 bytes at a time until any error."""
+    while True:
+        _, err = r.read(1024)
+        if err is not None:
+            return
+
+
+def _read_header_stream(r):
+    """packet.readHeader: (tag, contents reader, err)."""
+    b, err = _io_read_full(r, 1)
+    if err:
+        return 0, None, err                           # io.EOF here is the clean end of the stream
+    b0 = b[0]
+    if b0 & 0x80 == 0:
+        return 0, None, "STRUCT"                      # "tag byte does not have MSB set"
+    if b0 & 0x40 == 0:
+        tag, lt = (b0 & 0x3F) >> 2, b0 & 3
+        if lt == 3:
+            return tag, r, None                       # indeterminate length: the stream itself
+        nb = 1 << lt
+        b, err = _read_full(r, nb)
+        if err:
+            return 0, None, err
+        return tag, _SpanReader(r, int.from_bytes(b, "big")), None
+    tag = b0 & 0x3F
+    ln, partial, err = _read_length(r)
+    if err:
+        return 0, None, err
+    return tag, (_PartialLengthReader(r, ln) if partial else _SpanReader(r, ln)), None
+
+
+class _ReadErr(Exception):
+    """A reader ran dry in the middle of Signature.parse."""
+
+
+def _need(r, n: int) -> bytes:
+    d, err = _read_full(r, n)
+    if err:
+        raise _ReadErr(err)
+    return d
+
+
+def parse_signature_stream(r) -> "Signature":
+    """Signature.parse reading from r in x/crypto's order: 1, 5, hashed area, 2, unhashed area, 2, then 2 + n per MPI."""
+    v = _need(r, 1)
+    if v[0] != 4:
+        raise UnsupportedError("signature packet version %d" % v[0])
+    h = _need(r, 5)
+    sig = Signature(version=4, sig_type=h[0], pk_algo=h[1], hash_id=h[2])
+    if sig.pk_algo not in (PK_RSA, PK_RSA_SIGN_ONLY, PK_DSA, PK_ECDSA):
+        raise UnsupportedError("public key algorithm %d" % sig.pk_algo)
+    if sig.hash_id not in HASH_BY_ID:
+        raise UnsupportedError("hash function %d" % sig.hash_id)
+    hl = (h[3] << 8) | h[4]
+    hashed = _need(r, hl)
+    l = 6 + hl
+    sig.hash_suffix = v + h + hashed + bytes([4, 0xFF]) + struct.pack(">I", l)
+    _parse_subpackets(sig, hashed, True)
+    if sig.creation_time is None:
+        raise StructuralError("no creation time in signature")
+    u = _need(r, 2)
+    _parse_subpackets(sig, _need(r, (u[0] << 8) | u[1]), False)
+    sig.hash_tag = _need(r, 2)
+    for _ in range(1 if sig.pk_algo in (PK_RSA, PK_RSA_SIGN_ONLY) else 2):
+        b = _need(r, 2)
+        bits = (b[0] << 8) | b[1]
+        sig.mpis.append((bits, _need(r, (bits + 7) // 8)))
+    return sig
+
+
+def parse_signature_v3_stream(r) -> "Signature":
+    """SignatureV3.parse in its own order of reads: 1, 1, 5, 8, 2, 2, MPIs."""
+    v = _need(r, 1)
+    if v[0] < 2 or v[0] > 3:
+        raise UnsupportedError("signature packet version %d" % v[0])
+    ln = _need(r, 1)
+    if ln[0] != 5:
+        raise UnsupportedError("invalid hashed material length %d" % ln[0])
+    hm = _need(r, 5)
+    iss = _need(r, 8)
+    a = _need(r, 2)
+    sig = Signature(version=v[0], sig_type=hm[0], pk_algo=a[0], hash_id=a[1])
+    sig.creation_time = int.from_bytes(hm[1:5], "big")
+    sig.issuer = int.from_bytes(iss, "big")
+    if sig.pk_algo not in (PK_RSA, PK_RSA_SIGN_ONLY, PK_DSA):
+        raise UnsupportedError("public key algorithm %d" % sig.pk_algo)
+    if sig.hash_id not in HASH_BY_ID:
+        raise UnsupportedError("hash function %d" % sig.hash_id)
+    sig.hash_suffix = hm
+    sig.hash_tag = _need(r, 2)
+    for _ in range(2 if sig.pk_algo == PK_DSA else 1):
+        b = _need(r, 2)
+        bits = (b[0] << 8) | b[1]
+        sig.mpis.append((bits, _need(r, (bits + 7) // 8)))
+    return sig
+
+
+@dataclass
+class StreamPacket:
+    """One packet.Read call on the shared stream."""
+    kind: str                    # "sig" | "sig_error" | "not_signature" | "unknown" | "error" | "eof"
+    tag: int = 0
+    sig: Optional["Signature"] = None
+    pos: int = 0                 # where the shared reader stands after the call
+    body_unread: bool = False    # a parsed signature left bytes of its own packet in the stream (bufio stopped short of its end)
+    lazy_parser: bool = False    # a known non-signature type whose x/crypto parser may stop before the end of the body
+
+
+def packet_read_stream(buf: bytes, pos: int) -> StreamPacket:
+    """packet.Read on the shared reader at pos."""
+    s = _ByteStream(buf, pos)
+    tag, contents, err = _read_header_stream(s)
+    if err == "EOF":
+        return StreamPacket("eof", pos=s.pos)
+    if err:
+        return StreamPacket("error", pos=s.pos)
+    if tag != 2:
+        # every other type: the known ones are parsed by code this restatement does not follow (where their parser stops is the
+        # fence of position_is_type_dependent); here their whole body is taken, as consumeAll does for unknown types and errors
+        _consume_all(contents)
+        if tag in _KNOWN_TAGS:
+            return StreamPacket("not_signature", tag=tag, pos=s.pos, lazy_parser=tag not in _READS_TO_END)
+        return StreamPacket("unknown", tag=tag, pos=s.pos)
+    bufr = _Bufio(contents)
+    ver, err = bufr.peek1()
+    if err:
+        return StreamPacket("sig_error", tag=2, pos=s.pos)        # io.EOF (empty body) ends Reader.Next the same way an error does
+    try:
+        sig = parse_signature_v3_stream(bufr) if ver[0] < 4 else parse_signature_stream(bufr)
+    except (StructuralError, UnsupportedError, _ReadErr, RecursionError):
+        _consume_all(bufr)
+        return StreamPacket("sig_error", tag=2, pos=s.pos)
+    after = s.pos
+    _consume_all(contents)                                        # (not done by the reference: only to see whether anything was left)
+    return StreamPacket("sig", tag=2, sig=sig, pos=after, body_unread=s.pos != after)
+
+
 @dataclass
 class RawPacket:
     tag: int
@@ -333,34 +620,31 @@ _READS_TO_END = {5, 7, 13, 17}
 
 
 def position_is_type_dependent(buf: bytes, stop_at_error: bool = False) -> bool:
-    """Does this signature stream contain a packet after which the reference's reader may stand INSIDE the packet body?
+    """Does this signature stream contain a packet after which the verifier does not follow the reference's reader?
 
-    packet.Read drains a body on every error and -- through the 4096-byte bufio reader peekVersion wraps around it -- a
-    signature body of up to 4096 bytes.  On SUCCESS nothing else is drained: a literal-data / compressed / encrypted /
-    one-pass / key packet whose parser stops before the end of the body, or a signature body beyond 4096 bytes, leaves the
-    shared reader in mid-body, and PGPCollectiveSignature.Verify's next CheckDetachedSignature call parses packets out of
-    those bytes.  This restatement (next_packet: pos = end of the packet) does not model that; the verifier FENCES such items
-    (kernels.hip k_walk), and so must whoever compares against this oracle.  Partial / indeterminate lengths likewise."""
+    Two shapes (DESIGN.md "fenced inputs"; kernels.hip k_walk / parse_one raise the item's fence flag on them):
+      * a known non-signature packet whose x/crypto parser may return before the end of its body (literal data, compressed,
+        encrypted, one-pass, key packets ...: everything but user id / user attribute / private key, which end in ReadAll) --
+        this restatement does not model those parsers, it takes the whole body;
+      * a signature packet that PARSES while bufio's last fetch stopped short of the end of its packet (packet_read_stream's
+        body_unread: bodies beyond 4096 bytes, unread partial-length chunks, an indeterminate-length packet with more than the
+        signature behind it): the next CheckDetachedSignature call parses packets out of the middle of this one.  This
+        restatement DOES follow that exactly; the kernels do not.
+    stop_at_error: PGPSignature.Signers' walk, which the first error of Reader.Next ends."""
     pos = 0
-    while pos < len(buf):
-        try:
-            pkt = next_packet(buf, pos)
-        except UnsupportedError:
-            return True
-        except StructuralError as e:          # a stray byte: that call fails, the next one starts behind it
-            if stop_at_error:                 # (PGPSignature.Signers: the first error of Reader.Next ends the walk)
-                return False
-            pos = e.consumed
-            continue
-        except (_Truncated, EOFError):
+    while True:
+        pkt = packet_read_stream(buf, pos)
+        pos = pkt.pos
+        if pkt.kind == "eof":
             return False
-        if pkt.tag == 2:
-            if len(pkt.body) > 4096:
-                return True
-        elif pkt.tag in _KNOWN_TAGS and pkt.tag not in _READS_TO_END:
+        if pkt.kind in ("error", "sig_error"):
+            if stop_at_error:
+                return False
+            continue
+        if pkt.kind == "not_signature" and pkt.lazy_parser:
             return True
-        pos = pkt.end
-    return False
+        if pkt.kind == "sig" and pkt.body_unread:
+            return True
 
 
 # ------------------------------------------------------------------------------------------------
@@ -658,31 +942,19 @@ def check_detached_signature(keyring: List[Entity], signed: bytes, sigdata: byte
     bytes.Reader positioned at ``pos`` (crypto_pgp.go:321-329, 486-498).  B.3."""
     per_packet: List[int] = []
     while True:
-        try:
-            pkt = next_packet(sigdata, pos)
-        except EOFError:
+        pkt = packet_read_stream(sigdata, pos)
+        pos = pkt.pos                                     # wherever the readers of that packet.Read call stopped pulling
+        if pkt.kind == "eof":
             return StepResult(ST_UNKNOWN_ISSUER, None, pos, per_packet)  # io.EOF => ErrUnknownIssuer
-        except StructuralError as e:
-            per_packet.append(ST_PARSE_ERROR)
-            return StepResult(ST_PARSE_ERROR, None, e.consumed, per_packet)
-        except UnsupportedError as e:
-            per_packet.append(ST_UNSUPPORTED)
-            return StepResult(ST_UNSUPPORTED, None, e.consumed, per_packet)
-        except _Truncated:
-            per_packet.append(ST_PARSE_ERROR)
-            return StepResult(ST_PARSE_ERROR, None, len(sigdata), per_packet)
-        pos = pkt.end   # bufio inside peekVersion/consumeAll drains the whole body (<= 4096 B)
-        if pkt.tag != 2:
-            if pkt.tag in _KNOWN_TAGS:
-                per_packet.append(ST_NOT_SIGNATURE)
-                return StepResult(ST_NOT_SIGNATURE, None, pos, per_packet)
-            continue  # Reader.Next silently skips unknown packet types
-        try:
-            # packet.Read peeks the version: < 4 => *packet.SignatureV3, else *packet.Signature
-            sig = parse_signature_v3_body(pkt.body) if (len(pkt.body) >= 1 and pkt.body[0] < 4) else parse_signature_body(pkt.body)
-        except (StructuralError, UnsupportedError, _Truncated):
+        if pkt.kind == "unknown":
+            continue  # Reader.Next silently skips unknown packet types (their body drained by consumeAll)
+        if pkt.kind == "not_signature":
+            per_packet.append(ST_NOT_SIGNATURE)
+            return StepResult(ST_NOT_SIGNATURE, None, pos, per_packet)
+        if pkt.kind != "sig":                             # framing error, or a signature body that does not parse (drained)
             per_packet.append(ST_PARSE_ERROR)
             return StepResult(ST_PARSE_ERROR, None, pos, per_packet)
+        sig = pkt.sig
         if sig.issuer is None:
             per_packet.append(ST_NO_ISSUER)
             return StepResult(ST_NO_ISSUER, None, pos, per_packet)

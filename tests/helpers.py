@@ -106,6 +106,97 @@ def random_framing_streams(cl, n_items, seed=77):
     return tbs_l, ss_l, hdr, srng
 
 
+def sign_body(kp, signed: bytes, srng, hashed_extra: bytes = b"", unhashed: bytes = b"", trailing: bytes = b"") -> bytes:
+    """One valid v4 signature BODY (no packet header) over ``signed`` with extra hashed subpackets, an unhashed area and bytes
+    behind the MPIs."""
+    import hashlib, struct
+    prefix = cb.sig_prefix(0x00, kp.algo, cb._hashed_area(kp.key_id, hashed_extra))
+    digest = hashlib.sha256(signed + cb.hash_suffix(prefix)).digest()
+    pkt = cb.make_sig_packet(kp, prefix, digest, srng)
+    body = pkt[6:] if pkt[1] == 255 else (pkt[3:] if pkt[1] >= 192 else pkt[2:])
+    assert body[:len(prefix)] == prefix and body[len(prefix):len(prefix) + 2] == b"\0\0"
+    return prefix + struct.pack(">H", len(unhashed)) + unhashed + body[len(prefix) + 2:] + trailing
+
+
+def partial_frame(tag: int, body: bytes, rng, zero_final=False, max_pow=9) -> bytes:
+    """New-format packet with partial body lengths: 2^k-byte chunks (k random), the last chunk with a definite length in a
+    random encoding (zero-length when asked)."""
+    assert len(body) >= 1
+    out = bytearray([0xC0 | tag])
+    pos = 0
+    first = True
+    while True:
+        left = len(body) - pos
+        kmax = min(max_pow, left.bit_length() - 1) if left else -1
+        if kmax >= 0 and (first or (rng.random() < 0.7 and not (zero_final and left == 0))):
+            k = int(rng.integers(0, kmax + 1))
+            out.append(224 + k)
+            out += body[pos:pos + (1 << k)]
+            pos += 1 << k
+            first = False
+            continue
+        last = b"" if zero_final else body[pos:]
+        if zero_final and left:
+            # spend what is left in partial chunks first
+            k = left.bit_length() - 1
+            out.append(224 + k); out += body[pos:pos + (1 << k)]; pos += 1 << k
+            continue
+        ln = len(last)
+        enc = int(rng.integers(0, 3))
+        if enc == 0 and ln < 192: out.append(ln)
+        elif enc <= 1 and 192 <= ln < 8384: out += bytes([((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+        else: out += bytes([255]) + ln.to_bytes(4, "big")
+        out += last
+        return bytes(out)
+
+
+def exotic_framing_streams(cl, n_items, seed=1234):
+    """Signature streams in the shapes x/crypto reads but no writer of the path produces: partial body lengths (also on unknown
+    and user-id packets, also with a zero-length last chunk), old-format indeterminate lengths, lengths that run past the end of
+    the stream, bodies beyond bufio's 4096 bytes (a big hashed or unhashed area; bytes behind the MPIs), cut at random places.
+    Returns (tbs_list, stream_list)."""
+    import numpy as np, struct
+    from corpus.keys import DRBG
+    rng = np.random.default_rng(seed)
+    srng = DRBG("exotic-framing")
+
+    def notation(n):       # an unknown, non-critical subpacket (type 100) of n bytes in all
+        body = bytes(rng.integers(0, 256, size=n - 6, dtype=np.uint8))
+        return bytes([255]) + struct.pack(">I", len(body) + 1) + bytes([100]) + body
+
+    def definite(tag, body, declared=None):
+        ln = len(body) if declared is None else declared
+        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big") + body
+
+    tbs_l, ss_l = [], []
+    for i in range(n_items):
+        tbs = bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8))
+        parts = []
+        for _ in range(int(rng.integers(1, 8))):
+            kp = cl.replicas[int(rng.integers(0, len(cl.replicas)))]
+            shape = int(rng.integers(0, 14))
+            big = int(rng.integers(0, 6))
+            extra = notation(int(rng.choice([4090, 4096, 4200, 9000]))) if big == 0 else b""
+            unh = notation(int(rng.choice([4000, 4096, 5000]))) if big == 1 else b""
+            trail = bytes(rng.integers(0, 256, size=int(rng.choice([1, 100, 3800, 5000])), dtype=np.uint8)) if big == 2 else b""
+            body = sign_body(kp, tbs, srng, extra, unh, trail)
+            if shape <= 2: parts.append(definite(2, body))
+            elif shape <= 5: parts.append(partial_frame(2, body, rng, max_pow=int(rng.choice([3, 6, 9, 13]))))
+            elif shape == 6: parts.append(partial_frame(2, body, rng, zero_final=True))
+            elif shape == 7: parts.append(bytes([0x80 | (2 << 2) | 3]) + body)                       # indeterminate length
+            elif shape == 8: parts.append(definite(2, body, declared=len(body) + int(rng.integers(1, 6000))))
+            elif shape == 9: parts.append(partial_frame(int(rng.choice([20, 60, 63])), bytes(rng.integers(0, 256, size=int(rng.integers(1, 900)), dtype=np.uint8)), rng))
+            elif shape == 10: parts.append(partial_frame(13, b"user id " * int(rng.integers(1, 40)), rng))
+            elif shape == 11: parts.append(bytes([0x80 | (15 << 2) | 3]) + b"unknown old-format type, indeterminate")
+            elif shape == 12: parts.append(partial_frame(2, body[:int(rng.integers(1, len(body)))], rng))   # a chain that ends early
+            else: parts.append(cb.detach_sign(kp, tbs, srng))
+        data = b"".join(parts)
+        if i % 5 == 4 and len(data) > 8:
+            data = data[:int(rng.integers(1, len(data)))]
+        tbs_l.append(tbs); ss_l.append(data)
+    return tbs_l, ss_l
+
+
 def cat(parts):
     """byte strings -> (blob, n+1 offsets) as the batched entry points take them"""
     off = np.zeros(len(parts) + 1, dtype=np.uint64)

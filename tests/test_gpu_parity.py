@@ -930,9 +930,18 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
         enc = bytes([((n - 192) >> 8) + 192, (n - 192) & 0xFF]) if n >= 192 else bytes([n])
         hashed = ct + iss + enc + bytes([32]) + deep
         deep = bytes([4, 0x19, kp.algo, 8]) + struct.pack(">H", len(hashed)) + hashed + b"\x00\x00\x00\x00" + cb.go_mpi_bytes(b"\x01" * 256)
+    def pow2_chunks(b):                                   # the whole body in partial-length chunks, largest first
+        out = bytes([0xC2])
+        while b:
+            k = len(b).bit_length() - 1
+            out += bytes([0xE0 + k]) + b[:1 << k]
+            b = b[1 << k:]
+        return out
     fenced_cases = {
-        "partial-length": partial,
-        "indeterminate-length": indeterminate,
+        # a signature that parses while 5000 bytes of its packet were never fetched by bufio: the next call starts inside it
+        "bytes-behind-the-mpis": bytes([0xC2, 255]) + (len(body) + 5000).to_bytes(4, "big") + body + bytes(5000),
+        # partial lengths whose zero-length last chunk is never read: the next call trips over its length octet
+        "partial-length-zero-last-chunk": pow2_chunks(body) + b"\x00",
         "md5": cb._hdr(2, len(v4(hash_id=1, h=hashlib.md5))) + v4(hash_id=1, h=hashlib.md5),
         "value-beyond-R": cb._hdr(2, len(v4(value=kp.rsa_private(5) + (1 << 2200)))) + v4(value=kp.rsa_private(5) + (1 << 2200)),
         "nesting-3": cb._hdr(2, len(deep)) + deep,
@@ -957,6 +966,13 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
         # text mode over a payload without line ends: the canonical form IS the payload, the signature verifies
         "text-mode": cb._hdr(2, len(v4(sig_type=1))) + v4(sig_type=1) + good[1] + good[2] + good[3],
         "truncated": good[0][:100],
+        # partial body lengths, every chunk fetched whole: verified like any other packet (fenced until round 3)
+        "partial-length": partial + good[1] + good[2] + good[3],
+        # old-format indeterminate length: the rest of the stream IS the body -- the signature verifies, what follows is swallowed
+        "indeterminate-length": indeterminate + good[1] + good[2] + good[3],
+        "indeterminate-length-last": good[1] + good[2] + good[3] + indeterminate,
+        # a declared length beyond the end of the stream: the signature is all there and verifies
+        "length-past-the-end": good[1] + good[2] + bytes([0xC2, 255]) + (len(body) + 777).to_bytes(4, "big") + body,
     }
     names = list(fenced_cases) + list(plain_cases)
     ss_l = [fenced_cases[n] + good[1] + good[2] + good[3] for n in fenced_cases] + [plain_cases[n] for n in plain_cases]
@@ -1123,7 +1139,8 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx, exit_mode):
     for i in range(160):
         r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
         got = list(st[st_item == i])
-        assert got[:len(r.statuses)] == r.statuses, (i, got[:12], r.statuses[:12])
+        assert _events_until_unread_signature(pgp, ss_l[i]) is None        # (these streams are fenced for lazy parsers only: the
+        assert got[:len(r.statuses)] == r.statuses, (i, got[:12], r.statuses[:12])   # oracle takes those bodies whole, like the walk)
         assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), i
         n_long += len(got) > 96
     assert n_long >= 8 and (err == 0).any() and (err != 0).any()
@@ -1135,6 +1152,76 @@ def test_random_packet_framings_follow_the_oracle(gpu_ctx, exit_mode):
     for i in range(0, 160, 9):
         want = col.signers(kr, SignaturePacket(1, 0, False, ss_l[i] or None, None))
         assert [int(x) for x in ids[int(off[i]):int(off[i + 1])]] == want, i
+    gpu_ctx.quorum_destroy(qh)
+
+
+def _events_until_unread_signature(pgp, stream):
+    """Number of packet events up to and including the first signature that parses while part of its packet stays unread (the
+    oracle follows the reference's reader into that packet, the verifier does not): None when the stream has none."""
+    pos = n = 0
+    while True:
+        pk = pgp.packet_read_stream(stream, pos)
+        pos = pk.pos
+        if pk.kind == "eof":
+            return None
+        if pk.kind == "unknown":
+            continue
+        n += 1
+        if pk.kind == "sig" and pk.body_unread:
+            return n
+
+
+def test_exotic_framings_follow_the_reference_readers(gpu_ctx, exit_mode):
+    """The framings x/crypto reads and no writer of the path produces -- partial body lengths (signature, unknown and user-id
+    packets; a zero-length last chunk), indeterminate lengths, lengths past the end of the stream, bodies beyond bufio's 4096
+    bytes, cut at random places -- around VALID signatures: verdicts, exit counts and per-packet statuses are the oracle's
+    (whose reader objects restate packet.Read literally), the fence goes up exactly where a parsed signature leaves the
+    reference's reader inside its packet, and up to that packet the statuses still agree.  Chunked bodies are linearised by the
+    parse (k_parse_body) and walked in place by the parse-only kernel (k_signers)."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(5, dsa_fraction=0.4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    tbs_l, ss_l = H.exotic_framing_streams(cl, 320)
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(ss_l)
+    err, nver, verdict = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    fenced = gpu_ctx.last_fenced.copy()
+    want_fenced = [1 if pgp.position_is_type_dependent(s_) else 0 for s_ in ss_l]
+    assert list(fenced) == want_fenced and 60 < sum(want_fenced) < 200
+    n_chunked_ok = 0
+    for i in range(len(ss_l)):
+        r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
+        got = list(st[st_item == i])
+        k = _events_until_unread_signature(pgp, ss_l[i])
+        want = r.statuses if k is None else r.statuses[:k]
+        assert got[:len(want)] == want, (i, got[:10], want[:10])
+        if not fenced[i]:
+            assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), i
+            n_chunked_ok += sum(1 for x in r.statuses if x == 0)
+    assert n_chunked_ok > 200 and (err == 0).any()
+    # PGPSignature.Verify (every call must succeed) over the same streams
+    e1 = gpu_ctx.signature_verify(tb, to, sb, so)
+    assert list(gpu_ctx.last_fenced) == want_fenced
+    for i in range(0, len(ss_l), 3):
+        if not want_fenced[i]:
+            assert (e1[i] == 0) == (col.signature_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None)) is None), i
+    # Signers: the parse-only walk, chunked bodies read through the chunk-walking view
+    ids, off = gpu_ctx.signers(sb, so)
+    sf = gpu_ctx.last_fenced.copy()
+    assert list(sf) == [1 if pgp.position_is_type_dependent(s_, stop_at_error=True) else 0 for s_ in ss_l]
+    n_ids = 0
+    for i in range(len(ss_l)):
+        if sf[i]:
+            continue
+        want = col.signers(kr, SignaturePacket(1, 0, False, ss_l[i] or None, None))
+        assert [int(x) for x in ids[int(off[i]):int(off[i + 1])]] == want, i
+        n_ids += len(want)
+    assert n_ids > 150
     gpu_ctx.quorum_destroy(qh)
 
 

@@ -409,9 +409,31 @@ def test_signature_parser_fuzz_against_the_oracle(H):
     assert n_ok > 7000 and n_err > 7000
 
 
+def _oracle_scan(pgp, data):
+    """The literal reader model of the oracle over one stream, as bftkv_host_scan_stream reports it: statuses of the packet
+    events up to the first packet after which the verifier does not follow the reader, and whether there is such a packet."""
+    want, pos, fence = [], 0, False
+    while True:
+        pk = pgp.packet_read_stream(data, pos)
+        pos = pk.pos
+        if pk.kind == "eof":
+            return want, fence
+        if pk.kind == "unknown":
+            continue
+        if pk.kind == "not_signature":
+            want.append(pgp.ST_NOT_SIGNATURE)
+            fence |= pk.lazy_parser
+        elif pk.kind == "sig":
+            want.append(99)
+            if pk.body_unread:
+                return want, True
+        else:
+            want.append(pgp.ST_PARSE_ERROR)
+
+
 def test_packet_walk_fuzz_against_the_oracle(H):
-    """The packet framing the KERNELS walk (walk_step of kernels.hip) through bftkv_host_walk_stream against the oracle's
-    packet.Read restatement (oracle.openpgp.next_packet): random streams of packets in every header format, unknown and
+    """The packet framing the KERNELS walk (walk_step, chain_extent of kernels.hip) through bftkv_host_scan_stream against the
+    oracle's reader objects (oracle.openpgp.packet_read_stream): random streams of packets in every header format, unknown and
     non-signature types, partial / indeterminate lengths, stray bytes and truncations, then random byte mutations on top."""
     from oracle import openpgp as pgp
     rng = np.random.default_rng(99)
@@ -429,30 +451,7 @@ def test_packet_walk_fuzz_against_the_oracle(H):
         if tag < 16: return bytes([0x80 | (tag << 2) | 2]) + ln.to_bytes(4, "big")
         return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
 
-    def oracle_events(data):
-        ev, pos = [], 0
-        while True:
-            try:
-                pkt = pgp.next_packet(data, pos)
-            except EOFError:
-                return ev
-            except pgp.StructuralError as e:
-                ev.append((pgp.ST_PARSE_ERROR, None, None)); pos = e.consumed
-                continue
-            except pgp.UnsupportedError as e:
-                ev.append((pgp.ST_UNSUPPORTED, None, None)); pos = e.consumed
-                continue
-            except pgp._Truncated:
-                ev.append((pgp.ST_PARSE_ERROR, None, None))
-                return ev
-            start = pkt.end - len(pkt.body)
-            pos = pkt.end
-            if pkt.tag == 2:
-                ev.append((99, start, len(pkt.body)))
-            elif pkt.tag in pgp._KNOWN_TAGS:
-                ev.append((pgp.ST_NOT_SIGNATURE, start, len(pkt.body)))
-
-    n_events = n_err = 0
+    n_events = n_err = n_fenced = 0
     for it in range(10000):
         parts = []
         for _ in range(int(rng.integers(0, 14))):
@@ -469,16 +468,97 @@ def test_packet_walk_fuzz_against_the_oracle(H):
             for _ in range(int(rng.integers(1, 4))):
                 data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
         data = bytes(data)
-        got, n = H.walk_stream(data)
-        want = oracle_events(data)
-        assert n == len(want), (it, n, len(want), data[:64].hex())
-        for g, w in zip(got, want):
-            assert g[0] == w[0], (it, g, w)
-            if w[1] is not None:
-                assert (g[1], g[2]) == (w[1], w[2]), (it, g, w)
-            n_err += w[1] is None
+        got, n, fenced = H.scan_stream(data)
+        want, want_fenced = _oracle_scan(pgp, data)
+        assert fenced == want_fenced, (it, data[:64].hex())
+        assert got[:len(want)] == want and (fenced or n == len(want)), (it, got[:16], want[:16], data[:64].hex())
+        n_err += sum(1 for w in want if w == pgp.ST_PARSE_ERROR)
         n_events += len(want)
-    assert n_events > 12000 and n_err > 3000
+        n_fenced += fenced
+    assert n_events > 12000 and n_err > 3000 and 1000 < n_fenced < 9000
+
+
+def test_exotic_framings_follow_the_reference_readers(H):
+    """Valid signatures in the framings x/crypto reads and no writer of the path produces -- partial body lengths, indeterminate
+    lengths, lengths past the end of the stream, bodies beyond bufio's 4096 bytes: the kernels' walk + parse + reader-position
+    rule (host build of the same code) against the oracle's reader objects, and the C oracle against the Python one on the
+    verdicts.  Hand-made cases first, each with the outcome spelled out."""
+    from corpus import build as cb
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp, collective as col
+    from oracle.cbind import COracle
+    from oracle.packet import SignaturePacket
+    from tests import helpers as TH
+    cl = cb.make_cluster(5, dsa_fraction=0.4)
+    kr, q = TH.oracle_keyring(cl), TH.clique_quorum(cl)
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    srng = DRBG("exotic-hand")
+    rng = np.random.default_rng(5)
+    tbs = b"exotic framings"
+    kp = [r for r in cl.replicas if r.algo == cb.PK_RSA][0]
+    body = TH.sign_body(kp, tbs, srng)                   # 12 + 20 + 2 + 2 + 258 bytes
+    plain = cb.detach_sign([r for r in cl.replicas if r is not kp][0], tbs, srng)
+
+    def statuses(stream):
+        r = col.collective_verify(kr, tbs, SignaturePacket(1, 0, False, stream, None), q)
+        tr, nv, e = co.trace_item(tbs, stream)
+        assert tr == r.statuses and nv == len(r.verified), (tr, r.statuses)
+        return r.statuses, H.scan_stream(stream)
+
+    # two 128-byte chunks and a definite rest: every chunk is fetched whole, the reader ends behind the packet
+    chunked = bytes([0xC2, 224 + 7]) + body[:128] + bytes([224 + 7]) + body[128:256] + bytes([len(body) - 256]) + body[256:]
+    st, (scan, n, fenced) = statuses(chunked + plain)
+    assert st == [0, 0] and scan == [99, 99] and not fenced
+    # the same with a zero-length last chunk: its length octet is never read -- the next call trips over that 0x00 byte
+    zero = bytes([0xC2, 224 + 8]) + body[:256]
+    rest = body[256:]
+    while rest:                                         # spend the rest in power-of-two chunks
+        k = len(rest).bit_length() - 1
+        zero += bytes([224 + k]) + rest[:1 << k]
+        rest = rest[1 << k:]
+    zero += b"\x00"
+    st, (scan, n, fenced) = statuses(zero + plain)
+    assert st == [0, pgp.ST_PARSE_ERROR, 0] and fenced             # (the oracle follows the reader; the verifier fences)
+    # a declared length that runs past the end of the stream: the signature is all there, it verifies
+    long_decl = bytes([0xC2, 255]) + (len(body) + 1000).to_bytes(4, "big") + body
+    st, (scan, n, fenced) = statuses(plain + long_decl)
+    assert st == [0, 0] and scan == [99, 99] and not fenced
+    # ... and in mid-stream it swallows what follows (one fetch takes the whole declared span)
+    st, (scan, n, fenced) = statuses(bytes([0xC2, 255]) + (len(body) + len(plain)).to_bytes(4, "big") + body + plain)
+    assert st == [0] and scan == [99] and not fenced
+    # old-format indeterminate length: the rest of the stream is the body
+    st, (scan, n, fenced) = statuses(plain + bytes([0x8B]) + body)
+    assert st == [0, 0] and not fenced
+    st, (scan, n, fenced) = statuses(bytes([0x8B]) + body + plain)              # (<= 4096 bytes in all: taken by one fetch)
+    assert st == [0] and not fenced
+    st, (scan, n, fenced) = statuses(bytes([0x8B]) + body + plain * (5000 // len(plain) + 1))         # more than one buffer behind it: reader left in mid-stream
+    assert fenced
+    # a hashed area beyond the buffer: read straight into its slice, the rest arrives with the next fetch
+    big = TH.sign_body(kp, tbs, srng, hashed_extra=bytes([255]) + (5000).to_bytes(4, "big") + bytes([100]) + bytes(4999))
+    st, (scan, n, fenced) = statuses(cb._hdr(2, len(big)) + big + plain)
+    assert st == [0, 0] and not fenced
+    # 5000 bytes behind the MPIs: bufio never fetches them
+    trail = TH.sign_body(kp, tbs, srng, trailing=bytes(5000))
+    st, (scan, n, fenced) = statuses(cb._hdr(2, len(trail)) + trail + plain)
+    assert st[0] == 0 and fenced
+    # an unknown packet type with partial lengths is skipped whole; a user id likewise (its parser ends in ReadAll)
+    st, (scan, n, fenced) = statuses(TH.partial_frame(60, bytes(700), rng) + TH.partial_frame(13, b"u" * 300, rng) + plain)
+    assert st == [pgp.ST_NOT_SIGNATURE, 0] and not fenced
+    # the random mix
+    tbs_l, ss_l = TH.exotic_framing_streams(cl, 500)
+    n_fenced = n_ok = 0
+    for i, (t, s_) in enumerate(zip(tbs_l, ss_l)):
+        want, want_fenced = _oracle_scan(pgp, s_)
+        got, n, fenced = H.scan_stream(s_)
+        assert fenced == want_fenced and got[:len(want)] == want and (fenced or n == len(want)), (i, got, want)
+        r = col.collective_verify(kr, t, SignaturePacket(1, 0, False, s_, None), q)
+        tr, nv, e = co.trace_item(t, s_)
+        assert tr == r.statuses and nv == len(r.verified) and (e == 0) == (r.err is None), i
+        n_fenced += fenced
+        n_ok += sum(1 for x in r.statuses if x == 0)
+    assert 100 < n_fenced < 300 and n_ok > 500
 
 
 def test_host_sha256_matches_hashlib_on_both_code_paths(H):
