@@ -139,9 +139,12 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* ctx, int quorum);
 
 /* ---- fenced inputs ------------------------------------------------------------------------------------
  * A few OpenPGP shapes that the reference accepts are not followed by the kernels (DESIGN.md "Fenced inputs":
- * partial / indeterminate body lengths on signature packets, MD5 / RIPEMD-160 while their availability in the
- * reference binary is unknown (bftkv_gpu_set_hash_policy), ECDSA,
- * moduli beyond 4096 bits, signature values >= R, embedded signatures nested deeper than 2).  The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
+ * a packet after which the reference's shared reader stands INSIDE that packet -- a signature that parses while bufio's
+ * last fetch stopped short of its end (bodies over 4096 bytes with unread bytes, unread partial-length chunks), a known
+ * non-signature packet whose parser may stop early --, MD5 / RIPEMD-160 while their availability in the reference binary is
+ * unknown (bftkv_gpu_set_hash_policy), ECDSA, moduli beyond 4096 bits, signature values >= R, embedded signatures nested
+ * deeper than 2).  Partial and indeterminate body lengths as such are read like the reference reads them.
+ * The verify calls take an optional fenced_out[n_items]: fenced_out[i] = 1 when item i contains such a
  * shape -- its err_out is then NOT a statement about what the reference would decide, and the caller must run the
  * reference path for that item (the cgo shim calls the wrapped crypto/pgp implementation).  Items with
  * fenced_out[i] = 0 carry the reference's verdict.  None of the path's own writers produce a fenced shape. */

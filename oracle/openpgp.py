@@ -631,20 +631,26 @@ def position_is_type_dependent(buf: bytes, stop_at_error: bool = False) -> bool:
         signature behind it): the next CheckDetachedSignature call parses packets out of the middle of this one.  This
         restatement DOES follow that exactly; the kernels do not.
     stop_at_error: PGPSignature.Signers' walk, which the first error of Reader.Next ends."""
+    return fence_reason(buf, stop_at_error) is not None
+
+
+def fence_reason(buf: bytes, stop_at_error: bool = False) -> Optional[str]:
+    """The first of the two shapes of position_is_type_dependent in the stream: "lazy" (a parser this restatement does not
+    model: nothing to compare against), "unread" (followed exactly here, fenced by the verifier), or None."""
     pos = 0
     while True:
         pkt = packet_read_stream(buf, pos)
         pos = pkt.pos
         if pkt.kind == "eof":
-            return False
+            return None
         if pkt.kind in ("error", "sig_error"):
             if stop_at_error:
-                return False
+                return None
             continue
         if pkt.kind == "not_signature" and pkt.lazy_parser:
-            return True
+            return "lazy"
         if pkt.kind == "sig" and pkt.body_unread:
-            return True
+            return "unread"
 
 
 # ------------------------------------------------------------------------------------------------

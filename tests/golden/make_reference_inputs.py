@@ -7,7 +7,8 @@ tests/test_reference_vectors.py is skipped while that file is absent and strict 
 Contents, all seeded (corpus/keys.py) -- nothing here depends on the GPU:
   clusters   clique-certified rings (scripts/clique.sh shape: every member certifies every other), the node that plays
              "self", and quorum signatures over payloads: valid ones and every mutation class of corpus/build.py
-  streams    random packet framings around valid signatures (tests/helpers.py random_framing_streams)
+  streams    random packet framings around valid signatures (tests/helpers.py random_framing_streams), and the framings
+             no writer of the path produces (exotic_framing_streams: partial / indeterminate lengths, oversized bodies)
   gpg        the GnuPG fixtures and gpg-judged edge cases (tests/golden/gpg_vectors.json, gpg_negative_vectors.json)
 """
 import json
@@ -43,6 +44,10 @@ def main():
         if n == 7:
             tbs_l, stream_l, _, _ = H.random_framing_streams(cl, 24, seed=91)
             out["streams"] = [{"cluster": blk["name"], "tbs": t.hex(), "ss": s.hex()} for t, s in zip(tbs_l, stream_l)]
+            # partial / indeterminate lengths, lengths past the end of the stream, bodies beyond bufio's buffer: the reader
+            # model of oracle/openpgp.py B.1b (restated from memory of x/crypto and of Go's bufio) is pinned by these
+            tbs_l, stream_l = H.exotic_framing_streams(cl, 36, seed=92)
+            out["streams"] += [{"cluster": blk["name"], "tbs": t.hex(), "ss": s.hex()} for t, s in zip(tbs_l, stream_l)]
     vec = json.load(open(os.path.join(HERE, "gpg_vectors.json")))
     for ring_key, group in (("A_pubring", "A"), ("B_pubring", "B"), ("C_pubring", "C")):
         for k, v in enumerate(vec[group]):
