@@ -172,14 +172,22 @@ def exotic_framing_streams(cl, n_items, seed=1234):
     for i in range(n_items):
         tbs = bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8))
         parts = []
-        for _ in range(int(rng.integers(1, 8))):
+        long_item = i % 16 == 15                      # more packet events than the walk's scratch row holds (sequential fill pass)
+        pool = []
+        for _ in range(int(rng.integers(100, 130)) if long_item else int(rng.integers(1, 8))):
             kp = cl.replicas[int(rng.integers(0, len(cl.replicas)))]
             shape = int(rng.integers(0, 14))
-            big = int(rng.integers(0, 6))
+            if long_item:
+                shape = int(rng.choice([0, 3, 4, 9, 10, 13]))                 # (nothing that ends or swallows the stream)
+            big = 5 if long_item else int(rng.integers(0, 6))
             extra = notation(int(rng.choice([4090, 4096, 4200, 9000]))) if big == 0 else b""
             unh = notation(int(rng.choice([4000, 4096, 5000]))) if big == 1 else b""
             trail = bytes(rng.integers(0, 256, size=int(rng.choice([1, 100, 3800, 5000])), dtype=np.uint8)) if big == 2 else b""
-            body = sign_body(kp, tbs, srng, extra, unh, trail)
+            if long_item and len(pool) >= 6:
+                body = pool[int(rng.integers(0, len(pool)))]
+            else:
+                body = sign_body(kp, tbs, srng, extra, unh, trail)
+                pool.append(body)
             if shape <= 2: parts.append(definite(2, body))
             elif shape <= 5: parts.append(partial_frame(2, body, rng, max_pow=int(rng.choice([3, 6, 9, 13]))))
             elif shape == 6: parts.append(partial_frame(2, body, rng, zero_final=True))

@@ -65,13 +65,13 @@ def test_collect_signatures_scenarios(gpu_ctx, n):
     rng = np.random.default_rng(n)
     f, suff = oqa.qcs[0].f, oqa.qcs[0].suff
     tbss_l, replies_l = [], []
-    for w in range(36):
+    for w in range(40):
         tbs = cb.serialize_tbs(b"key%03d" % w, rng.bytes(32), w + 1)
         tbss = tbs + cb.sigpkt(cb.detach_sign(cl.client, tbs), cl.client.entity)
         other = tbs[:-1] + bytes([tbs[-1] ^ 1])                 # a conflicting <x,v,t'> colluders would sign
         order = [int(i) for i in rng.permutation(n)]
         reps = []
-        scenario = w % 9
+        scenario = w % 10
         for pos, i in enumerate(order):
             r = cl.replicas[i]
             good = opk.serialize_signature(opk.SignaturePacket(1, 0, False, cb.detach_sign(r, tbss), r.entity))
@@ -94,15 +94,22 @@ def test_collect_signatures_scenarios(gpu_ctx, n):
                 rep = host.Reply(Peer=r0.key_id, Data=opk.serialize_signature(opk.SignaturePacket(1, 0, False, cb.detach_sign(r0, tbss), None)))
             elif scenario == 8 and pos >= 1:                    # nobody else answers
                 break
+            elif scenario == 9 and pos == 0:                    # a signature with partial body lengths: verified by the kernels,
+                sig = cb.detach_sign(r, tbss)                   # not followed by the host's INCREMENTAL Signers walk => fenced
+                rep = host.Reply(Peer=r.key_id, Data=opk.serialize_signature(opk.SignaturePacket(
+                    1, 0, False, H.partial_frame(2, sig[3:] if sig[1] >= 192 else sig[2:], rng), r.entity)))
             reps.append(rep)
         tbss_l.append(tbss)
         replies_l.append(reps)
     data, consumed, err = host.Client(gpu_ctx).collect_signatures(hqa, tbss_l, replies_l)
     oks = 0
     for w in range(len(tbss_l)):
+        if w % 10 == 9:
+            assert err[w] == 0xFC, (w, err[w])                  # BFTKV_HOST_ERR_FENCED: the caller takes the reference path
+            continue
         wd, wc, we = _oracle_collect(kr, oqa, tbss_l[w], replies_l[w])
-        assert data[w] == wd and consumed[w] == wc, (w, w % 9, consumed[w], wc)
-        assert (err[w] == 0) == (we is None), (w, w % 9, err[w], we)
+        assert data[w] == wd and consumed[w] == wc, (w, w % 10, consumed[w], wc)
+        assert (err[w] == 0) == (we is None), (w, w % 10, err[w], we)
         oks += we is None
     assert 0 < oks < len(tbss_l)
     # honest rounds stop after exactly `suff` replies; duplicates of one signer also reach sufficiency
