@@ -62,7 +62,8 @@ def macs_per_calculate_r(k=8, windows=64, win_bits=4, ent=15):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg 2 -- 0.6 s of timed region, long past the "
+                    "fill and drain of the batches in flight --, 10 for the other configs)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--items", type=int, default=0, help="cfg 2: signed writes per GPU and step (default 10000); cfg 3: variables "
@@ -70,9 +71,14 @@ def parse_args(argv=None):
     ap.add_argument("--replicas", type=int, default=0, help="clique size (default 64; 256 for cfg 4)")
     ap.add_argument("--distinct", type=int, default=2500, help="cfg 4: distinctly signed writes the resident batch is tiled from")
     ap.add_argument("--chunk", type=int, default=125000, help="cfg 4: writes per verifier call (the resident batch)")
-    ap.add_argument("--inflight", type=int, default=1, help="cfg 2: batches in flight per GPU, each on its own verifier context "
-                    "(2 overlaps walk/parse and compare/tally of neighbouring steps with the modexp; then a launch's duration no "
-                    "longer measures the kernel, so the default 1 keeps the roofline line meaningful)")
+    ap.add_argument("--inflight", type=int, default=3, help="cfg 2: batches in flight per GPU, each on its own verifier context "
+                    "(its own arena and streams).  With more than one, walk/parse and compare/tally/exchange of one step run under "
+                    "the modexp of a neighbour -- what a fed verifier does; the machine-filling modexps themselves take turns "
+                    "(the library's per-device turnstile), so a launch's duration still measures the kernel.  3 is the default: "
+                    "under a saturating modexp the dozen small kernels of a step's tail and head only get SIMD slots when a round "
+                    "of modexp blocks retires (every ~0.3 ms), which takes about one modexp's duration -- two in flight leave gaps "
+                    "(3.03 ms per step), three do not (2.91; one: 3.2).  The line also carries the single-flight figures "
+                    "(kernel_ms.single_flight, int_mac.single_flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving", action="store_true", help="cfg 2: skip the one-Verify-per-call leg (tools/serving/batcher_load.c)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="after the timed region: keep running the same step, untimed for "
@@ -80,7 +86,10 @@ def parse_args(argv=None):
                     "otherwise never sees a timed region of tens of milliseconds.  0 disables")
     ap.add_argument("--corpus-cache", default="", help="path prefix of an .npz cache of the generated corpus (profiling reruns)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, sharding and exchange step only (no GPU, no number)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 200 if (args.config == 2 and not args.dry_run) else 10
+    return args
 
 
 def free_port():
@@ -406,6 +415,19 @@ def int_mac(macs, launch_ms, sclk_mhz=None):
     return out
 
 
+def int_mac_block(macs_per_step, ms_step, launch_ms, single_ms, sclk_mhz, in_flight):
+    """cfg 2's integer-MAC line.  Main figures: the MACs of a step over the WALL time of a step in the timed region -- what the chip
+    sustains over everything (walk, parse, hashing, tallies and the exchange included).  Beside it: the same MACs over the average
+    duration of the timed region's k_rsa_modexp launches (each with the small kernels of the neighbouring batches beside it) and
+    over the kernel's single-flight launch duration (the kernel with only its own hash stream beside it)."""
+    out = int_mac(macs_per_step, ms_step, sclk_mhz)
+    out["basis"] = "MACs of k_rsa_modexp per step / ms_per_step of the timed region (%d batches in flight)" % in_flight
+    pl, sf = int_mac(macs_per_step, launch_ms), int_mac(macs_per_step, single_ms)
+    out["per_launch_in_timed_region"] = {"launch_ms": launch_ms, "achieved": pl["achieved"], "frac": pl["frac"], "frac_of_theoretical": pl["frac_of_theoretical"]}
+    out["single_flight"] = {"launch_ms": single_ms, "achieved": sf["achieved"], "frac": sf["frac"], "frac_of_theoretical": sf["frac_of_theoretical"]}
+    return out
+
+
 def reference_pubkey_ops(st, item, err, nver, n_items):
     """Public-key operations the REFERENCE performs on this batch (crypto_pgp.go:485-500): per item the packets it examines
     -- all of them, or up to the packet that made IsSufficient true -- that reach rsa.VerifyPKCS1v15 / dsa.Verify, i.e. end in
@@ -566,6 +588,7 @@ def bench_cfg2(args, D):
                               "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed}), flush=True)
         return
 
+    V.run(V.n_ctx)               # one untimed call per verifier context: its arena is allocated at its first call
     elapsed = timed_region(D, V.run, args.steps, args.warmup, V.reset_timing)
     sclk = V.ctxs[0].last_sclk_mhz()
     timed_rsa, timed_total, timed_hash = list(V.rsa_ms), list(V.total_ms), list(V.hash_ms)
@@ -583,6 +606,7 @@ def bench_cfg2(args, D):
     sustained = soak(D, V.run, args.soak_seconds, ms_step, total_ref_ops)
     if D.rank == 0:
         rsa_ms = float(np.mean(timed_rsa))
+        iso_rsa = float(np.mean([t["rsa"] for t in iso]))
         alg_bytes = int(z["to"][-1]) + ref_ops * RSA_BYTES + (items + 7) // 8      # payload once + 291 B per verify + 1 bit
         out = base_line(args, D, "pgp_rsa2048_signature_verifies_per_sec", "verifies/s", total_ref_ops * args.steps / elapsed, elapsed, "u32",
                         "%d-replica quorum, %d RSA-2048 signed writes per GPU (cfg2 of BASELINE.json), %d signature packets per GPU, "
@@ -605,11 +629,15 @@ def bench_cfg2(args, D):
                           "via": "bftkv_gpu_allgather_errs_dev (library RCCL, verifier stream)"},
             "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_rsa_modexp_min_max": [float(np.min(timed_rsa)), float(np.max(timed_rsa))],
                           "hash_stream": float(np.mean(timed_hash)), "step_device_span": float(np.mean(timed_total)),
-                          "step_over_modexp": ms_step / rsa_ms if rsa_ms else None,
-                          "measured": "HIP events of the %d timed steps (%d in flight)" % (len(timed_rsa), V.n_ctx),
-                          "isolated_call": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]}},
-            "roofline": roofline(2, "k_rsa_modexp", alg_bytes, rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac"),
-            "int_mac": int_mac(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, rsa_ms, sclk),
+                          "step_over_modexp": ms_step / iso_rsa if iso_rsa else None,
+                          "step_over_modexp_is": "ms_per_step of the timed region over the kernel's single-flight launch duration",
+                          "measured": "HIP events of the %d timed steps (%d in flight; the modexps of different contexts take turns "
+                                      "at the library's turnstile, the duration runs from a launch's turn to its end)" % (len(timed_rsa), V.n_ctx),
+                          "single_flight": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]},
+                          "single_flight_is": "3 non-overlapped calls on one context right after the timed region"},
+            "roofline": roofline(2, "k_rsa_modexp", alg_bytes, rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac; "
+                                 "launch_ms = average HIP-event duration of the timed region's launches (%d in flight)" % V.n_ctx),
+            "int_mac": int_mac_block(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, ms_step, rsa_ms, iso_rsa, sclk, V.n_ctx),
             "sustained": sustained,
             "corpus_build_s": t_corpus,
         })

@@ -133,7 +133,9 @@ struct bftkv_gpu_ctx {
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
   uint32_t* d_mail = nullptr;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
-  hipEvent_t ev[10] = {};  // 0 start, 1 parsed, 2 modexp done, 3 compare + DSA done, 4 end, 5 hash start, 6 hash done, 7 DSA inverses done, 8 compare done
+  hipEvent_t ev[10] = {};  // 0 start, 1 parsed, 2 modexp done, 3 compare + DSA done, 4 end, 5 hash start, 6 hash done, 7 DSA inverses done, 8 compare done,
+                           // 9 modexp about to start (behind the turnstile)
+  hipEvent_t ev_turn = nullptr;   // this context's ticket in the device's modexp turnstile (below)
   bool have_timing = false;
   void* rccl_comm = nullptr;   // ncclComm_t
   int n_ranks = 1, rank = 0;
@@ -189,6 +191,16 @@ struct KtRead {
   }
   ~KtRead() { if (r && --c->kt_read_depth == 0) r->kt_rw.unlock_shared(); }
 };
+
+// The modexp turnstile of a device.  A resident batch's k_rsa_modexp fills every SIMD for milliseconds; everything else of a
+// call (walk, parse, plan; compare, tallies, exchange) is short and leaves most of the machine idle.  When several contexts have
+// calls in flight, two such modexps launched side by side share the machine AND their heads and tails coincide -- the overlap
+// that was wanted (one call's head and tail under the other's modexp) is lost as soon as the calls drift into step.  So the big
+// modexps take turns: each waits (on its stream, not on the host) for the one before it, whichever context launched that.
+// Calls too small to fill the machine (staged small calls, batches below TURNSTILE_MIN_PACKETS) do not queue here.
+struct Turnstile { std::mutex mu; hipEvent_t last = nullptr; const void* owner = nullptr; };
+Turnstile g_turnstile[16];
+constexpr uint32_t TURNSTILE_MIN_PACKETS = 98304;     // two rounds of 768 resident blocks x 64 signatures
 
 // live contexts: lets long-lived host objects (bftkv_quorum) notice that their context is gone
 std::mutex g_live_mu;
@@ -499,7 +511,19 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
-  if (total) launch_modexp(start0);
+  if (total >= TURNSTILE_MIN_PACKETS && !staged_cap && !getenv("BFTKV_NO_TURNSTILE")) {
+    Turnstile& g = g_turnstile[(unsigned)c->device & 15u];
+    std::lock_guard<std::mutex> tl(g.mu);
+    if (g.last && g.owner != c) HIPCHK(c, hipStreamWaitEvent(s, g.last, 0));
+    HIPCHK(c, rec(9, s));
+    launch_modexp(start0);
+    if (!c->ev_turn) HIPCHK(c, hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_turn, s));
+    g.last = c->ev_turn; g.owner = c;
+  } else {
+    HIPCHK(c, rec(9, s));
+    if (total) launch_modexp(start0);
+  }
   HIPCHK(c, rec(2, s));
   if (upload_tbs) {
     int hrc = (*upload_tbs)(sh);
@@ -981,6 +1005,12 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_turn) {
+    Turnstile& g = g_turnstile[(unsigned)c->device & 15u];
+    std::lock_guard<std::mutex> tl(g.mu);
+    if (g.owner == c) { g.last = nullptr; g.owner = nullptr; }      // (the streams were synchronised above: nobody waits on it any more)
+    (void)hipEventDestroy(c->ev_turn);
+  }
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->stream_h);
   (void)hipStreamDestroy(c->stream_d);
@@ -1322,7 +1352,7 @@ int bftkv_gpu_last_timing(bftkv_gpu_ctx* c, float ms[8]) {
   HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[4]));   // whole call
   HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]));   // walk + scan + parse (incl. the host read of the count)
   HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[5], c->ev[6]));   // hash stream: midstates + digests (overlaps the modexp)
-  HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[1], c->ev[2]));   // k_rsa_modexp on its own stream
+  HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[9], c->ev[2]));   // k_rsa_modexp on its own stream (from its turn at the turnstile)
   HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));   // tally
   HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[2], c->ev[8]));   // compare (incl. waiting for the hash stream)
   HIPCHK(c, hipEventElapsedTime(&ms[6], c->ev[8], c->ev[3]));   // k_dsa_mul + k_dsa_modexp (0 without DSA keys)

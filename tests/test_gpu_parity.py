@@ -496,6 +496,26 @@ def test_cfg2_full_size_identity_against_the_c_oracle(gpu_ctx):
     assert len(st) == c.n_sigs and bench.reference_pubkey_ops(st, st_item, err, nver, c.n_items) == ops
     assert 400000 < ops <= gpu_ctx.last_counters()["pubkey_ops"] < c.n_sigs
     assert (err == 0).sum() > 9000 and (err == 2).sum() > 50
+    # Several such batches in flight on forked contexts (what bench.py's default does): their machine-filling modexps take turns
+    # at the device's turnstile (capi.hip), each waiting on its stream for the one another context launched before it.  Same
+    # answers from every context, every time.
+    import threading
+    forks = [gpu_ctx.fork() for _ in range(2)]
+    got = {}
+
+    def storm(k, cx):
+        got[k] = [cx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off) for _ in range(3)]
+    ths = [threading.Thread(target=storm, args=(k, cx)) for k, cx in enumerate([gpu_ctx] + forks)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert len(got) == 3
+    for res in got.values():
+        for e2, nv2, vd2 in res:
+            assert (e2 == err).all() and (nv2 == nver).all() and (vd2 == verdict).all()
+    for f in forks:
+        f.close()
     gpu_ctx.quorum_destroy(qh)
 
 

@@ -7,7 +7,7 @@ cp bftkv_amd/libbftkv_gpu.so $OUT/_orig.so
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
     cp variants/$v bftkv_amd/libbftkv_gpu.so
-    python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-serving --corpus-cache /tmp/abcorpus > $OUT/r${r}_$v.json 2> $OUT/r${r}_$v.err
+    python bench.py --config $CFG --steps $STEPS --warmup 2 --inflight 1 --no-cpu-baseline --no-serving --corpus-cache /tmp/abcorpus > $OUT/r${r}_$v.json 2> $OUT/r${r}_$v.err
     python - "$OUT/r${r}_$v.json" "$v" <<'PY'
 import json, sys
 try:

@@ -66,8 +66,9 @@ def main(tag, rnd):
     plain = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
     out = {"source": "rocprofv3 separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over the bench command of tools/profile_bench.sh "
                      "(`python bench.py --config N --steps 5 --warmup 2 --no-cpu-baseline`)",
-           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced "
-                         "reads -> doubled; WRITE_SIZE taken as is (uncalibrated); both are KiB per dispatch",
+           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes moved -> doubled; calibrated "
+                         "for this path's access patterns (profiles/r03_fetch_size_calibration.csv: FETCH_SIZE = 1/2 x 128 B x lines "
+                         "touched for streaming and scattered reads alike, WRITE_SIZE exact); both are KiB per dispatch",
            "workload": plain["config"], "kernels": {}}
     with open(os.path.join(dst, "%s_pmc_hbm.csv" % rnd), "w") as f:
         f.write("Kernel,AvgDurationNs,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,HBM_bytes_corrected\n")
