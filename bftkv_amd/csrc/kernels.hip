@@ -250,6 +250,12 @@ __host__ __device__ __forceinline__ bool parse_sig_body_v3(B body, uint32_t blen
 // ------------------------------------------------------------------------------------------------
 constexpr uint8_t BODY_DEFINITE = 0, BODY_PARTIAL = 1, BODY_INDETERMINATE = 2;
 constexpr uint32_t BUFIO_SIZE = 4096;
+// Bounds on what is followed natively for partial-length packets (beyond them: ST_UNSUPPORTED + fence, the reference decides):
+// a chain is walked by ONE lane, one dependent load per length header, and a chunked signature body is copied by one lane byte
+// by byte -- a stream of a million one-byte chunks must not hold a whole batch for seconds.  Real chunked signatures (nobody
+// writes them) would have a handful of chunks and a body of a few hundred bytes.
+constexpr uint32_t CHAIN_MAX_HOPS = 1024;            // length headers followed per packet
+constexpr uint32_t CHUNKED_SIG_MAX_BODY = 16384;     // bytes of a partial-length signature body linearised / parsed
 
 // position of the next body byte in the item's stream, bytes left in the current chunk, another length header behind it?
 struct ChunkCursor { uint64_t pos; uint64_t rem; bool partial; };
@@ -423,8 +429,11 @@ __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, const uint8_t* b
   }
   uint64_t avail;
   if (r.kind == BODY_PARTIAL) {
-    const BodyExtent e = chain_extent(base, ChunkCursor{start, ln, true}, end, max_hops);
-    if (e.gave_up) { r.gave_up = true; r.event = false; r.next = ~0ull; return r; }
+    const BodyExtent e = chain_extent(base, ChunkCursor{start, ln, true}, end, max_hops < CHAIN_MAX_HOPS ? max_hops : CHAIN_MAX_HOPS);
+    if (e.gave_up) {
+      if (max_hops < CHAIN_MAX_HOPS) { r.gave_up = true; r.event = false; r.next = ~0ull; return r; }   // a speculating lane: nothing decided
+      r.next = end; r.status = ST_UNSUPPORTED; return r;      // too many chunks to follow: the stream ends here, fenced
+    }
     avail = e.avail; r.next = e.next;
   } else {
     const uint64_t room = end - start;
@@ -440,6 +449,7 @@ __host__ __device__ __forceinline__ WalkStep walk_step(HDR hdr, const uint8_t* b
     return r;
   }
   if (avail > 0xFFFFFF00ull) { r.status = ST_UNSUPPORTED; return r; }   // beyond the record's 32-bit fields: fenced
+  if (r.kind == BODY_PARTIAL && avail > CHUNKED_SIG_MAX_BODY) { r.status = ST_UNSUPPORTED; return r; }   // (see the bounds above)
   r.status = r.kind == BODY_PARTIAL ? ST_PENDING_CHUNKED : ST_PENDING_PARSE;
   return r;
 }

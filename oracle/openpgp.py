@@ -389,6 +389,8 @@ class _PartialLengthReader:
     """packet.partialLengthReader: chunk after chunk, each announced by its own length header."""
     def __init__(self, r, remaining: int):
         self.r, self.remaining, self.is_partial = r, remaining, True
+        self.headers = 0          # length headers read after the first one (bookkeeping for the tests, not in the reference)
+        self.delivered = 0        # body bytes handed out
 
     def read(self, k: int):
         while self.remaining == 0:
@@ -397,9 +399,11 @@ class _PartialLengthReader:
             self.remaining, self.is_partial, err = _read_length(self.r)
             if err:
                 return b"", err
+            self.headers += 1
         want = min(k, self.remaining)
         d, err = self.r.read(want)
         self.remaining -= len(d)
+        self.delivered += len(d)
         if len(d) < want and err == "EOF":
             err = "UEOF"
         return d, err
@@ -556,10 +560,28 @@ class StreamPacket:
     pos: int = 0                 # where the shared reader stands after the call
     body_unread: bool = False    # a parsed signature left bytes of its own packet in the stream (bufio stopped short of its end)
     lazy_parser: bool = False    # a known non-signature type whose x/crypto parser may stop before the end of the body
+    beyond_native_bounds: bool = False   # partial lengths past what the VERIFIER follows (kernels.hip CHAIN_MAX_HOPS /
+                                         # CHUNKED_SIG_MAX_BODY): it fences the stream from this packet on; the reference does not care
+
+
+VERIFIER_CHAIN_MAX_HOPS = 1024          # kernels.hip CHAIN_MAX_HOPS
+VERIFIER_CHUNKED_SIG_MAX_BODY = 16384   # kernels.hip CHUNKED_SIG_MAX_BODY
 
 
 def packet_read_stream(buf: bytes, pos: int) -> StreamPacket:
     """packet.Read on the shared reader at pos."""
+    pk = _packet_read_stream(buf, pos)
+    return pk
+
+
+def _beyond_bounds(contents, is_sig: bool) -> bool:
+    if not isinstance(contents, _PartialLengthReader):
+        return False
+    _consume_all(contents)             # (the whole chain: the verifier measures it before it parses anything)
+    return contents.headers > VERIFIER_CHAIN_MAX_HOPS or (is_sig and contents.delivered > VERIFIER_CHUNKED_SIG_MAX_BODY)
+
+
+def _packet_read_stream(buf: bytes, pos: int) -> StreamPacket:
     s = _ByteStream(buf, pos)
     tag, contents, err = _read_header_stream(s)
     if err == "EOF":
@@ -570,21 +592,22 @@ def packet_read_stream(buf: bytes, pos: int) -> StreamPacket:
         # every other type: the known ones are parsed by code this restatement does not follow (where their parser stops is the
         # fence of position_is_type_dependent); here their whole body is taken, as consumeAll does for unknown types and errors
         _consume_all(contents)
+        bb = _beyond_bounds(contents, False)
         if tag in _KNOWN_TAGS:
-            return StreamPacket("not_signature", tag=tag, pos=s.pos, lazy_parser=tag not in _READS_TO_END)
-        return StreamPacket("unknown", tag=tag, pos=s.pos)
+            return StreamPacket("not_signature", tag=tag, pos=s.pos, lazy_parser=tag not in _READS_TO_END, beyond_native_bounds=bb)
+        return StreamPacket("unknown", tag=tag, pos=s.pos, beyond_native_bounds=bb)
     bufr = _Bufio(contents)
     ver, err = bufr.peek1()
     if err:
         return StreamPacket("sig_error", tag=2, pos=s.pos)        # io.EOF (empty body) ends Reader.Next the same way an error does
     try:
         sig = parse_signature_v3_stream(bufr) if ver[0] < 4 else parse_signature_stream(bufr)
-    except (StructuralError, UnsupportedError, _ReadErr, RecursionError):
+    except (StructuralError, UnsupportedError, _ReadErr):
         _consume_all(bufr)
-        return StreamPacket("sig_error", tag=2, pos=s.pos)
+        return StreamPacket("sig_error", tag=2, pos=s.pos, beyond_native_bounds=_beyond_bounds(contents, True))
     after = s.pos
     _consume_all(contents)                                        # (not done by the reference: only to see whether anything was left)
-    return StreamPacket("sig", tag=2, sig=sig, pos=after, body_unread=s.pos != after)
+    return StreamPacket("sig", tag=2, sig=sig, pos=after, body_unread=s.pos != after, beyond_native_bounds=_beyond_bounds(contents, True))
 
 
 @dataclass
@@ -635,14 +658,17 @@ def position_is_type_dependent(buf: bytes, stop_at_error: bool = False) -> bool:
 
 
 def fence_reason(buf: bytes, stop_at_error: bool = False) -> Optional[str]:
-    """The first of the two shapes of position_is_type_dependent in the stream: "lazy" (a parser this restatement does not
-    model: nothing to compare against), "unread" (followed exactly here, fenced by the verifier), or None."""
+    """The first fenced shape in the stream: "lazy" (a parser this restatement does not model: nothing to compare against),
+    "unread" (followed exactly here, fenced by the verifier), "bounds" (a partial-length chain or chunked signature body past the
+    verifier's native bounds: it reports ST_UNSUPPORTED for that packet and fences), or None."""
     pos = 0
     while True:
         pkt = packet_read_stream(buf, pos)
         pos = pkt.pos
         if pkt.kind == "eof":
             return None
+        if pkt.beyond_native_bounds:
+            return "bounds"
         if pkt.kind in ("error", "sig_error"):
             if stop_at_error:
                 return None

@@ -962,6 +962,9 @@ def test_fenced_shapes_are_flagged_and_nothing_else_is(gpu_ctx):
         "bytes-behind-the-mpis": bytes([0xC2, 255]) + (len(body) + 5000).to_bytes(4, "big") + body + bytes(5000),
         # partial lengths whose zero-length last chunk is never read: the next call trips over its length octet
         "partial-length-zero-last-chunk": pow2_chunks(body) + b"\x00",
+        # past the bounds of the native path for partial lengths (kernels.hip CHAIN_MAX_HOPS / CHUNKED_SIG_MAX_BODY): not claimed
+        "partial-length-1100-chunks": bytes([0xC0 | 60]) + b"".join(bytes([0xE0, 7]) for _ in range(1100)) + b"\x00",
+        "partial-length-17000-byte-body": pow2_chunks(v4(hashed=ct + iss + bytes([255]) + (17000).to_bytes(4, "big") + bytes([100]) + bytes(16999))),
         "md5": cb._hdr(2, len(v4(hash_id=1, h=hashlib.md5))) + v4(hash_id=1, h=hashlib.md5),
         "value-beyond-R": cb._hdr(2, len(v4(value=kp.rsa_private(5) + (1 << 2200)))) + v4(value=kp.rsa_private(5) + (1 << 2200)),
         "nesting-3": cb._hdr(2, len(deep)) + deep,
@@ -1217,6 +1220,7 @@ def test_exotic_framings_follow_the_reference_readers(gpu_ctx, exit_mode):
     for i in range(len(ss_l)):
         r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
         got = list(st[st_item == i])
+        assert pgp.fence_reason(ss_l[i]) != "bounds"
         k = _events_until_unread_signature(pgp, ss_l[i])
         want = r.statuses if k is None else r.statuses[:k]
         assert got[:len(want)] == want, (i, got[:10], want[:10])

@@ -418,6 +418,8 @@ def _oracle_scan(pgp, data):
         pos = pk.pos
         if pk.kind == "eof":
             return want, fence
+        if pk.beyond_native_bounds:            # more chunks / a longer chunked signature than the verifier follows: not claimed
+            return want + [pgp.ST_UNSUPPORTED], True
         if pk.kind == "unknown":
             continue
         if pk.kind == "not_signature":
@@ -546,6 +548,14 @@ def test_exotic_framings_follow_the_reference_readers(H):
     # an unknown packet type with partial lengths is skipped whole; a user id likewise (its parser ends in ReadAll)
     st, (scan, n, fenced) = statuses(TH.partial_frame(60, bytes(700), rng) + TH.partial_frame(13, b"u" * 300, rng) + plain)
     assert st == [pgp.ST_NOT_SIGNATURE, 0] and not fenced
+    # bounds of the native path (kernels.hip CHAIN_MAX_HOPS, CHUNKED_SIG_MAX_BODY): past them the packet is not claimed
+    long_body = TH.sign_body(kp, tbs, srng, hashed_extra=bytes([255]) + (17000).to_bytes(4, "big") + bytes([100]) + bytes(16999))
+    for stream in ([TH.partial_frame(2, long_body, rng, max_pow=12) + plain] +
+                   [bytes([0xC0 | 60]) + b"".join(bytes([0xE0, 7]) for _ in range(1100)) + b"\x00" + plain]):
+        st, (scan, n, fenced) = statuses(stream)
+        assert fenced and scan[0] == pgp.ST_UNSUPPORTED and pgp.fence_reason(stream) == "bounds"
+    st, (scan, n, fenced) = statuses(bytes([0xC0 | 60]) + b"".join(bytes([0xE0, 7]) for _ in range(1000)) + b"\x00" + plain)
+    assert st == [0] and scan == [99] and not fenced                 # 1000 one-byte chunks of an unknown packet type: skipped whole
     # the random mix
     tbs_l, ss_l = TH.exotic_framing_streams(cl, 500)
     n_fenced = n_ok = 0
