@@ -310,21 +310,25 @@ __host__ __device__ inline void chain_copy(const uint8_t* base, ChunkCursor c, u
   }
 }
 
-// Byte view of a chunked body for the parsers (k_signers, which has no arena to linearise into): byte i is found by walking
-// the chain from its start -- a rare shape, a handful of chunks.
+// Byte view of a chunked body for the parsers (k_signers, which has no arena to linearise into).  The parsers read forwards
+// almost always: the view remembers the chunk it stood in and walks on from there (back to the start for a smaller index).
 struct ChainBytes {
   const uint8_t* base; ChunkCursor c0; uint64_t end; uint32_t skip;
+  mutable ChunkCursor cur; mutable uint64_t cur_at; mutable bool cur_ok;      // `cur` stands on logical byte cur_at (if cur_ok)
+  __host__ __device__ inline ChainBytes(const uint8_t* b, ChunkCursor c, uint64_t e, uint32_t s)
+      : base(b), c0(c), end(e), skip(s), cur(c), cur_at(0), cur_ok(true) {}
   __host__ __device__ inline uint8_t operator[](uint32_t i) const {
-    ChunkCursor c = c0;
-    uint64_t want = (uint64_t)skip + i;
+    const uint64_t want = (uint64_t)skip + i;
+    if (!cur_ok || want < cur_at) { cur = c0; cur_at = 0; cur_ok = true; }
     for (;;) {
-      if (c.rem == 0 && (!cursor_next_chunk(base, c, end) || c.rem == 0)) return 0;
-      if (want < c.rem) return c.pos + want < end ? base[c.pos + want] : 0;
-      want -= c.rem; c.pos += c.rem; c.rem = 0;
-      if (c.pos >= end) return 0;
+      if (cur.rem == 0 && (!cursor_next_chunk(base, cur, end) || cur.rem == 0)) { cur_ok = false; return 0; }
+      const uint64_t off = want - cur_at;
+      if (off < cur.rem) return cur.pos + off < end ? base[cur.pos + off] : 0;
+      cur_at += cur.rem; cur.pos += cur.rem; cur.rem = 0;
+      if (cur.pos >= end) { cur_ok = false; return 0; }
     }
   }
-  __host__ __device__ inline ChainBytes operator+(uint32_t d) const { return ChainBytes{base, c0, end, skip + d}; }
+  __host__ __device__ inline ChainBytes operator+(uint32_t d) const { ChainBytes r(*this); r.skip = skip + d; return r; }
 };
 __host__ __device__ inline ChainBytes raw_bytes(const ChainBytes& c) { return c; }
 
@@ -860,7 +864,7 @@ __global__ void __launch_bounds__(64) k_signers(const uint8_t* __restrict__ sig_
     if (w.status == ST_PENDING_CHUNKED) {
       // partial body lengths: parsed through a view that walks the chunks (no arena in this parse-only kernel)
       cur = ChunkCursor{w.body_off, 1ull << (sig_blob[w.body_off - 1] & 31u), true};
-      const ChainBytes body{sig_blob, cur, end, 0u};
+      const ChainBytes body(sig_blob, cur, end, 0u);
       v3 = w.body_len >= 1 && body[0] < 4;
       parsed = v3 ? parse_sig_body_v3(body, w.body_len, tmp, issuer) : parse_sig_body(body, w.body_len, tmp, have_issuer, issuer, &too_deep);
     } else {
