@@ -245,13 +245,14 @@ class Verifier:
         if D.dry:
             self.ctxs = []
             return
-        self.ctxs = [ctx0 or Context(D.local_rank)] + [Context(D.local_rank) for _ in range(n_ctx - 1)]
+        # one root context holds the key table (and the DSA window tables: GBs per key); the other batches in flight run on
+        # FORKS of it (bftkv_gpu_ctx_fork: own streams, arena, events, mailbox; the root's keys and quorum handles)
+        root = ctx0 or Context(D.local_rank)
         f, mn, thr, suff = cb.quorum_numbers(cl.n)
-        keys = abi_keys_of(cl)
-        self.qhs = []
-        for cx in self.ctxs:
-            cx.keyring_set(keys)
-            self.qhs.append(cx.quorum_create([(f, mn, thr, suff, [r.key_id for r in cl.replicas])]))
+        root.keyring_set(abi_keys_of(cl))
+        qh = root.quorum_create([(f, mn, thr, suff, [r.key_id for r in cl.replicas])])
+        self.ctxs = [root] + [root.fork() for _ in range(n_ctx - 1)]
+        self.qhs = [qh] * n_ctx
         D.comm_init(self.ctxs)
         dev = D.dev
         self.d_tbs = torch.from_numpy(tb).to(dev) if isinstance(tb, np.ndarray) else tb
@@ -306,7 +307,7 @@ class Verifier:
         return own_ok and int(rows.sum()) == total_ok
 
     def close(self):
-        for cx in self.ctxs:
+        for cx in reversed(self.ctxs):      # forks before their root
             cx.close()
 
 
@@ -421,10 +422,12 @@ def int_mac_block(macs_per_step, ms_step, launch_ms, single_ms, sclk_mhz, in_fli
     duration of the timed region's k_rsa_modexp launches (each with the small kernels of the neighbouring batches beside it) and
     over the kernel's single-flight launch duration (the kernel with only its own hash stream beside it)."""
     out = int_mac(macs_per_step, ms_step, sclk_mhz)
-    out["basis"] = "MACs of k_rsa_modexp per step / ms_per_step of the timed region (%d batches in flight)" % in_flight
-    pl, sf = int_mac(macs_per_step, launch_ms), int_mac(macs_per_step, single_ms)
+    out["basis"] = "MACs of the public-key kernels per step / ms_per_step of the timed region (%d batches in flight)" % in_flight
+    pl = int_mac(macs_per_step, launch_ms)
     out["per_launch_in_timed_region"] = {"launch_ms": launch_ms, "achieved": pl["achieved"], "frac": pl["frac"], "frac_of_theoretical": pl["frac_of_theoretical"]}
-    out["single_flight"] = {"launch_ms": single_ms, "achieved": sf["achieved"], "frac": sf["frac"], "frac_of_theoretical": sf["frac_of_theoretical"]}
+    if single_ms:
+        sf = int_mac(macs_per_step, single_ms)
+        out["single_flight"] = {"launch_ms": single_ms, "achieved": sf["achieved"], "frac": sf["frac"], "frac_of_theoretical": sf["frac_of_theoretical"]}
     return out
 
 
@@ -687,7 +690,7 @@ def bench_cfg3(args, D):
     rc = cb.make_read_corpus(cl, n_vars, seed=cb.MASTER_SEED + D.rank, batch_signer=rsa_signer, dsa_batch_pow=dsa_pow)
     t_corpus = time.time() - t0
     n_replies = len(rc.reply_var)
-    V = Verifier(D, cl, n_replies, rc.tbss_blob, rc.tbss_off, rc.ss_blob, rc.ss_off, ctx0=ctx0)
+    V = Verifier(D, cl, n_replies, rc.tbss_blob, rc.tbss_off, rc.ss_blob, rc.ss_off, n_ctx=max(1, args.inflight), ctx0=ctx0)
     # the read quorum: the n_storage storage nodes under the READ rule (wotqs.go:36-70: threshold = f + 1)
     ns = len(rc.storage_ids)
     f = (ns - 1) // 3
@@ -713,12 +716,20 @@ def bench_cfg3(args, D):
         e = np.ascontiguousarray(err if in_order else err[order], dtype=np.uint8)
         return HM.max_timestamped_value_masked(q_read, n_vars, peers_s, ts_s, vb_s, vo_s, roff, e)
 
-    def run(k):
-        for i in range(k):
-            V.submit(i); V.complete(i)
-            err = V.outs[0][0].cpu().numpy()            # 1 byte per reply back to the host
-            winners[0] = tally(err)
+    def finish(j):
+        V.complete(j)
+        err = V.outs[j % V.n_ctx][0].cpu().numpy()      # 1 byte per reply back to the host
+        winners[0] = tally(err)                         # (on the host, while the next steps' kernels run)
 
+    def run(k):
+        for i in range(k):                              # up to n_ctx steps in flight (see cfg 2)
+            V.submit(i)
+            if i >= V.n_ctx - 1:
+                finish(i - (V.n_ctx - 1))
+        for j in range(max(0, k - (V.n_ctx - 1)), k):
+            finish(j)
+
+    run(V.n_ctx)                 # one untimed step per verifier context: its arena is allocated at its first call
     elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
     sclk = V.ctxs[0].last_sclk_mhz()
     err, nver, bits = V.results(0)
@@ -741,7 +752,7 @@ def bench_cfg3(args, D):
                         "value), %d signature packets; reply verdicts on the GPU, then maxTimestampedValue per variable over the %d-node read "
                         "quorum" % (n, n_replies, n_vars, rc.writes.n_items, rc.n_sigs, ns),
                         {"replicas": n, "replies_per_gpu": n_replies, "variables_per_gpu": n_vars, "sigs_per_gpu": rc.n_sigs,
-                         "parallelism": "shard-by-variable x%d, RCCL all-gather of reply-verdict bitmaps" % D.world})
+                         "batches_in_flight": V.n_ctx, "parallelism": "shard-by-variable x%d, RCCL all-gather of reply-verdict bitmaps" % D.world})
         out.update({
             "value_counts": "RSA-2048 / DSA-2048 public-key verifications on the REFERENCE's operation count (packets "
                             "PGPCollectiveSignature.Verify examines before IsSufficient stops it that reach the public-key operation)",
@@ -756,7 +767,8 @@ def bench_cfg3(args, D):
                           "step_device_span": float(np.mean(V.total_ms)), "measured": "HIP events of the %d timed steps" % len(V.rsa_ms),
                           "last_call": V.last_tm},
             "roofline": roofline(3, dom, alg_bytes, max(rsa_ms, dsa_ms), "integer-VALU bound; see int_mac"),
-            "int_mac": int_mac(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * MACS_PER_DSA_VERIFY, rsa_ms + dsa_ms, sclk),
+            "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * MACS_PER_DSA_VERIFY, elapsed / args.steps * 1e3,
+                                     rsa_ms + dsa_ms, None, sclk, V.n_ctx),
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:
@@ -834,12 +846,16 @@ def bench_cfg4(args, D):
         body = (o[:-1].unsqueeze(0) + torch.arange(tiles, device=dev, dtype=torch.int64).unsqueeze(1) * step).reshape(-1)
         return torch.cat([body, torch.tensor([tiles * step], device=dev, dtype=torch.int64)])
     d_to, d_so = tile_off(z["to"]), tile_off(z["so"])
-    V = Verifier(D, cl, chunk, d_tb, d_to, d_sb, d_so, ctx0=ctx0, ss_len=tiles * int(z["so"][-1]))
+    # One call in flight: a second one (measured, 1124.3 vs 1123.8 ms per step) gains nothing here -- the 9 ms of walk / parse /
+    # compare per call are machine WORK, not latency, and while a 129 ms modexp has blocks pending the dispatcher hands every
+    # freed SIMD slot to it: the neighbour's small kernels run when it has drained, exactly as they do with one call in flight.
+    n_fl = 1
+    V = Verifier(D, cl, chunk, d_tb, d_to, d_sb, d_so, n_ctx=n_fl, ctx0=ctx0, ss_len=tiles * int(z["so"][-1]))
 
     def run(k):
-        for i in range(k):
-            for _ in range(calls):                      # the rank's share of the storm, one resident batch at a time
-                V.submit(0); V.complete(0)
+        V.run(k * calls)                                # the rank's share of the storm: `calls` resident batches per step, n_fl in flight
+
+    V.run(n_fl)                  # one untimed call per verifier context: its arena is allocated at its first call
 
     elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
     sclk = V.ctxs[0].last_sclk_mhz()
@@ -864,7 +880,7 @@ def bench_cfg4(args, D):
                          float(z["to"][-1]) / distinct / 1024, n_sigs_call),
                         {"replicas": n, "writes_per_step": chunk * calls * D.world, "writes_per_gpu_per_step": chunk * calls,
                          "writes_per_call": chunk, "sigs_per_call": n_sigs_call, "distinct_writes": distinct, "tiles": tiles,
-                         "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps per call" % D.world}, scaling="strong")
+                         "calls_in_flight": V.n_ctx, "parallelism": "shard-by-write x%d, RCCL all-gather of verdict bitmaps per call" % D.world}, scaling="strong")
         out.update({
             "data": "synthetic: %d distinctly signed writes tiled %dx in HBM (every copy is parsed, hashed and verified again; nothing is "
                     "cached across items)" % (distinct, tiles),
@@ -879,7 +895,7 @@ def bench_cfg4(args, D):
             "kernel_ms": {"k_rsa_modexp": rsa_ms, "hash_stream": hash_ms, "call_device_span": float(np.mean(V.total_ms)),
                           "measured": "HIP events of the %d timed calls" % len(V.rsa_ms), "last_call": V.last_tm},
             "roofline": roofline(4, "k_rsa_modexp", alg_bytes, rsa_ms, "integer-VALU bound; see int_mac"),
-            "int_mac": int_mac(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, rsa_ms, sclk),
+            "int_mac": int_mac_block(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY * calls, elapsed / args.steps * 1e3, rsa_ms * calls, None, sclk, V.n_ctx),
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:
