@@ -194,7 +194,13 @@ int bftkv_gpu_signature_verify(bftkv_gpu_ctx* ctx, uint32_t n_items,
  * verify calls (collective / signature / message / signers); whatever changes the key table or the quorums
  * (bftkv_gpu_keyring_set, bftkv_gpu_quorum_create / _destroy, the certificate sites of bftkv_host.h,
  * bftkv_gpu_set_early_exit) is done on the root, waits there until the forks' calls in flight have drained, and is seen
- * by every fork at its next call.  Destroy the forks before their root. */
+ * by every fork at its next call.  Destroy the forks before their root.
+ *
+ * Resident batches in flight on several contexts of one device (forks or not): the machine-filling RSA exponentiation of such
+ * a call (calls of >= 98,304 signature packets; not the staged small calls) takes turns with those of the other contexts -- it
+ * waits, on its stream, for the one launched before it -- so that one call's walk / parse / compare / tally run under another's
+ * exponentiation instead of two exponentiations sharing the machine.  Three batches in flight keep the device at 1.04 x the
+ * kernel's duration per batch (bench.py --config 2).  BFTKV_NO_TURNSTILE=1 in the environment turns it off. */
 int bftkv_gpu_ctx_fork(bftkv_gpu_ctx* root, bftkv_gpu_ctx** fork_out);
 
 /* ---- small batches: the latency route ---------------------------------------------------------------- */
