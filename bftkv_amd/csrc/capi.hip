@@ -680,7 +680,7 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   *bits_changed = false;
   auto assign = [&](std::vector<uint32_t>& new_slots, std::vector<uint32_t>& new_rows) {
     new_slots.clear(); new_rows.clear();
-    const size_t cert_cap = c->dsa_wbits == 16 ? 8 : 1024;
+    const size_t cert_cap = c->dsa_wbits >= 16 ? 8 : 1024;
     for (size_t i = 0; i < rows.size(); ++i) {
       if (algo[i] != PK_DSA || bits[i] == 0xFFFFFFFFu) continue;
       auto it = c->dsa_comb_slot.find(rows[i]->material);
@@ -723,15 +723,18 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   std::vector<uint32_t> new_slots, new_rows;
   assign(new_slots, new_rows);
   const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
-  // window width by DSA population: 16 bits (637 MB and <= 32 table multiplications per signature) while the tables of all
-  // keys fit a quarter of the free HBM and there are at most 64 of them, 8 bits (4.96 MB, <= 64) up to 4096 keys, 4 beyond
+  // window width by DSA population and free HBM: 18 bits (2.39 GB per key, 29 table multiplications per signature) while the
+  // tables of all keys -- with the half again the buffer grows by -- fit 45 % of what is free, 16 bits (637 MB, 31) while they
+  // fit a quarter; both only up to 64 keys; 8 bits (4.96 MB, <= 63) up to 4096 keys, 4 beyond
   auto policy = [&](size_t n_keys) -> uint32_t {
     if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
     if (n_keys <= 64) {
       size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-          (n_keys + 1) * dsa_slot_stride(16) * sizeof(uint32_t) * 3 / 2 < (free_b + c->dsa_comb.cap) / 4)
-        return 16u;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t room = free_b + c->dsa_comb.cap;
+        if ((n_keys + 1) * dsa_slot_stride(18) * sizeof(uint32_t) * 3 / 2 < room / 100 * 45) return 18u;
+        if ((n_keys + 1) * dsa_slot_stride(16) * sizeof(uint32_t) * 3 / 2 < room / 4) return 16u;
+      }
     }
     return n_keys > 4096 ? 4u : 8u;
   };
@@ -743,7 +746,15 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   }
   const uint32_t want_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : c->dsa_wbits_want;
   bool restart = false;
-  if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256) {   // width change, or mostly stale: restart
+  // tables of keys that left the keyring stay cached by key material (a key that comes back costs nothing) -- as long as they
+  // are few and the wide layouts do not crowd the HBM: past 45 % of what is free (with the buffer's growth margin) they go
+  bool crowded = false;
+  if (want_wbits >= 16 && c->dsa_comb_slot.size() > live) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      crowded = c->dsa_comb_slot.size() * dsa_slot_stride(want_wbits) * sizeof(uint32_t) * 3 / 2 > (free_b + c->dsa_comb.cap) / 100 * 45;
+  }
+  if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256 || crowded) {   // width change, mostly stale, or crowded: restart
     restart = true;
     c->dsa_comb_slot.clear();
     c->dsa_cert_materials.clear();
@@ -781,8 +792,8 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
                              rows[new_rows[k]]->qpow.data(), DSA_QTAIL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   DevBuf d_slots, d_rows;
   if ((rc = upload(c, d_slots, new_slots)) || (rc = upload(c, d_rows, new_rows))) { d_slots.release(); d_rows.release(); return rc; }
-  const uint32_t parts = c->dsa_wbits == 16 ? 16u : 1u;
-  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * (256u / c->dsa_wbits) * parts;
+  const uint32_t parts = c->dsa_wbits >= 16 ? 1u << (c->dsa_wbits - 12u) : 1u;       // 4,096 entries per quad at the wide widths
+  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * dsa_nwin(c->dsa_wbits) * parts;
   hipLaunchKernelGGL(k_dsa_build_comb, dim3((n_quads + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
                      (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -1057,7 +1068,7 @@ int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* c, int hash_id, int state) {
 }
 
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
-  if (!c || (bits != 0 && bits != 4 && bits != 8 && bits != 16)) return BFTKV_E_INVALID;
+  if (!c || (bits != 0 && bits != 4 && bits != 8 && bits != 16 && bits != 18)) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->dsa_wbits_pinned = bits;
   return 0;

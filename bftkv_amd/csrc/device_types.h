@@ -77,11 +77,14 @@ struct KeyTableDev {
   //   q_pow28[76][10] = 2^(28 j) mod q as radix-2^28 limbs, which folds v (mod p) down to v mod q.
   const uint32_t* dsa_slot;   // [n_keys] table slot of a DSA key (0xFFFFFFFF otherwise)
   const uint32_t* dsa_comb;
-  uint32_t dsa_wbits;         // 8 (4.96 MB per key) or 4 (0.58 MB per key, very large DSA keyrings)
+  uint32_t dsa_wbits;         // 18 (2.39 GB per key), 16 (637 MB), 8 (4.96 MB) or 4 (0.58 MB per key, very large DSA keyrings)
   uint32_t hash_policy;       // bits 0-1 MD5, bits 2-3 RIPEMD-160: 0 unknown (fenced), 1 available, 2 not available (bftkv_gpu_set_hash_policy)
 };
+// windows per 256-bit exponent: the top one is narrower when the width does not divide 256 (18 bits: 14 full windows + 4 bits;
+// its table is laid out like the others, only its first 15 entries are ever read)
+constexpr uint32_t dsa_nwin(uint32_t wbits) { return (256u + wbits - 1u) / wbits; }
 constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits) {
-  return 2ull * (256u / wbits) * ((1u << wbits) - 1u) * 76u;
+  return 2ull * dsa_nwin(wbits) * ((1u << wbits) - 1u) * 76u;
 }
 constexpr uint32_t DSA_QPOW_WORDS = 76 * 10;
 // ... followed by the mod-q Montgomery constants: 2^512 mod q (8 words), -q^-1 mod 2^32 (1 word), 3 words padding

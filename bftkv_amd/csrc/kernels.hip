@@ -1773,7 +1773,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, co
                                                               KeyTableDev kt, uint32_t* __restrict__ comb, uint32_t parts) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   constexpr int L = MONT_L;
-  const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
+  const uint32_t wbits = kt.dsa_wbits, nwin = dsa_nwin(wbits), nent = (1u << wbits) - 1u;
   const uint32_t n_quads = n_new * 2u * nwin * parts;
   const uint32_t quad = threadIdx.x >> 2;
   const int qlane = threadIdx.x & 3;
@@ -1894,7 +1894,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   const uint32_t* a_rd = a_sh + quad * MONT_N;
   uint32_t n[L], b[L], y[L], t[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t wbits = kt.dsa_wbits, nwin = 256u / wbits, nent = (1u << wbits) - 1u;
+  const uint32_t wbits = kt.dsa_wbits, nwin = dsa_nwin(wbits), nent = (1u << wbits) - 1u;
   const uint32_t* slot_base = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(wbits);
   const uint32_t* tab = slot_base + qlane * L;
 #pragma unroll
@@ -1903,8 +1903,11 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   const uint32_t* up = dsa_u + (uint64_t)di * DSA_U_WORDS;
   const bool live = active && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
   auto digit = [&](uint32_t step) -> uint32_t {
-    const uint32_t bitpos = (step >> 1) * wbits;
-    return live ? ((up[(step & 1u) * 8 + (bitpos >> 5)] >> (bitpos & 31)) & nent) : 0u;
+    const uint32_t bitpos = (step >> 1) * wbits, wi = bitpos >> 5, sh = bitpos & 31u;
+    if (!live) return 0u;
+    const uint32_t* e = up + (step & 1u) * 8;                       // u1 or u2: eight 32-bit words
+    const uint32_t lo = e[wi], hi = (wi < 7u && sh + wbits > 32u) ? e[wi + 1] : 0u;     // (a window may straddle two words)
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & nent;
   };
   auto entry = [&](uint32_t step, uint32_t d) -> const uint32_t* {
     return tab + ((uint64_t)((step & 1u) * nwin + (step >> 1)) * nent + (d ? d - 1 : 0)) * MONT_N;

@@ -100,10 +100,11 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* ctx, const bftkv_gpu_pubkey* keys, uint
 int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* ctx, int hash_id, int state);
 
 /* DSA verification (Go crypto/dsa.Verify under packet.PublicKey.VerifySignature) multiplies from per-key
- * fixed-base window tables kept in HBM: 16-bit windows cost 637 MB per key and <= 32 multiplications per
- * signature, 8-bit windows 4.96 MB and <= 64, 4-bit windows 0.58 MB and <= 128.  The default is 16 for up to
- * 64 DSA keys (41 GB of the part's 288 GB, if that much is free), 8 up to 4096 keys, 4 beyond; bits = 4, 8
- * or 16 pins the width, 0 returns to the default.  Takes effect at the next bftkv_gpu_keyring_set. */
+ * fixed-base window tables kept in HBM: 18-bit windows cost 2.39 GB per key and 29 multiplications per signature, 16-bit
+ * windows 637 MB and 31, 8-bit windows 4.96 MB and <= 63, 4-bit windows 0.58 MB and <= 127.  The default is the widest
+ * whose tables fit the free HBM with room to spare (18 bits: 45 % of it, e.g. 32 keys = 79 GB of the part's 288 GB;
+ * 16 bits: a quarter), both only up to 64 DSA keys; 8 up to 4096 keys, 4 beyond; bits = 4, 8, 16 or 18 pins the width,
+ * 0 returns to the default.  Takes effect at the next bftkv_gpu_keyring_set. */
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t bits);
 
 /* ---- transport message signatures: the signature half of PGPMessage.Decrypt (crypto/pgp/crypto_pgp.go:453-471) ----
