@@ -728,6 +728,10 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   // fit a quarter; both only up to 64 keys; 8 bits (4.96 MB, <= 63) up to 4096 keys, 4 beyond
   auto policy = [&](size_t n_keys) -> uint32_t {
     if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
+    if (const char* e = getenv("BFTKV_DSA_WBITS")) {            // experiments: the width without touching the caller
+      const uint32_t b = (uint32_t)atoi(e);
+      if (b == 4 || b == 8 || b == 16 || b == 18) return b;
+    }
     if (n_keys <= 64) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
