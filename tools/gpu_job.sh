@@ -1,7 +1,8 @@
 export TMPDIR=/tmp
-run() { BFTKV_DSA_WBITS=$1 python bench.py --config 3 --steps 12 --warmup 2 --inflight $2 --no-cpu-baseline --soak-seconds 0 --corpus-cache /tmp/cc 2>gpurun_out/b3.err | python -c "
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for a in "--steps 20 --warmup 2" "--steps 20 --warmup 5" "--steps 5 --warmup 1"; do
+python bench.py --gpus 1 $a --no-cpu-baseline --no-serving --soak-seconds 0 --corpus-cache /tmp/c2 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('cfg 3 wbits=$1 inflight $2  ms/step %.3f value %.1fM  kernel_ms %s'%(d['ms_per_step'], d['value']/1e6, {k:round(v,2) for k,v in d['kernel_ms'].items() if isinstance(v,(int,float))}))
-" || tail -5 gpurun_out/b3.err; }
-run 16 3; run 18 3; run 16 1; run 18 1; run 16 3; run 18 3
+d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1])
+print('$a  ms/step %.3f value %.1fM  rsa %.3f sf %.3f'%(d['ms_per_step'], d['value']/1e6, d['kernel_ms']['k_rsa_modexp'], d['kernel_ms']['single_flight']['rsa']))"
+done
