@@ -1,2 +1,3 @@
 export TMPDIR=/tmp
-timeout 900 python bench.py --config 5 > gpurun_out/bench_cfg5.json 2> gpurun_out/bench_cfg5.err; echo "rc=$?"
+bash tools/profile_bench.sh r03i_cfg5 5 10 2>&1 | tail -1
+bash tools/profile_bench.sh r03i_cfg3 3 6 2>&1 | tail -1
