@@ -379,6 +379,17 @@ def test_micro_batcher_concurrent_single_calls(gpu_ctx, n_lanes):
     for t in ths:
         t.join(timeout=120)
     st = b.stats()
+    # the framings no writer produces (partial / indeterminate lengths, bodies beyond bufio's buffer ...) through the batcher's
+    # staged route: error byte and fence flag of every call are those of the batched entry point on the same inputs
+    tbs_x, ss_x = H.exotic_framing_streams(cl, 28, seed=5)
+    tbx, tox = H.cat(tbs_x)
+    sbx, sox = H.cat(ss_x)
+    ex_err, _, _ = gpu_ctx.collective_verify(qh, tbx, tox, sbx, sox)
+    ex_fenced = gpu_ctx.last_fenced.copy()
+    for i in range(len(ss_x)):
+        rc, e1, f1 = b.collective_verify(qh, tbs_x[i], ss_x[i], raw=True)
+        assert rc == 0 and e1 == ex_err[i] and f1 == ex_fenced[i], (i, rc, e1, ex_err[i], f1, ex_fenced[i])
+    assert 3 < ex_fenced.sum() < 25 and (ex_err == 0).any()
     b.close()
     assert got == want and 0 < sum(g == 0 for g in got) < len(got)
     assert sig_got == [0 if i % 2 == 0 else 1 for i in range(16)]
