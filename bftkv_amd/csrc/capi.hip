@@ -495,7 +495,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   const dim3 qg8((total + MODEXP_BLOCK / MONT_TPI_BIG - 1) / (MODEXP_BLOCK / MONT_TPI_BIG));   // 8 lanes per number
   // A staged call with few signatures (no SIMD would get a second wave either way) spreads every <= 2048-bit number over
   // eight lanes: 0.68x the instructions per wave, and such a call lasts as long as ONE wave's chain of 18 products.
-  const bool wide8 = staged_cap != 0 && ss_len / 256 <= 8192 && !getenv("BFTKV_NO_WIDE8");
+  static const bool wide8_off = getenv("BFTKV_NO_WIDE8") != nullptr;
+  const bool wide8 = staged_cap != 0 && ss_len / 256 <= 8192 && !wide8_off;
   auto launch_modexp = [&](const uint32_t* start) {
     if (wide8)
       hipLaunchKernelGGL((k_rsa_modexp<10, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
@@ -511,7 +512,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       hipLaunchKernelGGL((k_rsa_modexp<MONT_L4096, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list4096.as<uint32_t>(),
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
-  if (total >= TURNSTILE_MIN_PACKETS && !staged_cap && !getenv("BFTKV_NO_TURNSTILE")) {
+  static const bool turnstile_off = getenv("BFTKV_NO_TURNSTILE") != nullptr;      // (read once: this is every big call's path)
+  if (total >= TURNSTILE_MIN_PACKETS && !staged_cap && !turnstile_off) {
     Turnstile& g = g_turnstile[(unsigned)c->device & 15u];
     std::lock_guard<std::mutex> tl(g.mu);
     if (g.last && g.owner != c) HIPCHK(c, hipStreamWaitEvent(s, g.last, 0));
