@@ -1,0 +1,38 @@
+"""CPU: the arithmetic behind bench.py's headline -- `value` counts the public-key operations the REFERENCE performs, computed
+from the verifier's per-packet statuses; checked here against the Python oracle's own walk on a small mutated corpus."""
+import numpy as np
+
+import bench
+from corpus import build as cb
+from oracle import openpgp as pgp
+from tests import helpers as H
+
+
+def test_reference_pubkey_ops_counts_what_the_reference_verifies():
+    cl = cb.make_cluster(7, dsa_fraction=0.3)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    c = cb.make_write_corpus(cl, 40, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.15, cb.MUT_DUP_SIGNER: 0.1,
+                                                      cb.MUT_ONE_SHORT: 0.2, cb.MUT_BAD_TAG: 0.1})
+    # what a verify-everything run of the verifier reports: the status of EVERY packet (the oracle with the early exit disabled)
+    st, item, err, nver, want_ops = [], [], [], [], 0
+    for i in range(c.n_items):
+        r = H.oracle_collective(kr, q, c, i)                       # the reference: stops at the first sufficient prefix
+        err.append(0 if r.err is None else 2)
+        nver.append(len(r.verified))
+        want_ops += sum(1 for s in r.statuses if s in (pgp.ST_OK, pgp.ST_BAD_SIG))
+        pos, data, tbs = 0, c.ss_data(i), c.tbss(i)
+        while pos < len(data):                                     # every packet, no exit
+            step = pgp.check_detached_signature(kr.get_keyring(), tbs, data, pos)
+            pos = step.pos
+            st.extend(step.statuses)
+            item.extend([i] * len(step.statuses))
+    got = bench.reference_pubkey_ops(np.array(st, dtype=np.uint8), np.array(item, dtype=np.int64), np.array(err, dtype=np.uint8),
+                                     np.array(nver, dtype=np.uint32), c.n_items)
+    assert got == want_ops and 0 < want_ops < len(st)
+
+
+def test_int_mac_block_bases():
+    b = bench.int_mac_block(1e9, 2.0, 1.6, 1.5, 2200.0, 3)
+    assert abs(b["achieved"] - 5e11) < 1 and b["per_launch_in_timed_region"]["launch_ms"] == 1.6 and b["single_flight"]["launch_ms"] == 1.5
+    assert b["single_flight"]["frac"] > b["per_launch_in_timed_region"]["frac"] > b["frac"] and "3 batches" in b["basis"]
+    assert "single_flight" not in bench.int_mac_block(1e9, 2.0, 1.6, None, None, 1)
