@@ -1,3 +1,7 @@
 export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python -m pytest tests -m gpu -x -q -k "collective_verify_matches or micro_batcher or fenced_shapes or exotic or cfg2_full_size" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -3
+for f in 3 4 3 4; do
+python bench.py --steps 300 --warmup 4 --inflight $f --no-cpu-baseline --no-serving --soak-seconds 0 --corpus-cache /tmp/c2 2>/dev/null | python -c "
+import sys,json
+d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1])
+print('inflight $f  ms/step %.3f value %.1fM  rsa %.3f sf %.3f'%(d['ms_per_step'], d['value']/1e6, d['kernel_ms']['k_rsa_modexp'], d['kernel_ms']['single_flight']['rsa']))"
+done
