@@ -205,6 +205,75 @@ def exotic_framing_streams(cl, n_items, seed=1234):
     return tbs_l, ss_l
 
 
+def plausible_unsigned_streams(n_streams, seed=4242, issuers=(0x1122334455667788,)):
+    """Streams of well-formed but UNSIGNED signature bodies (v4 RSA / DSA with issuers drawn from ``issuers``, 4096-bit and 8000-byte
+    MPIs, hashed / unhashed areas beyond bufio's buffer, bytes behind the MPIs, one v3 body) in every framing -- definite in all
+    header formats, partial chunks of random sizes, indeterminate, lengths past the end -- mixed with junk packets of known and
+    unknown types, every third stream cut, every fourth mutated."""
+    import struct
+    rng = np.random.default_rng(seed)
+    ct = b"\x05\x02" + struct.pack(">I", 1500000000)
+
+    def v4(issuer, extra=b"", unh=b"", nb=256, algo=1):
+        hashed = ct + b"\x09\x10" + struct.pack(">Q", issuer) + extra
+        b = bytes([4, 0, algo, 8]) + struct.pack(">H", len(hashed)) + hashed + struct.pack(">H", len(unh)) + unh + b"\xab\xcd"
+        b += struct.pack(">H", nb * 8) + bytes([0xD5]) * nb
+        return b + (struct.pack(">H", 160) + bytes([0xE6]) * 20 if algo == 17 else b"")
+
+    def notation(n):
+        return bytes([255]) + struct.pack(">I", n - 5) + bytes([100]) + bytes(n - 6)
+    bodies = []
+    for iss in issuers:
+        bodies += [v4(iss), v4(iss, algo=17, nb=20), v4(iss, extra=notation(4300)), v4(iss, unh=notation(5000)), v4(iss, nb=512), v4(iss, nb=8000),
+                   bytes([3, 5, 0]) + struct.pack(">I", 1) + struct.pack(">Q", iss) + bytes([1, 8]) + b"\x12\x34" + struct.pack(">H", 2048) + bytes([0xC1]) * 256]
+
+    def hdr(tag, ln, fmt):
+        if fmt == 0:
+            if ln < 192: return bytes([0xC0 | tag, ln])
+            if ln < 8384: return bytes([0xC0 | tag, ((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+        if fmt == 2 and tag < 16 and ln < 256: return bytes([0x80 | (tag << 2), ln])
+        if fmt == 3 and tag < 16 and ln < 65536: return bytes([0x80 | (tag << 2) | 1]) + ln.to_bytes(2, "big")
+        if fmt == 4 and tag < 16: return bytes([0x80 | (tag << 2) | 3])
+        if fmt == 5: return bytes([0xC0 | tag, 224 + int(rng.integers(0, 14))])
+        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
+
+    def chunked(tag, body):
+        out, pos, first = bytearray([0xC0 | tag]), 0, True
+        while True:
+            left = len(body) - pos
+            if left > 0 and (first or rng.random() < 0.75):
+                k = int(rng.integers(0, min(13, left.bit_length() - 1) + 1))
+                out.append(224 + k); out += body[pos:pos + (1 << k)]; pos += 1 << k; first = False
+                continue
+            last = body[pos:]
+            ln, enc = len(last), int(rng.integers(0, 3))
+            if enc == 0 and ln < 192: out.append(ln)
+            elif enc <= 1 and 192 <= ln < 8384: out += bytes([((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
+            else: out += bytes([255]) + ln.to_bytes(4, "big")
+            return bytes(out + last)
+
+    for it in range(n_streams):
+        parts = []
+        for _ in range(int(rng.integers(0, 8))):
+            if rng.random() < 0.45:
+                b = bodies[int(rng.integers(0, len(bodies)))]
+                if rng.random() < 0.3:
+                    b = b + rng.bytes(int(rng.choice([1, 50, 3900, 4200])))
+                m = int(rng.integers(0, 4))
+                parts.append(hdr(2, len(b), int(rng.integers(0, 4))) + b if m == 0 else chunked(2, b) if m == 1 else
+                             bytes([0x8B]) + b if m == 2 else hdr(2, len(b) + int(rng.integers(1, 5000)), 1) + b)
+            else:
+                ln = int(rng.integers(0, 300))
+                parts.append(hdr(int(rng.choice([2, 13, 11, 6, 14, 20, 40, 63, 1, 9, 17, 10, 12, 15])), ln, int(rng.integers(0, 7))) + rng.bytes(ln))
+        data = bytearray(b"".join(parts))
+        if it % 3 == 1 and len(data) > 1:
+            data = data[:int(rng.integers(1, len(data)))]
+        if it % 4 == 2 and len(data):
+            for _ in range(int(rng.integers(1, 4))):
+                data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+        yield bytes(data)
+
+
 def cat(parts):
     """byte strings -> (blob, n+1 offsets) as the batched entry points take them"""
     off = np.zeros(len(parts) + 1, dtype=np.uint64)

@@ -572,74 +572,14 @@ def test_exotic_framings_follow_the_reference_readers(H):
 
 
 def test_reader_model_fuzz_with_plausible_unsigned_bodies(H):
-    """The reader model again, cheaply and at volume: well-formed but UNSIGNED v4 / v3 signature bodies (RSA, DSA, 4096-bit and
-    8000-byte MPIs, hashed / unhashed areas beyond bufio's buffer, bytes behind the MPIs) in every framing -- definite in all
-    header formats, partial chunks of random sizes, indeterminate, lengths past the end -- mixed with junk packets, cut and
-    mutated: only framing, parsing and the reader's position are at stake, so no signing is needed.  The kernels' code on the host
-    against the oracle's reader objects, statuses up to the first fenced packet and the fence flag."""
-    import struct
+    """The reader model again, cheaply and at volume (tests/helpers.py plausible_unsigned_streams): well-formed but UNSIGNED v4 / v3
+    signature bodies in every framing, mixed with junk packets, cut and mutated -- only framing, parsing and the reader's position
+    are at stake, so no signing is needed.  The kernels' code on the host against the oracle's reader objects, statuses up to the
+    first fenced packet and the fence flag."""
     from oracle import openpgp as pgp
-    rng = np.random.default_rng(4242)
-    ct = b"\x05\x02" + struct.pack(">I", 1500000000)
-    iss = b"\x09\x10" + struct.pack(">Q", 0x1122334455667788)
-
-    def v4(extra=b"", unh=b"", nb=256, algo=1):
-        hashed = ct + iss + extra
-        b = bytes([4, 0, algo, 8]) + struct.pack(">H", len(hashed)) + hashed + struct.pack(">H", len(unh)) + unh + b"\xab\xcd"
-        b += struct.pack(">H", nb * 8) + bytes([0xD5]) * nb
-        return b + (struct.pack(">H", 160) + bytes([0xE6]) * 20 if algo == 17 else b"")
-
-    def notation(n):
-        return bytes([255]) + struct.pack(">I", n - 5) + bytes([100]) + bytes(n - 6)
-    bodies = [v4(), v4(algo=17, nb=20), v4(extra=notation(4300)), v4(unh=notation(5000)), v4(nb=512), v4(nb=8000),
-              bytes([3, 5, 0]) + struct.pack(">I", 1) + struct.pack(">Q", 5) + bytes([1, 8]) + b"\x12\x34" + struct.pack(">H", 2048) + bytes([0xC1]) * 256]
-
-    def hdr(tag, ln, fmt):
-        if fmt == 0:
-            if ln < 192: return bytes([0xC0 | tag, ln])
-            if ln < 8384: return bytes([0xC0 | tag, ((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
-        if fmt == 2 and tag < 16 and ln < 256: return bytes([0x80 | (tag << 2), ln])
-        if fmt == 3 and tag < 16 and ln < 65536: return bytes([0x80 | (tag << 2) | 1]) + ln.to_bytes(2, "big")
-        if fmt == 4 and tag < 16: return bytes([0x80 | (tag << 2) | 3])
-        if fmt == 5: return bytes([0xC0 | tag, 224 + int(rng.integers(0, 14))])
-        return bytes([0xC0 | tag, 255]) + ln.to_bytes(4, "big")
-
-    def chunked(tag, body):
-        out, pos, first = bytearray([0xC0 | tag]), 0, True
-        while True:
-            left = len(body) - pos
-            if left > 0 and (first or rng.random() < 0.75):
-                k = int(rng.integers(0, min(13, left.bit_length() - 1) + 1))
-                out.append(224 + k); out += body[pos:pos + (1 << k)]; pos += 1 << k; first = False
-                continue
-            last = body[pos:]
-            ln, enc = len(last), int(rng.integers(0, 3))
-            if enc == 0 and ln < 192: out.append(ln)
-            elif enc <= 1 and 192 <= ln < 8384: out += bytes([((ln - 192) >> 8) + 192, (ln - 192) & 0xFF])
-            else: out += bytes([255]) + ln.to_bytes(4, "big")
-            return bytes(out + last)
-
-    n_sig_ok = n_fenced = n_chunked_ok = 0
-    for it in range(4000):
-        parts = []
-        for _ in range(int(rng.integers(0, 8))):
-            if rng.random() < 0.45:
-                b = bodies[int(rng.integers(0, len(bodies)))]
-                if rng.random() < 0.3:
-                    b = b + rng.bytes(int(rng.choice([1, 50, 3900, 4200])))
-                m = int(rng.integers(0, 4))
-                parts.append(hdr(2, len(b), int(rng.integers(0, 4))) + b if m == 0 else chunked(2, b) if m == 1 else
-                             bytes([0x8B]) + b if m == 2 else hdr(2, len(b) + int(rng.integers(1, 5000)), 1) + b)
-            else:
-                ln = int(rng.integers(0, 300))
-                parts.append(hdr(int(rng.choice([2, 13, 11, 6, 14, 20, 40, 63, 1, 9, 17, 10, 12, 15])), ln, int(rng.integers(0, 7))) + rng.bytes(ln))
-        data = bytearray(b"".join(parts))
-        if it % 3 == 1 and len(data) > 1:
-            data = data[:int(rng.integers(1, len(data)))]
-        if it % 4 == 2 and len(data):
-            for _ in range(int(rng.integers(1, 4))):
-                data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
-        data = bytes(data)
+    from tests import helpers as TH
+    n_sig_ok = n_fenced = 0
+    for it, data in enumerate(TH.plausible_unsigned_streams(4000, seed=4242)):
         got, n, fenced = H.scan_stream(data, cap=40000)
         want, want_fenced = _oracle_scan(pgp, data)
         assert fenced == want_fenced and got[:len(want)] == want and (fenced or n == len(want)), (it, got[:12], want[:12], data[:64].hex())
