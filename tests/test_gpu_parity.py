@@ -1249,6 +1249,66 @@ def test_exotic_framings_follow_the_reference_readers(gpu_ctx, exit_mode):
     gpu_ctx.quorum_destroy(qh)
 
 
+def test_reader_model_at_volume_on_the_device(gpu_ctx, exit_mode):
+    """1,200 streams of plausible UNSIGNED signature bodies in every framing (tests/helpers.py plausible_unsigned_streams), issuers
+    known and unknown: nothing verifies, so this is the device's walk (speculating lanes, chunk chains, the sequential fill pass),
+    its parse (linearised chunks, LDS windows) and its reader-position rule against the oracle's reader objects -- per-packet
+    statuses up to the first fenced packet, exit counts, error bytes and the fence flags."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(5, dsa_fraction=0.4)
+    kr = _ring_and_ctx(gpu_ctx, cl)
+    q = H.clique_quorum(cl)
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    issuers = [cl.replicas[0].key_id, cl.replicas[1].key_id, 0x1122334455667788]
+    ss_l = list(H.plausible_unsigned_streams(1200, seed=7, issuers=issuers))
+    tbs = b"payload"
+    tb, to = _cat([tbs] * len(ss_l))
+    sb, so = _cat(ss_l)
+    err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    fenced = gpu_ctx.last_fenced.copy()
+    order = np.argsort(st_item, kind="stable")
+    first = np.searchsorted(st_item[order], np.arange(len(ss_l) + 1))
+    n_cmp = 0
+    rsa_ids = {r_.key_id for r_ in cl.replicas if r_.algo == cb.PK_RSA}
+
+    def semantic_fence(stream):
+        """Fences that are about a signature's content, not its framing: an RSA value beyond R under a known RSA
+        key (512- and 8000-byte MPIs here), MD5 / RIPEMD-160 under the default 'unknown' policy (a mutated hash byte)."""
+        pos = 0
+        while True:
+            pk = pgp.packet_read_stream(stream, pos)
+            pos = pk.pos
+            if pk.kind == "eof" or pk.beyond_native_bounds or (pk.kind == "not_signature" and pk.lazy_parser):
+                return False
+            if pk.kind == "sig":
+                g = pk.sig
+                if g.issuer in rsa_ids and g.pk_algo in (1, 3) and len(g.mpis[0][1].lstrip(b"\0")) > 266:
+                    return True
+                if g.issuer is not None and (g.issuer in rsa_ids or any(g.issuer == r_.key_id for r_ in cl.replicas)) and g.hash_id in (1, 3) and g.sig_type in (0, 1):
+                    return True
+                if pk.body_unread:
+                    return False
+
+    for i, s_ in enumerate(ss_l):
+        reason = pgp.fence_reason(s_)
+        assert fenced[i] == (1 if (reason or semantic_fence(s_)) else 0), (i, reason, fenced[i], s_[:48].hex())
+        r = col.collective_verify(kr, tbs, SignaturePacket(1, 0, False, s_ or None, None), q)
+        got = list(st[order[first[i]:first[i + 1]]])
+        if reason == "bounds":
+            continue
+        k = _events_until_unread_signature(pgp, s_)
+        want = r.statuses if k is None else r.statuses[:k]
+        assert got[:len(want)] == want, (i, got[:10], want[:10], s_[:48].hex())
+        if not fenced[i]:
+            assert err[i] != 0 and nver[i] == 0 and len(got) == len(r.statuses), i
+        n_cmp += len(want)
+    assert n_cmp > 5000 and 200 < fenced.sum() < 1000
+    gpu_ctx.quorum_destroy(qh)
+
+
 def test_mixed_modulus_sizes_2048_3072_4096(gpu_ctx):
     """One batch whose signers hold RSA-2048, -3072 and -4096 keys (own work lists, 4 / 8 / 8 lanes per number): verdicts and
     per-packet statuses follow the oracle, including values >= n, long MPIs, e = 3 on a 3072-bit key and corrupted values."""
