@@ -586,7 +586,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // (never to a verdict: see the kernel)
   if (total && c->have_ambiguous && !d_msg_slot)
     hipLaunchKernelGGL(k_candidates, dim3((total + 63) / 64), dim3(64), 0, s, d_tbs, d_tbs_off, d_ss, d_mid_in ? d_mid_in : c->mid.as<uint32_t>(),
-                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, n_recs_dev, d_tbs_prefix, c->kt, d_cert_ent, d_sig_class, txt);
+                       c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total, n_recs_dev, d_tbs_prefix, c->kt, d_cert_ent, d_sig_class, txt,
+                       c->hash_mask.as<uint32_t>());
   HIPCHK(c, rec(3, s));
   HIPCHK(c, hipGetLastError());
   return 0;

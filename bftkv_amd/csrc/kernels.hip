@@ -1260,15 +1260,16 @@ __global__ void __launch_bounds__(256) k_digest_other(const uint8_t* __restrict_
 // LAST error (openpgp.CheckDetachedSignature).  Only the first candidate that can sign ever sees the true digest -- it went
 // through the pipeline as the record's key (parse_one).  Each later one finds the hash suffix written once more into the
 // shared hash (candidate j hashes payload || suffix x (j+1)), so its tag check fails, or -- once in 2^16 -- passes and the
-// arithmetic over a foreign digest fails; a candidate that cannot sign fails before it writes anything.  None of them can
-// turn a failure into a success, so verdicts and tallies stand as the pipeline left them; this kernel, launched only when
-// the key table holds such ids, settles the STATUS of the records their first candidate did not verify.
+// arithmetic over a foreign digest fails unless the twin's owner signed that very digest (then the item is fenced, below);
+// a candidate that cannot sign fails before it writes anything.  Otherwise none of them can turn a failure into a success,
+// so verdicts and tallies stand as the pipeline left them; this kernel, launched only when the key table holds such ids,
+// settles the STATUS of the records their first candidate did not verify.
 __global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ tbs_blob, const uint64_t* __restrict__ tbs_off,
                                                    const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                    const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                    uint32_t n_recs, const uint32_t* __restrict__ n_recs_dev, const uint64_t* __restrict__ tbs_prefix,
                                                    KeyTableDev kt, const uint32_t* __restrict__ cert_ent, const uint8_t* __restrict__ sig_class,
-                                                   TextDev txt) {
+                                                   TextDev txt, uint32_t* __restrict__ item_hash_mask) {
   const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nr = n_recs_dev ? *n_recs_dev : n_recs;
   if (ri >= nr) return;
@@ -1301,7 +1302,15 @@ __global__ void __launch_bounds__(64) k_candidates(const uint8_t* __restrict__ t
       digest_body<false>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag);
     else digest_body<true>(tbs_blob, tbs_off, sig_blob, mid32, mid64, n_items, recs, nr, nullptr, ri, tbs_prefix, writes, &tag, txt);
     if ((uint8_t)(tag >> 8) != rec.hash_tag[0] || (uint8_t)tag != rec.hash_tag[1]) st = ST_HASH_TAG;
-    else st = (kt.pk_algo[k] != rec.pk_algo) ? (uint8_t)ST_ALGO_MISMATCH : (uint8_t)ST_BAD_SIG;
+    else if (kt.pk_algo[k] != rec.pk_algo) st = ST_ALGO_MISMATCH;
+    else {
+      // Tag and algorithm fit candidate j's digest H(payload || suffix x (j+1)): the reference now runs the public-key check
+      // over THAT digest, and whoever owns this twin key can have signed exactly it -- the reference would then return the
+      // twin as the signer.  The arithmetic is not repeated here (once in 2^16 by chance, otherwise a deliberate shape): the
+      // item is fenced and the reference decides; the status stays what an honest signature would leave.
+      st = ST_BAD_SIG;
+      atomicOr(&item_hash_mask[rec.item], ITEM_FENCED);
+    }
   }
   recs[ri].status = st;
 }

@@ -51,14 +51,20 @@ func (k *keyring) holds(e *openpgp.Entity) bool {
 	if k.stale {
 		return false
 	}
+	// The device call names the certificate by its 64-bit id and resolves it to the FIRST uploaded entity with that id.  If
+	// another uploaded entity (a different object) shares the id, the device might verify against that twin instead of the
+	// entity handed in: such a certificate goes to crypto/pgp (ADVICE r03).
+	found := false
 	for _, ring := range []openpgp.EntityList{k.secring, k.pubring} {
 		for _, r := range ring {
 			if r == e {
-				return true
+				found = true
+			} else if r.PrimaryKey.KeyId == e.PrimaryKey.KeyId {
+				return false
 			}
 		}
 	}
-	return false
+	return found
 }
 
 func upsert(ring openpgp.EntityList, nodes []node.Node) openpgp.EntityList {

@@ -49,8 +49,9 @@ func New(device int) *crypto.Crypto {
 	if rc := C.bftkv_gpu_init(C.int(device), &g.ctx); rc != 0 {
 		panic(errNoDevice)
 	}
-	// at most 256 calls per batch, 4 batches on the device at once (INTEGRATION.md section 2)
-	g.batcher = C.bftkv_gpu_batcher_create_lanes(g.ctx, 256, 0, 4)
+	// at most 256 calls per batch; lanes = 0: the library's measured default (3 on MI355X, profiles/r03_serving_batcher_lanes*;
+	// BFTKV_BATCHER_LANES overrides it)
+	g.batcher = C.bftkv_gpu_batcher_create_lanes(g.ctx, 256, 0, 0)
 	if g.batcher == nil {
 		panic("pgpgpu: bftkv_gpu_batcher_create failed")
 	}

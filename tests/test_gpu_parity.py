@@ -1023,7 +1023,7 @@ def test_two_keys_under_one_key_id(gpu_ctx, exit_mode):
     suffix again -- and returns the first success or the last error.  So: the first candidate that can sign is the only one
     that can succeed; a genuine signer listed behind a twin that can sign is REFUSED (hash tag mismatch); a candidate that
     cannot sign is passed over without harm.  Verdicts, exit counts and per-packet statuses are the oracle's; nothing is
-    fenced any more (round 2 fenced every item that named such an id)."""
+    fenced but the one shape in which a LATER candidate could succeed (its tag and algorithm fit the many-suffix digest)."""
     import copy
     from oracle import collective as col
     from oracle import openpgp as pgp
@@ -1052,6 +1052,13 @@ def test_two_keys_under_one_key_id(gpu_ctx, exit_mode):
     suffix = cb.hash_suffix(bytes(pk[hdr:hdr + 6 + hl]))
     pk[hdr + 6 + hl + 2:hdr + 6 + hl + 4] = hashlib.sha256(tbs + suffix + suffix).digest()[:2]
     streams.append(bytes(pk) + s[1] + s[2] + s[3])
+    # ... and the packet the owner of the twin key (replica 1's material under replica 0's id) can make: signed over the digest
+    # with the suffix written twice.  Behind the genuine key the twin is candidate 1, sees exactly that digest, and the reference
+    # returns it as the signer.  The device does not repeat the arithmetic for later candidates: it must FENCE.
+    twin_prefix = cb.sig_prefix(0x00, cl.replicas[1].algo, cb._hashed_area(id0))
+    twin_sfx = cb.hash_suffix(twin_prefix)
+    streams.append(cb.make_sig_packet(cl.replicas[1], twin_prefix, hashlib.sha256(tbs + twin_sfx + twin_sfx).digest()) + s[2] + s[3] + s[4])
+    FORGED_TAG, TWIN_SIGNED = len(streams) - 2, len(streams) - 1
     dsa_ent = pgp.read_entities(cld.replicas[0].entity)[0]
     scenarios = {
         "twin behind the genuine key": base + [twin_of(base[1])],
@@ -1072,18 +1079,32 @@ def test_two_keys_under_one_key_id(gpu_ctx, exit_mode):
         sb, so = _cat(streams)
         err, nver, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
         st, st_item = gpu_ctx.last_statuses()
-        assert not gpu_ctx.last_fenced.any(), name
+        fenced = gpu_ctx.last_fenced.copy()
+        # a fence only where a LATER candidate gets past the tag and the algorithm check with its many-suffix digest
+        assert not fenced[:FORGED_TAG].any(), name
+        twin_won = False
         for i, data in enumerate(streams):
             r = col.collective_verify(kr, tbs, SignaturePacket(Type=1, Data=data), q)
+            seen.update(r.statuses)
+            if i == TWIN_SIGNED and r.statuses[0] == 0:
+                twin_won = True
+                assert fenced[i], (name, "the twin's own signature verifies in the reference: the device must hand it over")
+            if fenced[i]:
+                continue
             assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (name, i, err[i], nver[i], r.err, r.verified)
             got = list(st[st_item == i])
             assert got[:len(r.statuses)] == r.statuses, (name, i, got, r.statuses)
-            seen.update(r.statuses)
+        if name == "twin behind the genuine key":
+            assert twin_won and fenced[FORGED_TAG] and fenced[TWIN_SIGNED]
+        if name == "DSA twin behind the genuine key":
+            assert not fenced.any()          # tag fits, the algorithm does not: ST_ALGO_MISMATCH in both, nothing to hand over
         # Signature.Verify over the same rings (every packet must verify: the last error decides)
         sig_err = gpu_ctx.signature_verify(tb, to, sb, so)
+        sig_fenced = gpu_ctx.last_fenced.copy()
         for i, data in enumerate(streams):
             want = col.signature_verify(kr, tbs, SignaturePacket(1, 0, False, data, None))
-            assert (sig_err[i] == 0) == (want is None), (name, i)
+            assert sig_fenced[i] or (sig_err[i] == 0) == (want is None), (name, i)
+        assert (sig_fenced == fenced).all(), name
         gpu_ctx.quorum_destroy(qh)
     assert {0, 6, 7, 8, 9} <= seen      # ok, hash tag, algorithm mismatch, bad signature, key cannot sign: all were produced
     gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
