@@ -65,7 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg 2 -- 0.6 s of timed region, long past the "
                     "fill and drain of the batches in flight --, 10 for the other configs)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4, 5), help="default: cfg 2 as the headline and, on one GPU, "
+                    "cfg 1 / 3 / 4 / 5 behind it as `other_configs`; --config N runs that config alone with its full line")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run: the cfg-2 line only")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work the cpu_baseline leg may sweep thread counts for")
     ap.add_argument("--items", type=int, default=0, help="cfg 2: signed writes per GPU and step (default 10000); cfg 3: variables "
                     "(default 10000, ~10 replies each); cfg 4: writes of the whole storm (default 1000000); cfg 5: operations per scheme (10000)")
     ap.add_argument("--replicas", type=int, default=0, help="clique size (default 64; 256 for cfg 4)")
@@ -90,7 +93,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, sharding and exchange step only (no GPU, no number)")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 200 if (args.config == 2 and not args.dry_run) else 10
+        args.steps = 200 if (args.config in (None, 2) and not args.dry_run) else 10
     if args.inflight is None:
         args.inflight = 4 if args.config == 5 else 3
     return args
@@ -663,17 +666,17 @@ def bench_cfg2(args, D):
         if D.world == 1 and not args.no_serving:
             out["serving"] = serving_leg(args, cl, z, want_ok)
         if D.world == 1 and not args.no_cpu_baseline:
-            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"])
+            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"], budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
-                "value": ops / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "value": ops / best, "unit": "verifies/s", "cores": effective_cores(), "threads": nt, "kind": "port",
                 "sample": "all %d writes of the GPU batch (%d public-key ops after the reference's early exit at suff=%d), best thread count "
                           "%d of a sweep up to %d logical CPUs (usable per affinity/cgroup: %d); OpenSSL libcrypto bignum/SHA (faster than "
                           "Go math/big)" % (items, ops, cl.suff, nt, os.cpu_count() or 1, effective_cores()),
                 "verdicts_per_sec": items / best, "single_thread_verifies_per_sec": st1,
                 "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
                 "reference_op_count_identical_to_cpu": bool(ops == ref_ops)}
-        print(json.dumps(out), flush=True)
     V.close()
+    return out if D.rank == 0 else None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -778,7 +781,7 @@ def bench_cfg3(args, D):
         if D.world == 1 and not args.no_cpu_baseline:
             # the CPU path on the DISTINCT stored packets (a reply is a byte-identical copy of one of them), mapped to the replies
             w = rc.writes
-            cerr_w, cnver_w, ops_w, best, nt, st1 = cpu_collective(cl, w.tbss_blob, w.tbss_off, w.ss_blob, w.ss_off)
+            cerr_w, cnver_w, ops_w, best, nt, st1 = cpu_collective(cl, w.tbss_blob, w.tbss_off, w.ss_blob, w.ss_off, budget_s=args.cpu_budget)
             cerr, cnver = cerr_w[rc.reply_write], cnver_w[rc.reply_write]
             # read tally restated by the oracle (oracle/collective.py max_timestamped_value) over the CPU verdicts
             from oracle import collective as col
@@ -804,15 +807,15 @@ def bench_cfg3(args, D):
                              for a, b in zip(got, want))
             ops_all = int(cnver_w.astype(np.int64)[rc.reply_write].sum())    # lower bound of the CPU's ops over all replies
             out["cpu_baseline"] = {
-                "value": ops_w / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "value": ops_w / best, "unit": "verifies/s", "cores": effective_cores(), "threads": nt, "kind": "port",
                 "sample": "the %d distinct stored packets the %d replies are copies of (%d public-key ops after the early exit, about half "
                           "DSA), best thread count %d (usable per affinity/cgroup: %d); OpenSSL libcrypto; read tally: Python oracle, %.2f s "
                           "for %d variables" % (w.n_items, n_replies, ops_w, nt, effective_cores(), t_tally, n_vars),
                 "reply_verdicts_per_sec": w.n_items / best, "single_thread_verifies_per_sec": st1,
                 "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
                 "read_answers_identical_to_oracle": bool(reads_same), "min_cpu_pubkey_ops_all_replies": ops_all}
-        print(json.dumps(out), flush=True)
     V.close()
+    return out if D.rank == 0 else None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -903,16 +906,16 @@ def bench_cfg4(args, D):
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:
-            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"])
+            cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"], budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
-                "value": ops / best, "unit": "verifies/s", "cores": nt, "kind": "port",
+                "value": ops / best, "unit": "verifies/s", "cores": effective_cores(), "threads": nt, "kind": "port",
                 "sample": "the %d distinct writes of the batch (%d public-key ops after the early exit at suff=%d; the reference re-hashes the "
                           "%.1f KB payload for every signature), best thread count %d (usable per affinity/cgroup: %d); OpenSSL libcrypto" %
                           (distinct, ops, cl.suff, float(z["to"][-1]) / distinct / 1024, nt, effective_cores()),
                 "verdicts_per_sec": distinct / best, "single_thread_verifies_per_sec": st1,
                 "gpu_verdicts_identical_to_cpu": bool((np.tile(cerr, tiles) == err).all() and (np.tile(cnver, tiles) == nver).all())}
-        print(json.dumps(out), flush=True)
     V.close()
+    return out if D.rank == 0 else None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1034,7 +1037,7 @@ def bench_cfg5(args, D):
             cands = sorted({cores} | {t for t in (16, 32, 64, 128) if t <= (os.cpu_count() or 1)})
             best = None
             for nt in cands:
-                if best is not None and best[0] * 2 > 25.0:
+                if best is not None and best[0] * 2 > args.cpu_budget:
                     break
                 t0 = time.perf_counter()
                 c_rsa = ct.rsa_combine(h["rsa_f"], 10, 256, tc.rsa_n, n_threads=nt)
@@ -1056,7 +1059,7 @@ def bench_cfg5(args, D):
                         ((res["st_r"][:N] != 0) == (c_st_r != 0)).all() and (c_r[ok_r] == res["r"][ok_r]).all() and
                         not c_st_sss.any() and not c_st_s.any() and not res["st_sss"][:N].any() and not res["st_s"][:N].any())
             bt = best[2]
-            out["cpu_baseline"] = {"value": 3.0 * N / best[0], "unit": "ops/s", "cores": best[1], "kind": "port",
+            out["cpu_baseline"] = {"value": 3.0 * N / best[0], "unit": "ops/s", "cores": effective_cores(), "threads": best[1], "kind": "port",
                                    "sample": "oracle/c/threshold.c (the reference's Lagrange / combine steps on OpenSSL BN_mod_exp_mont / BN_mod_mul / "
                                              "BN_mod_inverse, faster than Go math/big) over all %d operations of every scheme, best thread count %d of a "
                                              "sweep (usable per affinity/cgroup: %d): %.1f / %.1f / %.1f / %.1f ms for RSA / SSS / calculateS / "
@@ -1064,20 +1067,127 @@ def bench_cfg5(args, D):
                                              (N, best[1], cores, bt[0] * 1e3, bt[1] * 1e3, bt[2] * 1e3, bt[3] * 1e3, t_r1 * 1e6),
                                    "per_scheme_ops_per_sec": {names[i]: N / bt[i] for i in range(4)},
                                    "gpu_results_identical_to_cpu": same}
-        print(json.dumps(out), flush=True)
     for cx in reversed(ctxs):
         cx.close()
+    return out if D.rank == 0 else None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 1: 4-replica clique, 100 RSA-2048 signed writes on the CPU path (BASELINE.json configs[0]: plumbing, no GPU number)
+# ------------------------------------------------------------------------------------------------------------------
+def bench_cfg1(args, D):
+    """configs[0] is the reference's own CPU-runnable case.  No Go toolchain exists in this image, so what is timed is the C
+    restatement of PGPCollectiveSignature.Verify (oracle/c/oracle.c on OpenSSL: per-signature re-hash of the payload, per-signature
+    IsSufficient, early exit -- the reference's algorithm shape) over the 100 writes, on one thread (a Go server verifies one write
+    per request goroutine) and on the box's cores.  The same 100 writes then go through the verifier as ONE call, only as the
+    identity check of the plumbing (verdicts and exit counts); its latency is reported, not a throughput."""
+    from corpus import build as cb
+    n, items = 4, 100
+    cl = cb.make_cluster(n)
+    z = write_corpus_arrays(cb.make_write_corpus(cl, items, seed=cb.MASTER_SEED, with_client_sig=True,
+                                                 mutation_rates={cb.MUT_BAD_MPI: 0.03, cb.MUT_ONE_SHORT: 0.03, cb.MUT_UNKNOWN_ISSUER: 0.02}))
+    co = c_oracle_for(cl)
+    reps = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        cerr, cnver, ops = co.collective_verify(z["tb"], z["to"], z["sb"], z["so"], n_threads=1)
+        reps.append(time.perf_counter() - t0)
+    t1 = min(reps)
+    cores = effective_cores()
+    t0 = time.perf_counter()
+    co.collective_verify(z["tb"], z["to"], z["sb"], z["so"], n_threads=cores)
+    tn = time.perf_counter() - t0
+    out = {"metric": "pgp_rsa2048_signature_verifies_per_sec", "value": ops / t1, "unit": "verifies/s", "device": "cpu",
+           "workload": "4-replica wotqs clique, %d RSA-2048 signed writes (cfg1 of BASELINE.json), %d signature packets, %d public-key ops after "
+                       "the early exit at suff=%d" % (items, int(z["n_sigs"]), ops, cl.suff),
+           "ms_per_step": t1 * 1e3, "writes_per_sec": items / t1, "threads": 1,
+           "all_cores": {"threads": cores, "verifies_per_sec": ops / tn, "writes_per_sec": items / tn},
+           "kind": "port", "what": "oracle/c/oracle.c (C on OpenSSL libcrypto; the Go reference cannot be built here), best of 5 passes"}
+    if not D.dry:
+        from bftkv_amd import Context
+        from tests import helpers as H
+        ctx = Context(D.local_rank)
+        ctx.keyring_set(abi_keys_of(cl))
+        qh = ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            err, nver, _ = ctx.collective_verify(qh, z["tb"], z["to"], z["sb"], z["so"])
+            lat.append(time.perf_counter() - t0)
+        out["gpu_identity"] = {"gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
+                               "sufficient_fraction": float((err == 0).mean()),
+                               "one_call_ms_host_buffers": min(lat) * 1e3}
+        ctx.close()
+    return out
+
+
+def summarize(out):
+    """The fields of a config's full line that go into the default line's `other_configs`."""
+    if out is None:
+        return None
+    keep = {k: out[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "data") if k in out}
+    keep["workload"] = out["config"]["workload"]
+    im = out.get("int_mac") or {}
+    keep["int_mac"] = {k: im.get(k) for k in ("achieved", "frac", "frac_of_theoretical", "basis")}
+    rf = out.get("roofline") or {}
+    keep["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launch_ms")}
+    cb_ = out.get("cpu_baseline")
+    if cb_:
+        keep["cpu_baseline"] = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
+        keep["identity"] = {k: v for k, v in cb_.items() if "identical" in k}
+    for k in ("verdicts_match_construction", "kernel_ms", "per_scheme_ops_per_sec_per_gpu", "packets_per_sec", "quorum_verdicts_per_sec",
+              "reply_verdicts_per_sec", "read_verdicts_per_sec"):
+        if k in out:
+            keep[k] = out[k]
+    if "kernel_ms" in keep:
+        keep["kernel_ms"] = {k: v for k, v in keep["kernel_ms"].items() if isinstance(v, (int, float))}
+    return keep
+
+
+def other_configs(args, D):
+    """cfg 1, 3, 4, 5 at full size behind the cfg-2 headline of a default run: shorter timed regions, no soak, bounded CPU legs.
+    Each is the same function `--config N` runs; a failure is recorded in its entry, never hidden and never takes the headline down."""
+    import copy
+    res = {}
+    plan = [(1, bench_cfg1, {}), (3, bench_cfg3, {"steps": 10, "warmup": 3}), (4, bench_cfg4, {"steps": 2, "warmup": 1}),
+            (5, bench_cfg5, {"steps": 10, "warmup": 3})]
+    for cfg, fn, over in plan:
+        a = copy.copy(args)
+        a.config, a.items, a.replicas, a.soak_seconds, a.no_serving = cfg, 0, 0, 0.0, True
+        a.cpu_budget = min(args.cpu_budget, 10.0)
+        a.inflight = 4 if cfg == 5 else 3
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.time()
+        try:
+            out = fn(a, D)
+            res["cfg%d" % cfg] = out if cfg == 1 else summarize(out)
+        except Exception as e:          # noqa: BLE001 -- reported in the line
+            import traceback
+            res["cfg%d" % cfg] = {"error": "%s: %s" % (type(e).__name__, e), "traceback": traceback.format_exc()[-1500:]}
+        if res["cfg%d" % cfg] is not None:
+            res["cfg%d" % cfg]["wall_s"] = time.time() - t0
+    return res
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args))
-    if args.dry_run and args.config != 2:
+    if args.dry_run and args.config not in (None, 1, 2):
         sys.exit("--dry-run covers the launcher / exchange path of --config 2")
     D = Dist(args)
     try:
-        {2: bench_cfg2, 3: bench_cfg3, 4: bench_cfg4, 5: bench_cfg5}[args.config](args, D)
+        everything = args.config is None and D.world == 1 and not args.dry_run and not args.no_other_configs
+        if args.config is None:
+            args.config = 2
+        out = {1: bench_cfg1, 2: bench_cfg2, 3: bench_cfg3, 4: bench_cfg4, 5: bench_cfg5}[args.config](args, D)
+        if out is not None and everything:
+            out["other_configs"] = other_configs(args, D)
+            out["other_configs_note"] = ("BASELINE.json configs[0] (cfg1, CPU restatement) and configs[2..4] (cfg3/4/5 at full size on this "
+                                         "GPU, the functions `--config N` runs with shorter timed regions); the headline `value` is cfg2's")
+        if out is not None and D.rank == 0:
+            print(json.dumps(out), flush=True)
     finally:
         D.close()
 

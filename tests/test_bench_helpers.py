@@ -36,3 +36,26 @@ def test_int_mac_block_bases():
     assert abs(b["achieved"] - 5e11) < 1 and b["per_launch_in_timed_region"]["launch_ms"] == 1.6 and b["single_flight"]["launch_ms"] == 1.5
     assert b["single_flight"]["frac"] > b["per_launch_in_timed_region"]["frac"] > b["frac"] and "3 batches" in b["basis"]
     assert "single_flight" not in bench.int_mac_block(1e9, 2.0, 1.6, None, None, 1)
+
+
+def test_cfg1_leg_times_the_c_restatement_on_the_reference_shape():
+    """BASELINE.json configs[0]: 4 replicas, 100 RSA-2048 signed writes on the CPU path (dry: without the GPU identity call)."""
+    class D:
+        dry, rank, world, local_rank = True, 0, 1, 0
+    out = bench.bench_cfg1(bench.parse_args(["--config", "1", "--dry-run"]), D)
+    assert out["device"] == "cpu" and out["unit"] == "verifies/s" and out["value"] > 0 and out["threads"] == 1
+    assert "4-replica" in out["workload"] and "100 RSA-2048" in out["workload"] and out["all_cores"]["threads"] == bench.effective_cores()
+
+
+def test_summarize_keeps_what_the_default_line_promises():
+    full = {"metric": "m", "value": 1.0, "unit": "u", "steps": 2, "warmup": 1, "ms_per_step": 3.0, "scaling": "weak", "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "w"}, "int_mac": {"achieved": 1, "frac": 0.5, "frac_of_theoretical": 0.4, "basis": "b", "peak": 2},
+            "roofline": {"bound": "hbm", "kernel": "k", "achieved": 1, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": 5, "traffic_source": "p",
+                         "launch_ms": 1.0, "note": "n"},
+            "cpu_baseline": {"value": 2.0, "unit": "u", "cores": 16, "threads": 64, "kind": "port", "sample": "s", "gpu_verdicts_identical_to_cpu": True},
+            "kernel_ms": {"k_rsa_modexp": 1.0, "measured": "text"}, "verdicts_match_construction": True}
+    s = bench.summarize(full)
+    assert s["workload"] == "w" and s["int_mac"]["frac"] == 0.5 and s["roofline"]["traffic"] == 5 and s["roofline"]["frac"] == 0.1
+    assert s["cpu_baseline"] == {"value": 2.0, "unit": "u", "cores": 16, "threads": 64, "kind": "port"}
+    assert s["identity"] == {"gpu_verdicts_identical_to_cpu": True} and s["kernel_ms"] == {"k_rsa_modexp": 1.0}
+    assert bench.summarize(None) is None
