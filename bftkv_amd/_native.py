@@ -45,6 +45,7 @@ EXPORTS = [
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
+    "bftkv_gpu_set_host_pipeline",
 ]
 
 _lib = None
@@ -110,6 +111,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_allgather_verdicts.argtypes = [vp, u8p, C.c_uint64, u8p]
     lib.bftkv_gpu_stream.restype = vp
     lib.bftkv_gpu_set_early_exit.argtypes = [vp, C.c_int]
+    lib.bftkv_gpu_set_host_pipeline.argtypes = [vp, u32]
     lib.bftkv_gpu_last_sclk_mhz.argtypes = [vp, C.POINTER(C.c_float)]
     lib.bftkv_gpu_modexp_ops.argtypes = lib.bftkv_gpu_modexp.argtypes
     lib.bftkv_gpu_allgather_errs_dev.argtypes = [vp, u8p, u32, u32, u8p]
@@ -217,6 +219,10 @@ class Context:
     def set_early_exit(self, on: bool) -> None:
         """collective_verify: stop verifying where the reference stops reading (default) / verify every packet."""
         self._check(self.lib.bftkv_gpu_set_early_exit(self.h, 1 if on else 0), "set_early_exit")
+
+    def set_host_pipeline(self, pieces: int) -> None:
+        """collective_verify over host buffers: 0 = split big batches by size (default), 1 = never, 2..8 = that many pieces."""
+        self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces), "set_host_pipeline")
 
     def set_dsa_window_bits(self, bits: int) -> None:
         """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""

@@ -157,6 +157,16 @@ struct bftkv_gpu_ctx {
   DevBuf in_pack;
   uint8_t* h_out = nullptr; uint8_t* d_out = nullptr; size_t out_cap = 0;
   uint32_t out_seq = 0;
+  // Pipelined host-buffer calls (bftkv_gpu_collective_verify on a big batch, see collective_verify_pipelined): the batch is cut
+  // into pieces, each verified by a private worker context (own arena, streams, mailbox) over the ONE copy of the input this
+  // context holds, while the pieces behind it are still crossing PCIe on stream_c.
+  std::vector<bftkv_gpu_ctx*> hb_workers;   // private forks of the root (never handed out)
+  hipStream_t stream_c = nullptr;           // host-to-device copies of the pieces, in order
+  std::vector<hipEvent_t> hb_ev;            // [2k] signature streams of piece k on the device, [2k + 1] its payloads
+  uint8_t* hb_out = nullptr; size_t hb_out_cap = 0;   // pinned: per-piece results land here, copied to the caller after the last sync
+  uint32_t hb_pieces = 0;                   // bftkv_gpu_set_host_pipeline: 0 = by call size, 1 = never split, N = N pieces
+  uint32_t hb_last_pieces = 0;              // > 0: the last verify call ran pipelined over that many workers (diagnostics read them)
+  std::vector<uint32_t> hb_item0;           // first item of each piece of that call
   void* small_pin = nullptr;                // PinnedBuf[3] of bftkv_gpu_*_verify_small (batcher_capi.inc), created on first use
   uint32_t staged_spin_us = 50000;          // how long a staged call spins on its completion word before it blocks in the runtime (BFTKV_STAGED_SPIN_US)
 };
@@ -200,6 +210,9 @@ struct KtRead {
 // Calls too small to fill the machine (staged small calls, batches below TURNSTILE_MIN_PACKETS) do not queue here.
 struct Turnstile { std::mutex mu; hipEvent_t last = nullptr; const void* owner = nullptr; };
 Turnstile g_turnstile[16];
+// host-buffer pipeline (collective_verify_pipelined)
+constexpr uint64_t HB_PIPE_MIN_BYTES = 24ull << 20;      // below this a call is latency-, not PCIe-bound: one piece
+constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
 constexpr uint32_t TURNSTILE_MIN_PACKETS = 98304;     // two rounds of 768 resident blocks x 64 signatures
 
 // live contexts: lets long-lived host objects (bftkv_quorum) notice that their context is gone
@@ -322,7 +335,10 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                  const uint8_t* d_ss, const uint64_t* d_ss_off, const uint32_t* d_cert_ent, const uint8_t* d_sig_class = nullptr,
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
                  const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0,
-                 const uint32_t* d_mid_in = nullptr, const uint64_t* d_tbs_prefix = nullptr, uint32_t staged_cap = 0) {
+                 const uint32_t* d_mid_in = nullptr, const uint64_t* d_tbs_prefix = nullptr, uint32_t staged_cap = 0,
+                 hipEvent_t ev_input = nullptr) {
+  // ev_input (pipelined host-buffer calls): the signature streams and offsets of this call are still being copied by another
+  // stream; the main stream waits for that event first (the hash stream joins the main stream's start, so it waits too).
   // staged_cap (staged small calls): the arena and the grids are sized for that many packet events up front and the
   // kernels read the real count from the device -- no host round trip in mid-pipeline; a call with more events turns
   // itself into an empty one (k_scan_counts) and is run again through the ordinary path by its caller.
@@ -371,6 +387,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     HIPCHK(c, c->txt_len.ensure(sizeof(uint64_t) * N_HASHES * (size_t)n_items + 16));
     txt = TextDev{c->txt_mid32.as<uint32_t>(), c->txt_mid64.as<uint64_t>(), c->txt_tail.as<uint8_t>(), c->txt_len.as<uint64_t>()};
   }
+  if (ev_input) HIPCHK(c, hipStreamWaitEvent(s, ev_input, 0));
   HIPCHK(c, rec(0, s));
   // the payload midstates do not depend on the parse: start them right away on the hash stream
   HIPCHK(c, join(sh, 0));
@@ -406,6 +423,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (!staged_cap && (size_t)chunk_units * 16 > c->chunk_arena.cap) HIPCHK(c, c->chunk_arena.ensure((size_t)chunk_units * 16));
   c->last_total = staged_cap ? 0u : total;      // (per-packet diagnostics are not kept for staged calls)
   c->last_items = n_items;
+  c->hb_last_pieces = 0;
   const size_t tr = total ? total : 1;
   HIPCHK(c, c->recs.ensure(sizeof(SigRec) * tr));
   HIPCHK(c, c->digests.ensure(sizeof(uint32_t) * 16 * tr));
@@ -996,6 +1014,8 @@ int bftkv_gpu_ctx_fork(bftkv_gpu_ctx* root, bftkv_gpu_ctx** out) {
 
 void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (!c) return;
+  for (bftkv_gpu_ctx* w : c->hb_workers) bftkv_gpu_destroy(w);      // private forks of the root (host-buffer pipeline): they go first
+  c->hb_workers.clear();
   if (!c->root && c->n_forks.load() > 0) {     // its forks read this context's key table: they go first
     fprintf(stderr, "bftkv_gpu_destroy: context still has %d forked context(s); not destroyed\n", c->n_forks.load());
     return;
@@ -1021,6 +1041,9 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (DevBuf* b : c->scratch_pool) { b->release(); delete b; }
   for (auto& kv : c->modtab_cache) for (DevBuf& b : kv.second) b.release();
   if (c->h_mail) (void)hipHostFree(c->h_mail);
+  if (c->hb_out) (void)hipHostFree(c->hb_out);
+  for (hipEvent_t e : c->hb_ev) (void)hipEventDestroy(e);
+  if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_turn) {
@@ -1051,6 +1074,13 @@ void* bftkv_gpu_stream(bftkv_gpu_ctx* c) { return c ? (void*)c->stream : nullptr
 int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
   if (!c) return BFTKV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* c, uint32_t pieces) {
+  if (!c || pieces > HB_PIPE_MAX_PIECES) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  c->hb_pieces = pieces;
   return 0;
 }
 
@@ -1162,7 +1192,8 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
 
 static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                  uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs, uint64_t ss_len) {
+                                  uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs, uint64_t ss_len,
+                                  hipEvent_t ev_input = nullptr) {
   // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
@@ -1171,7 +1202,7 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
   const QuorumDev qd = quorum_dev(c, q);
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len, nullptr, nullptr, 0, ev_input))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
@@ -1201,6 +1232,162 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_ite
   return collective_verify_impl(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, nullptr, ss_len);
 }
 
+// A big batch handed over in HOST memory (what the cgo shim and every C caller do: crypto_pgp.go:485-500, the caller owns
+// the slices).  Copy, then verify, costs the sum of both; here the batch is cut into pieces of about equal signature bytes and
+// piece k is walked, parsed, exponentiated and tallied while pieces k+1.. are still crossing PCIe:
+//   * ONE copy of the input in this context's in_* buffers; a helper thread issues the copies piece by piece (signature
+//     streams, then payloads) on stream_c -- hipMemcpyAsync from pageable memory returns only when the runtime has staged or
+//     pinned the source, so the thread that issues copies cannot be the one that enqueues kernels -- and records an event behind each;
+//   * piece k runs on its own private worker context (a fork of the root: own arena, streams and mailbox, the resident key
+//     table shared) over pointers INTO those buffers (offset arrays advanced to the piece's first item: offsets are absolute);
+//     its main stream waits for the piece's signature event, its hash stream for the payload event (the upload_tbs hook of
+//     run_pipeline, i.e. after the modexp has been enqueued); the machine-filling modexps of the pieces take turns at the device
+//     turnstile like any other calls in flight;
+//   * results leave through pinned memory (a D2H copy into pageable memory would block the enqueuing thread until the piece is
+//     done) and reach the caller's arrays after the one synchronisation at the end.
+// Items are independent, so the verdicts are those of the unsplit call by construction (test_host_buffer_pipeline_*).
+
+struct HbPiece { uint32_t i0, i1; };
+
+static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n_items) {
+  static const int env = getenv("BFTKV_HB_PIECES") ? atoi(getenv("BFTKV_HB_PIECES")) : 0;
+  const uint32_t forced = c->hb_pieces ? c->hb_pieces : (uint32_t)std::max(env, 0);     // bftkv_gpu_set_host_pipeline, else the environment
+  if (forced == 1) return 1;
+  if (forced > 1) return std::max<uint32_t>(1, std::min<uint32_t>(std::min(forced, HB_PIPE_MAX_PIECES), n_items));
+  if (bytes < HB_PIPE_MIN_BYTES || n_items < 64) return 1;
+  const uint32_t p = (uint32_t)std::min<uint64_t>(6, std::max<uint64_t>(2, bytes / (40ull << 20)));
+  return std::min<uint32_t>(p, n_items / 32);
+}
+
+static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                       const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                       uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces) {
+  // caller holds c->mu and, on a fork, the root's key-table lock (shared)
+  bftkv_gpu_ctx* const root = c->root ? c->root : c;
+  int rc = check_quorum(c, quorum);
+  if (rc) return rc;
+  const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
+  // pieces of about equal bytes (signature streams + payloads), cut at item boundaries
+  std::vector<HbPiece> pc;
+  {
+    const uint64_t total = tl + sl;
+    uint32_t i = 0;
+    for (uint32_t k = 0; k < n_pieces && i < n_items; ++k) {
+      const uint64_t want = total * (k + 1) / n_pieces;
+      uint32_t lo = i + 1, hi = n_items;
+      while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (tbs_off[m] + ss_off[m] < want) lo = m + 1; else hi = m; }
+      const uint32_t j = (k + 1 == n_pieces) ? n_items : lo;
+      pc.push_back({i, j});
+      i = j;
+    }
+  }
+  const uint32_t P = (uint32_t)pc.size();
+  while (c->hb_workers.size() < P) {
+    bftkv_gpu_ctx* w = nullptr;
+    if ((rc = bftkv_gpu_init(c->device, &w))) return fail(c, rc, "host-buffer pipeline: worker context");
+    w->root = root; w->dsa_inv_mode = root->dsa_inv_mode;
+    root->n_forks.fetch_add(1);
+    c->hb_workers.push_back(w);
+  }
+  if (!c->stream_c) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+  while (c->hb_ev.size() < 2 * (size_t)P + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
+  HIPCHK(c, c->in_tbs.ensure(tl + 64));
+  HIPCHK(c, c->in_ss.ensure(sl + 64));
+  HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
+  const size_t o_err = 0, o_vd = (size_t)n_items, o_fn = 2 * (size_t)n_items, o_nv = (3 * (size_t)n_items + 15) & ~(size_t)15;
+  const size_t out_bytes = o_nv + sizeof(uint32_t) * (size_t)n_items;
+  if (c->hb_out_cap < out_bytes) {
+    if (c->hb_out) { (void)hipHostFree(c->hb_out); c->hb_out = nullptr; c->hb_out_cap = 0; }
+    HIPCHK(c, hipHostMalloc((void**)&c->hb_out, out_bytes + out_bytes / 4, hipHostMallocDefault));
+    c->hb_out_cap = out_bytes + out_bytes / 4;
+  }
+  // the offsets of the whole batch first (a few hundred KB), then the pieces
+  HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream_c));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream_c));
+  std::vector<std::atomic<int>> flag(2 * (size_t)P);      // 1: copy issued and its event recorded, -1: the copy failed
+  for (auto& f : flag) f.store(0);
+  hipError_t copy_err = hipSuccess;
+  std::thread copier([&] {
+    (void)hipSetDevice(c->device);
+    bool dead = false;
+    for (uint32_t k = 0; k < P; ++k) {
+      const uint64_t s0 = ss_off[pc[k].i0], s1 = ss_off[pc[k].i1], t0 = tbs_off[pc[k].i0], t1 = tbs_off[pc[k].i1];
+      for (int half = 0; half < 2; ++half) {
+        hipError_t e = hipSuccess;
+        if (!dead) {
+          if (half == 0 && s1 > s0) e = hipMemcpyAsync(c->in_ss.as<uint8_t>() + s0, ss + s0, s1 - s0, hipMemcpyHostToDevice, c->stream_c);
+          if (half == 1 && t1 > t0) e = hipMemcpyAsync(c->in_tbs.as<uint8_t>() + t0, tbs + t0, t1 - t0, hipMemcpyHostToDevice, c->stream_c);
+          if (e == hipSuccess) e = hipEventRecord(c->hb_ev[2 * k + half], c->stream_c);
+          if (e != hipSuccess) { copy_err = e; dead = true; }
+        }
+        flag[2 * k + half].store(dead ? -1 : 1, std::memory_order_release);
+      }
+    }
+  });
+  auto wait_flag = [&](size_t i) -> int {
+    for (uint32_t it = 0;; ++it) {
+      const int v = flag[i].load(std::memory_order_acquire);
+      if (v) return v;
+      if ((it & 63u) == 63u) std::this_thread::yield(); else __builtin_ia32_pause();
+    }
+  };
+  int first_rc = 0;
+  uint32_t launched = 0;
+  for (uint32_t k = 0; k < P && !first_rc; ++k) {
+    bftkv_gpu_ctx* w = c->hb_workers[k];
+    const uint32_t nk = pc[k].i1 - pc[k].i0;
+    if (wait_flag(2 * k) < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", copy_err); break; }
+    ctx_lock wl(w->mu);
+    if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
+    const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
+      if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", copy_err);
+      HIPCHK(w, hipStreamWaitEvent(sh, c->hb_ev[2 * k + 1], 0));
+      return 0;
+    };
+    hipError_t e;
+    if ((e = w->o_err.ensure(nk)) != hipSuccess || (e = w->o_fenced.ensure(nk)) != hipSuccess) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: result buffers", e); break; }
+    rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[k].i0, c->in_ss.as<uint8_t>(),
+                                c->in_ss_off.as<uint64_t>() + pc[k].i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
+                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ss_off[pc[k].i1] - ss_off[pc[k].i0], c->hb_ev[2 * k]);
+    ++launched;
+    if (rc) { c->err = "host-buffer pipeline, piece " + std::to_string(k) + ": " + w->err; first_rc = rc; break; }
+    const uint32_t i0 = pc[k].i0;
+    if ((e = hipMemcpyAsync(c->hb_out + o_err + i0, w->o_err.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->hb_out + o_vd + i0, w->o_verdict.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->hb_out + o_nv + sizeof(uint32_t) * (size_t)i0, w->o_nver.p, sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (fenced_out && (e = hipMemcpyAsync(c->hb_out + o_fn + i0, w->o_fenced.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess))
+      first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: results to the host", e);
+  }
+  copier.join();
+  // one synchronisation: every piece that was enqueued, and the copy stream (the caller's buffers must not be read after return)
+  hipError_t se = hipStreamSynchronize(c->stream_c);
+  for (uint32_t k = 0; k < launched; ++k) {
+    bftkv_gpu_ctx* w = c->hb_workers[k];
+    for (hipStream_t st : {w->stream_h, w->stream_d, w->stream}) { const hipError_t e = hipStreamSynchronize(st); if (se == hipSuccess) se = e; }
+  }
+  if (!first_rc && se != hipSuccess) first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: synchronise", se);
+  if (first_rc) {      // fail closed: no byte of the result reads as "verified"
+    if (err_out) memset(err_out, BFTKV_ERR_INSUFFICIENT_SIGNATURES, n_items);
+    if (verdict_out) memset(verdict_out, 0, n_items);
+    if (nver_out) memset(nver_out, 0, sizeof(uint32_t) * (size_t)n_items);
+    if (fenced_out) memset(fenced_out, 0, n_items);
+    return first_rc;
+  }
+  if (err_out) memcpy(err_out, c->hb_out + o_err, n_items);
+  if (verdict_out) memcpy(verdict_out, c->hb_out + o_vd, n_items);
+  if (fenced_out) memcpy(fenced_out, c->hb_out + o_fn, n_items);
+  if (nver_out) memcpy(nver_out, c->hb_out + o_nv, sizeof(uint32_t) * (size_t)n_items);
+  c->hb_last_pieces = P;
+  c->hb_item0.assign(P, 0);
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < P; ++k) { c->hb_item0[k] = pc[k].i0; total += c->hb_workers[k]->last_total; }
+  c->last_total = total;
+  c->last_items = n_items;
+  c->have_timing = false;       // (per-phase events live in the workers; bftkv_gpu_last_timing describes unsplit calls)
+  return 0;
+}
+
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                 const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                 uint8_t* verdict_out, uint8_t* fenced_out) {
@@ -1214,6 +1401,8 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
     return rco;
   const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
+  if (const uint32_t pieces = hb_pieces_for(c, tl + sl, n_items); pieces > 1)
+    return collective_verify_pipelined(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, pieces);
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
   HIPCHK(c, c->in_ss.ensure(sl + 64));
   HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
@@ -1325,6 +1514,18 @@ int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint3
   ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   *n_out = c->last_total;
+  if (c->hb_last_pieces) {      // the last call ran pipelined: the records live in the workers, piece after piece
+    uint32_t done = 0;
+    for (uint32_t k = 0; k < c->hb_last_pieces && st && done < cap; ++k) {
+      uint32_t nk = 0;
+      const int rc = bftkv_gpu_last_statuses(c->hb_workers[k], st + done, item ? item + done : nullptr, cap - done, &nk);
+      if (rc) return fail(c, rc, c->hb_workers[k]->err.c_str());
+      nk = std::min(nk, cap - done);
+      if (item) for (uint32_t j = 0; j < nk; ++j) item[done + j] += c->hb_item0[k];
+      done += nk;
+    }
+    return 0;
+  }
   uint32_t n = c->last_total < cap ? c->last_total : cap;
   if (!n || !st) return 0;
   HIPCHK(c, c->st_tmp.ensure(n));
@@ -1342,6 +1543,13 @@ int bftkv_gpu_last_counters(bftkv_gpu_ctx* c, uint64_t counters[4]) {
   ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t cnt[4] = {0, 0, 0, 0};
+  if (c->hb_last_pieces) {
+    for (uint32_t k = 0; k < c->hb_last_pieces; ++k) {
+      uint32_t ck[4] = {0, 0, 0, 0};
+      if (c->hb_workers[k]->pk_count.p) HIPCHK(c, hipMemcpy(ck, c->hb_workers[k]->pk_count.p, 16, hipMemcpyDeviceToHost));
+      for (int j = 0; j < 4; ++j) cnt[j] += ck[j];
+    }
+  } else
   if (c->pk_count.p) HIPCHK(c, hipMemcpy(cnt, c->pk_count.p, 16, hipMemcpyDeviceToHost));
   counters[0] = c->last_total;
   counters[1] = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];

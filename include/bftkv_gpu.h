@@ -167,6 +167,13 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_i
                                     const uint8_t* ss_blob, const uint64_t* ss_off, uint64_t ss_blob_len,
                                     uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out, uint8_t* fenced_out);
 int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
+/* Host-buffer calls of bftkv_gpu_collective_verify (the shape of crypto_pgp.go:485-500 seen from cgo: the caller owns the
+ * slices).  A big batch is cut into pieces of about equal bytes at item boundaries; piece k is verified by a private worker
+ * context while the pieces behind it are still crossing PCIe, and the results reach the caller's arrays after one
+ * synchronisation.  Items are independent: results are those of the unsplit call.  pieces = 0 (default): by call size (one
+ * piece below 24 MB), 1: never split, 2..8: that many pieces whatever the size (tests).  BFTKV_HB_PIECES in the environment
+ * sets the default of contexts this call has not touched. */
+int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* ctx, uint32_t pieces);
 /* PGPCollectiveSignature.Verify returns at the first packet after which q.IsSufficient(verified) holds and never reads the
  * rest of ss.Data (crypto_pgp.go:491-496).  By default the batched call does the same amount of public-key work: per item
  * it verifies the packets up to the position where the quorum would be sufficient if they all verified (plus a small

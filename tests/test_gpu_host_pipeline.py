@@ -1,0 +1,107 @@
+"""-m gpu: the pipelined host-buffer path of bftkv_gpu_collective_verify (capi.hip collective_verify_pipelined).
+
+A batch handed over in host memory is cut into pieces that are verified by private worker contexts while the pieces behind them
+cross PCIe.  Items are independent, so EVERYTHING a caller can observe must be what the unsplit call gives: error bytes, exit
+counts, verdict bits, fence flags, per-packet statuses with their item indices, the counters -- and, against the oracle, the
+reference's verdicts.  Full size (226 MB, cut by the size rule, three calls at once on a root and two forks):
+test_gpu_parity.py::test_cfg2_full_size_identity_against_the_c_oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from corpus import build as cb
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _observe(ctx, qh, tb, to, sb, so):
+    err, nver, verdict = ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = ctx.last_statuses()
+    return err.copy(), nver.copy(), verdict.copy(), ctx.last_fenced.copy(), st.copy(), st_item.copy(), dict(ctx.last_counters())
+
+
+@pytest.mark.parametrize("early", [True, False], ids=["early-exit", "every-packet"])
+def test_pieces_give_the_unsplit_answers(gpu_ctx, early):
+    cl = cb.make_cluster(10, dsa_fraction=0.3)
+    rates = {cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_BAD_TAG: 0.1}
+    c = cb.make_write_corpus(cl, 240, mutation_rates=rates)
+    # ragged on purpose: some items without any signature stream, one with a literal-data packet (fenced), one garbage
+    parts = [c.ss_data(i) for i in range(c.n_items)]
+    for i in (0, 57, 58, 119, 239):
+        parts[i] = b""
+    parts[100] = cb.literal_packet(b"f", b"hidden") + parts[100]
+    parts[101] = bytes(range(256)) * 3
+    so = np.zeros(c.n_items + 1, dtype=np.uint64)
+    so[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    sb = np.frombuffer(b"".join(parts) + b"\0", dtype=np.uint8)[:int(so[-1])].copy()
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    gpu_ctx.set_early_exit(early)
+    try:
+        gpu_ctx.set_host_pipeline(1)
+        base = _observe(gpu_ctx, qh, c.tbss_blob, c.tbss_off, sb, so)
+        assert base[3][100] == 1 and (base[0] == 0).any() and (base[0] == 2).any()
+        for pieces in (2, 3, 5, 8):
+            gpu_ctx.set_host_pipeline(pieces)
+            got = _observe(gpu_ctx, qh, c.tbss_blob, c.tbss_off, sb, so)
+            for name, a, b in zip(("err", "n_verified", "verdict", "fenced", "statuses", "status items"), base, got):
+                assert np.array_equal(a, b), (pieces, name)
+            assert got[6] == base[6], (pieces, got[6], base[6])
+        # and the reference's verdicts on the unfenced items
+        from oracle import collective as col
+        from oracle.packet import SignaturePacket
+        err, nver = got[0], got[1]
+        for i in range(c.n_items):
+            if got[3][i]:
+                continue
+            r = col.collective_verify(kr, c.tbss(i), SignaturePacket(Type=1, Data=parts[i] or None), q)
+            assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), i
+        # fewer items than pieces, and a single item
+        gpu_ctx.set_host_pipeline(8)
+        for n in (1, 3):
+            e, nv, _ = gpu_ctx.collective_verify(qh, c.tbss_blob[:int(c.tbss_off[n])], c.tbss_off[:n + 1], sb[:int(so[n])], so[:n + 1])
+            assert np.array_equal(e, base[0][:n]) and np.array_equal(nv, base[1][:n])
+    finally:
+        gpu_ctx.set_host_pipeline(0)
+        gpu_ctx.set_early_exit(True)
+        gpu_ctx.quorum_destroy(qh)
+
+
+def test_pipelined_calls_from_three_threads_on_a_root_and_its_forks(gpu_ctx):
+    """The cgo shim's shape: several goroutines, each with its own host slices, each call pipelined over its own workers."""
+    cl = cb.make_cluster(7)
+    c = cb.make_write_corpus(cl, 400, mutation_rates={cb.MUT_BAD_MPI: 0.1, cb.MUT_ONE_SHORT: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.05})
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    gpu_ctx.set_host_pipeline(1)
+    want = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+    forks = [gpu_ctx.fork() for _ in range(2)]
+    ctxs = [gpu_ctx] + forks
+    got, errs = {}, []
+
+    def storm(k, cx):
+        try:
+            cx.set_host_pipeline(2 + k)
+            got[k] = [cx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off) for _ in range(4)]
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, e))
+    try:
+        ths = [threading.Thread(target=storm, args=(k, cx)) for k, cx in enumerate(ctxs)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not errs, errs
+        assert len(got) == 3
+        for res in got.values():
+            for e2, nv2, vd2 in res:
+                assert np.array_equal(e2, want[0]) and np.array_equal(nv2, want[1]) and np.array_equal(vd2, want[2])
+    finally:
+        for f in forks:
+            f.close()
+        gpu_ctx.set_host_pipeline(0)
+        gpu_ctx.quorum_destroy(qh)
