@@ -45,7 +45,7 @@ EXPORTS = [
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
-    "bftkv_gpu_set_host_pipeline",
+    "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify",
 ]
 
 _lib = None
@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_destroy.restype = None
     lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p]
     lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p, u8p]
+    lib.bftkv_gpu_batcher_cert_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_batcher_times.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -524,6 +525,21 @@ class Batcher:
         if rc:
             raise NativeError("batcher signature_verify failed: %d" % rc)
         return int(err[0])
+
+    def cert_verify(self, cert: bytes, tbs: bytes, sig: Optional[bytes], raw: bool = False):
+        """bftkv_gpu_batcher_cert_verify: Signature.Issuer(sig) + VerifyWithCertificate(tbs, sig, issuer) for a principal outside the
+        node keyring; sig=None asks for the issuer alone.  Returns (err, fenced, issuer_key_id, fingerprint)."""
+        err = np.zeros(1, dtype=np.uint8)
+        fenced = np.zeros(1, dtype=np.uint8)
+        iid = np.zeros(1, dtype=np.uint64)
+        fp = np.zeros(20, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_cert_verify(self.h, cert, len(cert), tbs, len(tbs), sig, 0 if sig is None else len(sig), _ptr(err), _ptr(fenced),
+                                                    iid.ctypes.data, _ptr(fp))
+        if raw:
+            return rc, int(err[0]), int(fenced[0])
+        if rc:
+            raise NativeError("batcher cert_verify failed: %d" % rc)
+        return int(err[0]), int(fenced[0]), int(iid[0]), fp.tobytes()
 
     def message_verify(self, msg: bytes):
         """One transport message through the batcher: (status, signer_key_id, peer_id, plain, file_name)."""

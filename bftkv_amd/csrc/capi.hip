@@ -164,6 +164,10 @@ struct bftkv_gpu_ctx {
   hipStream_t stream_c = nullptr;           // host-to-device copies of the pieces, in order
   std::vector<hipEvent_t> hb_ev;            // [2k] signature streams of piece k on the device, [2k + 1] its payloads
   uint8_t* hb_out = nullptr; size_t hb_out_cap = 0;   // pinned: per-piece results land here, copied to the caller after the last sync
+  // Unused dynamic LDS added to every k_rsa_modexp<19,4> launch of this context: 38.9 KB + pad > 53 KB leaves room for two blocks
+  // per CU instead of three, i.e. 2 waves per SIMD and 192 of the 512 VGPRs free -- room in which the walk / parse / hash / tally
+  // kernels of OTHER calls (or pieces) start at once instead of waiting for a round of modexp blocks to retire.
+  uint32_t modexp_lds_pad = 0;
   uint32_t hb_pieces = 0;                   // bftkv_gpu_set_host_pipeline: 0 = by call size, 1 = never split, N = N pieces
   uint32_t hb_last_pieces = 0;              // > 0: the last verify call ran pipelined over that many workers (diagnostics read them)
   std::vector<uint32_t> hb_item0;           // first item of each piece of that call
@@ -520,7 +524,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
       hipLaunchKernelGGL((k_rsa_modexp<10, MONT_TPI_BIG>), qg8, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                          cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     else
-    hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(MODEXP_BLOCK), 0, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
+    hipLaunchKernelGGL((k_rsa_modexp<MONT_L, MONT_TPI>), qg, dim3(MODEXP_BLOCK), c->modexp_lds_pad, s, d_ss, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->r.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)(cnt_p + 16));
     // larger moduli: only when the keyring holds such keys (blocks beyond the queued count exit at once)
     if (c->have_rsa3072)
@@ -990,6 +994,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
       hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking) != hipSuccess) { delete c; return BFTKV_E_DEVICE; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live.push_back(c); }
   if (const char* e = getenv("BFTKV_STAGED_SPIN_US")) c->staged_spin_us = (uint32_t)atoi(e);
+  if (const char* e = getenv("BFTKV_MODEXP_LDS_PAD")) c->modexp_lds_pad = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_LANES")) c->multiexp_lanes = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_DSA_INV")) c->dsa_inv_mode = !strcmp(e, "batched") ? 2u : !strcmp(e, "single") ? 1u : 0u;
@@ -1286,6 +1291,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     bftkv_gpu_ctx* w = nullptr;
     if ((rc = bftkv_gpu_init(c->device, &w))) return fail(c, rc, "host-buffer pipeline: worker context");
     w->root = root; w->dsa_inv_mode = root->dsa_inv_mode;
+    if (const char* e = getenv("BFTKV_HB_MODEXP_LDS_PAD")) w->modexp_lds_pad = (uint32_t)atoi(e);
     root->n_forks.fetch_add(1);
     c->hb_workers.push_back(w);
   }
@@ -1717,6 +1723,13 @@ int bftkv_gpu_modexp_ops(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, 
 }
 
 }  // extern "C"
+
+#include "../../include/bftkv_host.h"
+// Issuer(sig) + VerifyWithCertificate over request certificates (host_capi.inc cert_signature_core; used by the batcher too)
+struct CertSigReq { const uint8_t* cert; uint64_t cert_len; const uint8_t* tbs; uint64_t tbs_len; const uint8_t* sig; uint64_t sig_len; };
+struct CertSigRes { uint8_t err = BFTKV_ERR_CERTIFICATE_NOT_FOUND; uint64_t issuer_id = 0; uint32_t n_entities = 0; std::vector<uint64_t> certifiers; };
+int cert_signature_core(bftkv_gpu_ctx* ctx, const std::vector<CertSigReq>& reqs, std::vector<CertSigRes>* res);
+extern "C" int bftkv_host_cert_fingerprint(const uint8_t* cert, uint64_t len, uint8_t out[20]);
 
 #include "rccl_capi.inc"
 #include "threshold_capi.inc"

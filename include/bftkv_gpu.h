@@ -54,6 +54,7 @@ typedef struct bftkv_gpu_ctx bftkv_gpu_ctx;
 #define BFTKV_ERR_NONE 0
 #define BFTKV_ERR_INVALID_SIGNATURE 1          /* crypto.ErrInvalidSignature */
 #define BFTKV_ERR_INSUFFICIENT_SIGNATURES 2    /* crypto.ErrInsufficientNumberOfSignatures */
+#define BFTKV_ERR_CERTIFICATE_NOT_FOUND 3      /* crypto.ErrCertificateNotFound (bftkv_gpu_batcher_cert_verify: Issuer(sig) == nil) */
 
 /* quorum predicate bits (quorum/wotqs/wotqs.go:144-185) */
 #define BFTKV_V_IS_QUORUM 1
@@ -250,6 +251,25 @@ int bftkv_gpu_batcher_collective_verify(bftkv_gpu_batcher* b, int quorum, const 
 /* Signature.Verify / VerifyWithCertificate (crypto_pgp.go:319-344); cert_key_id NULL = node keyring */
 int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs, uint64_t tbs_len, const uint8_t* sig,
                                        uint64_t sig_len, const uint64_t* cert_key_id, uint8_t* err_out, uint8_t* fenced_out);
+/* Signature.Issuer(sig) + Signature.VerifyWithCertificate(tbs, sig, issuer) for a principal that is NOT in the node keyring --
+ * the shape of protocol/server.go:199-207 (sign) and :460-468 (register), where the certificate travels inside the request
+ * (sig.Cert) -- as ONE micro-batched call.  Replaces crypto_pgp.go:392-405 -> :236-249 (Certificate.Parse ->
+ * openpgp.ReadEntity, which verifies every user-id self-signature and subkey binding of the entity) and :332-344:
+ *   cert / cert_len   sig.Cert: serialised entities; the issuer is the FIRST one ("has to be the first one", :404);
+ *   tbs, sig          packet.TBS(req) and sig.Data; sig == NULL asks for the issuer alone (Issuer(), server.go:330-331);
+ *   *err_out          BFTKV_ERR_NONE, BFTKV_ERR_INVALID_SIGNATURE (VerifyWithCertificate's error), or
+ *                     BFTKV_ERR_CERTIFICATE_NOT_FOUND (no entity parses, or ReadEntity would refuse the first one: the
+ *                     reference's Issuer() returns nil and the server answers crypto.ErrCertificateNotFound);
+ *   *fenced_out       1 = no verdict (a fenced shape in the certificate or the signature): take the reference path;
+ *   *issuer_id_out    primary key id of the first entity; fingerprint_out[20] its v4 fingerprint (so that a caller holding
+ *                     a parsed certificate can tell that it IS this one); either may be NULL.
+ * The entity is registered in the root context's key table as a certificate-only entity (bounded and recycled: at most 1024
+ * distinct certificates, certificate DSA keys share a bounded set of table slots) and its ReadEntity verdict is remembered
+ * by certificate bytes, so a client's second request costs one signature verification.  Calls of this kind are batched
+ * like the others but run on the ROOT context (registration changes the key table; the lanes' calls in flight drain first). */
+int bftkv_gpu_batcher_cert_verify(bftkv_gpu_batcher* b, const uint8_t* cert, uint64_t cert_len, const uint8_t* tbs, uint64_t tbs_len,
+                                  const uint8_t* sig, uint64_t sig_len, uint8_t* err_out, uint8_t* fenced_out,
+                                  uint64_t* issuer_id_out, uint8_t* fingerprint_out);
 /* stats[0] calls served, stats[1] device calls made, stats[2] largest batch, stats[3] lanes */
 /* One transport message (bftkv_gpu_message_verify for a single caller): blocks until its batch has run.  plain_out
  * receives the literal body (BFTKV_E_NOMEM if plain_cap is too small; msg_len always suffices), fname_out[256] the

@@ -148,6 +148,9 @@ int bftkv_host_certs_entity(const bftkv_certs* c, uint32_t e, uint64_t* id_out, 
                             const uint64_t** certifiers_out, uint32_t* n_certifiers_out);
 int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu_pubkey* out);   /* pointers into c */
 
+/* v4 fingerprint (SHA-1 over 0x99 || u16 length || body) of the primary key of the first entity of `cert` */
+int bftkv_host_cert_fingerprint(const uint8_t* cert, uint64_t len, uint8_t out[20]);
+
 /* What openpgp.ReadEntity verifies while reading, on the GPU: every user-id self-signature
  * (classes 0x10 / 0x13 issued by the primary key, over 0x99 len key || 0xB4 len uid) and every subkey binding
  * (0x18, over 0x99 len key || 0x99 len subkey) with the entity's own primary key.  valid_out[e] = 1 iff the entity

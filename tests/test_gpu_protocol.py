@@ -832,3 +832,108 @@ def test_read_proof_and_register_sites(gpu_ctx):
             else: want.append(0 if col.collective_verify(kr, x, ss, oq).err is None else 2)
     got = srv.register_verify(hq, reqs)
     assert list(got) == want and set(want) == {0, 1, 2, 0xFE, 0xFF}
+
+
+def test_batcher_cert_verify_for_principals_outside_the_keyring(gpu_ctx):
+    """SURVEY.md 8(f)-1 behind the Go seam: Signature.Issuer(sig) (-> Certificate.Parse -> openpgp.ReadEntity,
+    crypto_pgp.go:392-405, 236-249) and Signature.VerifyWithCertificate (crypto_pgp.go:332-344) for the principal whose certificate
+    travels INSIDE the request (server.go:199-207, 460-468) as ONE micro-batched call, bftkv_gpu_batcher_cert_verify.  The server's
+    keyring holds the replicas only; every verdict is the oracle's, nothing is fenced, and the node keyring is left as it was."""
+    import hashlib
+    import struct
+    import threading
+    from bftkv_amd import Batcher
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp
+    cl, og, hg, host = _world(10)
+    kr = H.oracle_keyring(cl)                                   # NOT the client, NOT the strangers below
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    weak = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 84)[79], "u02 <u02@bftkv.example>")
+    cb.build_entity(weak, [r for r in cl.replicas if r.algo == cb.PK_RSA][:2], DRBG("weak"))
+    sub_owner = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 84)[82], "s01 <s01@bftkv.example>")
+    sub = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 84)[83], "")
+    cb.build_entity(sub_owner, [], DRBG("sub"), subkey=sub)
+    dsa_stranger = cb.make_keypair(cb.PK_DSA, cb.load_keys("dsa2048", 12)[11], "d01 <d01@bftkv.example>")
+    cb.build_entity(dsa_stranger, cl.replicas[:4], DRBG("dsa-stranger"))
+    client = cl.client.entity
+    selfsig = client.index(b"\xc2", client.index(cl.client.name.encode()))
+    bad_self = bytearray(client); bad_self[selfsig + 200] ^= 1; bad_self = bytes(bad_self)
+    bad_binding = bytearray(sub_owner.entity); bad_binding[len(bad_binding) - 25] ^= 0x20; bad_binding = bytes(bad_binding)
+    tbs = cb.serialize_tbs(b"variable", b"value", 7)
+    S = lambda kp, data=tbs: cb.detach_sign(kp, data, DRBG("cert-verify"))
+    cases = [
+        ("client", client, tbs, S(cl.client)),
+        ("client, signature over other bytes", client, tbs, S(cl.client, tbs + b"x")),
+        ("somebody else's certificate", cl.replicas[0].entity, tbs, S(cl.client)),
+        ("forged self-signature: no issuer", bad_self, tbs, S(cl.client)),
+        ("no certificate", b"", tbs, S(cl.client)),
+        ("garbage certificate", bytes(range(200)), tbs, S(cl.client)),
+        ("weakly certified stranger (the quorum certificate is a later check)", weak.entity, tbs, S(weak)),
+        ("outsider nobody certified", cl.outsiders[0].entity, tbs, S(cl.outsiders[0])),
+        ("second packet by a key outside the certificate", client, tbs, S(cl.client) + S(cl.replicas[1])),
+        ("two packets by the certificate's key", client, tbs, S(cl.client) + S(cl.client)),
+        ("entity with a bound subkey", sub_owner.entity, tbs, S(sub_owner)),
+        ("forged subkey binding: no issuer", bad_binding, tbs, S(sub_owner)),
+        ("DSA stranger", dsa_stranger.entity, tbs, S(dsa_stranger)),
+        ("empty signature data", client, tbs, b""),
+        ("several entities: the first is the issuer", client + weak.entity, tbs, S(cl.client)),
+        ("several entities, signed by the second", client + weak.entity, tbs, S(weak)),
+        ("issuer alone", client, b"", None),
+        ("issuer alone, forged self-signature", bad_self, b"", None),
+    ]
+
+    def want_of(cert, tb, sig):
+        ents = pgp.entity_checks(cert)
+        if not ents or not ents[0]["valid"]:
+            return 3, 0
+        iid = ents[0]["primary"].key_id
+        if sig is None:
+            return 0, iid
+        e = col.signature_verify_with_certificate(tb, opk.SignaturePacket(1, 0, False, sig or None, cert), pgp.read_entities(cert)[0])
+        return (0 if e is None else 1), iid
+    wants = [want_of(c, t, s) for _, c, t, s in cases]
+    assert {w[0] for w in wants} == {0, 1, 3}
+    b = Batcher(gpu_ctx, max_items=64)
+    try:
+        for (name, cert, tb, sig), (w, iid) in zip(cases, wants):
+            err, fenced, got_id, fp = b.cert_verify(cert, tb, sig)
+            assert not fenced, name
+            assert err == w, (name, err, w)
+            if iid:
+                body = pgp.next_packet(cert, 0).body
+                assert got_id == iid and fp == hashlib.sha1(b"\x99" + struct.pack(">H", len(body)) + body).digest(), name
+        # the goroutine-per-request shape: many callers at once, certificates old and new mixed
+        got, errs = {}, []
+
+        def caller(k):
+            try:
+                rng = np.random.default_rng(100 + k)
+                for j in range(12):
+                    i = int(rng.integers(len(cases)))
+                    _, cert, tb, sig = cases[i]
+                    got[(k, j)] = (i, b.cert_verify(cert, tb, sig)[:2])
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=caller, args=(k,)) for k in range(24)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not errs, errs
+        assert len(got) == 24 * 12
+        for (k, j), (i, (err, fenced)) in got.items():
+            assert not fenced and err == wants[i][0], (cases[i][0], err, wants[i])
+        st = b.stats()
+        assert st["calls"] >= len(cases) + 24 * 12 and st["batches"] < st["calls"]
+        # fail closed
+        rc, err, _ = Batcher.cert_verify(b, client, tbs, S(cl.client), raw=True)
+        assert rc == 0 and err == 0
+    finally:
+        b.close()
+    # the node keyring is what it was: the client is still unknown to Signature.Verify, the replicas still verify
+    cs = S(cl.client, b"abc")
+    assert gpu_ctx.signature_verify(np.frombuffer(b"abc", dtype=np.uint8), np.array([0, 3], dtype=np.uint64),
+                                    np.frombuffer(cs, dtype=np.uint8), np.array([0, len(cs)], dtype=np.uint64))[0] == 1
+    rs = S(cl.replicas[3], b"abc")
+    assert gpu_ctx.signature_verify(np.frombuffer(b"abc", dtype=np.uint8), np.array([0, 3], dtype=np.uint64),
+                                    np.frombuffer(rs, dtype=np.uint8), np.array([0, len(rs)], dtype=np.uint64))[0] == 0
