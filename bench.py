@@ -656,19 +656,28 @@ def bench_cfg2(args, D):
             # Reported beside the headline, never as `value` (inputs resident in HBM).  The library cuts such a batch into pieces
             # and verifies piece k while the pieces behind it cross PCIe (capi.hip collective_verify_pipelined); `unsplit` is the
             # same call with that switched off (copy, then verify).
-            def host_call(cx, reps):
+            def host_call(cx, reps, fresh=False):
                 ts = []
                 for _ in range(reps):
+                    # fresh: buffers the runtime has never seen (a Go caller's slices are new memory every time)
+                    bufs = [np.copy(z[k]) for k in ("tb", "to", "sb", "so")] if fresh else [z[k] for k in ("tb", "to", "sb", "so")]
                     t_h = time.perf_counter()
-                    e_h, nv_h, _ = cx.collective_verify(V.qhs[0], z["tb"], z["to"], z["sb"], z["so"])
+                    e_h, nv_h, _ = cx.collective_verify(V.qhs[0], *bufs)
                     ts.append(time.perf_counter() - t_h)
                     assert (e_h == err).all() and (nv_h == nver).all()
                 return ts
             c0 = V.ctxs[0]
             host_call(c0, 2)                                  # worker arenas are allocated at the first pipelined call
             hb = host_call(c0, 7)
+            trace = c0.host_pipeline_trace()
+            hb_fresh = host_call(c0, 4, fresh=True)
+            c0.set_host_pipeline(0, "direct")
+            host_call(c0, 1)
+            hb_direct = host_call(c0, 5)
+            hb_direct_fresh = host_call(c0, 4, fresh=True)
             c0.set_host_pipeline(1)
             hb1 = host_call(c0, 3)
+            hb1_fresh = host_call(c0, 3, fresh=True)
             c0.set_host_pipeline(0)
             pcie_bytes = int(z["to"][-1]) + int(z["so"][-1]) + 16 * items + 7 * items
             # three callers at once, each on its own context with its own host slices (the shim's goroutines)
@@ -691,7 +700,13 @@ def bench_cfg2(args, D):
                 "verifies_per_sec": ref_ops / min(hb), "packets_per_sec": n_sigs / min(hb),
                 "bytes_over_pcie": pcie_bytes, "pcie_floor_ms_at_63GBps": pcie_bytes / 63e9 * 1e3,
                 "over_pcie_floor": min(hb) / (pcie_bytes / 63e9),
-                "unsplit_ms_per_step": min(hb1) * 1e3,
+                "fresh_buffers_ms_per_step": min(hb_fresh) * 1e3,
+                "copy": "page-locked staging ring inside the library (4 helper threads memcpy, DMA follows); "
+                        "direct = hipMemcpyAsync straight from the caller's pageable memory, which is fast only for memory the runtime has "
+                        "pinned before (the same arrays again) and pays the pinning for fresh memory",
+                "direct_ms_per_step": min(hb_direct) * 1e3, "direct_fresh_buffers_ms_per_step": min(hb_direct_fresh) * 1e3,
+                "unsplit_ms_per_step": min(hb1) * 1e3, "unsplit_fresh_buffers_ms_per_step": min(hb1_fresh) * 1e3,
+                "timeline_us": trace,
                 "three_callers": {"calls": 4 * len(t3), "ms_per_call": span3 / (4 * len(t3)) * 1e3, "verifies_per_sec": ref_ops * 4 * len(t3) / span3},
                 "note": "bftkv_gpu_collective_verify on pageable host memory in, verdicts out (best of 7; verdicts and exit counts checked "
                         "against the resident call every time); never the headline"}

@@ -45,7 +45,7 @@ EXPORTS = [
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
-    "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify",
+    "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_host_pipeline_trace",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_stream.restype = vp
     lib.bftkv_gpu_set_early_exit.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_set_host_pipeline.argtypes = [vp, u32]
+    lib.bftkv_gpu_host_pipeline_trace.argtypes = [vp, C.POINTER(C.c_float), u32, C.POINTER(u32)]
     lib.bftkv_gpu_last_sclk_mhz.argtypes = [vp, C.POINTER(C.c_float)]
     lib.bftkv_gpu_modexp_ops.argtypes = lib.bftkv_gpu_modexp.argtypes
     lib.bftkv_gpu_allgather_errs_dev.argtypes = [vp, u8p, u32, u32, u8p]
@@ -221,9 +222,24 @@ class Context:
         """collective_verify: stop verifying where the reference stops reading (default) / verify every packet."""
         self._check(self.lib.bftkv_gpu_set_early_exit(self.h, 1 if on else 0), "set_early_exit")
 
-    def set_host_pipeline(self, pieces: int) -> None:
-        """collective_verify over host buffers: 0 = split big batches by size (default), 1 = never, 2..8 = that many pieces."""
-        self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces), "set_host_pipeline")
+    def set_host_pipeline(self, pieces: int, copy: str = "") -> None:
+        """collective_verify over host buffers: 0 = split big batches by size (default), 1 = never, 2..8 = that many pieces;
+        copy = "ring" (page-locked staging ring, the default) or "direct" (hipMemcpyAsync from the caller's memory)."""
+        mode = {"": 0, "ring": 0x100, "direct": 0x200}[copy]
+        self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces | mode), "set_host_pipeline")
+
+    def host_pipeline_trace(self):
+        """Host-side timeline (microseconds) of the last pipelined host-buffer call: see bftkv_gpu_host_pipeline_trace."""
+        buf = (C.c_float * 64)()
+        n = C.c_uint32(0)
+        self._check(self.lib.bftkv_gpu_host_pipeline_trace(self.h, buf, 64, C.byref(n)), "host_pipeline_trace")
+        v = [float(buf[i]) for i in range(min(64, n.value))]
+        if not v:
+            return None
+        P = int(v[0])
+        names = ("ss_enqueued", "payload_enqueued", "picked_up", "payload_hook", "enqueued", "drained")
+        return {"pieces": P, "ring": bool(v[1]), "copiers_joined_us": v[2], "copy_stream_drained_us": v[3], "done_us": v[4], "largest_piece_items": int(v[5]),
+                "per_piece_us": [{nm: round(v[8 + 6 * k + j], 1) for j, nm in enumerate(names)} for k in range(P)]}
 
     def set_dsa_window_bits(self, bits: int) -> None:
         """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""

@@ -169,6 +169,10 @@ struct bftkv_gpu_ctx {
   // kernels of OTHER calls (or pieces) start at once instead of waiting for a round of modexp blocks to retire.
   uint32_t modexp_lds_pad = 0;
   uint32_t hb_pieces = 0;                   // bftkv_gpu_set_host_pipeline: 0 = by call size, 1 = never split, N = N pieces
+  uint32_t hb_copy_mode = 0;                // 0: $BFTKV_HB_COPY or the pinned ring, 1: ring, 2: direct hipMemcpyAsync from the caller's memory
+  void* hb_ring = nullptr;                  // HbRing: page-locked staging slots of the pipelined host-buffer path
+  std::vector<float> hb_trace;              // last pipelined call: [pieces, ring?, copiers joined, copy stream drained, done, ...] + per piece
+                                            // [ss enqueued, payload enqueued, piece picked up, payload hook, piece enqueued, piece drained] in us
   uint32_t hb_last_pieces = 0;              // > 0: the last verify call ran pipelined over that many workers (diagnostics read them)
   std::vector<uint32_t> hb_item0;           // first item of each piece of that call
   void* small_pin = nullptr;                // PinnedBuf[3] of bftkv_gpu_*_verify_small (batcher_capi.inc), created on first use
@@ -217,6 +221,30 @@ Turnstile g_turnstile[16];
 // host-buffer pipeline (collective_verify_pipelined)
 constexpr uint64_t HB_PIPE_MIN_BYTES = 24ull << 20;      // below this a call is latency-, not PCIe-bound: one piece
 constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
+// The caller's memory is pageable.  hipMemcpyAsync from it either pins the pages in place (the runtime caches such pins: fast
+// for a buffer it has seen, ~17 GB/s for a fresh one, profiles/r04_h2d_rates_microbench.txt) and returns only when the copy is
+// done.  The ring does not depend on that cache: helper threads memcpy chunk after chunk into page-locked slots (one thread
+// moves ~30 GB/s, three outrun PCIe) and hand each slot to the DMA engine as a truly asynchronous copy; a slot is reused when
+// the event behind its copy has fired.  Chunks are enqueued in plan order (a ticket), so the event recorded behind the last
+// chunk of a range says the whole range -- and every range before it -- is on the device.
+struct HbRing {
+  static constexpr size_t SLOT = 4u << 20;
+  static constexpr int NSLOT = 12;
+  static constexpr int THREADS = 4;
+  uint8_t* base = nullptr;
+  hipEvent_t ev[NSLOT] = {};
+  bool used[NSLOT] = {};
+  ~HbRing() { if (base) (void)hipHostFree(base); for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+  hipError_t init() {
+    if (base) return hipSuccess;
+    hipError_t e = hipHostMalloc((void**)&base, SLOT * NSLOT, hipHostMallocDefault);
+    if (e != hipSuccess) { base = nullptr; return e; }
+    for (auto& x : ev) if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
+    return hipSuccess;
+  }
+};
+
+
 constexpr uint32_t TURNSTILE_MIN_PACKETS = 98304;     // two rounds of 768 resident blocks x 64 signatures
 
 // live contexts: lets long-lived host objects (bftkv_quorum) notice that their context is gone
@@ -1047,6 +1075,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (auto& kv : c->modtab_cache) for (DevBuf& b : kv.second) b.release();
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->hb_out) (void)hipHostFree(c->hb_out);
+  if (c->hb_ring) { if (c->stream_c) (void)hipStreamSynchronize(c->stream_c); delete (HbRing*)c->hb_ring; }
   for (hipEvent_t e : c->hb_ev) (void)hipEventDestroy(e);
   if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
   rccl_release(c);
@@ -1083,9 +1112,20 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
 }
 
 int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* c, uint32_t pieces) {
-  if (!c || pieces > HB_PIPE_MAX_PIECES) return BFTKV_E_INVALID;
+  const uint32_t mode = pieces >> 8;
+  pieces &= 0xFFu;
+  if (!c || pieces > HB_PIPE_MAX_PIECES || mode > 2) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->hb_pieces = pieces;
+  c->hb_copy_mode = mode;
+  return 0;
+}
+
+int bftkv_gpu_host_pipeline_trace(bftkv_gpu_ctx* c, float* out, uint32_t cap, uint32_t* n_out) {
+  if (!c || !n_out) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  *n_out = (uint32_t)c->hb_trace.size();
+  if (out) memcpy(out, c->hb_trace.data(), sizeof(float) * std::min<size_t>(cap, c->hb_trace.size()));
   return 0;
 }
 
@@ -1254,31 +1294,41 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_ite
 
 struct HbPiece { uint32_t i0, i1; };
 
+// One contiguous range of the caller's buffers on its way to the device: `half` 0 = signature streams, 1 = payloads of piece k.
+struct HbCopy { uint32_t piece; int half; const uint8_t* src; uint8_t* dst; uint64_t len; };
+
 static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n_items) {
   static const int env = getenv("BFTKV_HB_PIECES") ? atoi(getenv("BFTKV_HB_PIECES")) : 0;
   const uint32_t forced = c->hb_pieces ? c->hb_pieces : (uint32_t)std::max(env, 0);     // bftkv_gpu_set_host_pipeline, else the environment
   if (forced == 1) return 1;
   if (forced > 1) return std::max<uint32_t>(1, std::min<uint32_t>(std::min(forced, HB_PIPE_MAX_PIECES), n_items));
   if (bytes < HB_PIPE_MIN_BYTES || n_items < 64) return 1;
-  const uint32_t p = (uint32_t)std::min<uint64_t>(6, std::max<uint64_t>(2, bytes / (40ull << 20)));
-  return std::min<uint32_t>(p, n_items / 32);
+  const uint32_t p = (uint32_t)std::min<uint64_t>(5, std::max<uint64_t>(3, bytes / (48ull << 20) + 1));
+  return std::min<uint32_t>(p, n_items / 16);
 }
 
 static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                        const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                        uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces) {
   // caller holds c->mu and, on a fork, the root's key-table lock (shared)
+  const auto t_call = std::chrono::steady_clock::now();
+  auto us_now = [&] { return (float)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call).count() * 1e-3f; };
   bftkv_gpu_ctx* const root = c->root ? c->root : c;
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
   const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
-  // pieces of about equal bytes (signature streams + payloads), cut at item boundaries
+  // Pieces cut at item boundaries by bytes (signature streams + payloads).  What the call costs beyond the copy is the
+  // LAST piece's walk / parse / modexp / tally, which start when its last byte has arrived: the last piece is small (a
+  // modexp of up to 768 resident blocks x 64 signatures is one round, ~0.33 ms, whatever its size), the ones before it share
+  // the rest evenly -- their work hides under the copies that follow them.
   std::vector<HbPiece> pc;
   {
     const uint64_t total = tl + sl;
+    const double last = n_pieces >= 3 ? std::min(1.0 / n_pieces, std::max(0.06, 12.0e6 / (double)total)) : 1.0 / n_pieces;
     uint32_t i = 0;
     for (uint32_t k = 0; k < n_pieces && i < n_items; ++k) {
-      const uint64_t want = total * (k + 1) / n_pieces;
+      const double upto = (k + 1 == n_pieces) ? 1.0 : (1.0 - last) * (double)(k + 1) / (double)(n_pieces - 1);
+      const uint64_t want = (uint64_t)((double)total * upto);
       uint32_t lo = i + 1, hi = n_items;
       while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (tbs_off[m] + ss_off[m] < want) lo = m + 1; else hi = m; }
       const uint32_t j = (k + 1 == n_pieces) ? n_items : lo;
@@ -1302,35 +1352,92 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
   HIPCHK(c, c->in_ss_off.ensure(sizeof(uint64_t) * (n_items + 1)));
   const size_t o_err = 0, o_vd = (size_t)n_items, o_fn = 2 * (size_t)n_items, o_nv = (3 * (size_t)n_items + 15) & ~(size_t)15;
-  const size_t out_bytes = o_nv + sizeof(uint32_t) * (size_t)n_items;
+  const size_t off_bytes = sizeof(uint64_t) * ((size_t)n_items + 1);
+  const size_t o_toff = (o_nv + sizeof(uint32_t) * (size_t)n_items + 15) & ~(size_t)15, o_soff = o_toff + off_bytes;
+  const size_t out_bytes = o_soff + off_bytes;
   if (c->hb_out_cap < out_bytes) {
     if (c->hb_out) { (void)hipHostFree(c->hb_out); c->hb_out = nullptr; c->hb_out_cap = 0; }
     HIPCHK(c, hipHostMalloc((void**)&c->hb_out, out_bytes + out_bytes / 4, hipHostMallocDefault));
     c->hb_out_cap = out_bytes + out_bytes / 4;
   }
-  // the offsets of the whole batch first (a few hundred KB), then the pieces
-  HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, tbs_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream_c));
-  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream_c));
-  std::vector<std::atomic<int>> flag(2 * (size_t)P);      // 1: copy issued and its event recorded, -1: the copy failed
+  // the offsets of the whole batch first (a few hundred KB, through pinned memory: asynchronous), then the pieces
+  memcpy(c->hb_out + o_toff, tbs_off, off_bytes);
+  memcpy(c->hb_out + o_soff, ss_off, off_bytes);
+  HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, c->hb_out + o_toff, off_bytes, hipMemcpyHostToDevice, c->stream_c));
+  HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, c->hb_out + o_soff, off_bytes, hipMemcpyHostToDevice, c->stream_c));
+  // copy plan: piece 0's signature streams first (its modexp can start), then for every piece the payloads BEFORE the signature
+  // streams of the next one -- when a piece's streams have arrived, everything of it has, and nothing waits for a payload
+  std::vector<HbCopy> plan;
+  for (uint32_t k = 0; k < P; ++k) {
+    const uint64_t s0 = ss_off[pc[k].i0], s1 = ss_off[pc[k].i1], t0 = tbs_off[pc[k].i0], t1 = tbs_off[pc[k].i1];
+    const HbCopy cs{k, 0, ss + s0, c->in_ss.as<uint8_t>() + s0, s1 - s0}, ct{k, 1, tbs + t0, c->in_tbs.as<uint8_t>() + t0, t1 - t0};
+    if (k == 0) { plan.push_back(cs); plan.push_back(ct); } else { plan.push_back(ct); plan.push_back(cs); }
+  }
+  std::vector<std::atomic<int>> flag(2 * (size_t)P);      // 1: the range is enqueued and its event recorded, -1: the copy failed
   for (auto& f : flag) f.store(0);
-  hipError_t copy_err = hipSuccess;
-  std::thread copier([&] {
-    (void)hipSetDevice(c->device);
-    bool dead = false;
-    for (uint32_t k = 0; k < P; ++k) {
-      const uint64_t s0 = ss_off[pc[k].i0], s1 = ss_off[pc[k].i1], t0 = tbs_off[pc[k].i0], t1 = tbs_off[pc[k].i1];
-      for (int half = 0; half < 2; ++half) {
-        hipError_t e = hipSuccess;
-        if (!dead) {
-          if (half == 0 && s1 > s0) e = hipMemcpyAsync(c->in_ss.as<uint8_t>() + s0, ss + s0, s1 - s0, hipMemcpyHostToDevice, c->stream_c);
-          if (half == 1 && t1 > t0) e = hipMemcpyAsync(c->in_tbs.as<uint8_t>() + t0, tbs + t0, t1 - t0, hipMemcpyHostToDevice, c->stream_c);
-          if (e == hipSuccess) e = hipEventRecord(c->hb_ev[2 * k + half], c->stream_c);
-          if (e != hipSuccess) { copy_err = e; dead = true; }
-        }
-        flag[2 * k + half].store(dead ? -1 : 1, std::memory_order_release);
-      }
+  std::atomic<int> copy_err{(int)hipSuccess};
+  static const bool ring_env = !(getenv("BFTKV_HB_COPY") && !strcmp(getenv("BFTKV_HB_COPY"), "direct"));
+  const bool use_ring = c->hb_copy_mode ? c->hb_copy_mode == 1 : ring_env;
+  std::vector<float>& tr = c->hb_trace;
+  tr.assign(8 + 6 * (size_t)P, 0.f);
+  tr[0] = (float)P; tr[1] = use_ring ? 1.f : 0.f;
+  std::vector<std::thread> copiers;
+  std::atomic<uint64_t> ticket{0};          // ring: the next chunk that may be enqueued
+  std::atomic<bool> dead{false};
+  // chunks of the plan, numbered in order
+  struct Chunk { uint32_t range; uint64_t off, len; bool last; };
+  std::vector<Chunk> chunks;
+  if (use_ring) {
+    if (!c->hb_ring) c->hb_ring = new HbRing();
+    HbRing& R = *(HbRing*)c->hb_ring;
+    hipError_t e = R.init();
+    if (e != hipSuccess) return fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: pinned ring", e);
+    for (uint32_t r = 0; r < plan.size(); ++r) {
+      if (plan[r].len == 0) { chunks.push_back({r, 0, 0, true}); continue; }
+      for (uint64_t o = 0; o < plan[r].len; o += HbRing::SLOT) chunks.push_back({r, o, std::min<uint64_t>(HbRing::SLOT, plan[r].len - o), o + HbRing::SLOT >= plan[r].len});
     }
-  });
+    const int nth = (int)std::min<size_t>(HbRing::THREADS, chunks.size());
+    for (int t = 0; t < nth; ++t)
+      copiers.emplace_back([&, t, nth] {
+        (void)hipSetDevice(c->device);
+        HbRing& R = *(HbRing*)c->hb_ring;
+        for (uint64_t i = (uint64_t)t; i < chunks.size(); i += (uint64_t)nth) {
+          const Chunk& ch = chunks[i];
+          const HbCopy& cp = plan[ch.range];
+          const int slot = (int)(i % HbRing::NSLOT);
+          hipError_t e = hipSuccess;
+          // chunk i - NSLOT used this slot: it was enqueued long ago (tickets are in order); wait for its DMA
+          if (!dead.load() && i >= (uint64_t)HbRing::NSLOT) {
+            while (ticket.load(std::memory_order_acquire) <= i - HbRing::NSLOT && !dead.load()) __builtin_ia32_pause();
+            e = hipEventSynchronize(R.ev[slot]);
+          }
+          if (e == hipSuccess && !dead.load() && ch.len) memcpy(R.base + (size_t)slot * HbRing::SLOT, cp.src + ch.off, ch.len);
+          while (ticket.load(std::memory_order_acquire) != i) { if ((i & 7) == 7) std::this_thread::yield(); else __builtin_ia32_pause(); }
+          if (e == hipSuccess && !dead.load()) {
+            if (ch.len) e = hipMemcpyAsync(cp.dst + ch.off, R.base + (size_t)slot * HbRing::SLOT, ch.len, hipMemcpyHostToDevice, c->stream_c);
+            if (e == hipSuccess) e = hipEventRecord(R.ev[slot], c->stream_c);
+            if (e == hipSuccess && ch.last) e = hipEventRecord(c->hb_ev[2 * cp.piece + cp.half], c->stream_c);
+          }
+          if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
+          if (ch.last) { flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release); tr[8 + 6 * cp.piece + cp.half] = us_now(); }
+          ticket.store(i + 1, std::memory_order_release);
+        }
+      });
+  } else {
+    copiers.emplace_back([&] {
+      (void)hipSetDevice(c->device);
+      for (const HbCopy& cp : plan) {
+        hipError_t e = hipSuccess;
+        if (!dead.load()) {
+          if (cp.len) e = hipMemcpyAsync(cp.dst, cp.src, cp.len, hipMemcpyHostToDevice, c->stream_c);
+          if (e == hipSuccess) e = hipEventRecord(c->hb_ev[2 * cp.piece + cp.half], c->stream_c);
+          if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
+        }
+        flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release);
+        tr[8 + 6 * cp.piece + cp.half] = us_now();
+      }
+    });
+  }
   auto wait_flag = [&](size_t i) -> int {
     for (uint32_t it = 0;; ++it) {
       const int v = flag[i].load(std::memory_order_acquire);
@@ -1343,11 +1450,13 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   for (uint32_t k = 0; k < P && !first_rc; ++k) {
     bftkv_gpu_ctx* w = c->hb_workers[k];
     const uint32_t nk = pc[k].i1 - pc[k].i0;
-    if (wait_flag(2 * k) < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", copy_err); break; }
+    if (wait_flag(2 * k) < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", (hipError_t)copy_err.load()); break; }
+    tr[8 + 6 * k + 2] = us_now();
     ctx_lock wl(w->mu);
     if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
     const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
-      if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", copy_err);
+      tr[8 + 6 * k + 3] = us_now();
+      if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load());
       HIPCHK(w, hipStreamWaitEvent(sh, c->hb_ev[2 * k + 1], 0));
       return 0;
     };
@@ -1364,13 +1473,18 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
         (e = hipMemcpyAsync(c->hb_out + o_nv + sizeof(uint32_t) * (size_t)i0, w->o_nver.p, sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
         (fenced_out && (e = hipMemcpyAsync(c->hb_out + o_fn + i0, w->o_fenced.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess))
       first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: results to the host", e);
+    tr[8 + 6 * k + 4] = us_now();
   }
-  copier.join();
+  if (first_rc) dead.store(true);
+  for (auto& t : copiers) t.join();
+  tr[2] = us_now();
   // one synchronisation: every piece that was enqueued, and the copy stream (the caller's buffers must not be read after return)
   hipError_t se = hipStreamSynchronize(c->stream_c);
+  tr[3] = us_now();
   for (uint32_t k = 0; k < launched; ++k) {
     bftkv_gpu_ctx* w = c->hb_workers[k];
     for (hipStream_t st : {w->stream_h, w->stream_d, w->stream}) { const hipError_t e = hipStreamSynchronize(st); if (se == hipSuccess) se = e; }
+    tr[8 + 6 * k + 5] = us_now();
   }
   if (!first_rc && se != hipSuccess) first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: synchronise", se);
   if (first_rc) {      // fail closed: no byte of the result reads as "verified"
@@ -1387,10 +1501,12 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   c->hb_last_pieces = P;
   c->hb_item0.assign(P, 0);
   uint32_t total = 0;
-  for (uint32_t k = 0; k < P; ++k) { c->hb_item0[k] = pc[k].i0; total += c->hb_workers[k]->last_total; }
+  for (uint32_t k = 0; k < P; ++k) { c->hb_item0[k] = pc[k].i0; total += c->hb_workers[k]->last_total; tr[8 + 6 * k] += 0.f; }
   c->last_total = total;
   c->last_items = n_items;
   c->have_timing = false;       // (per-phase events live in the workers; bftkv_gpu_last_timing describes unsplit calls)
+  tr[4] = us_now();
+  for (uint32_t k = 0; k < P; ++k) tr[5] = std::max(tr[5], (float)(pc[k].i1 - pc[k].i0));
   return 0;
 }
 

@@ -44,12 +44,14 @@ def test_pieces_give_the_unsplit_answers(gpu_ctx, early):
         gpu_ctx.set_host_pipeline(1)
         base = _observe(gpu_ctx, qh, c.tbss_blob, c.tbss_off, sb, so)
         assert base[3][100] == 1 and (base[0] == 0).any() and (base[0] == 2).any()
-        for pieces in (2, 3, 5, 8):
-            gpu_ctx.set_host_pipeline(pieces)
+        for pieces, copy in ((2, "ring"), (3, "direct"), (5, "ring"), (8, "direct"), (8, "ring")):
+            gpu_ctx.set_host_pipeline(pieces, copy)       # both copy routes: the page-locked ring and the caller's memory directly
             got = _observe(gpu_ctx, qh, c.tbss_blob, c.tbss_off, sb, so)
             for name, a, b in zip(("err", "n_verified", "verdict", "fenced", "statuses", "status items"), base, got):
-                assert np.array_equal(a, b), (pieces, name)
+                assert np.array_equal(a, b), (pieces, copy, name)
             assert got[6] == base[6], (pieces, got[6], base[6])
+            tr = gpu_ctx.host_pipeline_trace()
+            assert tr["pieces"] == pieces and tr["ring"] == (copy == "ring") and tr["done_us"] > 0
         # and the reference's verdicts on the unfenced items
         from oracle import collective as col
         from oracle.packet import SignaturePacket
@@ -73,7 +75,8 @@ def test_pieces_give_the_unsplit_answers(gpu_ctx, early):
 def test_pipelined_calls_from_three_threads_on_a_root_and_its_forks(gpu_ctx):
     """The cgo shim's shape: several goroutines, each with its own host slices, each call pipelined over its own workers."""
     cl = cb.make_cluster(7)
-    c = cb.make_write_corpus(cl, 400, mutation_rates={cb.MUT_BAD_MPI: 0.1, cb.MUT_ONE_SHORT: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.05})
+    # 64 KB values: ~26 MB of payloads, i.e. ranges of several 4 MB ring slots each and slots reused within a call
+    c = cb.make_write_corpus(cl, 400, value_len=65536, mutation_rates={cb.MUT_BAD_MPI: 0.1, cb.MUT_ONE_SHORT: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.05})
     kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
     gpu_ctx.keyring_set(H.abi_keys(kr))
     qh = gpu_ctx.quorum_create(H.abi_qcs(q))
