@@ -222,11 +222,11 @@ class Context:
         """collective_verify: stop verifying where the reference stops reading (default) / verify every packet."""
         self._check(self.lib.bftkv_gpu_set_early_exit(self.h, 1 if on else 0), "set_early_exit")
 
-    def set_host_pipeline(self, pieces: int, copy: str = "") -> None:
+    def set_host_pipeline(self, pieces: int, copy: str = "", tight: bool = False) -> None:
         """collective_verify over host buffers: 0 = split big batches by size (default), 1 = never, 2..8 = that many pieces;
         copy = "ring" (page-locked staging ring, the default) or "direct" (hipMemcpyAsync from the caller's memory)."""
         mode = {"": 0, "ring": 0x100, "direct": 0x200}[copy]
-        self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces | mode), "set_host_pipeline")
+        self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces | mode | (0x400 if tight else 0)), "set_host_pipeline")
 
     def host_pipeline_trace(self):
         """Host-side timeline (microseconds) of the last pipelined host-buffer call: see bftkv_gpu_host_pipeline_trace."""
@@ -238,7 +238,7 @@ class Context:
             return None
         P = int(v[0])
         names = ("ss_enqueued", "payload_enqueued", "picked_up", "payload_hook", "enqueued", "drained")
-        return {"pieces": P, "ring": bool(v[1]), "copiers_joined_us": v[2], "copy_stream_drained_us": v[3], "done_us": v[4], "largest_piece_items": int(v[5]),
+        return {"pieces": P, "ring": bool(v[1]), "copiers_joined_us": v[2], "copy_stream_drained_us": v[3], "done_us": v[4], "largest_piece_items": int(v[5]), "second_passes": int(v[6]),
                 "per_piece_us": [{nm: round(v[8 + 6 * k + j], 1) for j, nm in enumerate(names)} for k in range(P)]}
 
     def set_dsa_window_bits(self, bits: int) -> None:

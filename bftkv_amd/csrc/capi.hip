@@ -133,6 +133,7 @@ struct bftkv_gpu_ctx {
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
   uint32_t* d_mail = nullptr;
   uint32_t last_total = 0, last_rsa = 0, last_items = 0;
+  bool last_total_on_dev = false;      // the last call was sized by an upper bound: its packet count is c->total[0] on the device
   hipEvent_t ev[10] = {};  // 0 start, 1 parsed, 2 modexp done, 3 compare + DSA done, 4 end, 5 hash start, 6 hash done, 7 DSA inverses done, 8 compare done,
                            // 9 modexp about to start (behind the turnstile)
   hipEvent_t ev_turn = nullptr;   // this context's ticket in the device's modexp turnstile (below)
@@ -169,6 +170,7 @@ struct bftkv_gpu_ctx {
   // kernels of OTHER calls (or pieces) start at once instead of waiting for a round of modexp blocks to retire.
   uint32_t modexp_lds_pad = 0;
   uint32_t hb_pieces = 0;                   // bftkv_gpu_set_host_pipeline: 0 = by call size, 1 = never split, N = N pieces
+  bool hb_tight = false;                    // tests: pieces sized by a bound real streams exceed (BFTKV_HOST_PIPELINE_TIGHT_BOUND)
   uint32_t hb_copy_mode = 0;                // 0: $BFTKV_HB_COPY or the pinned ring, 1: ring, 2: direct hipMemcpyAsync from the caller's memory
   void* hb_ring = nullptr;                  // HbRing: page-locked staging slots of the pipelined host-buffer path
   std::vector<float> hb_trace;              // last pipelined call: [pieces, ring?, copiers joined, copy stream drained, done, ...] + per piece
@@ -228,8 +230,8 @@ constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
 // the event behind its copy has fired.  Chunks are enqueued in plan order (a ticket), so the event recorded behind the last
 // chunk of a range says the whole range -- and every range before it -- is on the device.
 struct HbRing {
-  static constexpr size_t SLOT = 4u << 20;
-  static constexpr int NSLOT = 12;
+  static constexpr size_t SLOT = 16u << 20;     // (4 MB slots: ~45 GB/s, the per-copy cost shows; 16 MB: 54 of the 57 GB/s one copy reaches)
+  static constexpr int NSLOT = 6;
   static constexpr int THREADS = 4;
   uint8_t* base = nullptr;
   hipEvent_t ev[NSLOT] = {};
@@ -386,7 +388,9 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // A staged small call keeps its hashing on the main stream: its digest kernel is a few microseconds, two cross-stream joins
   // cost more than that, and a lane that occupies ONE hardware queue leaves the others to the other lanes (the runtime maps
   // streams onto 4 queues by default: three streams per lane made four lanes run one after the other).
-  const bool one_stream = staged_cap != 0;
+  // (a capped call that waits for its input on an event is a PIECE of a pipelined host-buffer call: big, so it keeps the side
+  // streams and the turnstile of a resident batch, and like a staged call it never asks the host for its packet count)
+  const bool one_stream = staged_cap != 0 && !ev_input;
   hipStream_t s = c->stream, sh = one_stream ? c->stream : c->stream_h;
   auto rec = [&](int k, hipStream_t st) -> hipError_t { return one_stream ? hipSuccess : hipEventRecord(c->ev[k], st); };
   auto join = [&](hipStream_t st, int k) -> hipError_t { return one_stream ? hipSuccess : hipStreamWaitEvent(st, c->ev[k], 0); };
@@ -454,6 +458,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   }
   if (!staged_cap && (size_t)chunk_units * 16 > c->chunk_arena.cap) HIPCHK(c, c->chunk_arena.ensure((size_t)chunk_units * 16));
   c->last_total = staged_cap ? 0u : total;      // (per-packet diagnostics are not kept for staged calls)
+  c->last_total_on_dev = staged_cap != 0 && ev_input != nullptr;   // ... a piece's are: its count is read from the device when asked for
   c->last_items = n_items;
   c->hb_last_pieces = 0;
   const size_t tr = total ? total : 1;
@@ -563,7 +568,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                          cnt_p + 3, start + 3, c->kt, c->r4096.as<uint32_t>(), c->xr.as<uint32_t>(), (uint64_t*)nullptr);
   };
   static const bool turnstile_off = getenv("BFTKV_NO_TURNSTILE") != nullptr;      // (read once: this is every big call's path)
-  if (total >= TURNSTILE_MIN_PACKETS && !staged_cap && !turnstile_off) {
+  const bool big = staged_cap ? (ev_input != nullptr && ss_len / 320 >= TURNSTILE_MIN_PACKETS) : total >= TURNSTILE_MIN_PACKETS;
+  if (big && !turnstile_off) {
     Turnstile& g = g_turnstile[(unsigned)c->device & 15u];
     std::lock_guard<std::mutex> tl(g.mu);
     if (g.last && g.owner != c) HIPCHK(c, hipStreamWaitEvent(s, g.last, 0));
@@ -590,7 +596,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (total && !d_mid_in)
     hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
                        d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
-                       c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4, txt);
+                       c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4, txt, n_recs_dev);
   const dim3 cg(((uint64_t)total * CMP_LANES + 255) / 256);
   auto launch_compare = [&](const uint32_t* start) {
     hipLaunchKernelGGL(k_rsa_compare, cg, dim3(256), 0, s, c->recs.as<SigRec>(), c->pk_list.as<uint32_t>(),
@@ -1112,12 +1118,13 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* c) {
 }
 
 int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* c, uint32_t pieces) {
-  const uint32_t mode = pieces >> 8;
+  const uint32_t mode = (pieces >> 8) & 3u, tight = (pieces >> 10) & 1u;
+  if (!c || (pieces & 0xFFu) > HB_PIPE_MAX_PIECES || mode > 2 || (pieces >> 11)) return BFTKV_E_INVALID;
   pieces &= 0xFFu;
-  if (!c || pieces > HB_PIPE_MAX_PIECES || mode > 2) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->hb_pieces = pieces;
   c->hb_copy_mode = mode;
+  c->hb_tight = tight != 0;
   return 0;
 }
 
@@ -1238,7 +1245,7 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
 static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                   uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs, uint64_t ss_len,
-                                  hipEvent_t ev_input = nullptr) {
+                                  hipEvent_t ev_input = nullptr, uint32_t cap = 0) {
   // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
@@ -1247,7 +1254,7 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
   const QuorumDev qd = quorum_dev(c, q);
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len, nullptr, nullptr, 0, ev_input))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len, nullptr, nullptr, cap, ev_input))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
@@ -1354,7 +1361,8 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   const size_t o_err = 0, o_vd = (size_t)n_items, o_fn = 2 * (size_t)n_items, o_nv = (3 * (size_t)n_items + 15) & ~(size_t)15;
   const size_t off_bytes = sizeof(uint64_t) * ((size_t)n_items + 1);
   const size_t o_toff = (o_nv + sizeof(uint32_t) * (size_t)n_items + 15) & ~(size_t)15, o_soff = o_toff + off_bytes;
-  const size_t out_bytes = o_soff + off_bytes;
+  const size_t o_tot = o_soff + off_bytes;                  // per piece: [packet events, overflow] (k_scan_counts)
+  const size_t out_bytes = o_tot + 8 * (size_t)HB_PIPE_MAX_PIECES;
   if (c->hb_out_cap < out_bytes) {
     if (c->hb_out) { (void)hipHostFree(c->hb_out); c->hb_out = nullptr; c->hb_out_cap = 0; }
     HIPCHK(c, hipHostMalloc((void**)&c->hb_out, out_bytes + out_bytes / 4, hipHostMallocDefault));
@@ -1394,7 +1402,13 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     if (e != hipSuccess) return fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: pinned ring", e);
     for (uint32_t r = 0; r < plan.size(); ++r) {
       if (plan[r].len == 0) { chunks.push_back({r, 0, 0, true}); continue; }
-      for (uint64_t o = 0; o < plan[r].len; o += HbRing::SLOT) chunks.push_back({r, o, std::min<uint64_t>(HbRing::SLOT, plan[r].len - o), o + HbRing::SLOT >= plan[r].len});
+      // chunk sizes ramp up from 2 MB: the DMA engine starts after 70 us of copying, not after a whole slot's 0.5 ms
+      for (uint64_t o = 0; o < plan[r].len;) {
+        const uint64_t want = std::min<uint64_t>(HbRing::SLOT, (2ull << 20) << std::min<size_t>(3, chunks.size() / HbRing::THREADS));
+        const uint64_t len = std::min<uint64_t>(want, plan[r].len - o);
+        chunks.push_back({r, o, len, o + len >= plan[r].len});
+        o += len;
+      }
     }
     const int nth = (int)std::min<size_t>(HbRing::THREADS, chunks.size());
     for (int t = 0; t < nth; ++t)
@@ -1462,15 +1476,23 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     };
     hipError_t e;
     if ((e = w->o_err.ensure(nk)) != hipSuccess || (e = w->o_fenced.ensure(nk)) != hipSuccess) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: result buffers", e); break; }
+    // The piece is sized by an upper bound on its packet events (one per 64 stream bytes: 4.5 of the path's 287-byte signature
+    // packets) and reads the real count on the device, so that this thread never waits for the GPU in mid-pipeline: every piece
+    // is enqueued as soon as its copies are, and runs when its events fire.  A stream of junk denser than that turns the piece
+    // into an empty one (k_scan_counts); it is then run again below, sized by its real count.
+    const uint64_t ssk = ss_off[pc[k].i1] - ss_off[pc[k].i0];
+    const uint32_t cap = c->hb_tight ? (uint32_t)(ssk / 4096 + 1)       // (tests: a bound that real streams exceed, to exercise the second pass)
+                                     : (uint32_t)std::min<uint64_t>(1u << 26, ssk / 64 + 64ull * nk + 4096);
     rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[k].i0, c->in_ss.as<uint8_t>(),
                                 c->in_ss_off.as<uint64_t>() + pc[k].i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
-                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ss_off[pc[k].i1] - ss_off[pc[k].i0], c->hb_ev[2 * k]);
+                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap);
     ++launched;
     if (rc) { c->err = "host-buffer pipeline, piece " + std::to_string(k) + ": " + w->err; first_rc = rc; break; }
     const uint32_t i0 = pc[k].i0;
     if ((e = hipMemcpyAsync(c->hb_out + o_err + i0, w->o_err.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(c->hb_out + o_vd + i0, w->o_verdict.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(c->hb_out + o_nv + sizeof(uint32_t) * (size_t)i0, w->o_nver.p, sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->hb_out + o_tot + 8 * (size_t)k, w->total.p, 8, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
         (fenced_out && (e = hipMemcpyAsync(c->hb_out + o_fn + i0, w->o_fenced.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess))
       first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: results to the host", e);
     tr[8 + 6 * k + 4] = us_now();
@@ -1487,6 +1509,28 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     tr[8 + 6 * k + 5] = us_now();
   }
   if (!first_rc && se != hipSuccess) first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: synchronise", se);
+  // pieces that outgrew their bound: once more, sized by their real count (the input is on the device by now)
+  for (uint32_t k = 0; k < P && !first_rc; ++k) {
+    bftkv_gpu_ctx* w = c->hb_workers[k];
+    uint32_t tot[2];
+    memcpy(tot, c->hb_out + o_tot + 8 * (size_t)k, 8);
+    w->last_total = tot[0]; w->last_total_on_dev = false;
+    if (!tot[1]) continue;
+    ctx_lock wl(w->mu);
+    const uint32_t nk = pc[k].i1 - pc[k].i0, i0 = pc[k].i0;
+    rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + i0, c->in_ss.as<uint8_t>(),
+                                c->in_ss_off.as<uint64_t>() + i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
+                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, nullptr, ss_off[pc[k].i1] - ss_off[i0]);
+    hipError_t e = hipSuccess;
+    if (rc) { c->err = "host-buffer pipeline, piece " + std::to_string(k) + " (second pass): " + w->err; first_rc = rc; break; }
+    if ((e = hipMemcpyAsync(c->hb_out + o_err + i0, w->o_err.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->hb_out + o_vd + i0, w->o_verdict.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->hb_out + o_nv + sizeof(uint32_t) * (size_t)i0, w->o_nver.p, sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
+        (fenced_out && (e = hipMemcpyAsync(c->hb_out + o_fn + i0, w->o_fenced.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess) ||
+        (e = hipStreamSynchronize(w->stream)) != hipSuccess)
+      first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: second pass of a piece", e);
+    tr[6] += 1.f;
+  }
   if (first_rc) {      // fail closed: no byte of the result reads as "verified"
     if (err_out) memset(err_out, BFTKV_ERR_INSUFFICIENT_SIGNATURES, n_items);
     if (verdict_out) memset(verdict_out, 0, n_items);
@@ -1635,6 +1679,10 @@ int bftkv_gpu_last_statuses(bftkv_gpu_ctx* c, uint8_t* st, uint32_t* item, uint3
   if (!c || !n_out) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->last_total_on_dev && !c->hb_last_pieces) {
+    HIPCHK(c, hipMemcpy(&c->last_total, c->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    c->last_total_on_dev = false;
+  }
   *n_out = c->last_total;
   if (c->hb_last_pieces) {      // the last call ran pipelined: the records live in the workers, piece after piece
     uint32_t done = 0;

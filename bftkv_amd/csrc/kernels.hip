@@ -1247,8 +1247,10 @@ __global__ void __launch_bounds__(256) k_digest_other(const uint8_t* __restrict_
                                                          const uint8_t* __restrict__ sig_blob, const uint32_t* __restrict__ mid32,
                                                          const uint64_t* __restrict__ mid64, uint32_t n_items, SigRec* __restrict__ recs,
                                                          uint32_t n_recs, uint32_t* __restrict__ digests,
-                                                         const uint32_t* __restrict__ any_other /*set by k_parse_body*/, TextDev txt) {
+                                                         const uint32_t* __restrict__ any_other /*set by k_parse_body*/, TextDev txt,
+                                                         const uint32_t* __restrict__ n_recs_dev /*calls sized by an upper bound: the real count*/) {
   if (*any_other == 0) return;        // every signature of the batch is binary SHA-256 (the path's default): nothing to read
+  if (n_recs_dev) n_recs = *n_recs_dev;
   // bounded grid (the host launches at most DIGEST_OTHER_MAX_BLOCKS blocks): normally this kernel has nothing to do, and a
   // grid of one block per 256 records -- 104k blocks for a cfg-4 batch -- spent 40 ms just being dispatched beside the modexp
   for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n_recs; ri += (uint64_t)gridDim.x * blockDim.x)

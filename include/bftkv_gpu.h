@@ -180,8 +180,9 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
 int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* ctx, uint32_t pieces);
 #define BFTKV_HOST_PIPELINE_RING 0x100u    /* or-ed into `pieces`: copies staged through the library's page-locked ring (the default) */
 #define BFTKV_HOST_PIPELINE_DIRECT 0x200u  /* ... or issued straight from the caller's memory (fast only for memory the runtime has pinned before) */
+#define BFTKV_HOST_PIPELINE_TIGHT_BOUND 0x400u  /* tests: size every piece's arena by a bound real streams exceed, so that the second pass runs */
 /* Diagnostics: host-side timeline of the last pipelined call in microseconds from its start: [0] pieces, [1] 1 = ring,
- * [2] copier threads joined, [3] copy stream drained, [4] results in the caller's arrays, [5] items of the largest piece,
+ * [2] copier threads joined, [3] copy stream drained, [4] results in the caller's arrays, [5] items of the largest piece, [6] pieces that outgrew their bound and ran a second pass,
  * then per piece k at [8 + 6k]: signature streams enqueued, payloads enqueued, piece picked up by the enqueuing thread, its
  * payload hook reached, piece fully enqueued, piece drained. */
 int bftkv_gpu_host_pipeline_trace(bftkv_gpu_ctx* ctx, float* out, uint32_t cap, uint32_t* n_out);

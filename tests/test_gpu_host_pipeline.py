@@ -52,6 +52,12 @@ def test_pieces_give_the_unsplit_answers(gpu_ctx, early):
             assert got[6] == base[6], (pieces, got[6], base[6])
             tr = gpu_ctx.host_pipeline_trace()
             assert tr["pieces"] == pieces and tr["ring"] == (copy == "ring") and tr["done_us"] > 0
+        # pieces sized by a bound their streams exceed empty themselves on the device and run a second pass: same answers
+        gpu_ctx.set_host_pipeline(4, "ring", tight=True)
+        got = _observe(gpu_ctx, qh, c.tbss_blob, c.tbss_off, sb, so)
+        for name, a, b in zip(("err", "n_verified", "verdict", "fenced", "statuses", "status items"), base, got):
+            assert np.array_equal(a, b), ("second pass", name)
+        assert got[6] == base[6] and gpu_ctx.host_pipeline_trace()["second_passes"] >= 3
         # and the reference's verdicts on the unfenced items
         from oracle import collective as col
         from oracle.packet import SignaturePacket
