@@ -503,6 +503,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     int min_suff = 0;
     for (int i = 0; i < plan_q->n_qcs; ++i) if (plan_q->suff[i] > 0 && (min_suff == 0 || plan_q->suff[i] < min_suff)) min_suff = plan_q->suff[i];
     pl.margin = 1u + (uint32_t)min_suff / 64u;
+    pl.mail = c->d_mail ? c->d_mail + 3 : nullptr;
+    if (c->h_mail) __atomic_store_n(&c->h_mail[3], 0u, __ATOMIC_RELEASE);
     hipLaunchKernelGGL(k_plan<1>, dim3((n_items + PLAN_ITEMS - 1) / PLAN_ITEMS), dim3(PLAN_BLOCK), 0, s, pl, c->kt, *plan_q);
   }
   const bool dsa_side = total && c->have_dsa_keys;
@@ -593,7 +595,20 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   // digests of the hashes other than SHA-256: on the MAIN stream, after the modexp.  Normally there are none and the kernel
   // exits on a device-side flag; at its 203 VGPRs it cannot co-schedule beside k_rsa_modexp, and on the hash stream it sat
   // there until the modexp drained (1.7 ms per step in the trace) holding back the join.
-  if (total && !d_mid_in)
+  // ... and normally not even launched: k_plan<1> reports through the mailbox whether any signature named another hash; by now
+  // the machine-filling modexp is in the queue, so a host that waits a moment for that word delays nothing.  (A profile of the
+  // step used to show this no-op as the kernel that "ran" while a neighbour's modexp held the SIMDs.)
+  bool other_hashes = true;
+  if (total && !d_mid_in && plan_q && big && c->h_mail) {
+    const auto t_spin = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; ++it) {
+      const uint32_t v = __atomic_load_n(&c->h_mail[3], __ATOMIC_ACQUIRE);
+      if (v) { other_hashes = (v & 1u) != 0; break; }
+      if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(300)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (total && !d_mid_in && other_hashes)
     hipLaunchKernelGGL(k_digest_other, dim3(std::min<uint32_t>((total + 255) / 256, DIGEST_OTHER_MAX_BLOCKS)), dim3(256), 0, s,
                        d_tbs, d_tbs_off, d_ss, c->mid.as<uint32_t>(), c->mid64.as<uint64_t>(), n_items, c->recs.as<SigRec>(), total,
                        c->digests.as<uint32_t>(), c->pk_count.as<uint32_t>() + 4, txt, n_recs_dev);
@@ -1352,7 +1367,14 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     root->n_forks.fetch_add(1);
     c->hb_workers.push_back(w);
   }
-  if (!c->stream_c) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+  if (!c->stream_c) {
+    // Its own hardware queue, if the runtime has one to give: the runtime maps all streams of a priority level onto a few
+    // hardware queues (4 by default), and the markers behind this stream's copies -- which the ring waits on before it reuses a
+    // slot -- would otherwise sit behind whatever long kernel another stream put into the same queue.
+    int lo_p = 0, hi_p = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    if (hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, hi_p) != hipSuccess) { c->stream_c = nullptr; HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking)); }
+  }
   while (c->hb_ev.size() < 2 * (size_t)P + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
   HIPCHK(c, c->in_ss.ensure(sl + 64));
@@ -1465,12 +1487,23 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     bftkv_gpu_ctx* w = c->hb_workers[k];
     const uint32_t nk = pc[k].i1 - pc[k].i0;
     if (wait_flag(2 * k) < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", (hipError_t)copy_err.load()); break; }
+    // ... and ARRIVED, not merely enqueued: a piece enqueued ahead of its input parks a barrier at the head of its streams'
+    // hardware queues, and those queues are shared -- the streams of the pieces before it, whose input is there, would wait
+    // behind it (measured: every piece then finishes at the very end).  So the host paces the pieces by the copy events.
+    {
+      hipError_t q;
+      for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
+      if (q != hipSuccess) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy event", q); break; }
+    }
     tr[8 + 6 * k + 2] = us_now();
     ctx_lock wl(w->mu);
     if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
     const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
       tr[8 + 6 * k + 3] = us_now();
       if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load());
+      hipError_t q;      // arrived (only piece 0's payloads travel behind its signature streams: see the copy plan), for the same reason
+      for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k + 1])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
+      if (q != hipSuccess) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: payload copy event", q);
       HIPCHK(w, hipStreamWaitEvent(sh, c->hb_ev[2 * k + 1], 0));
       return 0;
     };

@@ -91,17 +91,30 @@ inline int packet_parse(const uint8_t* pkt, uint64_t len, bftkv_parsed* o) {   /
   return 0;
 }
 
-inline bool seek2tbs(const uint8_t* pkt, uint64_t len, uint64_t* off) {        // packet.go:142-154
-  uint64_t pos = 0;
-  for (int k = 0; k < 2; ++k) {
-    int64_t l = 0;
-    if (pos + 8 <= len) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | pkt[pos + i]; l = (int64_t)v; }
-    if (l < 0 || (uint64_t)l > len) return false;
-    pos += 8 + (uint64_t)l;
-  }
-  pos += 8;
-  *off = pos;
-  return pos <= len;
+// seek2tbs, packet.go:142-154, as it stands: the errors of binary.Read and of Seek are IGNORED there.  So a read that hits
+// the end leaves `l` at its previous value -- and consumes the bytes that were there (io.ReadFull's short read); Seek moves by
+// that stale `l`, may leave the position past the end (bytes.Reader allows it), and refuses only a negative target, leaving
+// the position where it was.  What the callers then see: TBS / TBSS fail when the final position is past the end.
+inline bool seek2tbs(const uint8_t* pkt, uint64_t len, uint64_t* off) {
+  int64_t pos = 0, l = 0;
+  const int64_t n = (int64_t)len;
+  auto read8 = [&](bool keep) {
+    if (pos >= n) return;                                   // io.EOF: nothing consumed, nothing stored
+    if (pos + 8 > n) { pos = n; return; }                   // io.ErrUnexpectedEOF: the tail is consumed, nothing stored
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i) v = (v << 8) | pkt[pos + i];
+    pos += 8;
+    if (keep) l = (int64_t)v;
+  };
+  auto seek = [&] {
+    const int64_t abs = (int64_t)((uint64_t)pos + (uint64_t)l);   // Go's int64 addition wraps
+    if (abs >= 0) pos = abs;                                // "bytes.Reader.Seek: negative position": position unchanged
+  };
+  read8(true); seek();        // the variable
+  read8(true); seek();        // the value
+  read8(false);               // the timestamp
+  *off = (uint64_t)pos;
+  return pos <= n;
 }
 inline int packet_tbs(const uint8_t* pkt, uint64_t len, uint64_t* n) {          // TBS, packet.go:156-168
   return seek2tbs(pkt, len, n) ? 0 : BFTKV_E_INVALID;

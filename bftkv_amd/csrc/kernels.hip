@@ -2196,6 +2196,7 @@ struct PlanArgs {
   uint32_t* plan_cut;          // [n_items] records covered so far
   const uint8_t* verdict;      // phase 2: verdict bits of the phase-1 tally
   uint32_t margin;
+  uint32_t* mail;              // phase 1: mapped host word that receives 0x80000000 | (some signature uses a hash other than SHA-256)
 };
 
 // One wave per item, 16 items per block.  Work-list slots come from ONE atomic per block and list: every wave first counts
@@ -2208,6 +2209,9 @@ __global__ void __launch_bounds__(PLAN_BLOCK) k_plan(PlanArgs a, KeyTableDev kt,
   __shared__ uint32_t cnt_sh[PLAN_ITEMS][4];
   const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t item = blockIdx.x * PLAN_ITEMS + wib;
+  // the parse is complete: tell the host whether k_digest_other has anything to do, so that it need not launch it
+  if (PHASE == 1 && a.mail && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(a.mail, 0x80000000u | (a.pk_count[4] ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool have = item < a.n_items;
   const uint32_t base = have ? a.rec_base[item] : 0, cnt = have ? a.counts[item] : 0;
   uint32_t* const lists[4] = {a.pk_list, a.dsa_list, a.pk_list3072, a.pk_list4096};

@@ -128,12 +128,31 @@ def parse(pkt: bytes):  # packet.go:62-115
     return variable, value, t, sig, ss, auth
 
 
-def _seek2tbs(pkt: bytes) -> int:  # packet.go:142-154 (errors of binary.Read are ignored there)
+def _seek2tbs(pkt: bytes) -> int:
+    """seek2tbs, packet.go:142-154, with what ignoring its errors means: a binary.Read that hits the end stores nothing (``l``
+    keeps its previous value) but consumes the bytes that were there (io.ReadFull); Seek moves by that stale ``l``, may park the
+    reader past the end, and refuses only a negative target (position unchanged).  Returns the final position."""
+    n = len(pkt)
     pos = 0
-    for _ in range(2):
-        l = struct.unpack(">q", pkt[pos:pos + 8].ljust(8, b"\0"))[0] if pos + 8 <= len(pkt) else 0
-        pos += 8 + l
-    pos += 8
+    l = 0
+
+    def read8(pos, l, keep=True):
+        if pos >= n:
+            return pos, l                   # io.EOF
+        if pos + 8 > n:
+            return n, l                     # io.ErrUnexpectedEOF: the tail is consumed
+        v = struct.unpack(">q", pkt[pos:pos + 8])[0]
+        return pos + 8, (v if keep else l)
+
+    def seek(pos, l):
+        a = (pos + l + (1 << 63)) % (1 << 64) - (1 << 63)      # int64 wrap-around
+        return a if a >= 0 else pos
+
+    pos, l = read8(pos, l)
+    pos = seek(pos, l)
+    pos, l = read8(pos, l)
+    pos = seek(pos, l)
+    pos, _ = read8(pos, l, keep=False)
     return pos
 
 

@@ -76,6 +76,33 @@ def test_packet_matches_oracle_on_random_packets(H):
                     assert getattr(H.packet, name.upper())(p) == w
 
 
+def test_tbs_on_arbitrary_bytes_follows_the_oracle(H):
+    """TBS / TBSS on byte strings that are NOT well-formed packets (truncations in every field, negative and absurd lengths):
+    seek2tbs ignores its errors in the reference (packet.go:142-154) and the mirror must do so the same way."""
+    import struct
+    rng = np.random.default_rng(9)
+    u64 = lambda v: struct.pack(">q", int(v))
+    lens = [0, 1, 2, 5, 8, 9, 17, -1, -9, (1 << 63) - 1, -(1 << 63), 1 << 40]
+    seen_ok = seen_err = 0
+    for trial in range(3000):
+        l1, l2 = (lens[int(rng.integers(len(lens)))] for _ in range(2))
+        body = u64(l1) + rng.bytes(int(rng.integers(0, 12))) + u64(l2) + rng.bytes(int(rng.integers(0, 12))) + u64(rng.integers(0, 1 << 62))
+        if rng.random() < 0.5:
+            body += opk.write_signature(opk.SignaturePacket(1, 0, False, rng.bytes(int(rng.integers(0, 9))), None))
+        p = body[:int(rng.integers(0, len(body) + 1))]
+        for name in ("tbs", "tbss"):
+            try:
+                w = getattr(opk, name)(p)
+            except opk.PacketError:
+                seen_err += 1
+                with pytest.raises(H.MalformedPacket):
+                    getattr(H.packet, name.upper())(p)
+            else:
+                seen_ok += 1
+                assert getattr(H.packet, name.upper())(p) == w, (name, p.hex())
+    assert seen_ok > 300 and seen_err > 300
+
+
 def _random_world(rng):
     """Disjoint complete cliques + peripheral nodes certified by / certifying clique members."""
     nodes, next_id = [], 1

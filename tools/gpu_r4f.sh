@@ -1,21 +1,21 @@
-# round 4, call E: pieces sized by an upper bound (no host wait in mid-pipeline), 16 MB ring slots: tests, then the sweep
+# round 4, call F: pieces enqueued when their input has ARRIVED (host-paced), copy stream on its own priority queue
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( time timeout 900 python -m pytest tests/test_gpu_host_pipeline.py tests/test_gpu_parity.py -m gpu -x -q -k "pipeline or pieces or cfg2_full_size" ) > gpurun_out/pytest_e.log 2>&1
-tail -15 gpurun_out/pytest_e.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"
+( time timeout 900 python -m pytest tests/test_gpu_host_pipeline.py tests/test_gpu_parity.py -m gpu -x -q -k "pipeline or pieces or cfg2_full_size" ) > gpurun_out/pytest_f.log 2>&1
+tail -15 gpurun_out/pytest_f.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"
 run() {
   name=$1; shift
-  env "$@" timeout 300 python bench.py --config 2 --steps 20 --warmup 5 --no-serving --no-cpu-baseline --soak-seconds 0 > gpurun_out/bench_e_$name.json 2> gpurun_out/bench_e_$name.err
+  env "$@" timeout 300 python bench.py --config 2 --steps 20 --warmup 5 --no-serving --no-cpu-baseline --soak-seconds 0 > gpurun_out/bench_f_$name.json 2> gpurun_out/bench_f_$name.err
   python - <<PY
 import json
 try:
-    d=json.loads(open('gpurun_out/bench_e_$name.json').read().strip().splitlines()[-1])
+    d=json.loads(open('gpurun_out/bench_f_$name.json').read().strip().splitlines()[-1])
     e=d['end_to_end']
     print('$name step', round(d['ms_per_step'],3), {k:(round(v,3) if isinstance(v,float) else v) for k,v in e.items() if k.endswith('ms_per_step') or k=='ms_per_step_median'}, '3callers', round(e['three_callers']['ms_per_call'],3))
     t=e['timeline_us']
     print('   done', round(t['done_us']), 'copy drained', round(t['copy_stream_drained_us']), 'second', t['second_passes'], [ (round(p['ss_enqueued']), round(p['enqueued']), round(p['drained'])) for p in t['per_piece_us']])
 except Exception as ex:
-    print('$name failed', ex); print(open('gpurun_out/bench_e_$name.err').read()[-1500:])
+    print('$name failed', ex); print(open('gpurun_out/bench_f_$name.err').read()[-1500:])
 PY
 }
 run auto_pad0
