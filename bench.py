@@ -671,10 +671,11 @@ def bench_cfg2(args, D):
             hb = host_call(c0, 7)
             trace = c0.host_pipeline_trace()
             hb_fresh = host_call(c0, 4, fresh=True)
-            c0.set_host_pipeline(0, "direct")
+            c0.set_host_pipeline(0, "ring")
             host_call(c0, 1)
-            hb_direct = host_call(c0, 5)
-            hb_direct_fresh = host_call(c0, 4, fresh=True)
+            hb_ring = host_call(c0, 5)
+            trace_ring = c0.host_pipeline_trace()
+            hb_ring_fresh = host_call(c0, 3, fresh=True)
             c0.set_host_pipeline(1)
             hb1 = host_call(c0, 3)
             hb1_fresh = host_call(c0, 3, fresh=True)
@@ -701,10 +702,10 @@ def bench_cfg2(args, D):
                 "bytes_over_pcie": pcie_bytes, "pcie_floor_ms_at_63GBps": pcie_bytes / 63e9 * 1e3,
                 "over_pcie_floor": min(hb) / (pcie_bytes / 63e9),
                 "fresh_buffers_ms_per_step": min(hb_fresh) * 1e3,
-                "copy": "page-locked staging ring inside the library (4 helper threads memcpy, DMA follows); "
-                        "direct = hipMemcpyAsync straight from the caller's pageable memory, which is fast only for memory the runtime has "
-                        "pinned before (the same arrays again) and pays the pinning for fresh memory",
-                "direct_ms_per_step": min(hb_direct) * 1e3, "direct_fresh_buffers_ms_per_step": min(hb_direct_fresh) * 1e3,
+                "copy": "hipMemcpyAsync from the caller's pageable memory, piece by piece, on a helper thread (the runtime pins the pages in "
+                        "place and remembers them; fresh_buffers = arrays copied anew before every call); ring = the library's page-locked staging "
+                        "ring instead (4 helper threads memcpy, DMA follows)",
+                "ring_ms_per_step": min(hb_ring) * 1e3, "ring_fresh_buffers_ms_per_step": min(hb_ring_fresh) * 1e3, "ring_timeline_us": trace_ring,
                 "unsplit_ms_per_step": min(hb1) * 1e3, "unsplit_fresh_buffers_ms_per_step": min(hb1_fresh) * 1e3,
                 "timeline_us": trace,
                 "three_callers": {"calls": 4 * len(t3), "ms_per_call": span3 / (4 * len(t3)) * 1e3, "verifies_per_sec": ref_ops * 4 * len(t3) / span3},

@@ -230,16 +230,16 @@ class Context:
 
     def host_pipeline_trace(self):
         """Host-side timeline (microseconds) of the last pipelined host-buffer call: see bftkv_gpu_host_pipeline_trace."""
-        buf = (C.c_float * 64)()
+        buf = (C.c_float * 96)()
         n = C.c_uint32(0)
-        self._check(self.lib.bftkv_gpu_host_pipeline_trace(self.h, buf, 64, C.byref(n)), "host_pipeline_trace")
-        v = [float(buf[i]) for i in range(min(64, n.value))]
+        self._check(self.lib.bftkv_gpu_host_pipeline_trace(self.h, buf, 96, C.byref(n)), "host_pipeline_trace")
+        v = [float(buf[i]) for i in range(min(96, n.value))]
         if not v:
             return None
         P = int(v[0])
-        names = ("ss_enqueued", "payload_enqueued", "picked_up", "payload_hook", "enqueued", "drained")
+        names = ("ss_enqueued", "payload_enqueued", "picked_up", "payload_hook", "enqueued", "drained", "gpu_start", "gpu_modexp_start", "gpu_modexp_end", "gpu_end")
         return {"pieces": P, "ring": bool(v[1]), "copiers_joined_us": v[2], "copy_stream_drained_us": v[3], "done_us": v[4], "largest_piece_items": int(v[5]), "second_passes": int(v[6]),
-                "per_piece_us": [{nm: round(v[8 + 6 * k + j], 1) for j, nm in enumerate(names)} for k in range(P)]}
+                "per_piece_us": [{nm: round(v[8 + 10 * k + j], 1) for j, nm in enumerate(names)} for k in range(P)]}
 
     def set_dsa_window_bits(self, bits: int) -> None:
         """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""

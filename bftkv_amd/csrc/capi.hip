@@ -170,6 +170,7 @@ struct bftkv_gpu_ctx {
   // kernels of OTHER calls (or pieces) start at once instead of waiting for a round of modexp blocks to retire.
   uint32_t modexp_lds_pad = 0;
   uint32_t hb_pieces = 0;                   // bftkv_gpu_set_host_pipeline: 0 = by call size, 1 = never split, N = N pieces
+  hipEvent_t hb_ev0 = nullptr;              // recorded on stream_c at the start of a pipelined call
   bool hb_tight = false;                    // tests: pieces sized by a bound real streams exceed (BFTKV_HOST_PIPELINE_TIGHT_BOUND)
   uint32_t hb_copy_mode = 0;                // 0: $BFTKV_HB_COPY or the pinned ring, 1: ring, 2: direct hipMemcpyAsync from the caller's memory
   void* hb_ring = nullptr;                  // HbRing: page-locked staging slots of the pipelined host-buffer path
@@ -223,6 +224,7 @@ Turnstile g_turnstile[16];
 // host-buffer pipeline (collective_verify_pipelined)
 constexpr uint64_t HB_PIPE_MIN_BYTES = 24ull << 20;      // below this a call is latency-, not PCIe-bound: one piece
 constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
+constexpr size_t HB_TR = 10;      // floats per piece in the timeline (bftkv_gpu_host_pipeline_trace)
 // The caller's memory is pageable.  hipMemcpyAsync from it either pins the pages in place (the runtime caches such pins: fast
 // for a buffer it has seen, ~17 GB/s for a fresh one, profiles/r04_h2d_rates_microbench.txt) and returns only when the copy is
 // done.  The ring does not depend on that cache: helper threads memcpy chunk after chunk into page-locked slots (one thread
@@ -1098,6 +1100,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (c->hb_out) (void)hipHostFree(c->hb_out);
   if (c->hb_ring) { if (c->stream_c) (void)hipStreamSynchronize(c->stream_c); delete (HbRing*)c->hb_ring; }
   for (hipEvent_t e : c->hb_ev) (void)hipEventDestroy(e);
+  if (c->hb_ev0) (void)hipEventDestroy(c->hb_ev0);
   if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1325,7 +1328,7 @@ static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n
   if (forced == 1) return 1;
   if (forced > 1) return std::max<uint32_t>(1, std::min<uint32_t>(std::min(forced, HB_PIPE_MAX_PIECES), n_items));
   if (bytes < HB_PIPE_MIN_BYTES || n_items < 64) return 1;
-  const uint32_t p = (uint32_t)std::min<uint64_t>(5, std::max<uint64_t>(3, bytes / (48ull << 20) + 1));
+  const uint32_t p = (uint32_t)std::min<uint64_t>(HB_PIPE_MAX_PIECES, std::max<uint64_t>(2, bytes / (40ull << 20)));
   return std::min<uint32_t>(p, n_items / 16);
 }
 
@@ -1339,18 +1342,17 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   int rc = check_quorum(c, quorum);
   if (rc) return rc;
   const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
-  // Pieces cut at item boundaries by bytes (signature streams + payloads).  What the call costs beyond the copy is the
-  // LAST piece's walk / parse / modexp / tally, which start when its last byte has arrived: the last piece is small (a
-  // modexp of up to 768 resident blocks x 64 signatures is one round, ~0.33 ms, whatever its size), the ones before it share
-  // the rest evenly -- their work hides under the copies that follow them.
+  // Pieces of equal bytes (signature streams + payloads), cut at item boundaries.  A piece's walk / parse / modexp / tally take
+  // about 0.72 of the time its bytes take to cross PCIe (2.9 ms of work per 226 MB against 4.0 ms of copy) plus ~0.2 ms of
+  // launches and dependent small kernels, so a piece of >= ~40 MB is done before the next one has arrived and the call ends one
+  // such piece behind the last byte; smaller pieces fall behind the copy (their fixed part does not shrink), larger ones leave
+  // more work for the end.  (A small LAST piece was tried: the piece before it is then large and late -- worse.)
   std::vector<HbPiece> pc;
   {
     const uint64_t total = tl + sl;
-    const double last = n_pieces >= 3 ? std::min(1.0 / n_pieces, std::max(0.06, 12.0e6 / (double)total)) : 1.0 / n_pieces;
     uint32_t i = 0;
     for (uint32_t k = 0; k < n_pieces && i < n_items; ++k) {
-      const double upto = (k + 1 == n_pieces) ? 1.0 : (1.0 - last) * (double)(k + 1) / (double)(n_pieces - 1);
-      const uint64_t want = (uint64_t)((double)total * upto);
+      const uint64_t want = total / n_pieces * (k + 1);
       uint32_t lo = i + 1, hi = n_items;
       while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (tbs_off[m] + ss_off[m] < want) lo = m + 1; else hi = m; }
       const uint32_t j = (k + 1 == n_pieces) ? n_items : lo;
@@ -1373,7 +1375,8 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     // slot -- would otherwise sit behind whatever long kernel another stream put into the same queue.
     int lo_p = 0, hi_p = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    if (hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, hi_p) != hipSuccess) { c->stream_c = nullptr; HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking)); }
+    static const bool prio = !getenv("BFTKV_HB_COPY_NO_PRIORITY");
+    if (!prio || hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, hi_p) != hipSuccess) { c->stream_c = nullptr; HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking)); }
   }
   while (c->hb_ev.size() < 2 * (size_t)P + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
@@ -1390,6 +1393,8 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     HIPCHK(c, hipHostMalloc((void**)&c->hb_out, out_bytes + out_bytes / 4, hipHostMallocDefault));
     c->hb_out_cap = out_bytes + out_bytes / 4;
   }
+  if (!c->hb_ev0) HIPCHK(c, hipEventCreate(&c->hb_ev0));
+  HIPCHK(c, hipEventRecord(c->hb_ev0, c->stream_c));      // origin of the device-side times of the timeline
   // the offsets of the whole batch first (a few hundred KB, through pinned memory: asynchronous), then the pieces
   memcpy(c->hb_out + o_toff, tbs_off, off_bytes);
   memcpy(c->hb_out + o_soff, ss_off, off_bytes);
@@ -1406,10 +1411,10 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   std::vector<std::atomic<int>> flag(2 * (size_t)P);      // 1: the range is enqueued and its event recorded, -1: the copy failed
   for (auto& f : flag) f.store(0);
   std::atomic<int> copy_err{(int)hipSuccess};
-  static const bool ring_env = !(getenv("BFTKV_HB_COPY") && !strcmp(getenv("BFTKV_HB_COPY"), "direct"));
+  static const bool ring_env = getenv("BFTKV_HB_COPY") && !strcmp(getenv("BFTKV_HB_COPY"), "ring");
   const bool use_ring = c->hb_copy_mode ? c->hb_copy_mode == 1 : ring_env;
   std::vector<float>& tr = c->hb_trace;
-  tr.assign(8 + 6 * (size_t)P, 0.f);
+  tr.assign(8 + HB_TR * (size_t)P, 0.f);
   tr[0] = (float)P; tr[1] = use_ring ? 1.f : 0.f;
   std::vector<std::thread> copiers;
   std::atomic<uint64_t> ticket{0};          // ring: the next chunk that may be enqueued
@@ -1455,7 +1460,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
             if (e == hipSuccess && ch.last) e = hipEventRecord(c->hb_ev[2 * cp.piece + cp.half], c->stream_c);
           }
           if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
-          if (ch.last) { flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release); tr[8 + 6 * cp.piece + cp.half] = us_now(); }
+          if (ch.last) { flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release); tr[8 + HB_TR * cp.piece + cp.half] = us_now(); }
           ticket.store(i + 1, std::memory_order_release);
         }
       });
@@ -1470,7 +1475,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
           if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
         }
         flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release);
-        tr[8 + 6 * cp.piece + cp.half] = us_now();
+        tr[8 + HB_TR * cp.piece + cp.half] = us_now();
       }
     });
   }
@@ -1495,11 +1500,11 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
       for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
       if (q != hipSuccess) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy event", q); break; }
     }
-    tr[8 + 6 * k + 2] = us_now();
+    tr[8 + HB_TR * k + 2] = us_now();
     ctx_lock wl(w->mu);
     if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
     const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
-      tr[8 + 6 * k + 3] = us_now();
+      tr[8 + HB_TR * k + 3] = us_now();
       if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load());
       hipError_t q;      // arrived (only piece 0's payloads travel behind its signature streams: see the copy plan), for the same reason
       for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k + 1])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
@@ -1528,7 +1533,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
         (e = hipMemcpyAsync(c->hb_out + o_tot + 8 * (size_t)k, w->total.p, 8, hipMemcpyDeviceToHost, w->stream)) != hipSuccess ||
         (fenced_out && (e = hipMemcpyAsync(c->hb_out + o_fn + i0, w->o_fenced.p, nk, hipMemcpyDeviceToHost, w->stream)) != hipSuccess))
       first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: results to the host", e);
-    tr[8 + 6 * k + 4] = us_now();
+    tr[8 + HB_TR * k + 4] = us_now();
   }
   if (first_rc) dead.store(true);
   for (auto& t : copiers) t.join();
@@ -1539,7 +1544,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   for (uint32_t k = 0; k < launched; ++k) {
     bftkv_gpu_ctx* w = c->hb_workers[k];
     for (hipStream_t st : {w->stream_h, w->stream_d, w->stream}) { const hipError_t e = hipStreamSynchronize(st); if (se == hipSuccess) se = e; }
-    tr[8 + 6 * k + 5] = us_now();
+    tr[8 + HB_TR * k + 5] = us_now();
   }
   if (!first_rc && se != hipSuccess) first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: synchronise", se);
   // pieces that outgrew their bound: once more, sized by their real count (the input is on the device by now)
@@ -1578,12 +1583,18 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   c->hb_last_pieces = P;
   c->hb_item0.assign(P, 0);
   uint32_t total = 0;
-  for (uint32_t k = 0; k < P; ++k) { c->hb_item0[k] = pc[k].i0; total += c->hb_workers[k]->last_total; tr[8 + 6 * k] += 0.f; }
+  for (uint32_t k = 0; k < P; ++k) { c->hb_item0[k] = pc[k].i0; total += c->hb_workers[k]->last_total; }
   c->last_total = total;
   c->last_items = n_items;
   c->have_timing = false;       // (per-phase events live in the workers; bftkv_gpu_last_timing describes unsplit calls)
   tr[4] = us_now();
-  for (uint32_t k = 0; k < P; ++k) tr[5] = std::max(tr[5], (float)(pc[k].i1 - pc[k].i0));
+  for (uint32_t k = 0; k < P; ++k) {
+    tr[5] = std::max(tr[5], (float)(pc[k].i1 - pc[k].i0));
+    // device side, from the worker's own events (run_pipeline): input there and pipeline started, modexp's turn, modexp done, piece done
+    bftkv_gpu_ctx* w = c->hb_workers[k];
+    const int evs[4] = {0, 9, 2, 4};
+    for (int j = 0; j < 4; ++j) { float ms = 0; if (hipEventElapsedTime(&ms, c->hb_ev0, w->ev[evs[j]]) == hipSuccess) tr[8 + HB_TR * k + 6 + j] = ms * 1e3f; }
+  }
   return 0;
 }
 

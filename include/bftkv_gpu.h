@@ -173,18 +173,19 @@ int bftkv_gpu_sync(bftkv_gpu_ctx* ctx);
  * context while the pieces behind it are still crossing PCIe, and the results reach the caller's arrays after one
  * synchronisation.  Items are independent: results are those of the unsplit call.  pieces = 0 (default): by call size (one
  * piece below 24 MB), 1: never split, 2..8: that many pieces whatever the size (tests).  BFTKV_HB_PIECES in the environment
- * sets the default of contexts this call has not touched.  The caller's memory is pageable: by default the library moves it
- * through its own ring of page-locked slots (helper threads copy, the DMA engine follows), which does not depend on the
- * runtime having pinned that memory before; BFTKV_HOST_PIPELINE_DIRECT (or BFTKV_HB_COPY=direct) hands the caller's pointers to
- * hipMemcpyAsync instead. */
+ * sets the default of contexts this call has not touched.  The caller's memory is pageable: by default its pointers go to
+ * hipMemcpyAsync, piece by piece, from a helper thread (the runtime pins the pages in place and remembers them: a long-running
+ * caller's heap is pinned once); BFTKV_HOST_PIPELINE_RING (or BFTKV_HB_COPY=ring) moves it through the library's own ring of
+ * page-locked slots instead (helper threads copy, the DMA engine follows), which does not depend on that memory. */
 int bftkv_gpu_set_host_pipeline(bftkv_gpu_ctx* ctx, uint32_t pieces);
-#define BFTKV_HOST_PIPELINE_RING 0x100u    /* or-ed into `pieces`: copies staged through the library's page-locked ring (the default) */
-#define BFTKV_HOST_PIPELINE_DIRECT 0x200u  /* ... or issued straight from the caller's memory (fast only for memory the runtime has pinned before) */
+#define BFTKV_HOST_PIPELINE_RING 0x100u    /* or-ed into `pieces`: copies staged through the library's page-locked ring (helper threads memcpy, DMA follows) */
+#define BFTKV_HOST_PIPELINE_DIRECT 0x200u  /* ... or issued straight from the caller's memory (the default; the runtime pins the pages and remembers them) */
 #define BFTKV_HOST_PIPELINE_TIGHT_BOUND 0x400u  /* tests: size every piece's arena by a bound real streams exceed, so that the second pass runs */
 /* Diagnostics: host-side timeline of the last pipelined call in microseconds from its start: [0] pieces, [1] 1 = ring,
  * [2] copier threads joined, [3] copy stream drained, [4] results in the caller's arrays, [5] items of the largest piece, [6] pieces that outgrew their bound and ran a second pass,
- * then per piece k at [8 + 6k]: signature streams enqueued, payloads enqueued, piece picked up by the enqueuing thread, its
- * payload hook reached, piece fully enqueued, piece drained. */
+ * then per piece k at [8 + 10k]: signature streams enqueued, payloads enqueued, piece picked up by the enqueuing thread, its
+ * payload hook reached, piece fully enqueued, piece drained (host clock); then on the device, from the call's first copy:
+ * piece started, its modexp's turn, modexp done, piece done. */
 int bftkv_gpu_host_pipeline_trace(bftkv_gpu_ctx* ctx, float* out, uint32_t cap, uint32_t* n_out);
 /* PGPCollectiveSignature.Verify returns at the first packet after which q.IsSufficient(verified) holds and never reads the
  * rest of ss.Data (crypto_pgp.go:491-496).  By default the batched call does the same amount of public-key work: per item
