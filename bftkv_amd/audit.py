@@ -10,7 +10,9 @@ The reference's plain storage keeps every accepted write as a file ``hex(x).t`` 
 ``audit_leveldb_db`` does the same for a storage/leveldb database (storage/leveldb/leveldb.go:30-53: key = variable || t as
 8 big-endian bytes, value = the stored packet), read with bftkv_amd/leveldb_reader.py -- no LevelDB library needed.
 
-CLI:  python -m bftkv_amd.audit --db DIR --pubring FILE --self KEYID_HEX [--kind plain|leveldb]
+``--kind http`` replays an opened-body HTTP exchange log instead (transport/http framing, bftkv_amd/wire.py).
+
+CLI:  python -m bftkv_amd.audit --db DIR|CAPTURE --pubring FILE --self KEYID_HEX [--kind plain|leveldb|http]
 """
 from __future__ import annotations
 
@@ -98,11 +100,26 @@ def main():
     ap.add_argument("--pubring", required=True)
     ap.add_argument("--self", dest="self_id", required=True, help="key id (hex) of the auditing node's own certificate")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--kind", choices=("plain", "leveldb"), default="plain")
+    ap.add_argument("--kind", choices=("plain", "leveldb", "http"), default="plain",
+                    help="plain / leveldb: a storage database; http: an opened-body HTTP exchange log (bftkv_amd/wire.py), --db names the file")
     args = ap.parse_args()
     ctx = Context(args.device)
     with open(args.pubring, "rb") as f:
         ring = f.read()
+    if args.kind == "http":
+        from . import wire
+        with open(args.db, "rb") as f:
+            exs = wire.replay(ctx, f.read(), ring, int(args.self_id, 16))
+        counts: Dict[str, int] = {}
+        for e in exs:
+            counts[e.verdict] = counts.get(e.verdict, 0) + 1
+            if e.verdict not in ("consistent", "not-judged"):
+                print("%-32s #%d %s %s: transport %s, %s %s, recorded %s %s" % (
+                    e.verdict, e.index, e.request.method, e.request.target, e.transport, e.site or "-", e.site_error or "ok",
+                    e.response.status if e.response else "-", (e.response.header("X-error") if e.response else "")))
+        print("replayed %d exchanges: %s" % (len(exs), ", ".join("%s=%d" % kv for kv in sorted(counts.items()))))
+        ctx.close()
+        return
     recs = (audit_plain_db if args.kind == "plain" else audit_leveldb_db)(ctx, args.db, ring, int(args.self_id, 16))
     counts: Dict[str, int] = {}
     for r in recs:

@@ -163,6 +163,8 @@ struct bftkv_gpu_ctx {
   // context holds, while the pieces behind it are still crossing PCIe on stream_c.
   std::vector<bftkv_gpu_ctx*> hb_workers;   // private forks of the root (never handed out)
   hipStream_t stream_c = nullptr;           // host-to-device copies of the pieces, in order
+  hipStream_t stream_c2 = nullptr;          // direct copies: a second helper thread and stream, so that the next range is already
+                                            // in the runtime's hands when one completes (a pageable copy call returns when it is done)
   std::vector<hipEvent_t> hb_ev;            // [2k] signature streams of piece k on the device, [2k + 1] its payloads
   uint8_t* hb_out = nullptr; size_t hb_out_cap = 0;   // pinned: per-piece results land here, copied to the caller after the last sync
   // Unused dynamic LDS added to every k_rsa_modexp<19,4> launch of this context: 38.9 KB + pad > 53 KB leaves room for two blocks
@@ -372,7 +374,10 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
                  const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0,
                  const uint32_t* d_mid_in = nullptr, const uint64_t* d_tbs_prefix = nullptr, uint32_t staged_cap = 0,
-                 hipEvent_t ev_input = nullptr) {
+                 hipEvent_t ev_input = nullptr, bool mid_prelaunched = false) {
+  // mid_prelaunched (pieces of a pipelined host-buffer call): the caller has already put k_sha256_mid for these items on the
+  // hash stream -- when the payloads arrived, ahead of the signature streams -- so the chain of 134 dependent compressions per
+  // payload is under way before the piece is picked up.
   // ev_input (pipelined host-buffer calls): the signature streams and offsets of this call are still being copied by another
   // stream; the main stream waits for that event first (the hash stream joins the main stream's start, so it waits too).
   // staged_cap (staged small calls): the arena and the grids are sized for that many packet events up front and the
@@ -590,7 +595,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (upload_tbs) {
     int hrc = (*upload_tbs)(sh);
     if (hrc) return hrc;
-    hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
+    if (!mid_prelaunched)
+      hipLaunchKernelGGL(k_sha256_mid, dim3((n_items + 63) / 64), dim3(64), 0, sh, d_tbs, d_tbs_off, n_items, c->mid.as<uint32_t>());
     if ((hrc = hash_stream_work())) return hrc;
   }
   HIPCHK(c, join(s, 6));
@@ -1102,6 +1108,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (hipEvent_t e : c->hb_ev) (void)hipEventDestroy(e);
   if (c->hb_ev0) (void)hipEventDestroy(c->hb_ev0);
   if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
+  if (c->stream_c2) { (void)hipStreamSynchronize(c->stream_c2); (void)hipStreamDestroy(c->stream_c2); }
   rccl_release(c);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_turn) {
@@ -1263,7 +1270,7 @@ int bftkv_gpu_quorum_destroy(bftkv_gpu_ctx* c, int quorum) {
 static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                   uint8_t* verdict_out, uint8_t* fenced_out, const std::function<int(hipStream_t)>* upload_tbs, uint64_t ss_len,
-                                  hipEvent_t ev_input = nullptr, uint32_t cap = 0) {
+                                  hipEvent_t ev_input = nullptr, uint32_t cap = 0, bool mid_prelaunched = false) {
   // caller holds c->mu
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_quorum(c, quorum);
@@ -1272,7 +1279,7 @@ static int collective_verify_impl(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   QuorumHost& q = c->quorums[quorum];
   if ((rc = build_member(c, q))) return rc;
   const QuorumDev qd = quorum_dev(c, q);
-  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len, nullptr, nullptr, cap, ev_input))) return rc;
+  if ((rc = run_pipeline(c, n_items, tbs, tbs_off, ss, ss_off, nullptr, nullptr, nullptr, nullptr, upload_tbs, c->early_exit ? &qd : nullptr, ss_len, nullptr, nullptr, cap, ev_input, mid_prelaunched))) return rc;
   HIPCHK(c, c->o_nver.ensure(sizeof(uint32_t) * n_items));
   HIPCHK(c, c->o_verdict.ensure(n_items));
   uint32_t* nv = nver_out ? nver_out : c->o_nver.as<uint32_t>();
@@ -1377,6 +1384,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
     static const bool prio = !getenv("BFTKV_HB_COPY_NO_PRIORITY");
     if (!prio || hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, hi_p) != hipSuccess) { c->stream_c = nullptr; HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking)); }
+    if (!prio || hipStreamCreateWithPriority(&c->stream_c2, hipStreamNonBlocking, hi_p) != hipSuccess) { c->stream_c2 = nullptr; HIPCHK(c, hipStreamCreateWithFlags(&c->stream_c2, hipStreamNonBlocking)); }
   }
   while (c->hb_ev.size() < 2 * (size_t)P + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->hb_ev.push_back(e); }
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
@@ -1465,19 +1473,27 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
         }
       });
   } else {
-    copiers.emplace_back([&] {
-      (void)hipSetDevice(c->device);
-      for (const HbCopy& cp : plan) {
-        hipError_t e = hipSuccess;
-        if (!dead.load()) {
-          if (cp.len) e = hipMemcpyAsync(cp.dst, cp.src, cp.len, hipMemcpyHostToDevice, c->stream_c);
-          if (e == hipSuccess) e = hipEventRecord(c->hb_ev[2 * cp.piece + cp.half], c->stream_c);
-          if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
+    // Two helper threads take the ranges of the plan alternately, each on its own stream: a copy from pageable memory returns
+    // when it is done, so one thread alone leaves the link idle between two calls.  A range's event says that THIS range is on
+    // the device (the offsets went first, on stream_c: the thread of stream_c2 waits for them once).
+    static const int n_copiers = getenv("BFTKV_HB_COPIERS") ? std::max(1, std::min(2, atoi(getenv("BFTKV_HB_COPIERS")))) : 2;
+    if (n_copiers > 1) { HIPCHK(c, hipEventRecord(c->hb_ev[2 * (size_t)P], c->stream_c)); HIPCHK(c, hipStreamWaitEvent(c->stream_c2, c->hb_ev[2 * (size_t)P], 0)); }
+    for (int t = 0; t < n_copiers; ++t)
+      copiers.emplace_back([&, t] {
+        (void)hipSetDevice(c->device);
+        hipStream_t st = t == 0 ? c->stream_c : c->stream_c2;
+        for (size_t r = (size_t)t; r < plan.size(); r += (size_t)n_copiers) {
+          const HbCopy& cp = plan[r];
+          hipError_t e = hipSuccess;
+          if (!dead.load()) {
+            if (cp.len) e = hipMemcpyAsync(cp.dst, cp.src, cp.len, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(c->hb_ev[2 * cp.piece + cp.half], st);
+            if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
+          }
+          flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release);
+          tr[8 + HB_TR * cp.piece + cp.half] = us_now();
         }
-        flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release);
-        tr[8 + HB_TR * cp.piece + cp.half] = us_now();
-      }
-    });
+      });
   }
   auto wait_flag = [&](size_t i) -> int {
     for (uint32_t it = 0;; ++it) {
@@ -1488,22 +1504,55 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   };
   int first_rc = 0;
   uint32_t launched = 0;
+  // range arrived?  1 yes, 0 not yet, -1 the copy failed.  ARRIVED, not merely enqueued: a piece enqueued ahead of its input
+  // parks a barrier at the head of its streams' hardware queues, and those queues are shared -- the streams of the pieces
+  // before it, whose input is there, would wait behind it (measured: every piece then finishes at the very end).  So the
+  // host paces the pieces by the copy events.
+  auto arrived = [&](size_t i) -> int {
+    const int v = flag[i].load(std::memory_order_acquire);
+    if (v <= 0) return v;
+    const hipError_t q = hipEventQuery(c->hb_ev[i]);
+    return q == hipSuccess ? 1 : q == hipErrorNotReady ? 0 : -1;
+  };
+  // Payload midstates start when the payloads arrive (they travel AHEAD of their piece's signature streams, see the plan): a
+  // payload's hash is one chain of dependent compressions, ~0.45 ms whatever the piece's size, and would otherwise begin only
+  // when the piece is picked up and end after its modexp.
+  uint32_t next_mid = 1;
+  auto launch_early_mids = [&]() -> int {
+    while (next_mid < P) {
+      const int a = arrived(2 * (size_t)next_mid + 1);
+      if (a < 0) return -1;
+      if (a == 0) return 0;
+      bftkv_gpu_ctx* w = c->hb_workers[next_mid];
+      const uint32_t n = pc[next_mid].i1 - pc[next_mid].i0;
+      if (w->mid.ensure(sizeof(uint32_t) * 8 * N_MID32 * (size_t)n + 16) != hipSuccess) return -1;
+      hipLaunchKernelGGL(k_sha256_mid, dim3((n + 63) / 64), dim3(64), 0, w->stream_h, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[next_mid].i0, n,
+                         w->mid.as<uint32_t>());
+      tr[8 + HB_TR * next_mid + 3] = us_now();
+      ++next_mid;
+    }
+    return 0;
+  };
   for (uint32_t k = 0; k < P && !first_rc; ++k) {
     bftkv_gpu_ctx* w = c->hb_workers[k];
     const uint32_t nk = pc[k].i1 - pc[k].i0;
-    if (wait_flag(2 * k) < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", (hipError_t)copy_err.load()); break; }
-    // ... and ARRIVED, not merely enqueued: a piece enqueued ahead of its input parks a barrier at the head of its streams'
-    // hardware queues, and those queues are shared -- the streams of the pieces before it, whose input is there, would wait
-    // behind it (measured: every piece then finishes at the very end).  So the host paces the pieces by the copy events.
-    {
-      hipError_t q;
-      for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
-      if (q != hipSuccess) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy event", q); break; }
+    for (uint32_t it = 0;; ++it) {
+      int a = launch_early_mids();
+      if (a >= 0) a = arrived(2 * (size_t)k);
+      if (a < 0) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the signature streams", (hipError_t)copy_err.load()); break; }
+      if (a > 0) break;
+      if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause();
+    }
+    if (first_rc) break;
+    if (k > 0 && next_mid <= k) {      // (cannot happen with the plan's order: payloads of piece k travel before its signature streams)
+      for (uint32_t it = 0; launch_early_mids() == 0 && next_mid <= k; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
+      if (next_mid <= k) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load()); break; }
     }
     tr[8 + HB_TR * k + 2] = us_now();
     ctx_lock wl(w->mu);
     if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
     const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
+      if (k > 0) return 0;                     // arrived long ago, midstates under way
       tr[8 + HB_TR * k + 3] = us_now();
       if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load());
       hipError_t q;      // arrived (only piece 0's payloads travel behind its signature streams: see the copy plan), for the same reason
@@ -1523,7 +1572,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
                                      : (uint32_t)std::min<uint64_t>(1u << 26, ssk / 64 + 64ull * nk + 4096);
     rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[k].i0, c->in_ss.as<uint8_t>(),
                                 c->in_ss_off.as<uint64_t>() + pc[k].i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
-                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap);
+                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap, k > 0);
     ++launched;
     if (rc) { c->err = "host-buffer pipeline, piece " + std::to_string(k) + ": " + w->err; first_rc = rc; break; }
     const uint32_t i0 = pc[k].i0;
@@ -1540,6 +1589,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   tr[2] = us_now();
   // one synchronisation: every piece that was enqueued, and the copy stream (the caller's buffers must not be read after return)
   hipError_t se = hipStreamSynchronize(c->stream_c);
+  { const hipError_t e2 = hipStreamSynchronize(c->stream_c2); if (se == hipSuccess) se = e2; }
   tr[3] = us_now();
   for (uint32_t k = 0; k < launched; ++k) {
     bftkv_gpu_ctx* w = c->hb_workers[k];

@@ -937,3 +937,136 @@ def test_batcher_cert_verify_for_principals_outside_the_keyring(gpu_ctx):
     rs = S(cl.replicas[3], b"abc")
     assert gpu_ctx.signature_verify(np.frombuffer(b"abc", dtype=np.uint8), np.array([0, 3], dtype=np.uint64),
                                     np.frombuffer(rs, dtype=np.uint8), np.array([0, len(rs)], dtype=np.uint64))[0] == 0
+
+
+def test_http_wire_replay(gpu_ctx):
+    """SURVEY.md 8(f)-4, transport half: an opened-body HTTP exchange log (transport/http/http.go framing: POST /bftkv/v1/<cmd>,
+    500 + X-error on failure) replayed through bftkv_amd.wire -- transport signatures, the command's verification site, and the
+    verdict on the recorded answer -- against what the oracle says about every request."""
+    from bftkv_amd import wire
+    from corpus.keys import DRBG
+    from oracle import message as om
+    from oracle import openpgp as pgp
+    cl = cb.make_cluster(10)
+    rng = DRBG("wire")
+    for r in cl.replicas:
+        cb.build_entity(r, [o for o in cl.replicas if o is not r], rng)
+    pubring = b"".join(r.entity for r in cl.replicas) + cl.client.entity      # the node knows the client: its messages verify
+    me = cl.replicas[2].key_id
+    ents = pgp.read_entities(pubring)
+    kr = col.Keyring(ents)
+    og = W.Graph()
+    og.add_nodes([(e.id, list(e.certifiers)) for e in ents])
+    og.set_self([me])
+    oq_auth, oq_cert = W.Wot(og).choose_quorum(W.AUTH), W.Wot(og).choose_quorum(W.AUTH | W.CERT)
+    c = cb.make_write_corpus(cl, 12, keep_requests=True, mutation_rates={cb.MUT_ONE_SHORT: 0.3, cb.MUT_BAD_MPI: 0.2})
+    nrng = np.random.default_rng(3)
+
+    def msg(kp, body, tamper=None):
+        m = bytearray(cb.signed_message(kp, body, nrng.bytes(16), rng, "go"))
+        if tamper == "sig":
+            m[-5] ^= 0x40
+        if tamper == "cut":
+            m = m[:len(m) // 3]
+        return bytes(m)
+
+    def sign_req(i, bad=None):
+        x, v, t = b"sk%02d" % i, nrng.bytes(24), i + 1
+        tbs = cb.serialize_tbs(x, v, t)
+        sigdata = cb.detach_sign(cl.client, tbs + (b"x" if bad == "sig" else b""))
+        return opk.serialize(x, v, t, opk.SignaturePacket(1, 0, False, sigdata, None if bad == "nocert" else cl.client.entity))
+
+    def oracle_expect(cmd, body):
+        """(transport, site error string) as the reference's handler would reach them"""
+        r = om.read_signed_message(ents, body)
+        if r.status == om.MSG_READ_ERROR:
+            return wire.ERR_DECRYPTION_FAILED, None
+        if r.status == om.MSG_NOT_SIGNED:
+            return wire.ERR_TRANSPORT_DATA, None
+        if r.status == om.MSG_SIGNATURE_ERROR:
+            return ("unverified" if cmd == "join" else wire.ERR_INVALID_SIGNATURE), None
+        tr = "ok" if r.status == om.MSG_OK else "unverified"
+        req = r.plain
+        if cmd == "write":
+            try:
+                x, v, t, sig, ss, _ = opk.parse(req)
+            except opk.PacketError:
+                return tr, wire.ERR_MALFORMED
+            if sig is None or ss is None:
+                return tr, wire.ERR_MALFORMED
+            return tr, (None if col.collective_verify(kr, opk.tbss(req), ss, oq_auth).err is None else wire.ERR_INSUFFICIENT_SIGNATURES)
+        if cmd == "sign":
+            try:
+                x, v, t, sig, ss, _ = opk.parse(req)
+            except opk.PacketError:
+                return tr, wire.ERR_MALFORMED
+            if sig is None:
+                return tr, wire.ERR_MALFORMED
+            es = pgp.read_entities(sig.Cert or b"")
+            if not es:
+                return tr, wire.ERR_CERT_NOT_FOUND
+            if col.signature_verify_with_certificate(opk.tbs(req), sig, es[0]) is not None:
+                return tr, wire.ERR_INVALID_SIGNATURE
+            nodes = [cid for cid in es[0].certifiers if kr.get_cert_by_id(cid) is not None]
+            return tr, (None if oq_cert.is_threshold(nodes) else wire.ERR_INVALID_QUORUM_CERT)
+        return tr, None
+
+    # (path, opened request body, how the LOG answers: "truth" = what the reference would answer, or a literal (status, X-error))
+    plan = []
+    for i, req in enumerate(c.requests):
+        plan.append(("/bftkv/v1/write", msg(cl.client, req), "truth"))
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[0][:40]), "truth"))                       # malformed request inside a good message
+    plan.append(("/BFTKV/v1/Write", msg(cl.client, c.requests[1], tamper="sig"), "truth"))              # transport signature broken
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[2], tamper="cut"), "truth"))              # not a readable message
+    plan.append(("/bftkv/v1/write", msg(cl.outsiders[0], c.requests[3]), "truth"))                      # signer unknown to the keyring: nil error, goes on
+    for i, bad in enumerate([None, None, "sig", "nocert"]):
+        plan.append(("/bftkv/v1/sign", msg(cl.client, sign_req(i, bad)), "truth"))
+    plan.append(("/bftkv/v1/time", msg(cl.client, b""), "truth"))
+    plan.append(("/bftkv/v1/join", msg(cl.client, cl.client.entity, tamper="sig"), "truth"))           # join goes on despite the signature error
+    plan.append(("/bftkv/v2/write", msg(cl.client, c.requests[0]), (404, None)))
+    bad_ss = next(i for i in range(c.n_items) if c.expected_valid[i] < cl.suff)
+    good = next(i for i in range(c.n_items) if c.expected_valid[i] >= cl.suff)
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[bad_ss]), (200, None)))                   # a node that ACCEPTED an insufficient write
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[good]), (500, "bad timestamp")))          # storage-level refusal: not judged
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[bad_ss]), (500, wire.ERR_MALFORMED)))     # refused with the wrong identity
+    plan.append(("/bftkv/v1/write", msg(cl.client, c.requests[good]), None))                            # no answer in the log
+    cap = bytearray()
+    want = []
+    for k, (path, body, answer) in enumerate(plan):
+        cmd = wire.command_of(path)
+        tr, site = oracle_expect(cmd, body) if cmd else ("", None)
+        failed = tr if tr not in ("ok", "unverified", "") else site
+        chunked = k % 3 == 1
+        if chunked:
+            cap += b"POST %s HTTP/1.1\r\nHost: n\r\nTransfer-Encoding: chunked\r\n\r\n%x\r\n%s\r\n0\r\n\r\n" % (path.encode(), len(body), body)
+        else:
+            cap += b"POST %s HTTP/1.1\r\nHost: n\r\nContent-Type: application/octet-stream\r\nContent-Length: %d\r\n\r\n%s" % (path.encode(), len(body), body)
+        if answer == "truth":
+            answer = (200, None) if failed is None else (500, failed)
+            verdict = "consistent"
+        elif answer is None:
+            verdict = "no-response"
+        elif cmd is None:
+            verdict = "consistent"
+        elif failed is None:
+            verdict = "consistent" if answer[0] == 200 else "not-judged"
+        elif answer[0] == 200:
+            verdict = "accepted-but-fails-verification"
+        else:
+            verdict = "consistent" if answer[1] == failed else "wrong-error"
+        if answer is not None:
+            st, xe = answer
+            cap += b"HTTP/1.1 %d X\r\n%sContent-Length: 2\r\n\r\nok" % (st, (b"X-Error: %s\r\n" % xe.encode()) if xe else b"")
+        want.append((cmd, tr, site, verdict))
+    exs = wire.replay(gpu_ctx, bytes(cap), pubring, me)
+    assert len(exs) == len(plan)
+    for e, (cmd, tr, site, verdict) in zip(exs, want):
+        assert e.command == cmd, e.index
+        if cmd:
+            assert e.transport == tr, (e.index, e.transport, tr)
+            assert e.site_error == site, (e.index, cmd, e.site_error, site)
+        assert e.verdict == verdict, (e.index, cmd, e.verdict, verdict, e.transport, e.site_error)
+    seen = {w[3] for w in want}
+    assert seen == {"consistent", "no-response", "not-judged", "accepted-but-fails-verification", "wrong-error"}
+    assert {w[2] for w in want} >= {None, wire.ERR_MALFORMED, wire.ERR_INSUFFICIENT_SIGNATURES, wire.ERR_CERT_NOT_FOUND, wire.ERR_INVALID_SIGNATURE}
+    assert {w[1] for w in want} >= {"ok", "unverified", wire.ERR_DECRYPTION_FAILED, wire.ERR_INVALID_SIGNATURE}
