@@ -224,7 +224,7 @@ class Context:
 
     def set_host_pipeline(self, pieces: int, copy: str = "", tight: bool = False) -> None:
         """collective_verify over host buffers: 0 = split big batches by size (default), 1 = never, 2..8 = that many pieces;
-        copy = "ring" (page-locked staging ring, the default) or "direct" (hipMemcpyAsync from the caller's memory)."""
+        copy = "direct" (hipMemcpyAsync from the caller's memory, the default) or "ring" (the library's page-locked staging ring)."""
         mode = {"": 0, "ring": 0x100, "direct": 0x200}[copy]
         self._check(self.lib.bftkv_gpu_set_host_pipeline(self.h, pieces | mode | (0x400 if tight else 0)), "set_host_pipeline")
 

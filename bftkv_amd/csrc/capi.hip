@@ -226,6 +226,7 @@ Turnstile g_turnstile[16];
 // host-buffer pipeline (collective_verify_pipelined)
 constexpr uint64_t HB_PIPE_MIN_BYTES = 24ull << 20;      // below this a call is latency-, not PCIe-bound: one piece
 constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
+std::mutex g_hb_mu[16];           // per device: pipelined host-buffer calls take turns (collective_verify_pipelined)
 constexpr size_t HB_TR = 10;      // floats per piece in the timeline (bftkv_gpu_host_pipeline_trace)
 // The caller's memory is pageable.  hipMemcpyAsync from it either pins the pages in place (the runtime caches such pins: fast
 // for a buffer it has seen, ~17 GB/s for a fresh one, profiles/r04_h2d_rates_microbench.txt) and returns only when the copy is
@@ -1343,6 +1344,9 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
                                        const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                        uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces) {
   // caller holds c->mu and, on a fork, the root's key-table lock (shared)
+  // One pipelined call per device at a time: such a call is bound by the PCIe link, which concurrent callers would only share
+  // (three at once: 7.2 ms per call against 5.2 alone, their 45 streams queueing on the runtime's four hardware queues).
+  std::lock_guard<std::mutex> one_at_a_time(g_hb_mu[(unsigned)c->device & 15u]);
   const auto t_call = std::chrono::steady_clock::now();
   auto us_now = [&] { return (float)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call).count() * 1e-3f; };
   bftkv_gpu_ctx* const root = c->root ? c->root : c;
@@ -1476,7 +1480,10 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     // Two helper threads take the ranges of the plan alternately, each on its own stream: a copy from pageable memory returns
     // when it is done, so one thread alone leaves the link idle between two calls.  A range's event says that THIS range is on
     // the device (the offsets went first, on stream_c: the thread of stream_c2 waits for them once).
-    static const int n_copiers = getenv("BFTKV_HB_COPIERS") ? std::max(1, std::min(2, atoi(getenv("BFTKV_HB_COPIERS")))) : 2;
+    // (Measured, profiles/r04_host_pipeline_*: two copiers drain the link 0.2 ms sooner, but a piece's payloads and signature streams
+    // then arrive together, the midstates lose their head start and run beside the previous piece's modexp: 5.35 against 5.25 ms.
+    // One is the default.)
+    static const int n_copiers = getenv("BFTKV_HB_COPIERS") ? std::max(1, std::min(2, atoi(getenv("BFTKV_HB_COPIERS")))) : 1;
     if (n_copiers > 1) { HIPCHK(c, hipEventRecord(c->hb_ev[2 * (size_t)P], c->stream_c)); HIPCHK(c, hipStreamWaitEvent(c->stream_c2, c->hb_ev[2 * (size_t)P], 0)); }
     for (int t = 0; t < n_copiers; ++t)
       copiers.emplace_back([&, t] {

@@ -83,7 +83,7 @@ HOST_EXPORTS = [
     "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
-    "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256",
+    "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256", "bftkv_host_cert_fingerprint",
 ]
 
 _ready = False
