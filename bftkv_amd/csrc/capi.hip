@@ -1511,6 +1511,13 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   };
   int first_rc = 0;
   uint32_t launched = 0;
+  // Arenas sized by the bound cost ~700 bytes per packet event; a call of gigabytes whose bound would take a third of the free
+  // HBM sizes its pieces by their real counts instead (each piece then asks the host once in mid-pipeline, as an unsplit call does).
+  bool use_cap = true;
+  if (sl > (1ull << 30)) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (sl / 64 + 8ull * n_items) * 700ull > free_b / 3) use_cap = false;
+  }
   // range arrived?  1 yes, 0 not yet, -1 the copy failed.  ARRIVED, not merely enqueued: a piece enqueued ahead of its input
   // parks a barrier at the head of its streams' hardware queues, and those queues are shared -- the streams of the pieces
   // before it, whose input is there, would wait behind it (measured: every piece then finishes at the very end).  So the
@@ -1575,8 +1582,9 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     // is enqueued as soon as its copies are, and runs when its events fire.  A stream of junk denser than that turns the piece
     // into an empty one (k_scan_counts); it is then run again below, sized by its real count.
     const uint64_t ssk = ss_off[pc[k].i1] - ss_off[pc[k].i0];
-    const uint32_t cap = c->hb_tight ? (uint32_t)(ssk / 4096 + 1)       // (tests: a bound that real streams exceed, to exercise the second pass)
-                                     : (uint32_t)std::min<uint64_t>(1u << 26, ssk / 64 + 64ull * nk + 4096);
+    const uint32_t cap = !use_cap ? 0u
+                         : c->hb_tight ? (uint32_t)(ssk / 4096 + 1)       // (tests: a bound that real streams exceed, to exercise the second pass)
+                                       : (uint32_t)std::min<uint64_t>(1u << 26, ssk / 64 + 8ull * nk + 4096);
     rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[k].i0, c->in_ss.as<uint8_t>(),
                                 c->in_ss_off.as<uint64_t>() + pc[k].i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
                                 fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap, k > 0);
@@ -1609,8 +1617,8 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     bftkv_gpu_ctx* w = c->hb_workers[k];
     uint32_t tot[2];
     memcpy(tot, c->hb_out + o_tot + 8 * (size_t)k, 8);
-    w->last_total = tot[0]; w->last_total_on_dev = false;
-    if (!tot[1]) continue;
+    if (use_cap) { w->last_total = tot[0]; w->last_total_on_dev = false; }
+    if (!use_cap || !tot[1]) continue;
     ctx_lock wl(w->mu);
     const uint32_t nk = pc[k].i1 - pc[k].i0, i0 = pc[k].i0;
     rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + i0, c->in_ss.as<uint8_t>(),
