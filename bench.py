@@ -86,6 +86,8 @@ def parse_args(argv=None):
                     "(kernel_ms.single_flight, int_mac.single_flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving", action="store_true", help="cfg 2: skip the one-Verify-per-call leg (tools/serving/batcher_load.c)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="cfg 2: skip the host-buffer legs (profiling runs: their piece-sized launches "
+                    "would mix into the per-kernel averages of the resident step)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="after the timed region: keep running the same step, untimed for "
                     "the headline, for about this long (reported as `sustained`); an activity sampler with a period of seconds "
                     "otherwise never sees a timed region of tens of milliseconds.  0 disables")
@@ -651,7 +653,7 @@ def bench_cfg2(args, D):
             "sustained": sustained,
             "corpus_build_s": t_corpus,
         })
-        if D.world == 1:
+        if D.world == 1 and not args.no_end_to_end:
             # the same batch handed over in HOST buffers (what a cgo caller does): H2D copy + pipeline + D2H of the verdicts.
             # Reported beside the headline, never as `value` (inputs resident in HBM).  The library cuts such a batch into pieces
             # and verifies piece k while the pieces behind it cross PCIe (capi.hip collective_verify_pipelined); `unsplit` is the

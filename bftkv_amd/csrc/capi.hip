@@ -1531,7 +1531,12 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   // Payload midstates start when the payloads arrive (they travel AHEAD of their piece's signature streams, see the plan): a
   // payload's hash is one chain of dependent compressions, ~0.45 ms whatever the piece's size, and would otherwise begin only
   // when the piece is picked up and end after its modexp.
-  uint32_t next_mid = 1;
+  // MEASURED AND SWITCHED OFF (profiles/r04_host_pipeline_*): the early kernel of piece k+1 needs 142 VGPRs and finds no room
+  // beside the three modexp waves per SIMD of piece k; it then sits at the head of a hardware queue it shares with piece k's
+  // hash stream, whose digests -- and with them the piece's compare and tally -- wait behind it: +0.5..0.9 ms per piece, 5.7
+  // against 5.2 ms per call.  BFTKV_HB_EARLY_MIDS=1 turns it on (it pays together with BFTKV_HB_MODEXP_LDS_PAD, two modexp waves per SIMD).
+  static const bool early_mids = getenv("BFTKV_HB_EARLY_MIDS") && atoi(getenv("BFTKV_HB_EARLY_MIDS")) != 0;
+  uint32_t next_mid = early_mids ? 1 : P;
   auto launch_early_mids = [&]() -> int {
     while (next_mid < P) {
       const int a = arrived(2 * (size_t)next_mid + 1);
@@ -1558,7 +1563,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
       if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause();
     }
     if (first_rc) break;
-    if (k > 0 && next_mid <= k) {      // (cannot happen with the plan's order: payloads of piece k travel before its signature streams)
+    if (early_mids && k > 0 && next_mid <= k) {      // (cannot happen with the plan's order: payloads of piece k travel before its signature streams)
       for (uint32_t it = 0; launch_early_mids() == 0 && next_mid <= k; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
       if (next_mid <= k) { first_rc = fail(c, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load()); break; }
     }
@@ -1566,7 +1571,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     ctx_lock wl(w->mu);
     if ((rc = fork_refresh(w))) { first_rc = rc; break; }     // (the caller's locks already keep the root's tables still)
     const std::function<int(hipStream_t)> payload_ready = [&, k](hipStream_t sh) -> int {
-      if (k > 0) return 0;                     // arrived long ago, midstates under way
+      if (early_mids && k > 0) return 0;       // arrived long ago, midstates under way
       tr[8 + HB_TR * k + 3] = us_now();
       if (wait_flag(2 * k + 1) < 0) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: copy of the payloads", (hipError_t)copy_err.load());
       hipError_t q;      // arrived (only piece 0's payloads travel behind its signature streams: see the copy plan), for the same reason
@@ -1587,7 +1592,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
                                        : (uint32_t)std::min<uint64_t>(1u << 26, ssk / 64 + 8ull * nk + 4096);
     rc = collective_verify_impl(w, quorum, nk, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>() + pc[k].i0, c->in_ss.as<uint8_t>(),
                                 c->in_ss_off.as<uint64_t>() + pc[k].i0, w->o_err.as<uint8_t>(), nullptr, nullptr,
-                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap, k > 0);
+                                fenced_out ? w->o_fenced.as<uint8_t>() : nullptr, &payload_ready, ssk, c->hb_ev[2 * k], cap, early_mids && k > 0);
     ++launched;
     if (rc) { c->err = "host-buffer pipeline, piece " + std::to_string(k) + ": " + w->err; first_rc = rc; break; }
     const uint32_t i0 = pc[k].i0;

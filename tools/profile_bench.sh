@@ -10,7 +10,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-serving --soak-seconds 0 --corpus-cache /tmp/bftkv_corpus"
+ARGS="--config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-serving --no-end-to-end --soak-seconds 0 --corpus-cache /tmp/bftkv_corpus"
 python bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
