@@ -1668,9 +1668,26 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   return 0;
 }
 
+static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                  const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                  uint8_t* verdict_out, uint8_t* fenced_out);
+
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                 const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                 uint8_t* verdict_out, uint8_t* fenced_out) {
+  const int rc = collective_verify_host(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out);
+  if (rc && n_items) {     // fail closed on EVERY path: no byte of the caller's arrays reads as "verified" beside a non-zero return code
+    if (err_out) memset(err_out, BFTKV_ERR_INSUFFICIENT_SIGNATURES, n_items);
+    if (verdict_out) memset(verdict_out, 0, n_items);
+    if (nver_out) memset(nver_out, 0, sizeof(uint32_t) * (size_t)n_items);
+    if (fenced_out) memset(fenced_out, 0, n_items);
+  }
+  return rc;
+}
+
+static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
+                                  const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                  uint8_t* verdict_out, uint8_t* fenced_out) {
   if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
   ctx_lock lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context

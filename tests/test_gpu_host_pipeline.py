@@ -114,3 +114,31 @@ def test_pipelined_calls_from_three_threads_on_a_root_and_its_forks(gpu_ctx):
             f.close()
         gpu_ctx.set_host_pipeline(0)
         gpu_ctx.quorum_destroy(qh)
+
+
+def test_pipelined_call_fails_closed(gpu_ctx):
+    """An infrastructure error inside the pipelined path (a quorum handle that does not exist) is a return code, and no byte of
+    the caller's result arrays reads as "verified"; non-monotone offsets are refused before anything is copied."""
+    import ctypes as C
+    from bftkv_amd._native import _ptr, _u8, _u64
+    cl = cb.make_cluster(4)
+    c = cb.make_write_corpus(cl, 64, mutation_rates={})
+    gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
+    qh = gpu_ctx.quorum_create(H.abi_qcs(H.clique_quorum(cl)))
+    gpu_ctx.set_host_pipeline(4)
+    try:
+        tb, to, sb, so = _u8(c.tbss_blob), _u64(c.tbss_off), _u8(c.ss_blob), _u64(c.ss_off)
+        n = c.n_items
+        err, vd, fn = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+        nver = np.full(n, 7, dtype=np.uint32)
+        rc = gpu_ctx.lib.bftkv_gpu_collective_verify(gpu_ctx.h, qh + 1000, n, _ptr(tb), _ptr(to), _ptr(sb), _ptr(so), _ptr(err), _ptr(nver), _ptr(vd), _ptr(fn))
+        assert rc != 0 and (err != 0).all() and not vd.any() and not nver.any()
+        bad = so.copy()
+        bad[5] = bad[7]
+        rc = gpu_ctx.lib.bftkv_gpu_collective_verify(gpu_ctx.h, qh, n, _ptr(tb), _ptr(to), _ptr(sb), _ptr(bad), _ptr(err), _ptr(nver), _ptr(vd), _ptr(fn))
+        assert rc != 0
+        e2, nv2, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)          # and the context is fine afterwards
+        assert (e2 == 0).all() and (nv2 >= cl.suff).all()
+    finally:
+        gpu_ctx.set_host_pipeline(0)
+        gpu_ctx.quorum_destroy(qh)
