@@ -124,6 +124,7 @@ struct bftkv_gpu_ctx {
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
   DevBuf chunk_arena, chunk_ctr;    // linearised partial-length signature bodies (parse_one) and their counters (k_walk / k_scan_counts)
   uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
+  uint32_t multiexp_block = 0;        // experiment knob (BFTKV_MULTIEXP_BLOCK = 64): one-wave blocks for the 4-lane k_multiexp
   uint32_t multiexp_lanes = 0;        // experiment knob (BFTKV_MULTIEXP_LANES = 4 | 8): lanes per number in k_multiexp, 0 = by call size
   uint32_t dsa_inv_mode = 0;          // experiment knob (BFTKV_DSA_INV = single | batched): 1 / 2, 0 = by batch shape
   uint32_t n_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -613,7 +614,8 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     for (uint32_t it = 0;; ++it) {
       const uint32_t v = __atomic_load_n(&c->h_mail[3], __ATOMIC_ACQUIRE);
       if (v) { other_hashes = (v & 1u) != 0; break; }
-      if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(300)) break;
+      // (the parse and the plan of a big batch take milliseconds themselves: ~0.1 ns per packet each, more beside a neighbour's modexp)
+      if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(300) + std::chrono::nanoseconds((uint64_t)total / 2)) break;
       __builtin_ia32_pause();
     }
   }
@@ -1055,6 +1057,7 @@ int bftkv_gpu_init(int device_ordinal, bftkv_gpu_ctx** out) {
   if (const char* e = getenv("BFTKV_MODEXP_LDS_PAD")) c->modexp_lds_pad = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_PARTS")) c->multiexp_parts = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_MULTIEXP_LANES")) c->multiexp_lanes = (uint32_t)atoi(e);
+  if (const char* e = getenv("BFTKV_MULTIEXP_BLOCK")) c->multiexp_block = (uint32_t)atoi(e);
   if (const char* e = getenv("BFTKV_DSA_INV")) c->dsa_inv_mode = !strcmp(e, "batched") ? 2u : !strcmp(e, "single") ? 1u : 0u;
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus; }
   *out = c;

@@ -233,12 +233,14 @@ constexpr int MULTIEXP_WIN = 4, MULTIEXP_ENT = 15;
 // either way; the 8-lane form reads zeros past them and stores nothing there (every value is below 2p < 2^2049).
 constexpr int MULTI_L8 = 10, MULTI_TPI8 = 8;
 constexpr int MONT_N_WIDE = MULTI_L8 * MULTI_TPI8;     // 80 limbs: row length of ModTab::r2w_limbs
-template <int L, int TPI>
-__global__ void __launch_bounds__(RSA_BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
+// BLOCK: the kernel's waves never meet (wavefront fences only), so the block size only decides in what units the dispatcher hands
+// waves to CUs: one-wave blocks go wherever a SIMD has room, four-wave blocks need room on all four SIMDs of one CU.
+template <int L, int TPI, int BLOCK = RSA_BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_multiexp(uint32_t n_ops, uint32_t k_bases, const uint32_t* __restrict__ base_limbs /*[n_ops][k][76]*/,
                                                         const uint32_t* __restrict__ exp_limbs /*[n_ops][k][76] radix 2^28*/,
                                                         const uint32_t* __restrict__ mod_idx, ModTab mt, uint32_t* __restrict__ scratch /*[n_ops][k][15][76]*/,
                                                         uint32_t* __restrict__ out_limbs, uint32_t idx_div, uint32_t exp_windows) {
-  constexpr int NL = L * TPI, GROUPS = RSA_BLOCK / TPI;
+  constexpr int NL = L * TPI, GROUPS = BLOCK / TPI;
   static_assert(NL >= MONT_N, "a group holds a whole row");
   __shared__ uint32_t a_sh[GROUPS * NL];
   const uint32_t grp = threadIdx.x / TPI;
