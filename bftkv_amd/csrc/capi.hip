@@ -640,6 +640,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   auto launch_dsa = [&](const uint32_t* start) {
     hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
+    static const bool dsa_dma = getenv("BFTKV_DSA_DMA") && atoi(getenv("BFTKV_DSA_DMA")) != 0;      // A/B: table rows by LDS-DMA
+    if (dsa_dma)
+      hipLaunchKernelGGL(k_dsa_modexp_dma, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
+    else
     hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
                        c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
   };
