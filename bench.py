@@ -687,12 +687,16 @@ def bench_cfg2(args, D):
             import threading
             t3 = {}
 
+            n_callers = min(3, V.n_ctx)
+            gate = threading.Barrier(n_callers)
+
             def caller(k):
-                host_call(V.ctxs[k], 1)
+                host_call(V.ctxs[k], 2)          # this context's workers and arenas are allocated at its first pipelined call
+                gate.wait()                      # ... every caller's, before anybody's clock starts
                 t0 = time.perf_counter()
                 host_call(V.ctxs[k], 4)
                 t3[k] = (t0, time.perf_counter())
-            ths = [threading.Thread(target=caller, args=(k,)) for k in range(min(3, V.n_ctx))]
+            ths = [threading.Thread(target=caller, args=(k,)) for k in range(n_callers)]
             for t in ths:
                 t.start()
             for t in ths:
