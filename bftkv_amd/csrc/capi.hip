@@ -1352,9 +1352,11 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
                                        const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
                                        uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces) {
   // caller holds c->mu and, on a fork, the root's key-table lock (shared)
-  // One pipelined call per device at a time: such a call is bound by the PCIe link, which concurrent callers would only share
-  // (three at once: 7.2 ms per call against 5.2 alone, their 45 streams queueing on the runtime's four hardware queues).
-  std::lock_guard<std::mutex> one_at_a_time(g_hb_mu[(unsigned)c->device & 15u]);
+  // One pipelined call per device COPIES at a time: such a call is bound by the PCIe link, which concurrent callers would only
+  // share (three at once: 7.2 ms per call against 5.2 alone, their 45 streams queueing on the runtime's four hardware queues).
+  // The turn ends when this call's last byte is on its way (copiers joined): the next caller's first pieces cross the link
+  // while this call's last piece is still being verified.
+  std::unique_lock<std::mutex> link_turn(g_hb_mu[(unsigned)c->device & 15u]);
   const auto t_call = std::chrono::steady_clock::now();
   auto us_now = [&] { return (float)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call).count() * 1e-3f; };
   bftkv_gpu_ctx* const root = c->root ? c->root : c;
@@ -1614,6 +1616,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   }
   if (first_rc) dead.store(true);
   for (auto& t : copiers) t.join();
+  link_turn.unlock();
   tr[2] = us_now();
   // one synchronisation: every piece that was enqueued, and the copy stream (the caller's buffers must not be read after return)
   hipError_t se = hipStreamSynchronize(c->stream_c);

@@ -19,7 +19,10 @@
 //	collective crypto.CollectiveSignature.Verify's error string, ss.Completed, len(verified)   crypto_pgp.go:485-500
 //	predicates IsQuorum / IsThreshold / IsSufficient / Reject over the verified list           quorum/wotqs/wotqs.go:144-185
 //
-// and per cluster the cliques ChooseQuorum(AUTH) built from the certified ring (f, min, threshold, suff, node ids).
+// and per cluster the cliques ChooseQuorum(AUTH) built from the certified ring (f, min, threshold, suff, node ids);
+// per entry of "packets" what packet.TBS / packet.TBSS return (packet/packet.go:142-190, whose seek2tbs ignores its read and
+// seek errors); per entry of "certs" the primary key ids crypto.Certificate.Parse returns (openpgp.ReadEntity until it fails:
+// self-signatures and subkey bindings verified, crypto_pgp.go:236-249).
 //
 // Not compiled in the bftkv_amd repository.  Written against the reference at go.mod:8.
 package main
@@ -71,6 +74,8 @@ type inputs struct {
 	Streams  []item            `json:"streams"`
 	Gpg      []item            `json:"gpg"`
 	Rings    map[string]string `json:"rings"`
+	Packets  []string          `json:"packets"` // byte strings for packet.TBS / packet.TBSS (well-formed, truncated, absurd lengths)
+	Certs    []string          `json:"certs"`   // certificate blobs for crypto.Certificate.Parse (openpgp.ReadEntity until it fails)
 }
 
 type cliqueOut struct {
@@ -97,6 +102,19 @@ type clusterOut struct {
 	Items   []itemOut   `json:"items"`
 }
 
+// packet.TBS / packet.TBSS of one byte string (packet/packet.go:142-190): the prefix returned, or the error's text
+type packetOut struct {
+	Tbs     string `json:"tbs"`
+	TbsErr  string `json:"tbs_err,omitempty"`
+	Tbss    string `json:"tbss"`
+	TbssErr string `json:"tbss_err,omitempty"`
+}
+
+// crypto.Certificate.Parse of one blob (crypto_pgp.go:236-249): the primary key ids of the entities it returned
+type certOut struct {
+	Ids []string `json:"ids"`
+}
+
 type outputs struct {
 	Format   int          `json:"format"`
 	XCrypto  string       `json:"x_crypto"`
@@ -106,6 +124,8 @@ type outputs struct {
 	Clusters []clusterOut `json:"clusters"`
 	Streams  []itemOut    `json:"streams"`
 	Gpg      []itemOut    `json:"gpg"`
+	Packets  []packetOut  `json:"packets"`
+	Certs    []certOut    `json:"certs"`
 }
 
 func unhex(s string) []byte {
@@ -299,6 +319,39 @@ func main() {
 		}
 		o := runItem(r.crypt, r.ring, nil, unhex(it.Tbs), unhex(it.Sig))
 		res.Gpg = append(res.Gpg, o)
+	}
+	// seek2tbs ignores the errors of binary.Read and Seek; an absurd length makes TBS allocate `offset` bytes and may panic
+	guarded := func(f func([]byte) ([]byte, error), b []byte) (out []byte, err error) {
+		defer func() {
+			if r := recover(); r != nil {
+				out, err = nil, fmt.Errorf("panic: %v", r)
+			}
+		}()
+		return f(b)
+	}
+	for _, p := range inp.Packets {
+		b := unhex(p)
+		var po packetOut
+		if t, err := guarded(packet.TBS, b); err != nil {
+			po.TbsErr = err.Error()
+		} else {
+			po.Tbs = hex.EncodeToString(t)
+		}
+		if t, err := guarded(packet.TBSS, b); err != nil {
+			po.TbssErr = err.Error()
+		} else {
+			po.Tbss = hex.EncodeToString(t)
+		}
+		res.Packets = append(res.Packets, po)
+	}
+	for _, cb := range inp.Certs {
+		crypt := pgp.New()
+		nodes, _ := crypt.Certificate.Parse(unhex(cb))
+		co := certOut{Ids: []string{}}
+		for _, n := range nodes {
+			co.Ids = append(co.Ids, fmt.Sprintf("%016x", n.Id()))
+		}
+		res.Certs = append(res.Certs, co)
 	}
 	enc, err := json.MarshalIndent(res, "", " ")
 	if err != nil {

@@ -36,6 +36,51 @@ def cluster_block(n, n_items, dsa_fraction, seed_tag):
             "members": ["%016x" % r.key_id for r in cl.replicas], "items": items}, cl
 
 
+def packet_cases():
+    """Byte strings for packet.TBS / packet.TBSS: well-formed requests, every truncation class, stale and negative lengths
+    (seek2tbs, packet/packet.go:142-154, ignores the errors of binary.Read and Seek -- round 4 restated that literally)."""
+    import struct
+    import numpy as np
+    from oracle import packet as opk
+    u64 = lambda v: struct.pack(">q", int(v))
+    sig = opk.SignaturePacket(1, 0, False, b"s" * 40, b"c" * 30)
+    ss = opk.SignaturePacket(1, 0, True, b"t" * 50, None)
+    full = opk.serialize(b"variable", b"value-bytes", 9, sig, ss, b"auth")
+    cases = [full, opk.serialize(b"v"), opk.serialize(b"v", b"w", 1), opk.serialize(b"v", b"w", 1, sig), b"", b"abc",
+             u64(0) + b"abcd", u64(2) + b"ab" + b"xyz", u64(5) + b"ab", u64(-9) + u64(1) + b"v" + u64(9) + b"tail", u64(-1) + u64(1) + b"v" + u64(9),
+             u64((1 << 63) - 1) + u64(0) + u64(7) + b"!", u64(0) + u64(0) + u64(3), u64(0) + u64(0) + u64(3) + bytes(22)]
+    cases += [full[:k] for k in range(0, len(full), 7)]
+    rng = np.random.default_rng(41)
+    lens = [0, 1, 2, 5, 8, 9, 17, -1, -9, -17, 1 << 20]          # (no absurd positive lengths: TBS would allocate them)
+    for _ in range(120):
+        l1, l2 = (lens[int(rng.integers(len(lens)))] for _ in range(2))
+        body = u64(l1) + rng.bytes(int(rng.integers(0, 12))) + u64(l2) + rng.bytes(int(rng.integers(0, 12))) + u64(rng.integers(0, 1 << 62))
+        if rng.random() < 0.5:
+            body += opk.write_signature(opk.SignaturePacket(1, 0, False, rng.bytes(int(rng.integers(0, 9))), None))
+        cases.append(body[:int(rng.integers(0, len(body) + 1))])
+    return [c.hex() for c in cases]
+
+
+def cert_cases():
+    """Certificate blobs for crypto.Certificate.Parse (openpgp.ReadEntity until it fails): what bftkv_gpu_batcher_cert_verify and
+    bftkv_host_certs_verify answer for on the GPU -- valid entities, forged self-signature, forged subkey binding, several
+    entities with a bad one in the middle, a DSA principal, garbage."""
+    cl = cb.make_cluster(6, dsa_fraction=0.34)
+    rng = DRBG("reference-inputs-certs")
+    client = cl.client.entity
+    selfsig = client.index(b"\xc2", client.index(cl.client.name.encode()))
+    bad_self = bytearray(client); bad_self[selfsig + 200] ^= 1
+    sub_owner = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 84)[82], "s01 <s01@bftkv.example>")
+    sub = cb.make_keypair(cb.PK_RSA, cb.load_keys("rsa2048", 84)[83], "")
+    cb.build_entity(sub_owner, [], rng, subkey=sub)
+    bad_binding = bytearray(sub_owner.entity); bad_binding[len(bad_binding) - 25] ^= 0x20
+    dsa = next(r for r in cl.replicas if r.algo == cb.PK_DSA)
+    blobs = [client, bytes(bad_self), sub_owner.entity, bytes(bad_binding), dsa.entity, b"".join(r.entity for r in cl.replicas[:3]),
+             cl.replicas[0].entity + bytes(bad_self) + cl.replicas[1].entity, bytes(bad_self) + cl.replicas[1].entity, b"", bytes(range(200)),
+             client[:len(client) // 2]]
+    return [b.hex() for b in blobs]
+
+
 def main():
     out = {"format": 1, "clusters": [], "streams": [], "gpg": [], "rings": {}}
     for n, k, dsa, tag in ((4, 24, 0.0, "a"), (10, 16, 0.0, "b"), (7, 16, 0.4, "c")):
@@ -57,6 +102,8 @@ def main():
     out["rings"]["neg"] = neg["pubring"]
     for v in neg["vectors"]:
         out["gpg"].append({"name": "neg/" + v["name"], "ring": "neg", "tbs": neg["payload"], "sig": v["sig"]})
+    out["packets"] = packet_cases()
+    out["certs"] = cert_cases()
     path = os.path.join(HERE, "reference_inputs.json")
     json.dump(out, open(path, "w"), separators=(",", ":"))
     print("wrote %s: %d clusters, %d streams, %d gpg vectors, %d bytes" % (path, len(out["clusters"]), len(out["streams"]), len(out["gpg"]), os.path.getsize(path)))
