@@ -70,9 +70,32 @@ def inputs():
     return json.load(open(INPUTS))
 
 
+def oracle_packet(b):
+    """packet.TBS / packet.TBSS of one byte string through the oracle: (prefix or None, prefix or None)"""
+    from oracle import packet as opk
+    res = []
+    for fn in (opk.tbs, opk.tbss):
+        try:
+            res.append(fn(b))
+        except opk.PacketError:
+            res.append(None)
+    return tuple(res)
+
+
+def oracle_cert(blob):
+    """crypto.Certificate.Parse: the entities ReadEntity accepts, in order, up to the first one it refuses (crypto_pgp.go:236-249)"""
+    ids = []
+    for e in pgp.entity_checks(blob):
+        if not e["valid"]:
+            break
+        ids.append(e["primary"].key_id)
+    return ids
+
+
 @pytest.fixture(scope="module")
 def replayed(inputs):
-    out = {"clusters": [], "streams": [], "gpg": []}
+    out = {"clusters": [], "streams": [], "gpg": [], "packets": [oracle_packet(bytes.fromhex(p)) for p in inputs.get("packets", [])],
+           "certs": [oracle_cert(bytes.fromhex(c)) for c in inputs.get("certs", [])]}
     by_name = {}
     for c in inputs["clusters"]:
         ents, q = cluster_quorum(c)
@@ -106,6 +129,11 @@ def test_inputs_are_replayable_and_cover_both_outcomes(inputs, replayed):
     assert pgp.ST_PARSE_ERROR in stream_statuses and pgp.ST_NOT_SIGNATURE in stream_statuses
     good = [g["signature"] is None for g in replayed["gpg"]]
     assert sum(good) > 40 and sum(not g for g in good) > 20
+    # packets: TBS / TBSS answers of both kinds; certificates: accepted, refused at the first entity, refused in the middle
+    assert len(replayed["packets"]) > 150 and any(t is None for t, _ in replayed["packets"]) and any(t is not None and u is None for t, u in replayed["packets"])
+    assert any(u is not None for _, u in replayed["packets"])
+    n_ents = [len(c) for c in replayed["certs"]]
+    assert 0 in n_ents and 1 in n_ents and 3 in n_ents and len(n_ents) >= 10
 
 
 def _same_item(tag, ours, ref):
@@ -158,6 +186,23 @@ def test_oracle_matches_the_reference_vectors(inputs, replayed):
     assert skipped < len(ref["streams"])
     for n, (a, b) in enumerate(zip(replayed["gpg"], ref["gpg"])):
         _same_item("gpg/%s" % inputs["gpg"][n]["name"], a, b)
+    # packet.TBS / TBSS (seek2tbs ignores its errors) and Certificate.Parse (ReadEntity), when the vectors carry them
+    if "packets" in ref:
+        assert len(ref["packets"]) == len(replayed["packets"])
+        for n, (a, b) in enumerate(zip(replayed["packets"], ref["packets"])):
+            _same_packet(n, a, b)
+    if "certs" in ref:
+        assert len(ref["certs"]) == len(replayed["certs"])
+        for n, (a, b) in enumerate(zip(replayed["certs"], ref["certs"])):
+            assert ["%016x" % i for i in a] == b["ids"], ("cert", n, a, b)
+
+
+def _same_packet(tag, ours, ref):
+    for (mine, key) in ((ours[0], "tbs"), (ours[1], "tbss")):
+        if mine is None:
+            assert ref.get(key + "_err"), (tag, key, "the reference returned a prefix, the oracle an error", ref)
+        else:
+            assert not ref.get(key + "_err") and ref[key] == mine.hex(), (tag, key, ref)
 
 
 REPRESENTATIVE = {
@@ -185,6 +230,16 @@ def test_comparison_accepts_the_oracles_own_answers_and_refuses_a_flipped_one(re
     items = [i for c in replayed["clusters"] for i in c["items"]] + replayed["streams"] + replayed["gpg"]
     for n, o in enumerate(items):
         _same_item(n, o, _as_reference_would_write(o))
+    for n, pk_ in enumerate(replayed["packets"]):
+        as_ref = {"tbs": "" if pk_[0] is None else pk_[0].hex(), "tbss": "" if pk_[1] is None else pk_[1].hex()}
+        if pk_[0] is None:
+            as_ref["tbs_err"] = "unexpected EOF"
+        if pk_[1] is None:
+            as_ref["tbss_err"] = "EOF"
+        _same_packet(n, pk_, as_ref)
+        if pk_[0] is not None:
+            with pytest.raises(AssertionError):
+                _same_packet(n, pk_, dict(as_ref, tbs=(pk_[0] + b"x").hex()))
     o = next(i for i in items if i.get("collective", 1) is None and len(i["calls"]) > 2)
     for tamper in ("calls", "collective", "n_verified", "signature"):
         ref = _as_reference_would_write(o)
