@@ -1,7 +1,8 @@
 """Differential fuzz of Signature.parse on the GPU box: valid quorum signatures with 1-3 bytes of the signature header /
 subpacket areas (the first 64 bytes of the packet body -- what the parse kernel reads through its LDS window -- and the MPI
 length fields) overwritten at random, several packets per item, GPU per-packet statuses and verdicts against the Python oracle.
-Items the library fences are skipped (it makes no claim for them).  usage: python tools/fuzz_bodies.py [rounds=20] [seed=1]"""
+Items the library fences are skipped (it makes no claim for them).  usage: python tools/fuzz_bodies.py [rounds=20] [seed=1]
+BFTKV_FUZZ_PIECES=N runs the same through the pipelined host-buffer path (N pieces on worker contexts)."""
 import os
 import sys
 
@@ -20,6 +21,8 @@ from oracle.packet import SignaturePacket
 
 def main(rounds, seed):
     ctx = Context(0)
+    if os.environ.get("BFTKV_FUZZ_PIECES"):          # the pipelined host-buffer path: that many pieces, bound-sized arenas
+        ctx.set_host_pipeline(int(os.environ["BFTKV_FUZZ_PIECES"]))
     cl = cb.make_cluster(7, dsa_fraction=0.3)
     kr = H.oracle_keyring(cl)
     ctx.keyring_set(H.abi_keys(kr))
