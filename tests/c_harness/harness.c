@@ -110,6 +110,27 @@ int main(int argc, char** argv) {
     uint8_t e_bad = 0, f_bad = 0;
     int rc_bad = bftkv_gpu_batcher_collective_verify(b, qh + 77, fx_tbss, fx_tbss_off[1], fx_ss, fx_ss_off[1], &e_bad, &f_bad);
     printf("gpu_fail_closed=%d,%u\n", rc_bad < 0, (unsigned)e_bad);
+    /* the same batch cut into pieces verified while the rest crosses PCIe (bftkv_gpu_set_host_pipeline): same answers */
+    uint8_t perr[FX_N_WRITES], pverdict[FX_N_WRITES], pfenced[FX_N_WRITES];
+    uint32_t pnver[FX_N_WRITES];
+    rc = bftkv_gpu_set_host_pipeline(ctx, 3);
+    rc |= bftkv_gpu_collective_verify(ctx, qh, FX_N_WRITES, fx_tbss, fx_tbss_off, fx_ss, fx_ss_off, perr, pnver, pverdict, pfenced);
+    rc |= bftkv_gpu_set_host_pipeline(ctx, 0);
+    printf("gpu_pipelined=%d,%d\n", rc, memcmp(perr, err, sizeof err) == 0 && memcmp(pnver, nver, sizeof nver) == 0 &&
+                                          memcmp(pverdict, verdict, sizeof verdict) == 0 && memcmp(pfenced, fenced, sizeof fenced) == 0);
+    /* Signature.Issuer + VerifyWithCertificate for a principal that is not in the keyring: its certificate travels with the
+     * request (server.go:199-207); then the same certificate with a forged self-signature (ReadEntity refuses it: no issuer) */
+    uint8_t cerr = 0xEE, cfen = 0xEE, fp[20];
+    uint64_t iid = 0;
+    rc = bftkv_gpu_batcher_cert_verify(b, fx_client_cert, sizeof fx_client_cert, fx_client_tbs, sizeof fx_client_tbs, fx_client_sig,
+                                       sizeof fx_client_sig, &cerr, &cfen, &iid, fp);
+    printf("gpu_cert_verify=%d,%u,%u,%d\n", rc, (unsigned)cerr, (unsigned)cfen, iid == FX_CLIENT_KEY_ID);
+    rc = bftkv_gpu_batcher_cert_verify(b, fx_client_cert_forged, sizeof fx_client_cert_forged, fx_client_tbs, sizeof fx_client_tbs,
+                                       fx_client_sig, sizeof fx_client_sig, &cerr, &cfen, &iid, fp);
+    printf("gpu_cert_verify_forged=%d,%u,%u\n", rc, (unsigned)cerr, (unsigned)cfen);
+    rc = bftkv_gpu_batcher_cert_verify(b, fx_client_cert, sizeof fx_client_cert, fx_client_tbs, sizeof fx_client_tbs - 1, fx_client_sig,
+                                       sizeof fx_client_sig, &cerr, &cfen, &iid, fp);
+    printf("gpu_cert_verify_other_bytes=%d,%u,%u\n", rc, (unsigned)cerr, (unsigned)cfen);
     bftkv_gpu_batcher_destroy(b);
     bftkv_gpu_quorum_destroy(ctx, qh);
   }

@@ -54,6 +54,10 @@ def test_c_caller_verifies_on_the_gpu(tmp_path):
     assert out["gpu_batcher_rc"] == "0" and [int(v) for v in out["gpu_batcher_err"].split(",")] == err
     assert out["gpu_signature_verify"] == "0,0,0"
     assert out["gpu_fail_closed"] == "1,2"
+    assert out["gpu_pipelined"] == "0,1"                      # three pieces on worker contexts: byte for byte the unsplit answers
+    assert out["gpu_cert_verify"] == "0,0,0,1"                # a stranger's certificate out of the request: issuer found, signature good
+    assert out["gpu_cert_verify_forged"] == "0,3,0"           # BFTKV_ERR_CERTIFICATE_NOT_FOUND: ReadEntity would refuse it
+    assert out["gpu_cert_verify_other_bytes"] == "0,1,0"      # crypto.ErrInvalidSignature
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")
