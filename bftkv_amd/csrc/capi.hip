@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
+#include <system_error>
 #include <thread>
 #include <string>
 #include <vector>
@@ -1439,6 +1440,13 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   tr.assign(8 + HB_TR * (size_t)P, 0.f);
   tr[0] = (float)P; tr[1] = use_ring ? 1.f : 0.f;
   std::vector<std::thread> copiers;
+  bool spawn_failed = false;
+  // (a thread the system refuses must end the call with an error, not the process: the copiers' loops are written so that the
+  // ones that did start finish by themselves once `dead` is set)
+  auto try_spawn = [&](std::vector<std::thread>& v, auto&& fn) {
+    if (spawn_failed) return;
+    try { v.emplace_back(std::forward<decltype(fn)>(fn)); } catch (const std::system_error&) { spawn_failed = true; }
+  };
   std::atomic<uint64_t> ticket{0};          // ring: the next chunk that may be enqueued
   std::atomic<bool> dead{false};
   // chunks of the plan, numbered in order
@@ -1461,7 +1469,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     }
     const int nth = (int)std::min<size_t>(HbRing::THREADS, chunks.size());
     for (int t = 0; t < nth; ++t)
-      copiers.emplace_back([&, t, nth] {
+      try_spawn(copiers, [&, t, nth] {
         (void)hipSetDevice(c->device);
         HbRing& R = *(HbRing*)c->hb_ring;
         for (uint64_t i = (uint64_t)t; i < chunks.size(); i += (uint64_t)nth) {
@@ -1475,7 +1483,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
             e = hipEventSynchronize(R.ev[slot]);
           }
           if (e == hipSuccess && !dead.load() && ch.len) memcpy(R.base + (size_t)slot * HbRing::SLOT, cp.src + ch.off, ch.len);
-          while (ticket.load(std::memory_order_acquire) != i) { if ((i & 7) == 7) std::this_thread::yield(); else __builtin_ia32_pause(); }
+          while (ticket.load(std::memory_order_acquire) != i && !dead.load()) { if ((i & 7) == 7) std::this_thread::yield(); else __builtin_ia32_pause(); }
           if (e == hipSuccess && !dead.load()) {
             if (ch.len) e = hipMemcpyAsync(cp.dst + ch.off, R.base + (size_t)slot * HbRing::SLOT, ch.len, hipMemcpyHostToDevice, c->stream_c);
             if (e == hipSuccess) e = hipEventRecord(R.ev[slot], c->stream_c);
@@ -1483,7 +1491,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
           }
           if (e != hipSuccess) { copy_err.store((int)e); dead.store(true); }
           if (ch.last) { flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release); tr[8 + HB_TR * cp.piece + cp.half] = us_now(); }
-          ticket.store(i + 1, std::memory_order_release);
+          if (!dead.load()) ticket.store(i + 1, std::memory_order_release);
         }
       });
   } else {
@@ -1496,7 +1504,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     static const int n_copiers = getenv("BFTKV_HB_COPIERS") ? std::max(1, std::min(2, atoi(getenv("BFTKV_HB_COPIERS")))) : 1;
     if (n_copiers > 1) { HIPCHK(c, hipEventRecord(c->hb_ev[2 * (size_t)P], c->stream_c)); HIPCHK(c, hipStreamWaitEvent(c->stream_c2, c->hb_ev[2 * (size_t)P], 0)); }
     for (int t = 0; t < n_copiers; ++t)
-      copiers.emplace_back([&, t] {
+      try_spawn(copiers, [&, t] {
         (void)hipSetDevice(c->device);
         hipStream_t st = t == 0 ? c->stream_c : c->stream_c2;
         for (size_t r = (size_t)t; r < plan.size(); r += (size_t)n_copiers) {
@@ -1511,6 +1519,13 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
           tr[8 + HB_TR * cp.piece + cp.half] = us_now();
         }
       });
+  }
+  if (spawn_failed) {
+    dead.store(true);        // (the copiers that did start leave their ticket waits on it)
+    for (auto& f : flag) f.store(-1, std::memory_order_release);
+    for (auto& t : copiers) t.join();
+    (void)hipStreamSynchronize(c->stream_c);
+    return fail(c, BFTKV_E_NOMEM, "host-buffer pipeline: cannot start a copier thread");
   }
   auto wait_flag = [&](size_t i) -> int {
     for (uint32_t it = 0;; ++it) {
