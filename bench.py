@@ -1206,8 +1206,8 @@ def other_configs(args, D):
     import copy
     res = {}
     # (timed regions long enough that the fill and drain of the steps in flight do not show: cfg 5's 10 steps read 9.0 ms where 40 read 7.6)
-    plan = [(1, bench_cfg1, {}), (3, bench_cfg3, {"steps": 20, "warmup": 3}), (4, bench_cfg4, {"steps": 2, "warmup": 1}),
-            (5, bench_cfg5, {"steps": 40, "warmup": 4})]
+    plan = [(1, bench_cfg1, {}), (5, bench_cfg5, {"steps": 40, "warmup": 4}), (3, bench_cfg3, {"steps": 20, "warmup": 3}),
+            (4, bench_cfg4, {"steps": 2, "warmup": 1})]
     for cfg, fn, over in plan:
         a = copy.copy(args)
         a.config, a.items, a.replicas, a.soak_seconds, a.no_serving = cfg, 0, 0, 0.0, True
