@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4|5]
 
-  --config 2 (default)  configs[1]: 64-replica quorum, 10k RSA-2048 signed writes per GPU, batched verify
+  (no --config)         cfg 2 as the headline `value`; on one GPU also `other_configs`: cfg 1 / 5 / 3 / 4, each as
+                        `python bench.py --config N` in a process of its own (shorter timed regions), summarised into the ONE line
+  --config 1            configs[0]: 4-replica clique, 100 RSA-2048 signed writes on the CPU path (the C restatement; plumbing, no GPU number)
+  --config 2            configs[1]: 64-replica quorum, 10k RSA-2048 signed writes per GPU, batched verify; beside the resident
+                        headline: `end_to_end` (the same batch handed over in pageable host memory: pipelined copy + verify, alone and
+                        from three callers at once), `serving` (one Verify per call through the micro-batcher), `cpu_baseline`
   --config 3            configs[2]: 64-replica quorum (half DSA-2048/256), 100k signed read replies over 10k variables,
                         reply verdicts on the GPU -> maxTimestampedValue per variable (protocol/client.go:181-205)
   --config 4            configs[3]: 256 replicas, 1M-write storm sharded over the ranks (strong scaling), RCCL all-gather
