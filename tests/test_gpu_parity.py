@@ -1479,3 +1479,39 @@ def test_dsa_batched_inversion_gives_the_per_signature_rows():
     for i in range(0, 700, 23):
         r = col.collective_verify(kr, tbs_l[i], SignaturePacket(1, 0, False, ss_l[i] or None, None), q)
         assert list(st[st_item == i])[:len(r.statuses)] == r.statuses and (err[i] == 0) == (r.err is None), i
+
+
+def test_big_batch_with_other_hashes_still_runs_their_digests(gpu_ctx):
+    """The host skips the k_digest_other launch of a big batch when k_plan reports (mailbox) that no signature names another hash
+    than SHA-256.  Here a batch above that size threshold DOES carry SHA-1 / 224 / 384 / 512 signatures (the gpg fixtures of group
+    A, RSA and DSA signers, tiled to 100,020 one-packet items): every item must get the verdict its vector gets in a small call."""
+    import json
+    import os
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_vectors.json")))
+    ring = pgp.read_entities(bytes.fromhex(vec["A_pubring"]))
+    kr = col.Keyring(keyring=ring)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    qh = gpu_ctx.quorum_create([(0, 1, 1, 1, [e.id for e in ring])])          # one verified signer suffices
+    tbs_l = [bytes.fromhex(v["payload"]) for v in vec["A"]]
+    sig_l = [bytes.fromhex(v["sig"]) for v in vec["A"]]
+    assert {v["digest"] for v in vec["A"]} >= {"SHA1", "SHA256", "SHA512"}
+    tb, to = _cat(tbs_l)
+    sb, so = _cat(sig_l)
+    err0, nver0, _ = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    from oracle.packet import SignaturePacket
+    want = [col.signature_verify(kr, t, SignaturePacket(1, 0, False, s_, None)) is None for t, s_ in zip(tbs_l, sig_l)]
+    assert [bool(e == 0) for e in err0] == want and sum(want) >= 25
+    T = 3334
+    tbT, toT = _cat(tbs_l * T)
+    sbT, soT = _cat(sig_l * T)
+    gpu_ctx.set_host_pipeline(1)          # one resident-sized call: 100,020 packets, above the turnstile / mailbox threshold
+    try:
+        err, nver, _ = gpu_ctx.collective_verify(qh, tbT, toT, sbT, soT)
+    finally:
+        gpu_ctx.set_host_pipeline(0)
+    assert len(err) == 30 * T and (err.reshape(T, 30) == err0[None, :]).all() and (nver.reshape(T, 30) == nver0[None, :]).all()
+    err2, _, _ = gpu_ctx.collective_verify(qh, tbT, toT, sbT, soT)            # and cut into pieces by the size rule
+    assert (err2 == err).all()
+    gpu_ctx.quorum_destroy(qh)
