@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=2500, help="cfg 4: distinctly signed writes the resident batch is tiled from")
     ap.add_argument("--chunk", type=int, default=125000, help="cfg 4: writes per verifier call (the resident batch)")
     ap.add_argument("--inflight", type=int, default=None, help="batches (steps) in flight per GPU, each on its own context; default 3 "
-                    "(cfg 2, 3), 4 (cfg 5: its CalculateR is a latency-bound chain that leaves most issue slots of one step empty), "
+                    "(cfg 2, 3), 16 (cfg 5 with its 16 hardware queues: its CalculateR is a chain that leaves most issue slots of one step empty; 4 with the runtime's default 4 queues), "
                     "cfg 4 always runs one call at a time.  cfg 2: batches in flight per GPU, each on its own verifier context "
                     "(its own arena and streams).  With more than one, walk/parse and compare/tally/exchange of one step run under "
                     "the modexp of a neighbour -- what a fed verifier does; the machine-filling modexps themselves take turns "
@@ -100,9 +100,17 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, sharding and exchange step only (no GPU, no number)")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 200 if (args.config in (None, 2) and not args.dry_run) else 10
+        args.steps = 200 if (args.config in (None, 2) and not args.dry_run) else 64 if args.config == 5 else 10
+    if args.config == 5 and not args.dry_run:
+        # Steps of cfg 5 are chains on too few waves to fill the chip: what buys throughput is MANY steps in
+        # flight, each on its own context, and their streams on hardware queues of their own.  The HIP runtime multiplexes all streams
+        # onto GPU_MAX_HW_QUEUES queues (4 by default; read when the runtime starts, so it is set here, before torch / HIP are
+        # loaded).  Measured (tools/gpu_r4z.sh): 4 queues x 4 steps in flight 7.6 ms per step, 16 x 8: 6.2, 16 x 12: 5.8, 16 x 16:
+        # 5.7 (24 or 32 queues are worse: a context's three streams then collide differently).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.inflight is None:
-        args.inflight = 4 if args.config == 5 else 3
+        many = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 16
+        args.inflight = (16 if many else 4) if args.config == 5 else 3
     return args
 
 
@@ -1212,8 +1220,8 @@ def other_configs(args, D):
     the runtime's hardware queues differently -- and 7.6 alone), and because a failure or a hang of one config is then recorded
     in its entry and can never take the headline down."""
     res = {}
-    # (timed regions long enough that the fill and drain of the steps in flight do not show: cfg 5's 10 steps read 9.0 ms where 40 read 7.6)
-    plan = [(1, []), (5, ["--steps", "40", "--warmup", "4"]), (3, ["--steps", "20", "--warmup", "3"]), (4, ["--steps", "2", "--warmup", "1"])]
+    # (timed regions long enough that the fill and drain of the steps in flight do not show: cfg 5 keeps 16 steps in flight)
+    plan = [(1, []), (5, ["--steps", "64", "--warmup", "16"]), (3, ["--steps", "20", "--warmup", "3"]), (4, ["--steps", "2", "--warmup", "1"])]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
