@@ -52,28 +52,29 @@ func (m *Message) openContainer(raw []byte) ([]byte, error) {
 		case *pgppacket.EncryptedKey:
 			pubKeys = append(pubKeys, p)
 		case *pgppacket.SymmetricallyEncrypted:
+			// candidates as ReadMessage collects them: EntityList.KeysById (primary keys and subkeys under the id the
+			// session key was encrypted to); only the node's own entities hold private keys
+			secring := m.keyring.privateKeys()
 			for _, ek := range pubKeys {
-				for _, e := range m.keyring.privateKeys() {
-					for _, k := range e.DecryptionKeys() {
-						if k.PublicKey.KeyId != ek.KeyId || k.PrivateKey == nil || k.PrivateKey.Encrypted {
-							continue
-						}
-						if err := ek.Decrypt(k.PrivateKey, nil); err != nil {
-							continue
-						}
-						rc, err := p.Decrypt(ek.CipherFunc, ek.Key)
-						if err != nil {
-							continue
-						}
-						seq, err := ioutil.ReadAll(rc)
-						if err != nil {
-							return nil, err
-						}
-						if err := rc.Close(); err != nil { // MDC
-							return nil, err
-						}
-						return seq, nil
+				for _, k := range secring.KeysById(ek.KeyId) {
+					if k.PrivateKey == nil || k.PrivateKey.Encrypted {
+						continue
 					}
+					if err := ek.Decrypt(k.PrivateKey, nil); err != nil {
+						continue
+					}
+					rc, err := p.Decrypt(ek.CipherFunc, ek.Key)
+					if err != nil {
+						continue
+					}
+					seq, err := ioutil.ReadAll(rc)
+					if err != nil {
+						return nil, err
+					}
+					if err := rc.Close(); err != nil { // MDC
+						return nil, err
+					}
+					return seq, nil
 				}
 			}
 			return nil, pgperrors.ErrKeyIncorrect
