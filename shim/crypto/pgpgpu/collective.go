@@ -22,13 +22,16 @@ type CollectiveSignature struct {
 // Verify replaces PGPCollectiveSignature.Verify (crypto_pgp.go:485-500); call sites protocol/server.go:182,237,300,473,
 // protocol/client.go:165,470, api/api.go:130.
 func (cs *CollectiveSignature) Verify(tbs []byte, ss *packet.SignaturePacket, q quorum.Quorum) error {
-	h, err := cs.g.quorumHandle(q)
-	if err != nil || !cs.keyring.fresh() {
-		// a quorum this package cannot describe, or a device table not known to equal the keyring: the reference decides
-		return cs.inner.Verify(tbs, ss, q)
+	if !cs.keyring.fresh() {
+		return cs.inner.Verify(tbs, ss, q) // a device table not known to equal the keyring: the reference decides
+	}
+	qe, err := cs.g.quorumAcquire(q)
+	if err != nil {
+		return cs.inner.Verify(tbs, ss, q) // a quorum this package cannot describe: the reference decides
 	}
 	var e, fenced C.uint8_t
-	rc := C.bftkv_gpu_batcher_collective_verify(cs.g.batcher, h, ptr(tbs), C.uint64_t(len(tbs)), ptr(ss.Data), C.uint64_t(len(ss.Data)), &e, &fenced)
+	rc := C.bftkv_gpu_batcher_collective_verify(cs.g.batcher, qe.h, ptr(tbs), C.uint64_t(len(tbs)), ptr(ss.Data), C.uint64_t(len(ss.Data)), &e, &fenced)
+	cs.g.quorumRelease(qe)
 	if rc != 0 {
 		// infrastructure error: never a verdict.  (The status byte is a failure too -- the library fails closed.)
 		return cs.g.infra(rc, "collective_verify")

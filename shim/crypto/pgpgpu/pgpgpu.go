@@ -36,7 +36,7 @@ type gpu struct {
 	batcher *C.bftkv_gpu_batcher
 
 	qmu    sync.Mutex
-	quorum map[string]C.int // quorum descriptor -> handle, see quorum.go
+	quorum map[string]*qentry // quorum descriptor -> handle, see quorum.go
 	qorder []string
 }
 
@@ -45,7 +45,7 @@ var errNoDevice = errors.New("pgpgpu: no usable MI355X (bftkv_gpu_init failed); 
 // New mirrors pgp.New() (crypto/pgp/crypto_pgp.go:583-593).
 func New(device int) *crypto.Crypto {
 	c := pgp.New()
-	g := &gpu{quorum: make(map[string]C.int)}
+	g := &gpu{quorum: make(map[string]*qentry)}
 	if rc := C.bftkv_gpu_init(C.int(device), &g.ctx); rc != 0 {
 		panic(errNoDevice)
 	}

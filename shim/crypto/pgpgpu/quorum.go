@@ -25,12 +25,20 @@ const maxCachedQuorums = 64
 
 var errForeignQuorum = errors.New("pgpgpu: quorum.Quorum is not a wotqs quorum (no Cliques())")
 
-// quorumHandle flattens q into bftkv_gpu_qc descriptors.  ChooseQuorum builds a fresh value on every call
-// (wotqs.go:117-127), so handles are cached by content; the oldest is destroyed beyond maxCachedQuorums.
-func (g *gpu) quorumHandle(q quorum.Quorum) (C.int, error) {
+// qentry is one cached quorum handle.  refs counts the device calls that are using it right now: an entry evicted from the
+// cache while a call holds it is destroyed by the last release, never under a call in flight.
+type qentry struct {
+	h    C.int
+	refs int
+	dead bool
+}
+
+// quorumAcquire flattens q into bftkv_gpu_qc descriptors and returns its handle, held until quorumRelease.  ChooseQuorum builds a
+// fresh value on every call (wotqs.go:117-127), so handles are cached by content; the oldest is retired beyond maxCachedQuorums.
+func (g *gpu) quorumAcquire(q quorum.Quorum) (*qentry, error) {
 	cl, ok := q.(cliqueLister)
 	if !ok {
-		return -1, errForeignQuorum
+		return nil, errForeignQuorum
 	}
 	cs := cl.Cliques()
 	key := make([]byte, 0, 64)
@@ -45,8 +53,9 @@ func (g *gpu) quorumHandle(q quorum.Quorum) (C.int, error) {
 	}
 	g.qmu.Lock()
 	defer g.qmu.Unlock()
-	if h, ok := g.quorum[string(key)]; ok {
-		return h, nil
+	if e, ok := g.quorum[string(key)]; ok {
+		e.refs++
+		return e, nil
 	}
 	qcs := make([]C.bftkv_gpu_qc, len(cs))
 	var frees []unsafe.Pointer
@@ -73,15 +82,31 @@ func (g *gpu) quorumHandle(q quorum.Quorum) (C.int, error) {
 		p = &qcs[0]
 	}
 	if err := g.infra(C.bftkv_gpu_quorum_create(g.ctx, p, C.uint32_t(len(qcs)), &h), "quorum_create"); err != nil {
-		return -1, err
+		return nil, err
 	}
 	if len(g.qorder) >= maxCachedQuorums {
 		old := g.qorder[0]
 		g.qorder = g.qorder[1:]
-		C.bftkv_gpu_quorum_destroy(g.ctx, g.quorum[old])
-		delete(g.quorum, old)
+		if e := g.quorum[old]; e != nil {
+			delete(g.quorum, old)
+			e.dead = true
+			if e.refs == 0 {
+				C.bftkv_gpu_quorum_destroy(g.ctx, e.h)
+			}
+		}
 	}
-	g.quorum[string(key)] = h
+	e := &qentry{h: h, refs: 1}
+	g.quorum[string(key)] = e
 	g.qorder = append(g.qorder, string(key))
-	return h, nil
+	return e, nil
+}
+
+// quorumRelease ends a call's hold on e; the last holder of a retired entry destroys the device-side quorum.
+func (g *gpu) quorumRelease(e *qentry) {
+	g.qmu.Lock()
+	defer g.qmu.Unlock()
+	e.refs--
+	if e.dead && e.refs == 0 {
+		C.bftkv_gpu_quorum_destroy(g.ctx, e.h)
+	}
 }

@@ -1,0 +1,171 @@
+"""CPU: the Go shim against the C header it binds, statically (there is no Go toolchain in the build image, so the shim has
+never met a compiler).  Every `C.bftkv_*(...)` call in shim/**/*.go must name a function include/bftkv_gpu.h declares and pass
+as many arguments as the prototype takes; every `C.BFTKV_*` constant must be #defined there; every field the shim sets on a
+C struct must be a member of it; braces and parentheses balance; every import of a file is used in it."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "shim")
+
+
+def go_files():
+    out = []
+    for dirpath, _, files in os.walk(SHIM):
+        out += [os.path.join(dirpath, f) for f in files if f.endswith(".go")]
+    assert len(out) >= 7
+    return sorted(out)
+
+
+def strip_go(src):
+    """Go source without comments, string / rune literals (replaced by blanks) -- enough for bracket matching and name lookups."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            assert j >= 0
+            out.append("\n" * src.count("\n", i, j))
+            i = j + 2
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""')
+            i = j + 1
+        elif c == "`":
+            j = src.find("`", i + 1)
+            out.append('""' + "\n" * src.count("\n", i, j))
+            i = j + 1
+        elif c == "'":
+            j = i + 1
+            while src[j] != "'":
+                j += 2 if src[j] == "\\" else 1
+            out.append("0")
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def split_args(s):
+    """Top-level comma split of an argument list."""
+    args, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    last = "".join(cur).strip()
+    if last:
+        args.append(last)
+    return args
+
+
+def call_args(src, open_paren):
+    depth = 0
+    for j in range(open_paren, len(src)):
+        if src[j] == "(":
+            depth += 1
+        elif src[j] == ")":
+            depth -= 1
+            if depth == 0:
+                return split_args(src[open_paren + 1:j])
+    raise AssertionError("unbalanced call")
+
+
+def header():
+    h = open(os.path.join(ROOT, "include", "bftkv_gpu.h")).read()
+    h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(bftkv_gpu_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", h):
+        params = m.group(2).strip()
+        protos[m.group(1)] = 0 if params in ("", "void") else len(split_args(params))
+    consts = set(re.findall(r"#define\s+(BFTKV_[A-Z_0-9]+)\b", h))
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(bftkv_gpu_[a-z_0-9]+)\s*;", h, flags=re.S):
+        fields = set()
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if decl:
+                for part in decl.split(","):
+                    fields.add(re.sub(r"\[.*\]", "", part.strip().split()[-1].lstrip("*")))
+        structs[m.group(2)] = fields
+    return protos, consts, structs
+
+
+def test_c_calls_match_the_header():
+    protos, consts, structs = header()
+    assert len(protos) >= 40 and {"bftkv_gpu_pubkey", "bftkv_gpu_qc"} <= set(structs)
+    seen = set()
+    for path in go_files():
+        src = strip_go(open(path).read())
+        for m in re.finditer(r"\bC\.(bftkv_gpu_[a-z_0-9]+)\s*\(", src):
+            name = m.group(1)
+            assert name in protos, "%s: %s is not declared in include/bftkv_gpu.h" % (path, name)
+            got = len(call_args(src, m.end() - 1))
+            assert got == protos[name], "%s: %s called with %d arguments, the prototype takes %d" % (path, name, got, protos[name])
+            seen.add(name)
+        for name in re.findall(r"\bC\.(BFTKV_[A-Z_0-9]+)\b", src):
+            assert name in consts, "%s: C.%s is not #defined in include/bftkv_gpu.h" % (path, name)
+        for t in re.findall(r"\bC\.(bftkv_gpu_[a-z_0-9]+)\b(?!\s*\()", src):
+            assert t in structs or t in ("bftkv_gpu_ctx", "bftkv_gpu_batcher") or t in protos, (path, t)
+    # the seam of the path: every verifying call of the shim is among them
+    assert {"bftkv_gpu_init", "bftkv_gpu_keyring_set", "bftkv_gpu_quorum_create", "bftkv_gpu_quorum_destroy",
+            "bftkv_gpu_batcher_collective_verify", "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_cert_verify",
+            "bftkv_gpu_batcher_message_verify", "bftkv_gpu_signers_fenced", "bftkv_gpu_set_hash_policy"} <= seen
+
+
+def test_struct_fields_the_shim_sets_exist():
+    _, _, structs = header()
+    kr = strip_go(open(os.path.join(SHIM, "crypto", "pgpgpu", "keyring.go")).read())
+    for f in re.findall(r"\brec\.([a-z_0-9]+)", kr):
+        assert f in structs["bftkv_gpu_pubkey"], f
+    q = strip_go(open(os.path.join(SHIM, "crypto", "pgpgpu", "quorum.go")).read())
+    for f in re.findall(r"\bqcs\[i\]\.([a-z_0-9]+)", q):
+        assert f in structs["bftkv_gpu_qc"], f
+
+
+def test_go_files_are_structurally_sound():
+    for path in go_files():
+        raw = open(path).read()
+        src = strip_go(raw)
+        for a, b in ("{}", "()", "[]"):
+            assert src.count(a) == src.count(b), "%s: unbalanced %s%s" % (path, a, b)
+        assert re.search(r"^package \w+$", src, flags=re.M), path
+        # every import is used (Go refuses an unused one): the package's local name followed by a dot somewhere below
+        m = re.search(r"^import \(\n(.*?)^\)", raw, flags=re.S | re.M)
+        if not m:
+            continue
+        body = src[src.index(")", src.index("import (")):]
+        for line in m.group(1).splitlines():
+            line = line.strip()
+            if not line or line.startswith("//"):
+                continue
+            mm = re.match(r'(?:(\w+)\s+)?"([^"]+)"', line)
+            assert mm, (path, line)
+            local = mm.group(1) or mm.group(2).rsplit("/", 1)[-1]
+            assert re.search(r"\b%s\." % re.escape(local), body), "%s: import %s (%s) is never used" % (path, mm.group(2), local)
+
+
+def test_interfaces_are_fully_implemented():
+    """crypto.Signature / CollectiveSignature / Message / Keyring (crypto/crypto.go:35-70): every method has a receiver in the shim."""
+    want = {
+        "Signature": ["Verify", "VerifyWithCertificate", "Sign", "Signers", "Issuer", "Certs"],
+        "CollectiveSignature": ["Verify", "Sign", "Combine", "Signers"],
+        "Message": ["Encrypt", "EncryptStream", "Decrypt"],
+        "keyring": ["Register", "Remove", "GetCertById", "GetKeyring"],
+    }
+    src = "\n".join(strip_go(open(p).read()) for p in go_files() if os.sep + "pgpgpu" + os.sep in p)
+    for typ, methods in want.items():
+        for meth in methods:
+            assert re.search(r"func \(\w+ \*%s\) %s\(" % (typ, meth), src), (typ, meth)
