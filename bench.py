@@ -105,7 +105,7 @@ def parse_args(argv=None):
         # Steps of cfg 5 are chains on too few waves to fill the chip: what buys throughput is MANY steps in
         # flight, each on its own context, and their streams on hardware queues of their own.  The HIP runtime multiplexes all streams
         # onto GPU_MAX_HW_QUEUES queues (4 by default; read when the runtime starts, so it is set here, before torch / HIP are
-        # loaded).  Measured (tools/gpu_r4z.sh): 4 queues x 4 steps in flight 7.6 ms per step, 16 x 8: 6.2, 16 x 12: 5.8, 16 x 16:
+        # loaded).  Measured (tools/runs/r04/gpu_r4z.sh): 4 queues x 4 steps in flight 7.6 ms per step, 16 x 8: 6.2, 16 x 12: 5.8, 16 x 16:
         # 5.7 (24 or 32 queues are worse: a context's three streams then collide differently).
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.inflight is None:
