@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r", "bftkv_gpu_selftest_reduce",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
@@ -69,6 +69,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_error_string.restype = C.c_char_p
     lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
     lib.bftkv_gpu_set_dsa_window_bits.argtypes = [vp, u32]
+    lib.bftkv_gpu_dsa_window_bits.argtypes = [vp, C.POINTER(u32)]
     lib.bftkv_gpu_set_hash_policy.argtypes = [vp, C.c_int, C.c_int]
     lib.bftkv_gpu_message_verify.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
@@ -242,8 +243,14 @@ class Context:
                 "per_piece_us": [{nm: round(v[8 + 10 * k + j], 1) for j, nm in enumerate(names)} for k in range(P)]}
 
     def set_dsa_window_bits(self, bits: int) -> None:
-        """Pin the DSA fixed-base table width (4 or 8 bits; 0 = default policy); applies at the next keyring_set."""
+        """Pin the DSA fixed-base table width (4, 8, 16 .. 20 bits; 0 = default policy); applies at the next keyring_set."""
         self._check(self.lib.bftkv_gpu_set_dsa_window_bits(self.h, bits), "set_dsa_window_bits")
+
+    def dsa_window_bits(self) -> int:
+        """The width the current key table's DSA tables were built at (0: no DSA key)."""
+        b = C.c_uint32(0)
+        self._check(self.lib.bftkv_gpu_dsa_window_bits(self.h, C.byref(b)), "dsa_window_bits")
+        return int(b.value)
 
     # ---- quorum
     def quorum_create(self, qcs) -> int:

@@ -821,7 +821,7 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
     if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
     if (const char* e = getenv("BFTKV_DSA_WBITS")) {            // experiments: the width without touching the caller
       const uint32_t b = (uint32_t)atoi(e);
-      if (b == 4 || b == 8 || b == 16 || b == 18) return b;
+      if (b == 4 || b == 8 || (b >= 16 && b <= 20)) return b;
     }
     if (n_keys <= 64) {
       size_t free_b = 0, total_b = 0;
@@ -873,7 +873,8 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   const size_t need = per_key * c->dsa_comb_slot.size();
   if (need > c->dsa_comb.cap) {           // grow, keeping the tables already built
     DevBuf bigger;
-    HIPCHK(c, bigger.ensure(need + need / 2));
+    // room to grow by half -- but a pinned width beyond 18 bits (4.46 / 8.3 GB per key) only by two more keys
+    HIPCHK(c, bigger.ensure(need + (c->dsa_wbits > 18 ? std::min(need / 2, 2 * per_key) : need / 2)));
     // every whole slot the old buffer holds (new and recycled slots are built below, in place)
     const size_t keep = restart ? 0 : std::min(need, (c->dsa_comb.cap / per_key) * per_key);
     if (keep && c->dsa_comb.p) HIPCHK(c, hipMemcpyAsync(bigger.p, c->dsa_comb.p, keep, hipMemcpyDeviceToDevice, c->stream));
@@ -1191,10 +1192,22 @@ int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* c, int hash_id, int state) {
   return 0;
 }
 
+// widths the tables can be built at: the policy's four, and 17 / 19 / 20 for callers that pin them (19: 4.46 GB per key and 27
+// table multiplications, 20: 8.3 GB and 25 -- never chosen by the policy)
+static bool dsa_width_ok(uint32_t bits) { return bits == 4 || bits == 8 || (bits >= 16 && bits <= 20); }
+
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
-  if (!c || (bits != 0 && bits != 4 && bits != 8 && bits != 16 && bits != 18)) return BFTKV_E_INVALID;
+  if (!c || (bits != 0 && !dsa_width_ok(bits))) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->dsa_wbits_pinned = bits;
+  return 0;
+}
+
+int bftkv_gpu_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t* bits_out) {
+  if (!c || !bits_out) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  const bftkv_gpu_ctx* r = c->root ? c->root : c;      // (a fork verifies over its root's tables)
+  *bits_out = r->dsa_comb_slot.empty() ? 0u : r->dsa_wbits;
   return 0;
 }
 

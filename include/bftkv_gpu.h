@@ -105,8 +105,13 @@ int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* ctx, int hash_id, int state);
  * windows 637 MB and 31, 8-bit windows 4.96 MB and <= 63, 4-bit windows 0.58 MB and <= 127.  The default is the widest
  * whose tables fit the free HBM with room to spare (18 bits: 45 % of it, e.g. 32 keys = 79 GB of the part's 288 GB;
  * 16 bits: a quarter), both only up to 64 DSA keys; 8 up to 4096 keys, 4 beyond; bits = 4, 8, 16 or 18 pins the width,
- * 0 returns to the default.  Takes effect at the next bftkv_gpu_keyring_set. */
+ * 0 returns to the default.  A caller that owns the device's memory may also pin 17, 19 (4.46 GB per key, 27
+ * multiplications) or 20 (8.3 GB, 25): the policy never chooses them, and a table that does not fit fails the upload
+ * with BFTKV_E_DEVICE.  Takes effect at the next bftkv_gpu_keyring_set. */
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t bits);
+/* The width the DSA tables of the current key table were built at (0: the table holds no DSA key): a verification is
+ * 2 * ceil(256 / bits) - 1 table multiplications at most. */
+int bftkv_gpu_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t* bits_out);
 
 /* ---- transport message signatures: the signature half of PGPMessage.Decrypt (crypto/pgp/crypto_pgp.go:453-471) ----
  * Every request and reply is an OpenPGP message encrypted to the peer and signed by the sender
