@@ -36,7 +36,8 @@ class AuditRecord:
 def load_ring(ctx: Context, pubring: bytes):
     """Certificate.ParseStream + Keyring.Register + graph.AddNodes (cmd/bftkv/main.go:70-98) for a key ring blob.
     Returns the trust graph (vertices = entities, edges = certifications) after uploading the key table."""
-    ents = host.Certificate.Parse(pubring)
+    # (ReadKeyRing skips the entities ReadEntity refuses; the refusals the walk alone decides are honoured here)
+    ents = [e for e in host.Certificate.Parse(pubring) if e["keys"] and not e["refused"]]
     keys = [k for e in ents for k in e["keys"]]
     ctx.keyring_set(keys)
     g = host.Graph()

@@ -595,7 +595,9 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want) {
 __device__ __forceinline__ bool sig_class_ok(uint32_t cls, uint32_t sig_type) {
   if (cls == 0) return sig_type == 0x00;
   if (cls == 1) return sig_type >= 0x10 && sig_type <= 0x13;
-  if (cls == 2) return sig_type == 0x18;
+  if (cls == 2) return sig_type == 0x18 || sig_type == 0x28;   // VerifyKeySignature: subkey binding or revocation, over key || subkey
+  if (cls == 3) return sig_type == 0x19;                       // ... the embedded cross-signature of a signing subkey, same bytes
+  if (cls == 4) return sig_type == 0x20;                       // VerifyRevocationSignature: over the key alone
   return false;
 }
 
@@ -741,7 +743,8 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
       if (slot < 0) st = ST_UNKNOWN_ISSUER;
       // hashForSignature: binary (0x00) only for detached signatures (text 0x01: fenced).  Certificate checks
       // (sig_class[item] != 0) hash caller-prepared key||uid / key||subkey bytes and accept exactly the classes
-      // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18.
+      // openpgp.ReadEntity verifies: 1 = certification 0x10..0x13, 2 = subkey binding 0x18 / revocation 0x28, 3 = the 0x19
+      // cross-signature embedded in a signing subkey's binding, 4 = key revocation 0x20 (sig_class_ok).
       else if (!msg_slot && !sig_class_ok(cls, rec.sig_type) && !(cls == 0 && rec.sig_type == 0x01)) st = ST_HASH_UNSUPPORTED;
       else if (hi.family == 0) st = ST_HASH_UNSUPPORTED;                                          // no such hash id (parse refuses them earlier)
       // MD5 / RIPEMD-160: hashForSignature fails with "hash not available" unless the binary links them -- a property of

@@ -80,7 +80,7 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_max_timestamped_value_masked", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
-    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key",
+    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key", "bftkv_host_certs_structure", "bftkv_host_certs_check",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
     "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256", "bftkv_host_cert_fingerprint",
@@ -138,6 +138,9 @@ def _lib():
         lib.bftkv_host_certs_n_entities.restype = C.c_uint32
         lib.bftkv_host_certs_entity.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_key.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(_native.PubKey)]
+        lib.bftkv_host_certs_structure.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]
+        lib.bftkv_host_certs_check.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64),
+                                               C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.bftkv_host_server_sign_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_server_read_proof_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         lib.bftkv_host_server_register_verify.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
@@ -378,7 +381,10 @@ class Certificate:
 
     @staticmethod
     def Parse(cert: bytes):
-        """-> list of entities: dict(id, keys=[dict(key_id, pk_algo, usable_sign, n, e, g, y)], certifiers=[ids])."""
+        """The certificate as openpgp.ReadEntity walks it -> list of entities (refused ones included; entity 0 is a request's
+        issuer): dict(id, keys=[dict(key_id, pk_algo, usable_sign, n, e, g, y)], certifiers=[ids of Signers()], refused, unknown,
+        why, checks=[dict(kind, key_index, signed, sig)] -- the signatures ReadEntity verifies (kind 2: third-party certifications,
+        which it does not))."""
         lib = _lib()
         h = C.c_void_p(lib.bftkv_host_certs_parse(cert, len(cert)))
         out = []
@@ -394,20 +400,30 @@ class Certificate:
                     g = lambda p, l: C.string_at(p, l) if l else b""
                     keys.append({"key_id": pk.key_id, "entity_id": pk.entity_id, "pk_algo": pk.pk_algo, "usable_sign": bool(pk.usable_sign),
                                  "n": g(pk.n, pk.n_len), "e": g(pk.e, pk.e_len), "g": g(pk.g, pk.g_len), "y": g(pk.y, pk.y_len)})
-                out.append({"id": eid.value, "keys": keys, "certifiers": certifiers})
+                refused, unknown, why, nchk = C.c_uint8(0), C.c_uint8(0), C.c_char_p(), C.c_uint32(0)
+                lib.bftkv_host_certs_structure(h, e, C.byref(refused), C.byref(unknown), C.byref(why), C.byref(nchk))
+                checks = []
+                for i in range(nchk.value):
+                    kind, ki, sp, sl, gp, gl = C.c_int(0), C.c_uint32(0), C.c_void_p(), C.c_uint64(0), C.c_void_p(), C.c_uint64(0)
+                    lib.bftkv_host_certs_check(h, e, i, C.byref(kind), C.byref(ki), C.byref(sp), C.byref(sl), C.byref(gp), C.byref(gl))
+                    checks.append({"kind": kind.value, "key_index": ki.value, "signed": C.string_at(sp.value, sl.value) if sl.value else b"",
+                                   "sig": C.string_at(gp.value, gl.value) if gl.value else b""})
+                out.append({"id": eid.value, "keys": keys, "certifiers": certifiers, "refused": bool(refused.value), "unknown": bool(unknown.value),
+                            "why": (why.value or b"").decode(), "checks": checks})
         finally:
             lib.bftkv_host_certs_free(h)
         return out
 
 
-def certs_verify(ctx: _native.Context, cert: bytes) -> List[bool]:
-    """Which entities of a certificate blob openpgp.ReadEntity would accept (self-signatures, subkey bindings)."""
+def certs_verify(ctx: _native.Context, cert: bytes) -> List[Optional[bool]]:
+    """Which entities of a certificate blob openpgp.ReadEntity returns: True, False (refused), None (no verdict: a shape left to
+    the reference, or a check that met a fenced shape)."""
     valid = np.zeros(64, dtype=np.uint8)
     n = C.c_uint32(0)
     rc = _lib().bftkv_host_certs_verify(ctx.h, cert, len(cert), valid.ctypes.data, len(valid), C.byref(n))
     if rc:
         raise _native.NativeError("certs_verify failed: %d" % rc)
-    return [bool(v) for v in valid[:n.value]]
+    return [None if v == 2 else bool(v) for v in valid[:n.value]]
 
 
 def quorum_cert_verify(ctx: _native.Context, q: "Quorum", cert: bytes):

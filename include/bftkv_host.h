@@ -136,28 +136,50 @@ int bftkv_host_vote_fold(const bftkv_quorum* q, uint32_t n_rounds, const uint64_
                          const uint64_t* reply_off, uint32_t* consumed_out, uint8_t* threshold_out);
 
 /* Certificates carried in SignaturePacket.Cert: PGPCertificate.Parse / PGPSignature.Issuer
- * (crypto_pgp.go:236-249, 392-405) reduced to what the path reads -- key material, the self-signature's key
- * flags (KeysByIdUsage) and the issuer ids of third-party certifications (PGPCertificateInstance.Signers,
- * crypto_pgp.go:80-88).  Self-signature VERIFICATION (done by openpgp.ReadEntity) is SURVEY.md 8(f)-1, not here. */
+ * (crypto_pgp.go:236-249, 392-405).  The certificate is walked the way openpgp.ReadEntity goes through its packets
+ * (x/crypto openpgp/keys.go ReadEntity / addUserID / addSubkey; the rules are listed in oracle/openpgp.py
+ * walk_certificate): per entity the key material (a key's identity and hash input are its re-serialization, not
+ * its packet body), the key flags KeysByIdUsage reads (the chosen identity self-signature; Subkey.Sig), the
+ * issuer ids of PGPCertificateInstance.Signers (crypto_pgp.go:80-88: the signatures on identities that have a
+ * self-signature) and the list of signatures ReadEntity verifies.  No signature is verified here
+ * (bftkv_host_certs_verify does that on the GPU).  Every entity the walk meets is listed, refused ones included
+ * (Parse itself stops at the first one ReadEntity refuses): the issuer of a request is entity 0. */
 typedef struct bftkv_certs bftkv_certs;
 bftkv_certs* bftkv_host_certs_parse(const uint8_t* cert, uint64_t len);
 void bftkv_host_certs_free(bftkv_certs* c);
 uint32_t bftkv_host_certs_n_entities(const bftkv_certs* c);
-/* entity e: primary key id, number of keys (primary + subkeys), certifier ids (in packet order) */
+/* entity e: primary key id, number of keys (primary + subkeys; 0: the primary key packet did not parse or is of a
+ * shape left to the reference), certifier ids (Signers(), in packet order) */
 int bftkv_host_certs_entity(const bftkv_certs* c, uint32_t e, uint64_t* id_out, uint32_t* n_keys_out,
                             const uint64_t** certifiers_out, uint32_t* n_certifiers_out);
 int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu_pubkey* out);   /* pointers into c */
+/* What the walk alone says about entity e.  *refused_out: ReadEntity returns an error whatever the signatures say
+ * (no identity with a self-signature, a subkey without or with a wrong-typed signature, a signing subkey without
+ * cross-signature, a packet that does not parse, a primary key that cannot sign, ...).  *unknown_out: the entity has
+ * a shape this library does not follow (elliptic-curve or version-3 keys, user attributes and other packet types
+ * whose parsers are not restated, bodies over 4096 bytes, partial lengths, binding / revocation / cross signatures
+ * that do not name the key they are verified with): no verdict, the reference decides.  *why_out: the reference's
+ * message or the shape (a string owned by c).  *n_checks_out: the signatures ReadEntity verifies. */
+int bftkv_host_certs_structure(const bftkv_certs* c, uint32_t e, uint8_t* refused_out, uint8_t* unknown_out,
+                               const char** why_out, uint32_t* n_checks_out);
+/* check i of entity e, in the order ReadEntity meets them (third-party certifications, which it does not verify,
+ * come last but for key revocations).  kind: 0 user-id self-signature, 1 subkey binding / subkey revocation,
+ * 2 third-party certification (CheckQuorumCert only), 3 cross-signature of a signing subkey, 4 key revocation;
+ * key_index: the key of the entity it is verified with; the bytes it is computed over; the signature packet. */
+int bftkv_host_certs_check(const bftkv_certs* c, uint32_t e, uint32_t i, int* kind_out, uint32_t* key_index_out,
+                           const uint8_t** signed_out, uint64_t* signed_len_out, const uint8_t** sig_out, uint64_t* sig_len_out);
 
-/* v4 fingerprint (SHA-1 over 0x99 || u16 length || body) of the primary key of the first entity of `cert` */
+/* v4 fingerprint (SHA-1 over 0x99 || u16 length || the key as re-serialized) of the primary key of the first entity */
 int bftkv_host_cert_fingerprint(const uint8_t* cert, uint64_t len, uint8_t out[20]);
 
-/* What openpgp.ReadEntity verifies while reading, on the GPU: every user-id self-signature
- * (classes 0x10 / 0x13 issued by the primary key, over 0x99 len key || 0xB4 len uid) and every subkey binding
- * (0x18, over 0x99 len key || 0x99 len subkey) with the entity's own primary key.  valid_out[e] = 1 iff the entity
- * has a signing-capable primary key, at least one validly self-signed identity, no invalid self-signature and a valid
- * binding for every subkey; valid_out[e] = 2 when one of its checks met a fenced shape (e.g. a DSA certificate key beyond
- * the bounded table slots of certificate keys): no verdict, nothing is remembered about the certificate.  (The embedded
- * cross-signature of signing subkeys is not checked: fenced.) */
+/* What openpgp.ReadEntity verifies while reading, on the GPU, with the entity's own keys: every
+ * user-id self-signature (0x10 / 0x13 issued by the primary key, over 0x99 len key || 0xB4 len uid), every subkey
+ * binding and subkey revocation (0x18 / 0x28, over 0x99 len key || 0x99 len subkey), the embedded 0x19
+ * cross-signature of every binding whose key flags say "sign" (same bytes, under the subkey), and every key
+ * revocation outside a user-id / subkey run (0x20, over the key alone).  valid_out[e] = 1 iff ReadEntity returns the
+ * entity; 0 iff it refuses it (bftkv_host_certs_structure's refusals, or a check that fails); 2: no verdict -- a
+ * shape left to the reference, or a check that met a fenced shape (e.g. a DSA certificate key beyond the bounded
+ * table slots of certificate keys); nothing is remembered about such a certificate. */
 int bftkv_host_certs_verify(bftkv_gpu_ctx* ctx, const uint8_t* cert, uint64_t len, uint8_t* valid_out, uint32_t cap, uint32_t* n_out);
 
 /* CheckQuorumCert as the paper states it (docs/tex/algo.tex:68-83; the code only counts certifier key ids,

@@ -51,7 +51,7 @@ class COracle:
     def set_keyring(self, keyring):
         """keyring: oracle.collective.Keyring"""
         for e in keyring.get_keyring():
-            cands = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + [(k, fv, fs, False) for k, fv, fs in e.subkeys]
+            cands = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + [(k, fv, fs, rr) for k, fv, fs, rr in e.subkeys]
             for k, fv, fs, rr in cands:
                 usable = int(not (e.revoked or rr) and not (fv and not fs))
                 if k.pk_algo == 17:

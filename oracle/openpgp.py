@@ -132,6 +132,7 @@ class Signature:
     is_primary_id: Optional[bool] = None
     revocation_reason: Optional[int] = None
     embedded: Optional["Signature"] = None
+    embedded_body: bytes = b""
 
 
 def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
@@ -210,6 +211,7 @@ def _parse_subpackets(sig: Signature, area: bytes, hashed: bool) -> None:
             if sig.embedded is not None:
                 raise StructuralError("Cannot have multiple embedded signatures")
             sig.embedded = parse_signature_body(body)
+            sig.embedded_body = bytes(body)
             if sig.embedded.sig_type != 0x19:
                 raise StructuralError("cross-signature has unexpected type %d" % sig.embedded.sig_type)
         else:
@@ -712,7 +714,7 @@ class Entity:
     flag_certify: bool = True
     self_sig_revoked: bool = False
     revoked: bool = False                      # len(Entity.Revocations) > 0
-    subkeys: List[Tuple[PublicKey, bool, bool]] = field(default_factory=list)  # (key, flags_valid, flag_sign)
+    subkeys: List[Tuple[PublicKey, bool, bool, bool]] = field(default_factory=list)  # (key, flags_valid, flag_sign, revocation reason) of Subkey.Sig
     certifiers: List[int] = field(default_factory=list)   # issuer key ids of 3rd-party certifications
     serialized: bytes = b""
 
@@ -728,9 +730,9 @@ def keys_by_id_usage_sign(keyring: List[Entity], key_id: int) -> List[Tuple[Enti
         cands = []
         if e.primary.key_id == key_id:
             cands.append((e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked))
-        for sk, fv, fs in e.subkeys:
+        for sk, fv, fs, rr in e.subkeys:
             if sk.key_id == key_id:
-                cands.append((sk, fv, fs, False))
+                cands.append((sk, fv, fs, rr))            # Subkey.Sig.RevocationReason != nil
         for k, fv, fs, rr in cands:
             if e.revoked or rr:
                 continue
@@ -1080,65 +1082,305 @@ def parse_public_key_body(body: bytes, is_subkey: bool = False) -> PublicKey:
     raise UnsupportedError("public key algorithm %d" % algo)
 
 
-def read_entities(blob: bytes) -> List[Entity]:
-    """ReadKeyRing / repeated ReadEntity reduced to key material, self-signature key flags and the
-    list of third-party certifier ids (B.6).  Self-signature *verification* (which ReadEntity
-    performs) is row 8(f)-1 of SURVEY.md, not part of this restatement yet."""
-    ents: List[Entity] = []
+# ------------------------------------------------------------------------------------------------
+# B.6  openpgp.ReadEntity, packet by packet (x/crypto openpgp/keys.go @ go.mod:8: ReadEntity, addUserID, addSubkey,
+# shouldReplaceSubkeySig; packet/public_key.go: parse, VerifyKeySignature, VerifyUserIdSignature, VerifyRevocationSignature).
+#
+# PGPCertificate.Parse (crypto/pgp/crypto_pgp.go:236-249) calls ReadEntity on one packet.Reader until the first error; the
+# entities before it are the certificate.  What ReadEntity does with each packet that Reader.Next hands it:
+#   first packet        must be a public-key packet (tag 6 -- or 14: the type assertion does not look at IsSubkey), else "first
+#                       packet was not a public/private key"; a primary key that cannot sign (RSA encrypt-only, ElGamal) is refused
+#   user id (13)        addUserID: the v4 signature packets that follow belong to it.  A 0x10 / 0x13 signature whose issuer is the
+#                       primary key MUST verify (else the entity is refused); each one that does replaces identity.SelfSignature
+#                       and puts the identity into Entity.Identities (keyed by the uid string).  Every other signature in the run
+#                       -- 0x11 / 0x12 by the primary key, 0x30, a 0x20 -- goes to identity.Signatures unverified.  The first
+#                       packet that is not a v4 signature ends the run.  An identity that never got a self-signature is dropped
+#                       with the signatures collected on it (PGPCertificateInstance.Signers walks Entity.Identities only)
+#   subkey (14)         addSubkey: the v4 signatures that follow must be 0x18 or 0x28 ("subkey signature with wrong type"), and
+#                       each must verify under the primary key over key || subkey (VerifyKeySignature; when the signature's key
+#                       flags say "sign", its embedded 0x19 cross-signature must be there and verify under the SUBKEY over the same
+#                       bytes).  A 0x28 becomes Subkey.Sig; a 0x18 does when none is there yet or it is newer than a 0x18 that is
+#                       (a revocation is never replaced).  No signature at all: "subkey packet not followed by signature"
+#   signature (2)       outside such a run: a 0x20 is kept and verified at the end under the primary key over the key alone (a
+#                       failure refuses the entity, a success fills Entity.Revocations); anything else is ignored
+#   public key (6)      ends the entity (unread: the next ReadEntity starts there)
+#   other packets       ignored -- but they do end a signature run
+#   errors of Next      refuse the entity (Reader.Next itself skips packet types packet.Read does not know).  A key or signature
+#                       packet cut off by the end of the certificate parses when everything its parser asks for is there
+#                       (peekVersion's bufio has fetched what there was); a user id (ReadAll) does not
+#   at the end          no identity: "entity without any identities"
+# The bytes a key contributes to a hash or a fingerprint are its RE-SERIALIZATION (SerializeSignaturePrefix +
+# serializeWithoutHeaders: version, creation time, algorithm, the MPIs as read), not the packet body: bytes behind the last MPI
+# take no part (key packets are read through peekVersion's bufio, which swallows them with the rest of a body of <= 4096 bytes).
+# Shapes outside this restatement are reported as `unknown` (the verifier fences them, the reference decides): version-2/3 keys,
+# elliptic-curve keys, secret-key packets, user attributes and the other packet types whose parsers are not modelled, key or
+# signature bodies over 4096 bytes, partial / indeterminate lengths, signatures the device cannot look up by issuer (binding / revocation signatures whose issuer
+# subpacket does not name the primary key, cross-signatures that do not name the subkey).
+# ------------------------------------------------------------------------------------------------
+_KNOWN_TAGS = {1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 14, 17, 18}     # packet.Read's switch; everything else: UnknownPacketTypeError
+
+
+@dataclass
+class CertCheck:
+    """One signature ReadEntity verifies: `kind` uid / binding / cross / revocation, the key it is verified with, the bytes it
+    is computed over and the signature (raw = its packet, or for a cross-signature the embedded body framed as a packet)."""
+    kind: str
+    key: "PublicKey"
+    signed: bytes
+    sig: Signature
+    raw: bytes
+
+
+@dataclass
+class EntityWalk:
+    start: int
+    end: int = 0
+    primary: Optional[PublicKey] = None
+    error: Optional[str] = None          # ReadEntity refuses the entity whatever its signatures say
+    unknown: Optional[str] = None        # a shape this restatement does not follow (see above)
+    identities: list = field(default_factory=list)   # dicts: name, self_sig (last one), sigs [(Signature, raw)], uid_framed
+    subkeys: list = field(default_factory=list)      # dicts: key, sig (Subkey.Sig)
+    revocations: list = field(default_factory=list)
+    checks: List[CertCheck] = field(default_factory=list)
+    key_hash: bytes = b""
+
+
+def _read_mpi_strict(body: bytes, p: int) -> Tuple[int, bytes, int]:
+    if p + 2 > len(body):
+        raise _Truncated()
+    bits = (body[p] << 8) | body[p + 1]
+    nb = (bits + 7) // 8
+    if p + 2 + nb > len(body):
+        raise _Truncated()
+    return bits, body[p + 2:p + 2 + nb], p + 2 + nb
+
+
+def parse_public_key_strict(body: bytes, is_subkey: bool) -> Tuple[Optional[PublicKey], bytes, Optional[str]]:
+    """PublicKey.parse of a version-4 body: (key, re-serialization, None), or (None, b"", "unknown: ...") for the shapes left to
+    the reference.  Raises UnsupportedError / _Truncated as the reference's parser would fail."""
+    if len(body) < 6:
+        raise _Truncated()
+    if body[0] != 4:
+        raise UnsupportedError("public key version")
+    algo = body[5]
+    if algo in (PK_ECDH, PK_ECDSA):
+        return None, b"", "elliptic-curve key"
+    n_mpi = {PK_RSA: 2, PK_RSA_ENCRYPT_ONLY: 2, PK_RSA_SIGN_ONLY: 2, PK_DSA: 4, PK_ELGAMAL: 3}.get(algo)
+    if n_mpi is None:
+        raise UnsupportedError("public key type: %d" % algo)
+    p = 6
+    vals = []
+    for _ in range(n_mpi):
+        bits, raw, p = _read_mpi_strict(body, p)
+        vals.append(raw)
+    if algo in (PK_RSA, PK_RSA_ENCRYPT_ONLY, PK_RSA_SIGN_ONLY) and len(vals[1]) > 3:
+        raise UnsupportedError("large public exponent")
+    ser = body[:p]
+    fp = fingerprint_v4(ser)
+    kid = int.from_bytes(fp[12:20], "big")
+    iv = [int.from_bytes(v, "big") for v in vals]
+    if algo == PK_DSA:
+        key = PublicKey(kid, algo, p=iv[0], q=iv[1], g=iv[2], y=iv[3], fingerprint=fp, is_subkey=is_subkey)
+    elif algo == PK_ELGAMAL:
+        key = PublicKey(kid, algo, p=iv[0], g=iv[1], y=iv[2], fingerprint=fp, is_subkey=is_subkey)
+    else:
+        key = PublicKey(kid, algo, n=iv[0], e=iv[1], fingerprint=fp, is_subkey=is_subkey)
+    return key, b"\x99" + struct.pack(">H", len(ser)) + ser, None
+
+
+def _frame_sig(body: bytes) -> bytes:
+    return new_format_header(2, len(body)) + body
+
+
+def walk_certificate(blob: bytes) -> List[EntityWalk]:
+    """Every entity of a certificate as ReadEntity would go through it (see the table above).  A refused entity does not end the
+    walk here (the next one starts at the next primary-key packet, as ReadKeyRing's readToNextPublicKey would): `parse_certificate`
+    applies Parse's stop-at-the-first-error."""
+    out: List[EntityWalk] = []
     pos = 0
-    cur: Optional[Entity] = None
-    last_pub: Optional[PublicKey] = None
-    in_sub = False
-    while pos < len(blob):
-        try:
-            pkt = next_packet(blob, pos)
-        except (EOFError, _Truncated, StructuralError, UnsupportedError):
-            break
-        start, pos = pos, pkt.end
-        if pkt.tag == 6:  # public key
-            cur = Entity(primary=parse_public_key_body(pkt.body), flags_valid=False, flag_sign=False,
-                         flag_certify=False)
-            cur._start = start
-            ents.append(cur)
-            in_sub = False
-            cur._have_self = False
-        elif cur is None:
-            continue
-        elif pkt.tag == 13:
-            cur.name = cur.name or pkt.body.decode("utf-8", "replace")
-            in_sub = False
-        elif pkt.tag == 14:
-            last_pub = parse_public_key_body(pkt.body, True)
-            cur.subkeys.append((last_pub, False, False))
-            in_sub = True
-        elif pkt.tag == 2:
+    cur: Optional[EntityWalk] = None
+    run = None                      # None | ("uid", identity) | ("sub", subkey)
+    leading_junk = False
+
+    def close(at: int):
+        nonlocal cur, run
+        if cur is None:
+            return
+        cur.end = at
+        for sk in cur.subkeys:
+            if sk["sig"] is None and cur.error is None:
+                cur.error = "subkey packet not followed by signature"
+        run = None
+        if cur.error is None and not any(i["self_sig"] is not None for i in cur.identities):
+            cur.error = "entity without any identities"
+        for sig, raw in cur.revocations:
+            if sig.issuer != cur.primary.key_id:
+                cur.unknown = cur.unknown or "revocation signature not issued under the primary key id"
+            cur.checks.append(CertCheck("revocation", cur.primary, cur.key_hash, sig, raw))
+        cur = None
+
+    def fail(msg: str):
+        if cur is not None and cur.error is None:
+            cur.error = msg
+
+    def skip_to_next_primary(p: int) -> int:
+        """readToNextPublicKey: the position of the next complete tag-6 packet, or the end."""
+        while p < len(blob):
             try:
-                s = parse_signature_body(pkt.body)
-            except Exception:
+                tag, start, ln = read_header(blob, p)
+            except (EOFError, _Truncated, StructuralError):
+                return len(blob)
+            if ln < 0 or start + ln > len(blob):
+                return len(blob)
+            if tag == 6:
+                return p
+            p = start + ln
+        return len(blob)
+
+    while pos < len(blob):
+        at = pos
+        try:
+            tag, start, ln = read_header(blob, pos)
+        except (EOFError, _Truncated, StructuralError):
+            fail("packet header")                 # Reader.Next returns the error; outside an entity Parse just ends
+            break
+        if ln < 0:
+            if cur is not None:
+                cur.unknown = cur.unknown or "partial / indeterminate length"
+            break
+        truncated = start + ln > len(blob)
+        body = blob[start:start + ln]
+        pos = min(start + ln, len(blob))
+        if tag not in _KNOWN_TAGS:
+            continue                              # UnknownPacketTypeError: Reader.Next goes on (a body cut short too: consumeAll's own error is dropped)
+        if tag in (2, 6, 14) and len(body) == 0 and not truncated:
+            break                                 # peekVersion's Peek(1) returns io.EOF: Reader.Next takes it for the end of the stream
+        # ---- a key packet
+        if tag in (6, 14) and (cur is None or tag == 6):
+            close(at)
+            cur = EntityWalk(start=at)
+            out.append(cur)
+            if leading_junk:
+                cur.error = "first packet was not a public/private key"
+            leading_junk = False
+            key = None
+            try:
+                if ln > 4096:
+                    cur.unknown = "body over 4096 bytes"
+                elif len(body) == 0:
+                    raise _Truncated()
+                elif body[0] < 4:
+                    cur.unknown = "version-3 key"
+                else:
+                    key, cur.key_hash, unk = parse_public_key_strict(body, False)
+                    if unk:
+                        cur.unknown = unk
+            except (UnsupportedError, _Truncated) as e:
+                cur.error = cur.error or ("public key: %s" % (e or "truncated"))
+            cur.primary = key
+            if key is not None and not key.can_sign() and cur.error is None:
+                cur.error = "primary key cannot be used for signatures"
+            if key is None:
+                # nothing more can be said about this entity: go to where the next one starts (readToNextPublicKey)
+                pos = skip_to_next_primary(pos)
+                cur.end = pos
+                cur = None
+            run = None
+            continue
+        if tag in (2, 14) and ln > 4096:
+            if cur is not None:
+                cur.unknown = cur.unknown or "body over 4096 bytes"
+                run = ("dead", None)
+            else:
+                leading_junk = True
+            continue
+        if cur is None:
+            # ReadEntity's first packet is not a key: Parse ends with no (further) entity.  Only possible at the very start.
+            leading_junk = True
+            continue
+        if cur.error is not None and tag != 6:
+            continue                              # already refused: its remaining packets change nothing
+        if truncated and tag == 13:
+            fail("truncated packet")              # UserId.parse is ioutil.ReadAll: io.ErrUnexpectedEOF
+            break
+        if tag == 13:
+            ident = {"name": body, "self_sig": None, "sigs": [], "framed": b"\xb4" + struct.pack(">I", len(body)) + body, "at": at}
+            cur.identities.append(ident)
+            run = ("uid", ident)
+            continue
+        if tag == 14:
+            sk = {"key": None, "sig": None, "framed": b""}
+            try:
+                if len(body) == 0:
+                    raise _Truncated()
+                if body[0] < 4:
+                    cur.unknown = cur.unknown or "version-3 key"
+                else:
+                    sk["key"], sk["framed"], unk = parse_public_key_strict(body, True)
+                    if unk:
+                        cur.unknown = cur.unknown or unk
+            except (UnsupportedError, _Truncated) as e:
+                fail("subkey: %s" % (e or "truncated"))
+            if sk["key"] is None:
+                run = ("dead", None)               # no verdict about what follows this subkey (or the entity is refused already)
+                if cur.error is None and cur.unknown is None:
+                    fail("subkey")
                 continue
-            if in_sub:
-                if s.sig_type == 0x18 and cur.subkeys:
-                    k, _, _ = cur.subkeys[-1]
-                    cur.subkeys[-1] = (k, s.flags_valid, s.flag_sign)
-            elif s.sig_type in (0x10, 0x11, 0x12, 0x13) and cur.name:   # only signatures that follow a user id attach
-                if s.issuer == cur.primary.key_id:
-                    if not cur._have_self:
-                        cur.flags_valid, cur.flag_sign, cur.flag_certify = s.flags_valid, s.flag_sign, s.flag_certify
-                        cur.self_sig_revoked = s.revocation_reason is not None
-                        cur._have_self = True
-                elif s.issuer is not None:
-                    cur.certifiers.append(s.issuer)
-            elif s.sig_type == 0x20:
-                cur.revoked = True
-        cur.serialized = blob[cur._start:pos]
-    return ents
+            cur.subkeys.append(sk)
+            run = ("sub", sk)
+            continue
+        if tag == 2:
+            v3 = len(body) > 0 and body[0] < 4
+            try:
+                sig = parse_signature_v3_body(body) if v3 else parse_signature_body(body)
+            except (StructuralError, UnsupportedError, _Truncated) as e:
+                fail("signature: %s" % (e or "truncated"))
+                continue
+            raw = blob[at:pos]
+            if v3:
+                run = None                         # a SignatureV3 is not a *packet.Signature: it ends the run and is ignored
+                continue
+            if run is not None and run[0] == "dead":
+                continue
+            if run is not None and run[0] == "uid":
+                ident = run[1]
+                if sig.sig_type in (0x10, 0x13) and sig.issuer is not None and sig.issuer == cur.primary.key_id:
+                    cur.checks.append(CertCheck("uid", cur.primary, cur.key_hash + ident["framed"], sig, raw))
+                    ident["self_sig"] = sig
+                else:
+                    ident["sigs"].append((sig, raw, cur.key_hash + ident["framed"]))
+                continue
+            if run is not None and run[0] == "sub":
+                sk = run[1]
+                if sig.sig_type not in (0x18, 0x28):
+                    fail("subkey signature with wrong type")
+                    continue
+                signed = cur.key_hash + sk["framed"]
+                if sig.issuer != cur.primary.key_id:
+                    cur.unknown = cur.unknown or "subkey signature not issued under the primary key id"
+                cur.checks.append(CertCheck("binding", cur.primary, signed, sig, raw))
+                if sig.flag_sign:
+                    if sig.embedded is None:
+                        fail("signing subkey is missing cross-signature")
+                        continue
+                    if sig.embedded.issuer != sk["key"].key_id:
+                        cur.unknown = cur.unknown or "cross-signature not issued under the subkey id"
+                    cur.checks.append(CertCheck("cross", sk["key"], signed, sig.embedded, _frame_sig(sig.embedded_body)))
+                if sig.sig_type == 0x28:
+                    sk["sig"] = sig
+                elif sk["sig"] is None or (sk["sig"].sig_type != 0x28 and sig.creation_time > sk["sig"].creation_time):
+                    sk["sig"] = sig
+                continue
+            if sig.sig_type == 0x20:
+                cur.revocations.append((sig, raw))
+            continue
+        # every other packet type packet.Read knows: ignored by ReadEntity, but its parser is not modelled here
+        cur.unknown = cur.unknown or ("packet type %d" % tag)
+        run = None
+    close(pos)
+    return out
 
 
-# ------------------------------------------------------------------------------------------------
-# What openpgp.ReadEntity VERIFIES while reading (B.6): user-id self-signatures and subkey bindings
-# (SURVEY.md 8(f)-1); third-party certifications are only collected -- verifying them is what the
-# paper's CheckQuorumCert asks for (docs/tex/algo.tex:68-83).
-# ------------------------------------------------------------------------------------------------
 def _verify_with_key(key: PublicKey, signed: bytes, sig: Signature) -> bool:
     name = HASH_BY_ID.get(sig.hash_id)
     if name in (None, "md5", "ripemd160"):
@@ -1149,60 +1391,99 @@ def _verify_with_key(key: PublicKey, signed: bytes, sig: Signature) -> bool:
     return verify_signature(key, sig.hash_id, h.digest(), sig) == ST_OK
 
 
-def entity_checks(blob: bytes):
-    """Per entity of a certificate blob: (entity_valid, [verified third-party certifier ids are computed by the caller]).
-    Returns a list of dicts: primary, valid (ReadEntity would accept it), third_party = [(issuer, signed_data, Signature)]."""
-    out = []
-    pos = 0
-    cur = None
-    key_hdr = last_uid = last_sub = b""
-    in_sub = False
-    while pos < len(blob):
-        try:
-            pkt = next_packet(blob, pos)
-        except (EOFError, _Truncated, StructuralError, UnsupportedError):
+def _check_ok(c: CertCheck) -> bool:
+    """VerifySignature of one certificate check: CanSign, hash tag, algorithm match, the public-key operation."""
+    return _verify_with_key(c.key, c.signed, c.sig)
+
+
+def walk_valid(w: EntityWalk) -> Optional[bool]:
+    """Would ReadEntity return this entity?  True / False, or None when the walk met a shape left to the reference and nothing it
+    did follow refuses the entity."""
+    if w.error is not None:
+        return False
+    if not all(_check_ok(c) for c in w.checks):
+        return False
+    return None if w.unknown is not None else True
+
+
+def walk_signers(w: EntityWalk) -> List[int]:
+    """PGPCertificateInstance.Signers (crypto_pgp.go:80-88): the issuers of identity.Signatures over Entity.Identities -- the
+    identities that have a self-signature, a later one of the same name replacing an earlier one.  (Go walks the map in random
+    order; here: order of appearance.  A signature without issuer subpacket makes the reference dereference nil: skipped.)"""
+    by_name = {}
+    for ident in w.identities:
+        if ident["self_sig"] is not None:
+            by_name[ident["name"]] = ident
+    return [s.issuer for ident in by_name.values() for s, _, _ in ident["sigs"] if s.issuer is not None]
+
+
+def _primary_self_sig(w: EntityWalk) -> Optional[Signature]:
+    """EntityList.KeysById's choice for the primary key: the first identity's self-signature unless a later identity's says
+    "primary user id" (map order in Go; order of appearance here)."""
+    by_name = {}
+    for ident in w.identities:
+        if ident["self_sig"] is not None:
+            by_name[ident["name"]] = ident
+    chosen = None
+    for ident in by_name.values():
+        if chosen is None:
+            chosen = ident["self_sig"]
+        elif ident["self_sig"].is_primary_id:
+            chosen = ident["self_sig"]
             break
-        pos = pkt.end
-        if pkt.tag == 6:
-            try:
-                pk = parse_public_key_body(pkt.body)
-            except Exception:
-                break
-            cur = {"primary": pk, "valid": pk.can_sign(), "uids_ok": 0, "third_party": [], "subkeys": 0, "bound": 0}
-            out.append(cur)
-            key_hdr = b"\x99" + struct.pack(">H", len(pkt.body)) + pkt.body
-            last_uid, in_sub = b"", False
-        elif cur is None:
+    return chosen
+
+
+def read_entities(blob: bytes) -> List[Entity]:
+    """Key material, KeysByIdUsage facts and Signers() of every entity of a certificate / keyring blob whose key packets parse
+    (no signature is verified here: `entity_checks` / `parse_certificate` do that)."""
+    ents: List[Entity] = []
+    for w in walk_certificate(blob):
+        if w.primary is None:
             continue
-        elif pkt.tag == 13:
-            last_uid = b"\xb4" + struct.pack(">I", len(pkt.body)) + pkt.body
-            in_sub = False
-        elif pkt.tag == 14:
-            last_sub = b"\x99" + struct.pack(">H", len(pkt.body)) + pkt.body
-            in_sub = True
-            cur["subkeys"] += 1
-        elif pkt.tag == 2:
-            try:
-                s = parse_signature_body(pkt.body)
-            except Exception:
-                continue
-            if in_sub:
-                if s.sig_type == 0x18:
-                    cur["bound"] += 1
-                    if not _verify_with_key(cur["primary"], key_hdr + last_sub, s):
-                        cur["valid"] = False          # "subkey signature invalid"
-            elif s.sig_type in (0x10, 0x11, 0x12, 0x13) and last_uid:
-                if s.issuer == cur["primary"].key_id:
-                    if s.sig_type in (0x10, 0x13):
-                        if _verify_with_key(cur["primary"], key_hdr + last_uid, s):
-                            cur["uids_ok"] += 1
-                        else:
-                            cur["valid"] = False      # "user ID self-signature invalid"
-                elif s.issuer is not None:
-                    cur["third_party"].append((s.issuer, key_hdr + last_uid, s))
-    for e in out:
-        if e["uids_ok"] == 0 or e["bound"] < e["subkeys"]:
-            e["valid"] = False                        # no self-signed identity / subkey without binding signature
+        ss = _primary_self_sig(w)
+        e = Entity(primary=w.primary,
+                   flags_valid=bool(ss and ss.flags_valid), flag_sign=bool(ss and ss.flag_sign), flag_certify=bool(ss and ss.flag_certify))
+        e.self_sig_revoked = bool(ss and ss.revocation_reason is not None)
+        e.revoked = bool(w.revocations)
+        named = [i for i in w.identities if i["self_sig"] is not None] or w.identities
+        e.name = named[0]["name"].decode("utf-8", "replace") if named else ""
+        for sk in w.subkeys:
+            s = sk["sig"]
+            e.subkeys.append((sk["key"], bool(s and s.flags_valid), bool(s and s.flag_sign), bool(s and s.revocation_reason is not None)))
+        e.certifiers = walk_signers(w)
+        e.serialized = blob[w.start:w.end]
+        ents.append(e)
+    return ents
+
+
+def entity_checks(blob: bytes):
+    """Per entity the walk meets (as bftkv_host_certs_verify lists them): primary (None: its key packet does not parse or is of a
+    shape left to the reference), valid (ReadEntity returns it: True / False, None = left to the reference), third_party =
+    [(issuer, signed bytes, Signature)] of the identities Signers() walks."""
+    out = []
+    for w in walk_certificate(blob):
+        by_name = {}
+        for ident in w.identities:
+            if ident["self_sig"] is not None:
+                by_name[ident["name"]] = ident
+        tp = [(s.issuer, signed, s) for ident in by_name.values() for s, _, signed in ident["sigs"] if s.issuer is not None]
+        out.append({"primary": w.primary, "valid": walk_valid(w), "third_party": tp, "walk": w})
+    return out
+
+
+def parse_certificate(blob: bytes) -> List[EntityWalk]:
+    """PGPCertificate.Parse (crypto_pgp.go:236-249): the entities ReadEntity returns before its first error.  An entity whose
+    validity is left to the reference (`unknown`) ends the list with a None."""
+    out = []
+    for w in walk_certificate(blob):
+        v = walk_valid(w)
+        if v is None:
+            out.append(None)
+            break
+        if not v:
+            break
+        out.append(w)
     return out
 
 

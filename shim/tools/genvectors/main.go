@@ -21,7 +21,8 @@
 //
 // and per cluster the cliques ChooseQuorum(AUTH) built from the certified ring (f, min, threshold, suff, node ids);
 // per entry of "packets" what packet.TBS / packet.TBSS return (packet/packet.go:142-190, whose seek2tbs ignores its read and
-// seek errors); per entry of "certs" the primary key ids crypto.Certificate.Parse returns (openpgp.ReadEntity until it fails:
+// seek errors); per entry of "certs" the primary key ids crypto.Certificate.Parse returns, the first entity's Signers() and
+// sign-usable key ids (openpgp.ReadEntity until it fails:
 // self-signatures and subkey bindings verified, crypto_pgp.go:236-249).
 //
 // Not compiled in the bftkv_amd repository.  Written against the reference at go.mod:8.
@@ -40,6 +41,7 @@ import (
 
 	"golang.org/x/crypto/openpgp"
 	pgperrors "golang.org/x/crypto/openpgp/errors"
+	pgppacket "golang.org/x/crypto/openpgp/packet"
 
 	"github.com/yahoo/bftkv/crypto"
 	"github.com/yahoo/bftkv/crypto/pgp"
@@ -110,9 +112,36 @@ type packetOut struct {
 	TbssErr string `json:"tbss_err,omitempty"`
 }
 
-// crypto.Certificate.Parse of one blob (crypto_pgp.go:236-249): the primary key ids of the entities it returned
+// crypto.Certificate.Parse of one blob (crypto_pgp.go:236-249): the primary key ids of the entities it returned; for the first
+// one (a request's issuer) node.Signers() (crypto_pgp.go:80-88; "panic" when it dereferences a nil issuer) and the ids of its
+// keys that EntityList.KeysByIdUsage(id, KeyFlagSign) returns -- what CheckDetachedSignature would verify with
 type certOut struct {
-	Ids []string `json:"ids"`
+	Ids     []string `json:"ids"`
+	Signers []string `json:"signers"`
+	Panic   bool     `json:"signers_panic,omitempty"`
+	Usable  []string `json:"usable"`
+}
+
+func firstEntityFacts(n node.Node, co *certOut) {
+	defer func() {
+		if recover() != nil {
+			co.Panic = true
+		}
+	}()
+	e := n.Instance().(*openpgp.Entity)
+	l := openpgp.EntityList{e}
+	ids := []uint64{e.PrimaryKey.KeyId}
+	for _, sk := range e.Subkeys {
+		ids = append(ids, sk.PublicKey.KeyId)
+	}
+	for _, id := range ids {
+		if len(l.KeysByIdUsage(id, pgppacket.KeyFlagSign)) > 0 {
+			co.Usable = append(co.Usable, fmt.Sprintf("%016x", id))
+		}
+	}
+	for _, id := range n.Signers() {
+		co.Signers = append(co.Signers, fmt.Sprintf("%016x", id))
+	}
 }
 
 type outputs struct {
@@ -347,9 +376,12 @@ func main() {
 	for _, cb := range inp.Certs {
 		crypt := pgp.New()
 		nodes, _ := crypt.Certificate.Parse(unhex(cb))
-		co := certOut{Ids: []string{}}
+		co := certOut{Ids: []string{}, Signers: []string{}, Usable: []string{}}
 		for _, n := range nodes {
 			co.Ids = append(co.Ids, fmt.Sprintf("%016x", n.Id()))
+		}
+		if len(nodes) > 0 {
+			firstEntityFacts(nodes[0], &co)
 		}
 		res.Certs = append(res.Certs, co)
 	}

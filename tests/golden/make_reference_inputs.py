@@ -78,6 +78,12 @@ def cert_cases():
     blobs = [client, bytes(bad_self), sub_owner.entity, bytes(bad_binding), dsa.entity, b"".join(r.entity for r in cl.replicas[:3]),
              cl.replicas[0].entity + bytes(bad_self) + cl.replicas[1].entity, bytes(bad_self) + cl.replicas[1].entity, b"", bytes(range(200)),
              client[:len(client) // 2]]
+    # the ReadEntity walk shape by shape (tests/cert_shapes.py: hand-built entities, verdicts worked from x/crypto's rules) and
+    # the certificates GnuPG made (gpg_cert_vectors.json: cross-signed signing subkeys, revocations, several user ids ...)
+    from tests import cert_shapes as CS
+    blobs += [blob for _, blob, _, _, _ in CS.scenarios()]
+    gv = json.load(open(os.path.join(HERE, "gpg_cert_vectors.json")))
+    blobs += [bytes.fromhex(c["blob"]) for c in gv["certificates"] + gv["tampered"]]
     return [b.hex() for b in blobs]
 
 

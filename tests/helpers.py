@@ -27,7 +27,7 @@ def abi_keys(kr: col.Keyring):
     """bftkv_gpu_pubkey records from an oracle keyring, in getKeyring() order (secring first)."""
     out = []
     for e in kr.get_keyring():
-        cands = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + [(k, fv, fs, False) for k, fv, fs in e.subkeys]
+        cands = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + [(k, fv, fs, rr) for k, fv, fs, rr in e.subkeys]
         for k, fv, fs, rr in cands:
             usable = not (e.revoked or rr) and not (fv and not fs)
             d = {"key_id": k.key_id, "entity_id": e.id, "pk_algo": k.pk_algo, "usable_sign": usable}

@@ -1,0 +1,129 @@
+"""openpgp.ReadEntity as PGPCertificate.Parse / PGPSignature.Issuer reach it (crypto/pgp/crypto_pgp.go:236-249, 392-405): the
+oracle's packet-by-packet restatement (oracle/openpgp.py walk_certificate) against verdicts worked out by hand from x/crypto's rules
+and against certificates GnuPG made; the host mirror (bftkv_host_certs_parse) against the oracle, entity by entity and check by check,
+on those and on random packet sequences."""
+import json
+import os
+
+import pytest
+
+from oracle import openpgp as pgp
+from tests import cert_shapes as CS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KIND = {"uid": 0, "binding": 1, "cross": 3, "revocation": 4}
+
+
+def usable_keys(blob):
+    """Key ids of entity 0 that KeysByIdUsage(id, KeyFlagSign) returns."""
+    e = pgp.read_entities(blob)[0]
+    ids = [e.primary.key_id] + [k.key_id for k, _, _, _ in e.subkeys]
+    return [i for i in ids if pgp.keys_by_id_usage_sign([e], i)]
+
+
+@pytest.fixture(scope="module")
+def shapes():
+    return CS.scenarios()
+
+
+def test_oracle_walk_gives_the_hand_worked_verdicts(shapes):
+    seen = set()
+    for name, blob, valid, signers, usable in shapes:
+        ws = pgp.walk_certificate(blob)
+        got = [pgp.walk_valid(w) for w in ws]
+        assert got == valid, (name, got, [(w.error, w.unknown) for w in ws])
+        seen.update(got)
+        if signers is not None:
+            assert pgp.walk_signers(ws[0]) == signers, name
+            assert pgp.read_entities(blob)[0].certifiers == signers, name
+        if usable is not None:
+            assert usable_keys(blob) == usable, name
+        # Parse stops at the first refusal
+        want_parse = []
+        for v in valid:
+            if v is not True:
+                if v is None:
+                    want_parse.append(None)
+                break
+            want_parse.append(True)
+        assert [None if w is None else True for w in pgp.parse_certificate(blob)] == want_parse, name
+    assert seen == {True, False, None}
+
+
+def compare_with_mirror(host, blob, label=""):
+    ws = pgp.walk_certificate(blob)
+    got = host.Certificate.Parse(blob)
+    assert len(got) == len(ws), (label, len(got), len(ws))
+    for g, w in zip(got, ws):
+        ctx = (label, g["why"], w.error, w.unknown)
+        assert g["refused"] == (w.error is not None), ctx
+        assert g["unknown"] == (w.unknown is not None or w.primary is None), ctx
+        if w.primary is None:
+            assert g["keys"] == [], ctx
+            continue
+        assert g["id"] == w.primary.key_id, ctx
+        if w.error is not None:
+            continue          # refused: both stop looking at the entity's packets there
+        assert g["certifiers"] == pgp.walk_signers(w), ctx
+        own = [c for c in g["checks"] if c["kind"] != 2]
+        assert [(c["kind"], c["signed"], c["sig"]) for c in own] == [(KIND[c.kind], c.signed, c.raw) for c in w.checks], ctx
+        for c, oc in zip(own, w.checks):
+            assert g["keys"][c["key_index"]]["key_id"] == oc.key.key_id, ctx
+        third = [(c["signed"], c["sig"]) for c in g["checks"] if c["kind"] == 2]
+        by_name = {}
+        for ident in w.identities:
+            if ident["self_sig"] is not None:
+                by_name[ident["name"]] = ident
+        assert third == [(signed, raw) for ident in by_name.values() for s, raw, signed in ident["sigs"] if s.issuer is not None], ctx
+        # KeysByIdUsage facts
+        e = [x for x in pgp.read_entities(blob) if x.serialized == blob[w.start:w.end]][0]
+        wkeys = [(e.primary, e.flags_valid, e.flag_sign, e.self_sig_revoked)] + list(e.subkeys)
+        assert len(g["keys"]) == len(wkeys), ctx
+        for gk, (wk, fv, fs, rr) in zip(g["keys"], wkeys):
+            assert gk["key_id"] == wk.key_id and gk["pk_algo"] == wk.pk_algo, ctx
+            assert gk["usable_sign"] == (not (e.revoked or rr) and not (fv and not fs)), ctx
+    return ws
+
+
+@pytest.fixture(scope="module")
+def host():
+    from bftkv_amd import host as h
+    return h
+
+
+def test_mirror_walks_the_shapes_like_the_oracle(host, shapes):
+    for name, blob, valid, _, _ in shapes:
+        ws = compare_with_mirror(host, blob, name)
+        assert len(ws) == len(valid)
+
+
+def test_mirror_walks_random_packet_sequences_like_the_oracle(host):
+    blobs = CS.random_blobs(3000)
+    stats = {"refused": 0, "unknown": 0, "plain": 0, "entities": 0}
+    for i, blob in enumerate(blobs):
+        for w in compare_with_mirror(host, blob, "blob %d" % i):
+            stats["entities"] += 1
+            stats["refused" if w.error else "unknown" if (w.unknown or w.primary is None) else "plain"] += 1
+    assert min(stats.values()) > 200, stats
+
+
+def test_gpg_made_certificates(host):
+    """Certificates GnuPG 2.2 made (tests/golden/make_gpg_cert_vectors.py): gen.sh's default key, signing subkeys with their
+    cross-signatures, revoked subkeys and keys, several user ids, a DSA / ElGamal key.  gpg accepts its own output; the oracle must
+    return every entity, with the usable keys gpg lists as signing-capable, and the mirror walks them like the oracle."""
+    path = os.path.join(ROOT, "tests", "golden", "gpg_cert_vectors.json")
+    vec = json.load(open(path))
+    assert len(vec["certificates"]) >= 8
+    kinds = set()
+    for c in vec["certificates"]:
+        blob = bytes.fromhex(c["blob"])
+        ws = compare_with_mirror(host, blob, c["name"])
+        assert [pgp.walk_valid(w) for w in ws] == [True] * len(ws), (c["name"], [(w.error, w.unknown) for w in ws])
+        assert len(ws) == 1 and "%016X" % ws[0].primary.key_id == c["primary_key_id"], c["name"]
+        assert sorted("%016X" % k for k in usable_keys(blob)) == sorted(c["signing_key_ids"]), c["name"]
+        assert sorted("%016X" % s for s in pgp.walk_signers(ws[0])) == sorted(c["signers"]), c["name"]
+        kinds.update(ck.kind for ck in ws[0].checks)
+    assert kinds == {"uid", "binding", "cross", "revocation"}
+    for c in vec["tampered"]:
+        ws = compare_with_mirror(host, bytes.fromhex(c["blob"]), c["name"])
+        assert pgp.walk_valid(ws[0]) is False, c["name"]

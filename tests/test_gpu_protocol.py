@@ -1070,3 +1070,67 @@ def test_http_wire_replay(gpu_ctx):
     assert seen == {"consistent", "no-response", "not-judged", "accepted-but-fails-verification", "wrong-error"}
     assert {w[2] for w in want} >= {None, wire.ERR_MALFORMED, wire.ERR_INSUFFICIENT_SIGNATURES, wire.ERR_CERT_NOT_FOUND, wire.ERR_INVALID_SIGNATURE}
     assert {w[1] for w in want} >= {"ok", "unverified", wire.ERR_DECRYPTION_FAILED, wire.ERR_INVALID_SIGNATURE}
+
+
+def test_read_entity_shape_by_shape_on_the_gpu(gpu_ctx):
+    """openpgp.ReadEntity as Certificate.Parse / Signature.Issuer reach it (crypto_pgp.go:236-249, 392-405), signature checks on
+    the GPU (bftkv_host_certs_verify): every hand-worked shape of tests/cert_shapes.py (self-signatures that must verify and the
+    last of which counts, subkey bindings and revocations, the cross-signature a signing subkey's binding must carry -- verified
+    under the SUBKEY --, key revocations verified at the end, refusals the walk alone decides, shapes left to the reference) and
+    every certificate GnuPG made (tests/golden/gpg_cert_vectors.json) gets the verdict x/crypto's rules give; then Issuer +
+    VerifyWithCertificate through the batcher for requests signed with a stranger's signing SUBKEY."""
+    import json
+    import os
+    from bftkv_amd import Batcher, host
+    from oracle import openpgp as pgp
+    from tests import cert_shapes as CS
+    cl = cb.make_cluster(4)
+    gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
+    seen = set()
+    for name, blob, valid, _, _ in CS.scenarios():
+        got = host.certs_verify(gpu_ctx, blob)
+        assert got == valid, (name, got, valid)
+        seen.update(got)
+    assert seen == {True, False, None}
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_cert_vectors.json")))
+    for c in vec["certificates"]:
+        assert host.certs_verify(gpu_ctx, bytes.fromhex(c["blob"])) == [True], c["name"]
+    for c in vec["tampered"]:
+        assert host.certs_verify(gpu_ctx, bytes.fromhex(c["blob"])) == [False], c["name"]
+    # ---- a stranger whose request is signed with its signing subkey
+    a, b_, s, s2, d = CS.keys()
+    uid = a.name.encode()
+    head = CS.pkt(6, a.pub_body) + CS.pkt(13, uid) + CS.self_sig(a, uid) + CS.pkt(14, s.pub_body)
+    tbs = cb.serialize_tbs(b"variable", b"value", 9)
+    by_sub, by_primary = cb.detach_sign(s, tbs), cb.detach_sign(a, tbs)
+    certs = {
+        "cross-signed signing subkey": head + CS.binding(a, s, flags=0x02),
+        "the subkey is for encryption": head + CS.binding(a, s, flags=0x0c),
+        "the subkey is revoked": head + CS.binding(a, s, flags=0x02) + CS.binding(a, s, sig_type=0x28, flags=None, reason=1),
+        "no cross-signature: ReadEntity refuses the certificate": head + CS.binding(a, s, flags=0x02, cross=None),
+        "the key is revoked": CS.pkt(6, a.pub_body) + CS.key_revocation(a) + CS.pkt(13, uid) + CS.self_sig(a, uid) + CS.pkt(14, s.pub_body) + CS.binding(a, s, flags=0x02),
+        "a user attribute: left to the reference": head + CS.binding(a, s, flags=0x02) + CS.pkt(17, b"\x01\x01"),
+    }
+    bt = Batcher(gpu_ctx, max_items=16)
+    try:
+        outcomes = set()
+        for name, cert in certs.items():
+            ent = pgp.entity_checks(cert)[0]
+            for who, sig in (("subkey", by_sub), ("primary", by_primary)):
+                err, fenced, got_id, _ = bt.cert_verify(cert, tbs, sig)
+                if ent["valid"] is None:
+                    assert fenced, (name, who)
+                    outcomes.add("fenced")
+                    continue
+                assert not fenced, (name, who)
+                if not ent["valid"]:
+                    want = 3                                                         # no issuer: crypto.ErrCertificateNotFound
+                else:
+                    e = col.signature_verify_with_certificate(tbs, opk.SignaturePacket(1, 0, False, sig, cert), pgp.read_entities(cert)[0])
+                    want = 0 if e is None else 1
+                    assert got_id == a.key_id, (name, who)
+                assert err == want, (name, who, err, want)
+                outcomes.add((who, want))
+        assert outcomes == {"fenced", ("subkey", 0), ("subkey", 1), ("subkey", 3), ("primary", 0), ("primary", 1), ("primary", 3)}
+    finally:
+        bt.close()

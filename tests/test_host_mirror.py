@@ -258,7 +258,7 @@ def test_certificate_parse_matches_oracle(H):
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert g["id"] == w.id and g["certifiers"] == w.certifiers
-            wkeys = [(w.primary, w.flags_valid, w.flag_sign, w.self_sig_revoked)] + [(k, fv, fs, False) for k, fv, fs in w.subkeys]
+            wkeys = [(w.primary, w.flags_valid, w.flag_sign, w.self_sig_revoked)] + [(k, fv, fs, rr) for k, fv, fs, rr in w.subkeys]
             assert len(g["keys"]) == len(wkeys)
             for gk, (wk, fv, fs, rr) in zip(g["keys"], wkeys):
                 assert gk["key_id"] == wk.key_id and gk["pk_algo"] == wk.pk_algo
