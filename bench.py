@@ -49,7 +49,15 @@ DSA_BYTES = 99                 # per DSA-2048/256 signature veri
 # limb MACs actually executed (mont28.h): a general Montgomery product = 76x76 (a*b) + 76x76 (m*n) = 11,552; a squaring forms
 # only the triangles of a*a: 4 lanes x (4 x 190 + 1,444) = 8,816.  e = 65537: 16 squarings + 2 products.
 MACS_PER_RSA_VERIFY = 16 * 8816 + 2 * 11552
-MACS_PER_DSA_VERIFY = 31 * 11552           # 16-bit windows: 32 table entries, the first taken as is, the last stored in plain form
+
+
+def macs_per_dsa_verify(table_bits):
+    """Limb MACs of one DSA verification from fixed-base tables of `table_bits`-bit windows (k_dsa_modexp): g^u1 y^u2 is one table
+    entry per window of u1 and of u2, the first taken as it is and the last stored in plain form -- 2 * ceil(256 / bits) - 1
+    general Montgomery products (18 bits: 29, 16: 31, 19: 27, 8: 63) of 11,552 MACs."""
+    if not table_bits:
+        return 0
+    return (2 * ((256 + table_bits - 1) // table_bits) - 1) * 11552
 
 
 def macs_per_calculate_r(k=8, windows=64, win_bits=4, ent=15):
@@ -820,6 +828,7 @@ def bench_cfg3(args, D):
     if D.rank == 0:
         rsa_ms, dsa_ms = float(np.mean(V.rsa_ms)), float(np.mean(V.dsa_ms))
         n_rsa_ops = int(counters["pubkey_ops"]) - n_dsa_ops
+        dsa_bits = V.ctxs[0].dsa_window_bits()        # the width the tables were built at decides the MAC count of a verification
         dom = "k_dsa_modexp" if dsa_ms >= rsa_ms else "k_rsa_modexp"
         alg_bytes = int(rc.tbss_off[-1]) + n_rsa_ops * RSA_BYTES + n_dsa_ops * DSA_BYTES + (n_replies + 7) // 8
         out = base_line(args, D, "pgp_mixed_rsa_dsa_signature_verifies_per_sec", "verifies/s", tot_ref_ops * args.steps / elapsed, elapsed, "u32",
@@ -843,8 +852,10 @@ def bench_cfg3(args, D):
                           "step_device_span": float(np.mean(V.total_ms)), "measured": "HIP events of the %d timed steps" % len(V.rsa_ms),
                           "last_call": V.last_tm},
             "roofline": roofline(3, dom, alg_bytes, max(rsa_ms, dsa_ms), "integer-VALU bound; see int_mac"),
-            "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * MACS_PER_DSA_VERIFY, elapsed / args.steps * 1e3,
+            "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * macs_per_dsa_verify(dsa_bits), elapsed / args.steps * 1e3,
                                      rsa_ms + dsa_ms, None, sclk, V.n_ctx),
+            "dsa_tables": {"window_bits": dsa_bits, "products_per_verify": macs_per_dsa_verify(dsa_bits) // 11552,
+                           "note": "width chosen by the library for this keyring and the free HBM (bftkv_gpu_dsa_window_bits); BFTKV_DSA_WBITS pins it"},
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:

@@ -59,3 +59,10 @@ def test_summarize_keeps_what_the_default_line_promises():
     assert s["cpu_baseline"] == {"value": 2.0, "unit": "u", "cores": 16, "threads": 64, "kind": "port"}
     assert s["identity"] == {"gpu_verdicts_identical_to_cpu": True} and s["kernel_ms"] == {"k_rsa_modexp": 1.0}
     assert bench.summarize(None) is None
+
+
+def test_dsa_mac_count_follows_the_table_width():
+    """bench.py prices a DSA verification by the width the library built its tables at (bftkv_gpu_dsa_window_bits): 2 * ceil(256 / bits) - 1
+    Montgomery products of 11,552 limb MACs."""
+    assert [bench.macs_per_dsa_verify(b) // 11552 for b in (4, 8, 16, 17, 18, 19, 20)] == [127, 63, 31, 31, 29, 27, 25]
+    assert bench.macs_per_dsa_verify(0) == 0 and bench.macs_per_dsa_verify(18) == 29 * 11552
