@@ -27,6 +27,7 @@
 #include <system_error>
 #include <thread>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "host_bignum.h"

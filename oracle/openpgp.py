@@ -1115,7 +1115,8 @@ def parse_public_key_body(body: bytes, is_subkey: bool = False) -> PublicKey:
 # Shapes outside this restatement are reported as `unknown` (the verifier fences them, the reference decides): version-2/3 keys,
 # elliptic-curve keys, secret-key packets, user attributes and the other packet types whose parsers are not modelled, key or
 # signature bodies over 4096 bytes, partial / indeterminate lengths, signatures the device cannot look up by issuer (binding / revocation signatures whose issuer
-# subpacket does not name the primary key, cross-signatures that do not name the subkey).
+# subpacket does not name the primary key, cross-signatures that do not name the subkey).  (The mirror also gives no verdict on
+# a certificate whose signatures are computed over more than 16 MB in all: it hands the device a copy per signature.)
 # ------------------------------------------------------------------------------------------------
 _KNOWN_TAGS = {1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 14, 17, 18}     # packet.Read's switch; everything else: UnknownPacketTypeError
 

@@ -127,3 +127,27 @@ def test_gpg_made_certificates(host):
     for c in vec["tampered"]:
         ws = compare_with_mirror(host, bytes.fromhex(c["blob"]), c["name"])
         assert pgp.walk_valid(ws[0]) is False, c["name"]
+
+
+def test_mirror_bounds_what_a_hostile_certificate_costs(host):
+    """Certificates arrive inside unauthenticated requests: a hundred thousand user ids are walked in time linear in their number,
+    and a certificate whose signatures would need more copied bytes than the device path takes gets no verdict (x/crypto hashes it in
+    place: the reference decides) instead of gigabytes of copies."""
+    import time
+    a, b, s, s2, d = CS.keys()
+    uid = a.name.encode()
+    head = CS.pkt(6, a.pub_body) + CS.pkt(13, uid) + CS.self_sig(a, uid, fake=True)
+    many = head + b"".join(CS.pkt(13, b"u%06d" % i) + (CS.self_sig(a, b"u", fake=True) if i % 7 == 0 else b"") for i in range(100000))
+    t0 = time.perf_counter()
+    ents = host.Certificate.Parse(many)
+    assert time.perf_counter() - t0 < 5.0
+    assert len(ents) == 1 and not ents[0]["refused"]
+    # one megabyte of user id under a thousand certifications: 1 GB of copies if every check carried its own
+    big_uid = b"x" * (1 << 20)
+    heavy = CS.pkt(6, a.pub_body) + CS.pkt(13, big_uid) + CS.self_sig(a, big_uid, fake=True) + CS.certification(b, a, big_uid, fake=True) * 1000
+    t0 = time.perf_counter()
+    ents = host.Certificate.Parse(heavy)
+    assert time.perf_counter() - t0 < 5.0
+    assert len(ents) == 1 and ents[0]["unknown"] and not ents[0]["refused"]
+    assert sum(len(c["signed"]) for c in ents[0]["checks"]) <= 17 << 20
+    assert len(ents[0]["certifiers"]) == 1000                     # Signers() is still complete
