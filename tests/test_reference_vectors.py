@@ -199,14 +199,18 @@ def test_oracle_matches_the_reference_vectors(inputs, replayed):
     if "certs" in ref:
         assert len(ref["certs"]) == len(replayed["certs"])
         for n, (a, b) in enumerate(zip(replayed["certs"], ref["certs"])):
-            if None in a["ids"]:
-                continue          # a shape left to the reference: nothing to compare
-            assert ["%016x" % i for i in a["ids"]] == b["ids"], ("cert", n, a, b)
-            if "usable" in b:
-                assert ["%016x" % i for i in a["usable"]] == b["usable"], ("cert", n, "KeysByIdUsage", a, b)
-            # Signers() walks a Go map: the order across identities is not defined
-            if "signers" in b and not b.get("signers_panic"):
-                assert sorted("%016x" % i for i in a["signers"]) == sorted(b["signers"]), ("cert", n, "Signers()", a, b)
+            _same_cert(n, a, b)
+
+
+def _same_cert(n, a, b):
+    if None in a["ids"]:
+        return            # a shape left to the reference: nothing to compare
+    assert ["%016x" % i for i in a["ids"]] == b["ids"], ("cert", n, a, b)
+    if "usable" in b:
+        assert ["%016x" % i for i in a["usable"]] == b["usable"], ("cert", n, "KeysByIdUsage", a, b)
+    # Signers() walks a Go map: the order across identities is not defined
+    if "signers" in b and not b.get("signers_panic"):
+        assert sorted("%016x" % i for i in a["signers"]) == sorted(b["signers"]), ("cert", n, "Signers()", a, b)
 
 
 def _same_packet(tag, ours, ref):
@@ -252,6 +256,18 @@ def test_comparison_accepts_the_oracles_own_answers_and_refuses_a_flipped_one(re
         if pk_[0] is not None:
             with pytest.raises(AssertionError):
                 _same_packet(n, pk_, dict(as_ref, tbs=(pk_[0] + b"x").hex()))
+    n_cmp = 0
+    for n, c in enumerate(replayed["certs"]):
+        if None in c["ids"]:
+            continue
+        as_ref = {"ids": ["%016x" % i for i in c["ids"]], "signers": ["%016x" % i for i in reversed(c["signers"])], "usable": ["%016x" % i for i in c["usable"]]}
+        _same_cert(n, c, as_ref)
+        n_cmp += 1
+        for tampered in (dict(as_ref, ids=as_ref["ids"] + ["00" * 8]), dict(as_ref, usable=as_ref["usable"][1:] if as_ref["usable"] else ["00" * 8]),
+                         dict(as_ref, signers=as_ref["signers"] + ["00" * 8])):
+            with pytest.raises(AssertionError):
+                _same_cert(n, c, tampered)
+    assert n_cmp > 50
     o = next(i for i in items if i.get("collective", 1) is None and len(i["calls"]) > 2)
     for tamper in ("calls", "collective", "n_verified", "signature"):
         ref = _as_reference_would_write(o)
