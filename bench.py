@@ -1216,7 +1216,7 @@ def summarize(out):
         keep["cpu_baseline"] = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
         keep["identity"] = {k: v for k, v in cb_.items() if "identical" in k}
     for k in ("verdicts_match_construction", "kernel_ms", "per_scheme_ops_per_sec_per_gpu", "packets_per_sec", "quorum_verdicts_per_sec",
-              "reply_verdicts_per_sec", "read_verdicts_per_sec"):
+              "reply_verdicts_per_sec", "read_verdicts_per_sec", "dsa_tables"):
         if k in out:
             keep[k] = out[k]
     if "kernel_ms" in keep:

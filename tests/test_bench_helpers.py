@@ -66,3 +66,15 @@ def test_dsa_mac_count_follows_the_table_width():
     Montgomery products of 11,552 limb MACs."""
     assert [bench.macs_per_dsa_verify(b) // 11552 for b in (4, 8, 16, 17, 18, 19, 20)] == [127, 63, 31, 31, 29, 27, 25]
     assert bench.macs_per_dsa_verify(0) == 0 and bench.macs_per_dsa_verify(18) == 29 * 11552
+
+
+def test_summarize_keeps_what_the_default_line_shows_per_config():
+    import json
+    import os
+    full = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_cfg3_bench_18bit_tables.json")))
+    s = bench.summarize(full)
+    assert s["metric"] == full["metric"] and s["value"] == full["value"] and s["workload"] == full["config"]["workload"]
+    assert s["dsa_tables"] == {"window_bits": 18, "products_per_verify": 29, "note": full["dsa_tables"]["note"]}
+    assert set(s["int_mac"]) == {"achieved", "frac", "frac_of_theoretical", "basis"} and s["roofline"]["kernel"] == "k_dsa_modexp"
+    assert all(isinstance(v, (int, float)) for v in s["kernel_ms"].values())
+    assert bench.summarize(None) is None
