@@ -271,7 +271,8 @@ int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs,
 /* Signature.Issuer(sig) + Signature.VerifyWithCertificate(tbs, sig, issuer) for a principal that is NOT in the node keyring --
  * the shape of protocol/server.go:199-207 (sign) and :460-468 (register), where the certificate travels inside the request
  * (sig.Cert) -- as ONE micro-batched call.  Replaces crypto_pgp.go:392-405 -> :236-249 (Certificate.Parse ->
- * openpgp.ReadEntity, which verifies every user-id self-signature and subkey binding of the entity) and :332-344:
+ * openpgp.ReadEntity, which verifies every user-id self-signature, every subkey binding / revocation with the cross-signature
+ * of a signing subkey, and every key revocation of the entity: bftkv_host.h bftkv_host_certs_verify) and :332-344:
  *   cert / cert_len   sig.Cert: serialised entities; the issuer is the FIRST one ("has to be the first one", :404);
  *   tbs, sig          packet.TBS(req) and sig.Data; sig == NULL asks for the issuer alone (Issuer(), server.go:330-331);
  *   *err_out          BFTKV_ERR_NONE, BFTKV_ERR_INVALID_SIGNATURE (VerifyWithCertificate's error), or
