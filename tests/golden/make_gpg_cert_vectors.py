@@ -83,11 +83,28 @@ def main():
     out = {"gpg_version": subprocess.run(["gpg", "--version"], stdout=subprocess.PIPE).stdout.decode().splitlines()[0], "certificates": [], "tampered": []}
     homes = []
 
-    def record(name, home, fpr):
+    def record(name, home, fpr, sign_with=()):
         blob = gpg(home, "--export", fpr).stdout
         primary, signing, signers = describe(home, fpr)
-        out["certificates"].append({"name": name, "blob": blob.hex(), "primary_key_id": primary, "signing_key_ids": signing, "signers": signers})
+        rec = {"name": name, "blob": blob.hex(), "primary_key_id": primary, "signing_key_ids": signing, "signers": signers, "detached": []}
+        # binary detached signatures made with a NAMED key of the certificate ("keyid!": no automatic choice of the newest signing
+        # subkey), judged by gpg on the intact and on a changed payload
+        for kid in sign_with:
+            pl = b"signed with " + kid.encode()
+            sig = gpg(home, "--digest-algo", "SHA256", "-u", kid + "!", "--detach-sign", "-o", "-", inp=pl, when=T2).stdout
+            verdicts = []
+            for data in (pl, pl + b"!"):
+                with open(os.path.join(home, "pl"), "wb") as f:
+                    f.write(data)
+                with open(os.path.join(home, "sg"), "wb") as f:
+                    f.write(sig)
+                verdicts.append(gpg(home, "--verify", os.path.join(home, "sg"), os.path.join(home, "pl"), ok=None, when=T2).returncode == 0)
+            rec["detached"].append({"key_id": kid, "payload": pl.hex(), "sig": sig.hex(), "gpg_good": verdicts[0], "gpg_tampered_good": verdicts[1]})
+        out["certificates"].append(rec)
         return blob
+
+    def keys_of(home, fpr):
+        return [ln.split(":")[4] for ln in gpg(home, "--with-colons", "--list-keys", fpr).stdout.decode().splitlines() if ln[:4] in ("pub:", "sub:")]
 
     try:
         # 1. scripts/gen.sh's command, word for word (gpg 2.2's "default": rsa3072 [SC] + rsa3072 [E])
@@ -100,10 +117,11 @@ def main():
         f = fpr_of(h, "s01@gpg.example")
         gpg(h, "--quick-add-key", f, "rsa2048", "sign", "never", when=T1)
         gpg(h, "--quick-add-key", f, "rsa2048", "encr", "never", when=T1)
-        signing_blob = record("signing subkey (cross-signature) and an encryption subkey", h, f)
+        ks = keys_of(h, f)
+        signing_blob = record("signing subkey (cross-signature) and an encryption subkey", h, f, sign_with=ks[:2])
         # 3. DSA signing subkey under an RSA primary
         gpg(h, "--quick-add-key", f, "dsa2048", "sign", "never", when=T2)
-        record("... plus a DSA signing subkey", h, f)
+        record("... plus a DSA signing subkey", h, f, sign_with=[keys_of(h, f)[-1]])
         # 4. two user ids, the second flagged primary; then the first revoked
         h = new_home(); homes.append(h)
         gpg(h, "--quick-gen-key", "u01 <u01@gpg.example>", "rsa2048", "sign,cert", "never")
@@ -125,8 +143,20 @@ def main():
         gpg(h, "--quick-gen-key", "r01 <r01@gpg.example>", "rsa2048", "sign,cert", "never")
         f = fpr_of(h, "r01@gpg.example")
         gpg(h, "--quick-add-key", f, "rsa2048", "sign", "never", when=T1)
+        sub_id = keys_of(h, f)[1]
+        pl = b"signed before the revocation"
+        early = gpg(h, "--digest-algo", "SHA256", "-u", sub_id + "!", "--detach-sign", "-o", "-", inp=pl, when=T1).stdout
         edit(h, f, "key 1\nrevkey\ny\n1\n\ny\nsave\n", when=T2)
         record("signing subkey revoked (0x28 with a reason)", h, f)
+        # a signature the subkey made while it was good: gpg still calls it good (with a warning); x/crypto's KeysByIdUsage drops a
+        # subkey whose Sig carries a revocation reason, so CheckDetachedSignature ends in ErrUnknownIssuer -- recorded, not compared
+        with open(os.path.join(h, "pl"), "wb") as fh:
+            fh.write(pl)
+        with open(os.path.join(h, "sg"), "wb") as fh:
+            fh.write(early)
+        v = gpg(h, "--verify", os.path.join(h, "sg"), os.path.join(h, "pl"), ok=None, when=T2)
+        out["certificates"][-1]["detached_by_revoked_subkey"] = {"key_id": sub_id, "payload": pl.hex(), "sig": early.hex(), "gpg_rc": v.returncode,
+                                                                 "gpg_says": v.stderr.decode()[-300:]}
         # 7. revoked key (the revocation certificate gpg prepares at key generation)
         h = new_home(); homes.append(h)
         gpg(h, "--quick-gen-key", "k01 <k01@gpg.example>", "default", "default", "never")

@@ -108,6 +108,14 @@ def main():
     out["rings"]["neg"] = neg["pubring"]
     for v in neg["vectors"]:
         out["gpg"].append({"name": "neg/" + v["name"], "ring": "neg", "tbs": neg["payload"], "sig": v["sig"]})
+    # detached signatures gpg made with named keys of certificates that carry signing subkeys (KeysByIdUsage over Subkey.Sig)
+    gv = json.load(open(os.path.join(HERE, "gpg_cert_vectors.json")))
+    for k, c in enumerate(gv["certificates"]):
+        dets = list(c.get("detached", [])) + ([c["detached_by_revoked_subkey"]] if "detached_by_revoked_subkey" in c else [])
+        if dets:
+            out["rings"]["cert/%d" % k] = c["blob"]
+        for j, d in enumerate(dets):
+            out["gpg"].append({"name": "cert/%d/%d by %s" % (k, j, d["key_id"]), "ring": "cert/%d" % k, "tbs": d["payload"], "sig": d["sig"]})
     out["packets"] = packet_cases()
     out["certs"] = cert_cases()
     path = os.path.join(HERE, "reference_inputs.json")

@@ -124,6 +124,26 @@ def test_gpg_made_certificates(host):
         assert sorted("%016X" % s for s in pgp.walk_signers(ws[0])) == sorted(c["signers"]), c["name"]
         kinds.update(ck.kind for ck in ws[0].checks)
     assert kinds == {"uid", "binding", "cross", "revocation"}
+    # detached signatures gpg made with a NAMED key of the certificate (primary, RSA signing subkey, DSA signing subkey): the ring
+    # read off the certificate (key flags from the chosen self-signature / Subkey.Sig) verifies them, gpg agrees
+    n_det = 0
+    for c in vec["certificates"]:
+        ring = pgp.read_entities(bytes.fromhex(c["blob"]))
+        for d in c["detached"]:
+            pl, sig = bytes.fromhex(d["payload"]), bytes.fromhex(d["sig"])
+            r = pgp.check_detached_signature(ring, pl, sig, 0)
+            assert d["gpg_good"] and not d["gpg_tampered_good"]
+            assert r.status == pgp.ST_OK and "%016X" % r.signer.primary.key_id == c["primary_key_id"], (c["name"], d["key_id"], r.status)
+            assert pgp.check_detached_signature(ring, pl + b"!", sig, 0).status == pgp.ST_HASH_TAG, c["name"]
+            n_det += 1
+        if "detached_by_revoked_subkey" in c:
+            # gpg: "Good signature" with a warning (rc 0); x/crypto: KeysByIdUsage drops a subkey whose Sig carries a revocation
+            # reason, so the packet has no candidate and the call ends in ErrUnknownIssuer
+            d = c["detached_by_revoked_subkey"]
+            r = pgp.check_detached_signature(ring, bytes.fromhex(d["payload"]), bytes.fromhex(d["sig"]), 0)
+            assert d["gpg_rc"] == 0 and r.status == pgp.ST_UNKNOWN_ISSUER
+            n_det += 1
+    assert n_det >= 4
     for c in vec["tampered"]:
         ws = compare_with_mirror(host, bytes.fromhex(c["blob"]), c["name"])
         assert pgp.walk_valid(ws[0]) is False, c["name"]
