@@ -1382,17 +1382,21 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
     return out
 
 
-def _verify_with_key(key: PublicKey, signed: bytes, sig: Signature) -> bool:
+def _verify_with_key(key: PublicKey, signed: bytes, sig: Signature) -> Optional[bool]:
+    """VerifyUserIdSignature / VerifyKeySignature / VerifyRevocationSignature: hash (the reference's `hashFunc.Available()` first:
+    MD5 / RIPEMD-160 by HASH_POLICY -- None when the deployment has not said whether its binary links them), then VerifySignature."""
     name = HASH_BY_ID.get(sig.hash_id)
-    if name in (None, "md5", "ripemd160"):
+    if name is None:
         return False
-    h = hashlib.new(name)
+    if name in HASH_POLICY and HASH_POLICY[name] is not True:
+        return None if HASH_POLICY[name] is None else False
+    h = new_hash(name)
     h.update(signed)
     h.update(sig.hash_suffix)
     return verify_signature(key, sig.hash_id, h.digest(), sig) == ST_OK
 
 
-def _check_ok(c: CertCheck) -> bool:
+def _check_ok(c: CertCheck) -> Optional[bool]:
     """VerifySignature of one certificate check: CanSign, hash tag, algorithm match, the public-key operation."""
     return _verify_with_key(c.key, c.signed, c.sig)
 
@@ -1402,9 +1406,10 @@ def walk_valid(w: EntityWalk) -> Optional[bool]:
     did follow refuses the entity."""
     if w.error is not None:
         return False
-    if not all(_check_ok(c) for c in w.checks):
+    verdicts = [_check_ok(c) for c in w.checks]
+    if any(v is False for v in verdicts):
         return False
-    return None if w.unknown is not None else True
+    return None if (w.unknown is not None or any(v is None for v in verdicts)) else True
 
 
 def walk_signers(w: EntityWalk) -> List[int]:

@@ -171,3 +171,31 @@ def test_mirror_bounds_what_a_hostile_certificate_costs(host):
     assert len(ents) == 1 and ents[0]["unknown"] and not ents[0]["refused"]
     assert sum(len(c["signed"]) for c in ents[0]["checks"]) <= 17 << 20
     assert len(ents[0]["certifiers"]) == 1000                     # Signers() is still complete
+
+
+def test_md5_self_signature_follows_the_availability_policy():
+    """VerifyUserIdSignature asks `hashFunc.Available()` first: a self-signature over MD5 verifies, fails ("hash function") or has no
+    verdict depending on whether the reference binary links crypto/md5 (oracle HASH_POLICY = bftkv_gpu_set_hash_policy)."""
+    import hashlib
+    import struct
+    from corpus import build as cb
+    a, b, s, s2, d = CS.keys()
+    uid = a.name.encode()
+    hashed = CS.hashed_area(a.key_id, CS.T0, CS.sub(27, b"\x03"))
+    prefix = bytes([4, 0x13, a.algo, 1]) + struct.pack(">H", len(hashed)) + hashed          # hash id 1: MD5
+    digest = hashlib.md5(CS.key_framed(a) + CS.uid_framed(uid) + cb.hash_suffix(prefix)).digest()
+    k = (a.n.bit_length() + 7) // 8
+    t = pgp.HASH_PREFIXES["md5"] + digest
+    em = int.from_bytes(b"\x00\x01" + b"\xff" * (k - len(t) - 3) + b"\x00" + t, "big")
+    sig = prefix + b"\x00\x00" + digest[:2] + cb.go_mpi_bytes(a.rsa_private(em).to_bytes(k, "big"))
+    blob = CS.pkt(6, a.pub_body) + CS.pkt(13, uid) + CS.pkt(2, sig)
+    saved = dict(pgp.HASH_POLICY)
+    try:
+        for policy, want in ((None, None), (False, False), (True, True)):
+            pgp.HASH_POLICY["md5"] = policy
+            assert [pgp.walk_valid(w) for w in pgp.walk_certificate(blob)] == [want], policy
+        pgp.HASH_POLICY["md5"] = True
+        spoiled = bytearray(blob); spoiled[-5] ^= 1
+        assert [pgp.walk_valid(w) for w in pgp.walk_certificate(bytes(spoiled))] == [False]
+    finally:
+        pgp.HASH_POLICY.update(saved)
