@@ -172,6 +172,11 @@ def scenarios():
         [False])
     add("the uid cut off by the end of the certificate", (K + U)[:-3], [False])
     add("the last certification cut off inside its signature value", (K + U + ss + cert_b)[:-40], [False])
+    add("an empty-bodied signature packet is the END of the stream for Reader.Next: the certification behind it is never read",
+        K + U + ss + pkt(2, b"") + cert_b, [True], [], [a.key_id])
+    add("a stray byte behind the last packet is an error of Next: the entity it ends is refused", K + U + ss + b"\x00", [False])
+    add("an unknown packet type cut off by the end of the certificate is skipped like a whole one", K + U + ss + pkt(12, b"abcdef")[:-2], [True], [], [a.key_id])
+    add("a second primary key packet that does not parse refuses only its own entity", K + U + ss + pkt(6, a.pub_body[:20]), [True, False], [], [a.key_id])
     add("empty", b"", [])
     add("not a packet", bytes(range(200)), [])
     # a key packet with bytes behind its last MPI: key id, fingerprint and hashes are those of the key without them
