@@ -169,3 +169,36 @@ def test_interfaces_are_fully_implemented():
     for typ, methods in want.items():
         for meth in methods:
             assert re.search(r"func \(\w+ \*%s\) %s\(" % (typ, meth), src), (typ, meth)
+
+
+REFERENCE = "/root/reference"
+# names of the reference's own API the shim and genvectors call or read (methods of its interfaces, fields of its structs, its
+# constants and error values): each must be declared somewhere in the reference tree -- or, for the per-clique accessor, in
+# shim/patches.  (x/crypto and the standard library are not checkable here.)
+REFERENCE_NAMES = [
+    "AddNodes", "Certs", "ChooseQuorum", "Cliques", "Decrypt", "Encrypt", "EncryptStream", "GetCertById", "GetKeyring", "Id", "Instance",
+    "IsQuorum", "IsSufficient", "IsThreshold", "Issuer", "Parse", "Register", "Reject", "Remove", "SetSelfNodes", "Sign", "Signers", "Verify",
+    "VerifyWithCertificate", "AUTH", "Cert", "Certificate", "CollectiveSignature", "Completed", "Crypto", "Data", "ErrDecryptionFailed",
+    "ErrInsufficientNumberOfSignatures", "ErrInvalidSignature", "ErrInvalidTransportSecurityData", "Keyring", "Message", "Signature",
+    "SignaturePacket", "SignatureTypeNil", "SignatureTypePGP", "TBS", "TBSS", "Type", "Clique", "Threshold", "Suff", "Min", "Nodes",
+]
+
+
+def test_reference_api_names_the_shim_uses_exist():
+    import pytest
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not here")
+    decls = []
+    for dirpath, _, files in os.walk(REFERENCE):
+        decls += [open(os.path.join(dirpath, f), errors="replace").read() for f in files if f.endswith(".go") and not f.endswith("_test.go")]
+    for f in sorted(os.listdir(os.path.join(SHIM, "patches"))):
+        decls.append("\n".join(ln[1:] for ln in open(os.path.join(SHIM, "patches", f)).read().splitlines() if ln.startswith("+")))
+    text = "\n".join(decls)
+    used = set()
+    for p in go_files():
+        src = strip_go(open(p).read())
+        used.update(re.findall(r"\.([A-Z]\w*)\b", src))
+    for name in REFERENCE_NAMES:
+        assert name in used, "%s is not used by the shim any more: drop it from the list" % name
+        pat = r"(func (\([^)]*\) )?%s\(|^\s*%s(\(|\s+[\w\[\]\*\.]+|\s*=)|type %s\b)" % (name, name, name)
+        assert re.search(pat, text, flags=re.M), "the reference declares no %s" % name
