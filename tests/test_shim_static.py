@@ -202,3 +202,20 @@ def test_reference_api_names_the_shim_uses_exist():
         assert name in used, "%s is not used by the shim any more: drop it from the list" % name
         pat = r"(func (\([^)]*\) )?%s\(|^\s*%s(\(|\s+[\w\[\]\*\.]+|\s*=)|type %s\b)" % (name, name, name)
         assert re.search(pat, text, flags=re.M), "the reference declares no %s" % name
+
+
+def test_no_variable_is_declared_and_never_used():
+    """Go refuses a local variable that is declared and not used.  Rough, but it costs nothing: every name introduced by `:=` or
+    `var` inside a function must occur at least once more in that function."""
+    for p in go_files():
+        src = strip_go(open(p).read())
+        for m in re.finditer(r"^func [^\n]*\{\n(.*?)^\}", src, flags=re.S | re.M):
+            body = m.group(0)
+            names = []
+            for d in re.finditer(r"(?:^|[\s;{(])((?:[A-Za-z_]\w*\s*,\s*)*[A-Za-z_]\w*)\s*:=", body):
+                names += [x.strip() for x in d.group(1).split(",")]
+            for d in re.finditer(r"\bvar\s+((?:[A-Za-z_]\w*\s*,\s*)*[A-Za-z_]\w*)\s", body):
+                names += [x.strip() for x in d.group(1).split(",")]
+            for name in names:
+                if name != "_":
+                    assert len(re.findall(r"\b%s\b" % re.escape(name), body)) >= 2, (p, name, body.split("\n")[0])
