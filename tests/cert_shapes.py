@@ -194,6 +194,7 @@ def random_blobs(n: int, seed: int = 7):
     a, b, s, s2, d = keys()
     uid, uid2 = a.name.encode(), b"other"
     fake = dict(fake=True)
+    body_of = lambda p: p[2 if p[1] < 192 else 3 if p[1] < 224 else 6:]      # a new-format packet without its header
     blocks = [
         lambda: pkt(6, a.pub_body), lambda: pkt(6, b.pub_body), lambda: pkt(6, d.pub_body),
         lambda: pkt(13, uid), lambda: pkt(13, uid), lambda: pkt(13, uid2), lambda: pkt(14, s.pub_body), lambda: pkt(14, s2.pub_body),
@@ -209,6 +210,13 @@ def random_blobs(n: int, seed: int = 7):
         lambda: pkt(6, a.pub_body[:5] + bytes([rnd.choice([2, 16, 19, 22, 18])]) + a.pub_body[6:]), lambda: pkt(14, bytes([3]) + a.pub_body[1:]),
         lambda: pkt(6, a.pub_body + b"tail"), lambda: pkt(14, s.pub_body[:rnd.randrange(1, len(s.pub_body))]),
         lambda: bytes([0x88, 3]) + b"\x04\x00\x01",                      # old-format header, one length byte
+        lambda: b"\x99" + struct.pack(">H", len(b.pub_body)) + b.pub_body,                       # old-format key packet (what gpg exports)
+        lambda: b"\xb4" + bytes([len(uid)]) + uid,                                                # old-format user id
+        lambda: b"\x89" + struct.pack(">H", len(body_of(self_sig(a, uid, **fake)))) + body_of(self_sig(a, uid, **fake)),   # old-format signature
+        lambda: pkt(5, a.pub_body + b"\x00" + bytes(16)), lambda: pkt(7, s.pub_body + b"\x00" + bytes(16)),     # secret key / subkey packets
+        lambda: pkt(6, b""), lambda: pkt(14, b""), lambda: pkt(13, b""),                             # empty bodies
+        lambda: bytes([0xC6, 0xFF]) + struct.pack(">I", len(a.pub_body)) + a.pub_body,              # five-octet length
+        lambda: bytes([0xCD, 0xC0, 0x10]) + bytes(208),                                              # two-octet length, a 208-byte user id
         lambda: bytes([0xC2, 0xE0]) + b"\x04",                          # partial length
         lambda: pkt(2, self_sig(a, uid, **fake)[3:] + bytes(4200)),      # a signature body over 4096 bytes
     ]
