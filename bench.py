@@ -98,7 +98,7 @@ def parse_args(argv=None):
                     "(3.03 ms per step), three do not (2.91; one: 3.2).  The line also carries the single-flight figures "
                     "(kernel_ms.single_flight, int_mac.single_flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-serving", action="store_true", help="cfg 2: skip the one-Verify-per-call leg (tools/serving/batcher_load.c)")
+    ap.add_argument("--no-serving", action="store_true", help="cfg 2 / cfg 5: skip the one-call-per-operation leg (tools/serving/batcher_load.c, threshold_load.c)")
     ap.add_argument("--no-end-to-end", action="store_true", help="cfg 2: skip the host-buffer legs (profiling runs: their piece-sized launches "
                     "would mix into the per-kernel averages of the resident step)")
     ap.add_argument("--soak-seconds", type=float, default=6.0, help="after the timed region: keep running the same step, untimed for "
@@ -1001,6 +1001,56 @@ def bench_cfg4(args, D):
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 5: threshold share-combine, 10k operations per scheme
 # ------------------------------------------------------------------------------------------------------------------
+def threshold_serving_leg(tc, res, n, threads="1,64,256", seconds=1.0):
+    """ONE share-combine operation per CALL from many caller threads through the micro-batcher (bftkv_gpu_batcher_modmul_product /
+    _lagrange_combine / _dsa_calculate_r) -- the shape of Client.DistSign (protocol/client.go:509-546: one ThresholdProcess per signature)
+    -- measured by the plain-C load generator tools/serving/threshold_load.c in its own process on the first `n` operations of this
+    run's corpus; every answer is compared byte for byte with the batched entry points' result for the same operation (`res`, which
+    the cpu_baseline leg compares with oracle/c/threshold.c).  Beside the headline, never `value`."""
+    import shutil
+    import struct
+    import tempfile
+    if shutil.which("gcc") is None:
+        return None
+    from bftkv_amd._native import _ints_to_be
+    tmp = tempfile.mkdtemp(prefix="bftkv_thserving")
+    try:
+        exe = os.path.join(tmp, "threshold_load")
+        lib_dir = os.path.join(ROOT, "bftkv_amd")
+        cc = subprocess.run(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "serving", "threshold_load.c"),
+                             "-L", lib_dir, "-lbftkv_gpu", "-lpthread", "-Wl,-rpath," + lib_dir, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if cc.returncode != 0:
+            return {"error": "gcc: " + cc.stderr.decode(errors="replace")[-300:]}
+        flat = lambda rows: [v for r in rows for v in r]
+        i32 = lambda a: np.ascontiguousarray(a[:n], dtype="<i4").tobytes()
+        path = os.path.join(tmp, "ops.bin")
+        with open(path, "wb") as fh:
+            fh.write(struct.pack("<I", n))
+            fh.write(tc.rsa_n.to_bytes(256, "big") + _ints_to_be(flat(tc.rsa_factors[:n]), 256).tobytes() + res["rsa"][:n].tobytes())
+            fh.write(tc.sss_mod.to_bytes(256, "big") + i32(tc.sss_xs) + _ints_to_be(flat(tc.sss_ys[:n]), 256).tobytes() + res["sss"][:n].tobytes())
+            fh.write(tc.dsa_q.to_bytes(32, "big") + i32(tc.s_xs) + _ints_to_be(flat(tc.s_ys[:n]), 32).tobytes() + res["s"][:n].tobytes())
+            fh.write(tc.dsa_p.to_bytes(256, "big") + i32(tc.r_xs) + _ints_to_be(flat(tc.r_ri[:n]), 256).tobytes() +
+                     _ints_to_be(flat(tc.r_vi[:n]), 32).tobytes() + res["r"][:n].tobytes() + res["st_r"][:n].tobytes())
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)          # the serving process runs on the runtime's defaults, like the cfg-2 leg
+        r = subprocess.run([exe, path, "256", "0", threads, str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
+        if r.returncode != 0:
+            return {"error": "threshold_load rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"what": "one bftkv_gpu_batcher_{modmul_product,lagrange_combine,dsa_calculate_r} per call from N caller threads (plain-C load "
+                        "generator in its own process, %.1f s per point after 0.3 s of warm-up, runtime-default hardware queues); every answer "
+                        "compared byte for byte with the batched entry point's; `distsign_mix` = RSA product : CalculateR : calculateS in turn"
+                        % seconds,
+                "lanes": d["lanes"], "max_items_per_batch": d["max_items"], "ops_per_scheme": n,
+                "runs": [{"scheme": x["scheme"], "caller_threads": x["threads"], "ops_per_s": x["ops_per_s"], "latency_ms": x["latency_ms"],
+                          "wrong_answers": x["wrong"], "device_calls": x["device_calls"]} for x in d["runs"]],
+                "usable_host_cores": effective_cores(), "tool": "tools/serving/threshold_load.c"}
+    except Exception as e:      # noqa: BLE001  (a side measurement must not take the bench line down)
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def bench_cfg5(args, D):
     from corpus import build as cb
     from bftkv_amd import Context, dist as BD
@@ -1080,8 +1130,18 @@ def bench_cfg5(args, D):
             assert torch.equal(other[k], o[k]), "contexts disagree on " + k
     tot_ops = D.sum_ints([3 * N])[0]
     sustained = soak(D, run, args.soak_seconds, elapsed / args.steps * 1e3, tot_ops)
+    # ONE batch at a time -- the workload BASELINE configs[4] names, without the steps in flight that the headline needs: each step
+    # is waited for before the next is issued
+    n_single = 6
+    spans_timed = [list(x) for x in spans]
+    spans.clear()
+    t0 = time.perf_counter()
+    for _ in range(n_single):
+        run(1)
+    single_ms = D.max_float(time.perf_counter() - t0) / n_single * 1e3
+    single_r_ms = float(np.mean(np.array(spans), axis=0)[3])
     if D.rank == 0:
-        sp = np.mean(np.array(spans), axis=0)
+        sp = np.mean(np.array(spans_timed), axis=0)
         names = ["rsa_combine_n10", "sss_calculate_secret_k7_2048", "dsa_calculate_s_2t8_q256", "dsa_calculate_r_2t8_2048_256"]
         # dominant: CalculateR.  Algorithmic bytes per op: 2t x (|p| + |q|) in, |q| out
         alg_r = N * (8 * (256 + 32) + 32)
@@ -1090,7 +1150,9 @@ def bench_cfg5(args, D):
                         "threshold share-combine (cfg5 of BASELINE.json): per step %d operations of each scheme over %d GPU(s) -- RSA calculateSignature "
                         "(product of 10 partial signatures mod the 2048-bit N of rsa/test.pkcs8), SSS calculateSecret (k=7 of n=10, mod the 2048-bit "
                         "prime of sss_test.go), threshold-DSA combine = calculateS (2t=8, 256-bit q) + CalculateR (2t=8, 2048/256-bit group); one "
-                        "operation = one scheme-level combine (3 per index)" % (n_total, D.world),
+                        "operation = one scheme-level combine (3 per index); %d independent steps in flight on %d contexts with GPU_MAX_HW_QUEUES=%s "
+                        "(set before the HIP runtime loads: a service must export it itself) -- ONE step at a time is `single_flight`"
+                        % (n_total, D.world, n_ctx, n_ctx, os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")),
                         {"ops_per_scheme": n_total, "ops_per_scheme_per_gpu": N, "schemes": 3, "steps_in_flight": n_ctx,
                          "parallelism": "shard-by-operation x%d, no exchange step (results go back to the one client that asked)" % D.world},
                         scaling="strong")
@@ -1107,6 +1169,14 @@ def bench_cfg5(args, D):
             "sustained": sustained,
             "corpus_build_s": t_corpus,
         })
+        sf = int_mac(N * macs_per_calculate_r(8, 64), single_ms)
+        out["single_flight"] = {"what": "the same step with ONE batch of %d operations per scheme on the device at a time (no steps in flight): "
+                                        "what a lone caller of the batched entry points sees" % N,
+                                "steps": n_single, "ms_per_step": single_ms, "value": tot_ops / (single_ms * 1e-3), "unit": "ops/s",
+                                "calculate_r_ms": single_r_ms,
+                                "int_mac": {"achieved": sf["achieved"], "frac": sf["frac"], "frac_of_theoretical": sf["frac_of_theoretical"]}}
+        if D.world == 1 and not args.no_serving:
+            out["serving"] = threshold_serving_leg(tc, res, min(N, 2048))
         if D.world == 1 and not args.no_cpu_baseline:
             # the reference's combine arithmetic restated in C on OpenSSL bignums (oracle/c/threshold.c), threads over operations:
             # all N operations of every scheme, checked against the GPU's bytes; thread counts swept like cfg 2's baseline
@@ -1216,7 +1286,7 @@ def summarize(out):
         keep["cpu_baseline"] = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
         keep["identity"] = {k: v for k, v in cb_.items() if "identical" in k}
     for k in ("verdicts_match_construction", "kernel_ms", "per_scheme_ops_per_sec_per_gpu", "packets_per_sec", "quorum_verdicts_per_sec",
-              "reply_verdicts_per_sec", "read_verdicts_per_sec", "dsa_tables"):
+              "reply_verdicts_per_sec", "read_verdicts_per_sec", "dsa_tables", "single_flight", "serving"):
         if k in out:
             keep[k] = out[k]
     if "kernel_ms" in keep:
@@ -1237,8 +1307,10 @@ def other_configs(args, D):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     for cfg, extra in plan:
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--soak-seconds", "0", "--no-serving",
-               "--cpu-budget", str(min(args.cpu_budget, 10.0))] + extra + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        # (cfg 5 keeps its `serving` leg: one share-combine per call through the micro-batcher, ~20 s)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--soak-seconds", "0",
+               "--cpu-budget", str(min(args.cpu_budget, 10.0))] + ([] if cfg == 5 else ["--no-serving"]) + extra + \
+              (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
         t0 = time.time()
         key = "cfg%d" % cfg
         try:

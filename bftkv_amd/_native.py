@@ -46,6 +46,7 @@ EXPORTS = [
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
     "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_host_pipeline_trace",
+    "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r", "bftkv_gpu_batcher_modexp",
 ]
 
 _lib = None
@@ -103,6 +104,10 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_cert_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.bftkv_gpu_batcher_modmul_product.argtypes = [vp, u32, u8p, u32, u8p, u8p, u8p]
+    lib.bftkv_gpu_batcher_lagrange_combine.argtypes = [vp, u32, vp, u8p, u32, u8p, u8p, u8p]
+    lib.bftkv_gpu_batcher_dsa_calculate_r.argtypes = [vp, u32, vp, u8p, u32, u8p, u32, u8p, u8p, u8p, u8p]
+    lib.bftkv_gpu_batcher_modexp.argtypes = [vp, u8p, u32, u8p, u32, u8p, u8p, u8p]
     lib.bftkv_gpu_batcher_times.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_sss_distribute.argtypes = [vp, u32, u32, u32, u8p, u32, vp, u32, u8p, u8p]
     lib.bftkv_gpu_modinv.argtypes = [vp, u32, u8p, u32, vp, u32, u8p, u8p, u8p]
@@ -577,6 +582,38 @@ class Batcher:
         if rc:
             raise NativeError("batcher message_verify failed: %d" % rc)
         return int(st[0]), int(ids[0]), int(ids[1]), plain[:int(plen[0])].tobytes(), fn[:int(fl[0])].tobytes()
+
+    # ---- one threshold share-combine operation per call (numbers are Python ints; returns (rc, status, value))
+    def modmul_product(self, factors, mod: int, nbytes: int = 256):
+        """prod factors mod `mod` (calculateSignature, rsa.go:318-329) as ONE micro-batched operation."""
+        f, m = _ints_to_be(factors, nbytes), _ints_to_be([mod], nbytes)
+        out, st = np.full(nbytes, 0xAA, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_modmul_product(self.h, len(factors), _ptr(f), nbytes, _ptr(m), _ptr(out), _ptr(st))
+        return rc, int(st[0]), int.from_bytes(out.tobytes(), "big")
+
+    def lagrange_combine(self, xs, ys, mod: int, nbytes: int = 256):
+        """sum Lagrange(x_j) y_j mod `mod` (calculateSecret sss.go:81-92, calculateS dsa_core.go:389-403)."""
+        x = np.ascontiguousarray(np.array(xs, dtype=np.int32))
+        y, m = _ints_to_be(ys, nbytes), _ints_to_be([mod], nbytes)
+        out, st = np.full(nbytes, 0xAA, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_lagrange_combine(self.h, len(xs), _ptr(x), _ptr(y), nbytes, _ptr(m), _ptr(out), _ptr(st))
+        return rc, int(st[0]), int.from_bytes(out.tobytes(), "big")
+
+    def dsa_calculate_r(self, xs, ri, vi, p: int, q: int, pbytes: int = 256, qbytes: int = 32):
+        """CalculateR (dsa.go:33-52)."""
+        x = np.ascontiguousarray(np.array(xs, dtype=np.int32))
+        r, v = _ints_to_be(ri, pbytes), _ints_to_be(vi, qbytes)
+        pb, qb = _ints_to_be([p], pbytes), _ints_to_be([q], qbytes)
+        out, st = np.full(qbytes, 0xAA, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_dsa_calculate_r(self.h, len(xs), _ptr(x), _ptr(r), pbytes, _ptr(v), qbytes, _ptr(pb), _ptr(qb), _ptr(out), _ptr(st))
+        return rc, int(st[0]), int.from_bytes(out.tobytes(), "big")
+
+    def modexp(self, base: int, exp: int, mod: int, nbytes: int = 256, exp_len: int = 32):
+        """base^exp mod `mod` (CalculatePartialR dsa.go:27-31; the per-fragment power of rsa.go:161-171)."""
+        b, e, m = _ints_to_be([base], nbytes), _ints_to_be([exp], exp_len), _ints_to_be([mod], nbytes)
+        out, st = np.full(nbytes, 0xAA, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        rc = self.lib.bftkv_gpu_batcher_modexp(self.h, _ptr(b), nbytes, _ptr(e), exp_len, _ptr(m), _ptr(out), _ptr(st))
+        return rc, int(st[0]), int.from_bytes(out.tobytes(), "big")
 
     def stats(self):
         st = (C.c_uint64 * 4)()

@@ -2004,58 +2004,7 @@ int bftkv_gpu_signers_fenced(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* 
   return 0;
 }
 
-static int modexp_impl(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
-                       uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, bool exp_per_op, uint8_t* out) {
-  if (!c || nbytes == 0 || nbytes > 256 || exp_len == 0 || (n_ops && (!base || !mod_idx || !mods || !exps || !out))) return BFTKV_E_INVALID;
-  if (n_ops == 0) return 0;
-  ctx_lock lk(c->mu);
-  HIPCHK(c, hipSetDevice(c->device));
-  hipStream_t s = c->stream;
-  std::vector<uint32_t> nl((size_t)n_mods * MONT_N), r2((size_t)n_mods * MONT_N), n0(n_mods);
-  const uint32_t ew = (exp_len + 3) / 4;
-  const size_t n_exp = exp_per_op ? n_ops : n_mods;
-  std::vector<uint32_t> ex(n_exp * ew, 0);
-  for (uint32_t m = 0; m < n_mods; ++m) {
-    if (hostbn::bit_length(mods + (size_t)m * nbytes, nbytes) > 2048) return fail(c, BFTKV_E_UNSUPPORTED, "modulus wider than 2048 bits");
-    if (!hostbn::mont_setup(mods + (size_t)m * nbytes, nbytes, MONT_N, &nl[(size_t)m * MONT_N], &r2[(size_t)m * MONT_N], &n0[m]))
-      return fail(c, BFTKV_E_UNSUPPORTED, "even modulus");
-  }
-  for (size_t m = 0; m < n_exp; ++m) hostbn::from_be(exps + m * exp_len, exp_len, &ex[m * ew], (int)ew);
-  for (uint32_t i = 0; i < n_ops; ++i) if (mod_idx[i] >= n_mods) return fail(c, BFTKV_E_INVALID, "mod_idx out of range");
-  DevBuf d_nl, d_r2, d_n0, d_ex, d_mi, d_in, d_inl, d_outl, d_out;
-  struct Guard { std::vector<DevBuf*> v; ~Guard() { for (auto* b : v) b->release(); } } g{{&d_nl, &d_r2, &d_n0, &d_ex, &d_mi, &d_in, &d_inl, &d_outl, &d_out}};
-  HIPCHK(c, d_nl.ensure(nl.size() * 4)); HIPCHK(c, d_r2.ensure(r2.size() * 4)); HIPCHK(c, d_n0.ensure(n0.size() * 4));
-  HIPCHK(c, d_ex.ensure(ex.size() * 4 + 16)); HIPCHK(c, d_mi.ensure((size_t)n_ops * 4));
-  HIPCHK(c, d_in.ensure((size_t)n_ops * nbytes)); HIPCHK(c, d_inl.ensure((size_t)n_ops * MONT_N * 4));
-  HIPCHK(c, d_outl.ensure((size_t)n_ops * MONT_N * 4)); HIPCHK(c, d_out.ensure((size_t)n_ops * nbytes));
-  HIPCHK(c, hipMemcpyAsync(d_nl.p, nl.data(), nl.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(d_r2.p, r2.data(), r2.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(d_n0.p, n0.data(), n0.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(d_ex.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(d_mi.p, mod_idx, (size_t)n_ops * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(d_in.p, base, (size_t)n_ops * nbytes, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_bytes_to_limbs, dim3((n_ops * MONT_N + 255) / 256), dim3(256), 0, s, d_in.as<uint8_t>(), nbytes, n_ops,
-                     d_inl.as<uint32_t>());
-  hipLaunchKernelGGL(k_modexp, dim3((n_ops + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s, n_ops,
-                     d_inl.as<uint32_t>(), d_mi.as<uint32_t>(), d_nl.as<uint32_t>(), d_r2.as<uint32_t>(), d_n0.as<uint32_t>(),
-                     d_ex.as<uint32_t>(), ew, exp_per_op ? 1u : 0u, d_outl.as<uint32_t>());
-  hipLaunchKernelGGL(k_limbs_to_bytes, dim3((n_ops * nbytes + 255) / 256), dim3(256), 0, s, d_outl.as<uint32_t>(), nbytes, n_ops,
-                     d_out.as<uint8_t>());
-  HIPCHK(c, hipMemcpyAsync(out, d_out.p, (size_t)n_ops * nbytes, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-int bftkv_gpu_modexp(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
-                     uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
-  return modexp_impl(c, n_ops, base, nbytes, mod_idx, n_mods, mods, exps, exp_len, false, out);
-}
-
-int bftkv_gpu_modexp_ops(bftkv_gpu_ctx* c, uint32_t n_ops, const uint8_t* base, uint32_t nbytes, const uint32_t* mod_idx,
-                         uint32_t n_mods, const uint8_t* mods, const uint8_t* exps, uint32_t exp_len, uint8_t* out) {
-  return modexp_impl(c, n_ops, base, nbytes, mod_idx, n_mods, mods, exps, exp_len, true, out);
-}
+// bftkv_gpu_modexp / bftkv_gpu_modexp_ops: threshold_capi.inc (pooled temporaries, cached Montgomery tables)
 
 }  // extern "C"
 

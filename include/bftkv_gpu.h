@@ -295,6 +295,39 @@ int bftkv_gpu_batcher_cert_verify(bftkv_gpu_batcher* b, const uint8_t* cert, uin
 int bftkv_gpu_batcher_message_verify(bftkv_gpu_batcher* b, const uint8_t* msg, uint64_t msg_len, uint8_t* status_out,
                                      uint64_t* signer_key_id_out, uint64_t* peer_id_out, uint8_t* plain_out, uint64_t plain_cap,
                                      uint64_t* plain_len_out, uint8_t* fname_out, uint8_t* fname_len_out);
+/* ---- ONE threshold share-combine operation per call, micro-batched (BASELINE config 5 behind the reference's seam) ----
+ * The reference combines one signature at a time: Client.DistSign (protocol/client.go:509-546) drives ONE
+ * crypto.ThresholdProcess (crypto/crypto.go:98-101) whose ProcessResponse ends in exactly one of the operations below, and a
+ * server answers one Server.distSign (protocol/server.go:528-541) per request.  Concurrent callers (one goroutine per
+ * request) are gathered like the verify calls above: operations of one shape (kind, k, widths) share a device call on a
+ * lane, whatever their moduli; each caller blocks until its batch has run.  Numbers are big-endian, fixed width.
+ *   *status_out   BFTKV_TH_OK; BFTKV_TH_NO_INVERSE (math/big's ModInverse would return nil and the reference would
+ *                 dereference it: take the reference path); BFTKV_TH_FENCED (Lagrange integers beyond 2^31: the reference
+ *                 path decides); BFTKV_TH_FAILED whenever the return code is not 0 -- the byte starts out as a failure and
+ *                 `out` as zeroes (fail closed: no caller reads a result out of an infrastructure error).
+ * An even modulus or one wider than 2048 bits returns BFTKV_E_UNSUPPORTED for that caller alone. */
+#define BFTKV_TH_OK 0
+#define BFTKV_TH_NO_INVERSE 1
+#define BFTKV_TH_FENCED 2
+#define BFTKV_TH_FAILED 0xFF
+/* s = prod_j factors[j] mod N: the fold of calculateSignature over the completed tree's partial signatures
+ * (crypto/threshold/rsa/rsa.go:235-253, 318-329).  factors: [k][nbytes]; any value below 2^(8 nbytes) is reduced like
+ * big.Int.Mod does. */
+int bftkv_gpu_batcher_modmul_product(bftkv_gpu_batcher* b, uint32_t k, const uint8_t* factors, uint32_t nbytes, const uint8_t* mod,
+                                     uint8_t* out, uint8_t* status_out);
+/* S = sum_j Lagrange(x_j; xs) * y_j mod m: SSSProcess.calculateSecret (crypto/sss/sss.go:81-92) and calculateS
+ * (crypto/threshold/dsa/dsa_core.go:389-403).  xs: [k] int32, ys: [k][nbytes]. */
+int bftkv_gpu_batcher_lagrange_combine(bftkv_gpu_batcher* b, uint32_t k, const int32_t* xs, const uint8_t* ys, uint32_t nbytes,
+                                       const uint8_t* mod, uint8_t* out, uint8_t* status_out);
+/* dsaGroupOperations.CalculateR (crypto/threshold/dsa/dsa.go:33-52): ri [k][pbytes], vi [k][qbytes], r_out [qbytes]. */
+int bftkv_gpu_batcher_dsa_calculate_r(bftkv_gpu_batcher* b, uint32_t k, const int32_t* xs, const uint8_t* ri, uint32_t pbytes,
+                                      const uint8_t* vi, uint32_t qbytes, const uint8_t* p, const uint8_t* q, uint8_t* r_out,
+                                      uint8_t* status_out);
+/* out = base ^ exp mod m: dsaGroupOperations.CalculatePartialR (crypto/threshold/dsa/dsa.go:27-31) and the per-fragment
+ * m^d_i mod N of rsaContext.Sign (crypto/threshold/rsa/rsa.go:161-171) -- exponents that are SECRET shares: a deployment
+ * decides whether they may leave the host (the shim leaves these two on the CPU unless asked). */
+int bftkv_gpu_batcher_modexp(bftkv_gpu_batcher* b, const uint8_t* base, uint32_t nbytes, const uint8_t* exp, uint32_t exp_len,
+                             const uint8_t* mod, uint8_t* out, uint8_t* status_out);
 int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
 /* where the callers' time went, nanoseconds summed over all calls so far: [0] hashing their payloads, [1] leaders waiting
  * for a lane, [2] leaders assembling batches, [3] leaders inside device calls, of which [4] enqueueing and [5] waiting

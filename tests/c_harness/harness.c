@@ -131,6 +131,34 @@ int main(int argc, char** argv) {
     rc = bftkv_gpu_batcher_cert_verify(b, fx_client_cert, sizeof fx_client_cert, fx_client_tbs, sizeof fx_client_tbs - 1, fx_client_sig,
                                        sizeof fx_client_sig, &cerr, &cfen, &iid, fp);
     printf("gpu_cert_verify_other_bytes=%d,%u,%u\n", rc, (unsigned)cerr, (unsigned)cfen);
+    /* config 5 behind the same handle: ONE share-combine operation per call (what one DistSign's ThresholdProcess ends in).
+     * Under the first replica's modulus N: (N-1)(N-1)(N-1) = -1 mod N; the shares f(1), f(2), f(3) of f(x) = 7 + 3x + 2x^2
+     * recover f(0) = 7 (sss.go:81-92); 3^5 mod N = 243; an even modulus is refused for this caller and fails closed. */
+    {
+      uint8_t nm1[3 * 256], ys[3 * 256], base[256], out[256], st = 0x55;
+      const uint8_t* N = fx_key_n;
+      for (int j = 0; j < 3; ++j) { memcpy(nm1 + 256 * j, N, 256); nm1[256 * j + 255] ^= 1; }      /* N is odd: N - 1 clears the low bit */
+      rc = bftkv_gpu_batcher_modmul_product(b, 3, nm1, 256, N, out, &st);
+      printf("gpu_th_product=%d,%u,%d\n", rc, (unsigned)st, memcmp(out, nm1, 256) == 0);
+      int32_t xs[3] = {1, 2, 3};
+      memset(ys, 0, sizeof ys);
+      ys[255] = 12; ys[256 + 255] = 21; ys[512 + 255] = 34;
+      rc = bftkv_gpu_batcher_lagrange_combine(b, 3, xs, ys, 256, N, out, &st);
+      int zeros = 1;
+      for (int i = 0; i < 255; ++i) zeros &= out[i] == 0;
+      printf("gpu_th_lagrange=%d,%u,%d,%u\n", rc, (unsigned)st, zeros, (unsigned)out[255]);
+      uint8_t e5 = 5;
+      memset(base, 0, sizeof base); base[255] = 3;
+      rc = bftkv_gpu_batcher_modexp(b, base, 256, &e5, 1, N, out, &st);
+      zeros = 1;
+      for (int i = 0; i < 255; ++i) zeros &= out[i] == 0;
+      printf("gpu_th_modexp=%d,%u,%d,%u\n", rc, (unsigned)st, zeros, (unsigned)out[255]);
+      memset(out, 0x77, sizeof out);
+      rc = bftkv_gpu_batcher_modmul_product(b, 3, ys, 256, nm1, out, &st);       /* N - 1 is even */
+      zeros = 1;
+      for (int i = 0; i < 256; ++i) zeros &= out[i] == 0;
+      printf("gpu_th_fail_closed=%d,%u,%d\n", rc, (unsigned)st, zeros);
+    }
     bftkv_gpu_batcher_destroy(b);
     bftkv_gpu_quorum_destroy(ctx, qh);
   }

@@ -58,6 +58,11 @@ def test_c_caller_verifies_on_the_gpu(tmp_path):
     assert out["gpu_cert_verify"] == "0,0,0,1"                # a stranger's certificate out of the request: issuer found, signature good
     assert out["gpu_cert_verify_forged"] == "0,3,0"           # BFTKV_ERR_CERTIFICATE_NOT_FOUND: ReadEntity would refuse it
     assert out["gpu_cert_verify_other_bytes"] == "0,1,0"      # crypto.ErrInvalidSignature
+    # config 5, one share-combine operation per call (bftkv_gpu_batcher_modmul_product / _lagrange_combine / _modexp)
+    assert out["gpu_th_product"] == "0,0,1"                   # (N-1)^3 = N-1 mod N
+    assert out["gpu_th_lagrange"] == "0,0,1,7"                # f(0) of f(x) = 7 + 3x + 2x^2 out of f(1), f(2), f(3)
+    assert out["gpu_th_modexp"] == "0,0,1,243"
+    assert out["gpu_th_fail_closed"] == "-4,255,1"            # even modulus: BFTKV_E_UNSUPPORTED, status BFTKV_TH_FAILED, zeroes
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")

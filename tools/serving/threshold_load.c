@@ -1,0 +1,165 @@
+/* Serving-shaped load on the threshold share-combine entries of the micro-batcher: T caller threads, each issuing ONE combine per
+ * call -- the shape of Client.DistSign (protocol/client.go:509-546: one ThresholdProcess per signature, whose ProcessResponse ends
+ * in one calculateSignature / calculateS / CalculateR, crypto/threshold/rsa/rsa.go:235-253, dsa/dsa_core.go:318-362) and of
+ * SSSProcess.ProcessResponse (crypto/sss/sss.go:69-79).  Every answer is compared byte for byte with the expected result in the
+ * input file (bench.py --config 5 writes the batched entry points' results there, which it checks against oracle/c/threshold.c).
+ *   gcc -O2 -std=gnu99 -I include tools/serving/threshold_load.c -L bftkv_amd -lbftkv_gpu -lpthread -Wl,-rpath,$PWD/bftkv_amd -o threshold_load
+ *   ./threshold_load ops.bin [max_items=256] [lanes=0 (library default)] [threads,threads,...] [seconds per point=1.0]
+ * Prints one JSON object: per scheme and thread count ops/s and latency percentiles. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "bftkv_gpu.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+enum { K_RSA = 0, K_SSS = 1, K_S = 2, K_R = 3, K_MIX = 4, N_KINDS = 5 };
+static const char* kind_name[N_KINDS] = {"rsa_calculate_signature_n10", "sss_calculate_secret_k7_2048", "dsa_calculate_s_2t8_q256",
+                                         "dsa_calculate_r_2t8_2048_256", "distsign_mix"};
+
+typedef struct {
+  uint32_t n;
+  uint8_t *rsa_n, *rsa_f, *rsa_want;                 /* [256], [n][10][256], [n][256] */
+  uint8_t *sss_m, *sss_y, *sss_want; int32_t* sss_x; /* [256], [n][7][256], [n][256], [n][7] */
+  uint8_t *q, *s_y, *s_want; int32_t* s_x;           /* [32], [n][8][32], [n][32], [n][8] */
+  uint8_t *p, *r_ri, *r_vi, *r_want, *r_st; int32_t* r_x;   /* [256], [n][8][256], [n][8][32], [n][32], [n], [n][8] */
+} ops;
+
+typedef struct {
+  bftkv_gpu_batcher* b; const ops* o; int kind, tid, n_threads; volatile int* stop;
+  uint64_t calls, wrong; double* lat; uint64_t lat_cap, lat_skip;
+} worker;
+
+static int one(bftkv_gpu_batcher* b, const ops* o, int kind, uint32_t i) {
+  uint8_t out[256], st = 0x55;
+  int rc;
+  switch (kind) {
+    case K_RSA:
+      rc = bftkv_gpu_batcher_modmul_product(b, 10, o->rsa_f + (size_t)i * 2560, 256, o->rsa_n, out, &st);
+      return rc == 0 && st == BFTKV_TH_OK && memcmp(out, o->rsa_want + (size_t)i * 256, 256) == 0;
+    case K_SSS:
+      rc = bftkv_gpu_batcher_lagrange_combine(b, 7, o->sss_x + (size_t)i * 7, o->sss_y + (size_t)i * 7 * 256, 256, o->sss_m, out, &st);
+      return rc == 0 && st == BFTKV_TH_OK && memcmp(out, o->sss_want + (size_t)i * 256, 256) == 0;
+    case K_S:
+      rc = bftkv_gpu_batcher_lagrange_combine(b, 8, o->s_x + (size_t)i * 8, o->s_y + (size_t)i * 8 * 32, 32, o->q, out, &st);
+      return rc == 0 && st == BFTKV_TH_OK && memcmp(out, o->s_want + (size_t)i * 32, 32) == 0;
+    default:
+      rc = bftkv_gpu_batcher_dsa_calculate_r(b, 8, o->r_x + (size_t)i * 8, o->r_ri + (size_t)i * 8 * 256, 256, o->r_vi + (size_t)i * 8 * 32, 32, o->p, o->q,
+                                             out, &st);
+      if (rc != 0 || (st != 0) != (o->r_st[i] != 0)) return 0;
+      return st != 0 || memcmp(out, o->r_want + (size_t)i * 32, 32) == 0;
+  }
+}
+
+static void* run(void* p) {
+  worker* w = (worker*)p;
+  uint32_t i = (uint32_t)w->tid;
+  while (!*w->stop) {
+    const uint32_t k = i % w->o->n;
+    /* the mix: a DistSign of every algorithm in turn -- RSA ends in one product, threshold DSA in one CalculateR and one calculateS */
+    const int kind = w->kind != K_MIX ? w->kind : (int)((i / (uint32_t)w->n_threads) % 3 == 0 ? K_RSA : (i / (uint32_t)w->n_threads) % 3 == 1 ? K_R : K_S);
+    const double t0 = now_s();
+    const int ok = one(w->b, w->o, kind, k);
+    const double dt = now_s() - t0;
+    if (!ok) ++w->wrong;
+    if (w->calls < w->lat_cap) w->lat[w->calls] = dt;
+    ++w->calls;
+    i += (uint32_t)w->n_threads;
+  }
+  return NULL;
+}
+
+static int cmp_d(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
+
+static void* slurp(FILE* f, size_t bytes) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p || fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short input file\n"); exit(2); }
+  return p;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s ops.bin [max_items] [lanes] [threads,...] [seconds]\n", argv[0]); return 2; }
+  const uint32_t max_items = argc > 2 ? (uint32_t)atoi(argv[2]) : 256, lanes = argc > 3 ? (uint32_t)atoi(argv[3]) : 0;
+  int sweep[16] = {1, 64, 256};
+  unsigned n_sweep = 3;
+  if (argc > 4) {
+    n_sweep = 0;
+    for (char* tok = strtok(argv[4], ","); tok && n_sweep < 16; tok = strtok(NULL, ",")) sweep[n_sweep++] = atoi(tok);
+  }
+  const double seconds = argc > 5 ? atof(argv[5]) : 1.0;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("ops"); return 2; }
+  ops o;
+  if (fread(&o.n, 4, 1, f) != 1 || o.n == 0) return 2;
+  const size_t n = o.n;
+  o.rsa_n = slurp(f, 256); o.rsa_f = slurp(f, n * 2560); o.rsa_want = slurp(f, n * 256);
+  o.sss_m = slurp(f, 256); o.sss_x = slurp(f, n * 7 * 4); o.sss_y = slurp(f, n * 7 * 256); o.sss_want = slurp(f, n * 256);
+  o.q = slurp(f, 32); o.s_x = slurp(f, n * 8 * 4); o.s_y = slurp(f, n * 8 * 32); o.s_want = slurp(f, n * 32);
+  o.p = slurp(f, 256); o.r_x = slurp(f, n * 8 * 4); o.r_ri = slurp(f, n * 8 * 256); o.r_vi = slurp(f, n * 8 * 32); o.r_want = slurp(f, n * 32);
+  o.r_st = slurp(f, n);
+  fclose(f);
+  bftkv_gpu_ctx* ctx = NULL;
+  if (bftkv_gpu_init(0, &ctx)) { fprintf(stderr, "no GPU\n"); return 1; }
+  bftkv_gpu_batcher* b = bftkv_gpu_batcher_create_lanes(ctx, max_items, 0, lanes);
+  if (!b) { fprintf(stderr, "batcher: %s\n", bftkv_gpu_last_error(ctx)); return 1; }
+  uint64_t st0[4] = {0, 0, 0, 0};
+  bftkv_gpu_batcher_stats(b, st0);
+  printf("{\"max_items\": %u, \"lanes\": %llu, \"ops_per_scheme\": %u, \"seconds_per_point\": %.2f, \"runs\": [", max_items, (unsigned long long)st0[3], o.n,
+         seconds);
+  int first = 1;
+  for (int kind = 0; kind < N_KINDS; ++kind) {
+    for (unsigned s = 0; s < n_sweep; ++s) {
+      const int T = sweep[s];
+      volatile int stop = 0;
+      worker* ws = calloc((size_t)T, sizeof *ws);
+      pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
+      for (int t = 0; t < T; ++t) {
+        ws[t].b = b; ws[t].o = &o; ws[t].kind = kind; ws[t].tid = t; ws[t].n_threads = T; ws[t].stop = &stop;
+        ws[t].lat_cap = 400000 / (uint64_t)T + 64; ws[t].lat = malloc(8 * ws[t].lat_cap);
+        pthread_create(&th[t], NULL, run, &ws[t]);
+      }
+      /* warm-up: scratch pools, pinned buffers and the moduli's Montgomery tables of every lane, then the measured window */
+      struct timespec warm = {0, 300000000};
+      nanosleep(&warm, NULL);
+      uint64_t base_calls = 0;
+      for (int t = 0; t < T; ++t) { ws[t].lat_skip = ws[t].calls; base_calls += ws[t].calls; }
+      uint64_t stw[4] = {0, 0, 0, 0};
+      bftkv_gpu_batcher_stats(b, stw);
+      const double t0 = now_s();
+      struct timespec nap = {(time_t)seconds, (long)((seconds - (double)(time_t)seconds) * 1e9)};
+      nanosleep(&nap, NULL);
+      stop = 1;
+      for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+      const double dt = now_s() - t0;      /* (includes the last calls in flight: they are counted) */
+      uint64_t calls = 0, wrong = 0, nl = 0;
+      for (int t = 0; t < T; ++t) { calls += ws[t].calls; wrong += ws[t].wrong; nl += ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap; }
+      calls -= base_calls;
+      double* all = malloc(8 * (nl + 1));
+      uint64_t k = 0;
+      for (int t = 0; t < T; ++t) {
+        uint64_t m = ws[t].calls < ws[t].lat_cap ? ws[t].calls : ws[t].lat_cap;
+        const uint64_t sk = ws[t].lat_skip < m ? ws[t].lat_skip : m;
+        memcpy(all + k, ws[t].lat + sk, 8 * (m - sk)); k += m - sk;
+      }
+      nl = k;
+      qsort(all, nl, 8, cmp_d);
+      uint64_t st[4] = {0, 0, 0, 0};
+      bftkv_gpu_batcher_stats(b, st);
+      printf("%s{\"scheme\": \"%s\", \"threads\": %d, \"ops_per_s\": %.0f, \"wrong\": %llu, \"latency_ms\": {\"p50\": %.3f, \"p99\": %.3f, \"max\": %.3f}, "
+             "\"calls\": %llu, \"device_calls\": %llu}",
+             first ? "" : ", ", kind_name[kind], T, calls / dt, (unsigned long long)wrong, nl ? all[nl / 2] * 1e3 : 0.0,
+             nl ? all[(uint64_t)(nl * 0.99)] * 1e3 : 0.0, nl ? all[nl - 1] * 1e3 : 0.0, (unsigned long long)(st[0] - stw[0]),
+             (unsigned long long)(st[1] - stw[1]));
+      first = 0;
+      fflush(stdout);
+      for (int t = 0; t < T; ++t) free(ws[t].lat);
+      free(ws); free(th); free(all);
+    }
+  }
+  printf("]}\n");
+  bftkv_gpu_batcher_destroy(b);
+  bftkv_gpu_destroy(ctx);
+  return 0;
+}
