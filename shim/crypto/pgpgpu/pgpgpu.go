@@ -83,6 +83,17 @@ func Close(c *crypto.Crypto) {
 	}
 }
 
+// BatcherHandle returns the micro-batcher of a bundle built by New, as an opaque pointer (a *C.bftkv_gpu_batcher of THIS
+// package is a different Go type in any other package: cgo types are package-local), or nil for a bundle of crypto/pgp.
+// crypto/thresholdgpu hands its one-operation-per-call share combines to the same batcher, so that config-5 traffic and
+// verification traffic share the lanes of one device.
+func BatcherHandle(c *crypto.Crypto) unsafe.Pointer {
+	if kr, ok := c.Keyring.(*keyring); ok {
+		return unsafe.Pointer(kr.g.batcher)
+	}
+	return nil
+}
+
 // ptr returns the address of the first byte (nil for an empty slice).  The library reads the buffer for the duration of
 // the call only and keeps nothing (cgo pointer rules).
 func ptr(b []byte) *C.uint8_t {

@@ -72,16 +72,21 @@ def test_lagrange_combine_sss_and_calculate_s(gpu_ctx):
     assert got[0] == secret
 
 
-@pytest.mark.parametrize("lanes", (4, 8))
-def test_dsa_calculate_r(lanes):
+@pytest.mark.parametrize("lanes,parts", ((4, 1), (8, 1), (8, 0), (4, 2), (8, 4), (4, 8)))
+def test_dsa_calculate_r(lanes, parts):
     """CalculateR through both forms of k_multiexp: 4 lanes x 19 limbs (R = 2^2128) and 8 lanes x 10 limbs (R = 2^2240, picked by
-    default for calls of at most one wave per SIMD)."""
+    default for calls of at most one wave per SIMD); with the bases of an operation in one chain (parts = 1), spread over 2 / 4 / 8
+    quad groups whose partial products k_modmul_product multiplies up, and by the default policy (parts = 0: a small call spreads
+    its 8 bases over 8 groups)."""
     from bftkv_amd import Context
     os.environ["BFTKV_MULTIEXP_LANES"] = str(lanes)        # read when a context is created
+    if parts:
+        os.environ["BFTKV_MULTIEXP_PARTS"] = str(parts)
     try:
         gpu_ctx = Context(0)
     finally:
         del os.environ["BFTKV_MULTIEXP_LANES"]
+        os.environ.pop("BFTKV_MULTIEXP_PARTS", None)
     g_ = KAT["dsa_group"]
     p, q, g = int(g_["p"], 16), int(g_["q"], 16), int(g_["g"], 16)
     rng = np.random.default_rng(8)

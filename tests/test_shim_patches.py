@@ -12,13 +12,15 @@ REF = "/root/reference"
 
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="reference tree or patch(1) not available")
 def test_patches_apply_in_order(tmp_path):
-    for rel in ("quorum/wotqs/wotqs.go", "node/graph/graph.go"):
+    for rel in ("quorum/wotqs/wotqs.go", "node/graph/graph.go", "crypto/sss/sss.go", "crypto/threshold/dsa/dsa.go", "crypto/threshold/dsa/dsa_core.go",
+                "crypto/threshold/rsa/rsa.go"):
         dst = tmp_path / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
         shutil.copy(os.path.join(REF, rel), dst)
     pdir = os.path.join(ROOT, "shim", "patches")
     names = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
-    assert names[:2] == ["0001-wotqs-export-cliques.patch", "0002-wotqs-selector-cache-counted-membership.patch"]
+    assert names[:3] == ["0001-wotqs-export-cliques.patch", "0002-wotqs-selector-cache-counted-membership.patch",
+                         "0003-threshold-combine-hooks.patch"]
     for name in names:
         r = subprocess.run(["patch", "-p1", "--batch", "-d", str(tmp_path)], stdin=open(os.path.join(pdir, name)), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT)
@@ -28,6 +30,21 @@ def test_patches_apply_in_order(tmp_path):
     assert "func (q *wotq) Cliques() []Clique" in w and "cache map[selector]*wotq" in w and "qc.count(nodes)" in w
     assert "len(intersection(nodes, qc.nodes))" not in w          # every predicate counts members through the id set
     assert g.count("g.touch()") == 5 and "func (g *Graph) Epoch() uint64" in g
+    # 0003: the share-combine arithmetic of config 5 becomes replaceable, the bookkeeping around it does not move
+    sss = (tmp_path / "crypto/sss/sss.go").read_text()
+    dsa = (tmp_path / "crypto/threshold/dsa/dsa.go").read_text()
+    core = (tmp_path / "crypto/threshold/dsa/dsa_core.go").read_text()
+    rsa = (tmp_path / "crypto/threshold/rsa/rsa.go").read_text()
+    assert "var CombineHook func(coords []*Coordinate, m *big.Int) *big.Int" in sss and "CombineHook(p.res, p.m)" in sss
+    assert "sss.CombineHook(res, q)" in core
+    assert "var CalculateRHook func(rs []*PartialR, p, q *big.Int) *big.Int" in dsa and "CalculateRHook(rs, g.params.P, g.params.Q)" in dsa
+    assert "ModExpHook(g.params.G, ai, g.params.P)" in dsa
+    assert "var CombineHook func(psigs []*big.Int, N *big.Int) *big.Int" in rsa and "CombineHook(collectPartialSignatures(p.tree, nil), N)" in rsa
+    assert rsa.count("modExp(ci, m, di") == 2 and "ci.Exp(m, di" not in rsa
+    # every hook falls through to the reference's own arithmetic, which is still there, untouched
+    for src, kept in ((sss, "S.Mod(S.Add(S, l.Mul(l, r.Y)), p.m)"), (core, "s.Mod(s.Add(s, t), q)"), (dsa, "r.Exp(r, v, g.params.P)"),
+                      (rsa, "s.Mod(s.Mul(s, st.psig), N)"), (rsa, "z.Exp(base, exp, N)")):
+        assert kept in src, kept
     # braces balance (no Go toolchain here: the cheapest structural check there is)
-    for src in (w, g):
+    for src in (w, g, sss, dsa, core, rsa):
         assert src.count("{") == src.count("}") and src.count("(") == src.count(")")

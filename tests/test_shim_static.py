@@ -122,7 +122,10 @@ def test_c_calls_match_the_header():
     # the seam of the path: every verifying call of the shim is among them
     assert {"bftkv_gpu_init", "bftkv_gpu_keyring_set", "bftkv_gpu_quorum_create", "bftkv_gpu_quorum_destroy",
             "bftkv_gpu_batcher_collective_verify", "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_cert_verify",
-            "bftkv_gpu_batcher_message_verify", "bftkv_gpu_signers_fenced", "bftkv_gpu_set_hash_policy"} <= seen
+            "bftkv_gpu_batcher_message_verify", "bftkv_gpu_signers_fenced", "bftkv_gpu_set_hash_policy",
+            # config 5 behind crypto.Threshold (shim/crypto/thresholdgpu)
+            "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r",
+            "bftkv_gpu_batcher_modexp"} <= seen
 
 
 def test_struct_fields_the_shim_sets_exist():
@@ -181,6 +184,8 @@ REFERENCE_NAMES = [
     "VerifyWithCertificate", "AUTH", "Cert", "Certificate", "CollectiveSignature", "Completed", "Crypto", "Data", "ErrDecryptionFailed",
     "ErrInsufficientNumberOfSignatures", "ErrInvalidSignature", "ErrInvalidTransportSecurityData", "Keyring", "Message", "Signature",
     "SignaturePacket", "SignatureTypeNil", "SignatureTypePGP", "TBS", "TBSS", "Type", "Clique", "Threshold", "Suff", "Min", "Nodes",
+    # crypto/thresholdgpu: the hooks of shim/patches/0003 and the reference types they carry
+    "CombineHook", "CalculateRHook", "ModExpHook", "Coordinate", "PartialR", "Ri", "Vi",
 ]
 
 
@@ -200,7 +205,7 @@ def test_reference_api_names_the_shim_uses_exist():
         used.update(re.findall(r"\.([A-Z]\w*)\b", src))
     for name in REFERENCE_NAMES:
         assert name in used, "%s is not used by the shim any more: drop it from the list" % name
-        pat = r"(func (\([^)]*\) )?%s\(|^\s*%s(\(|\s+[\w\[\]\*\.]+|\s*=)|type %s\b)" % (name, name, name)
+        pat = r"(func (\([^)]*\) )?%s\(|^\s*%s(\(|\s+[\w\[\]\*\.]+|\s*=)|type %s\b|^var %s\b)" % (name, name, name, name)
         assert re.search(pat, text, flags=re.M), "the reference declares no %s" % name
 
 
