@@ -186,6 +186,22 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [int(v) for v in t.tolist()]
 
+    def max_int(self, v):
+        if not self.dist:
+            return int(v)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def gather_ints(self, vals):
+        """every rank's list of ints, rank-major: [world][len(vals)]"""
+        if not self.dist:
+            return [[int(v) for v in vals]]
+        t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=self.dev)
+        out = self.torch.empty(self.world * t.numel(), dtype=self.torch.int64, device=self.dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.view(self.world, -1).tolist()
+
     def comm_init(self, ctxs):
         """The library's own RCCL communicator on every verifier context: rank 0 draws the unique id
         (bftkv_gpu_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins."""
@@ -267,7 +283,9 @@ class Verifier:
         from bftkv_amd import Context
         from corpus import build as cb
         self.D, self.n_items, self.n_ctx = D, n_items, n_ctx
-        self.slots = n_items                       # every rank contributes the same number of bitmap bits
+        # every rank contributes the same number of bitmap bits: the LARGEST shard (cfg 3's ranks hold different reply counts; an
+        # all-gather with per-rank counts would be a different collective on every rank)
+        self.slots = D.max_int(n_items)
         self.rsa_ms, self.dsa_ms, self.hash_ms, self.total_ms = [], [], [], []
         self.gathers = 0
         self.ss_len = int(so[-1]) if ss_len is None else ss_len
@@ -331,8 +349,8 @@ class Verifier:
         """Every rank's row of the gathered bitmap must be that rank's verdicts; this rank checks its own row and the
         population count of all rows against the all-reduced count of accepted writes."""
         nbytes = (self.slots + 7) // 8
-        rows = np.unpackbits(bits.reshape(self.D.world, nbytes), axis=1, bitorder="little")[:, :self.n_items]
-        own_ok = bool((rows[self.D.rank] == (err == 0)).all())
+        rows = np.unpackbits(bits.reshape(self.D.world, nbytes), axis=1, bitorder="little")[:, :self.slots]     # (padding bits are zero)
+        own_ok = bool((rows[self.D.rank][:self.n_items] == (err == 0)).all())
         total_ok = self.D.sum_ints([int((err == 0).sum())])[0]
         return own_ok and int(rows.sum()) == total_ok
 
@@ -351,6 +369,18 @@ def dry_exchange(D, ok_local, slots):
     out = torch.empty(D.world * bits.numel(), dtype=torch.uint8)
     D.dist.all_gather_into_tensor(out, bits)
     return out.numpy()
+
+
+def constructed_ok(lo, hi, salt):
+    """--dry-run: the verdict 'constructed' for the unit (write, reply) with GLOBAL index i in [lo, hi) -- a fixed function of
+    the index, so that a test can rebuild the verdict vector of the whole job and compare it with what the ranks gathered."""
+    i = np.arange(lo, hi, dtype=np.uint64)
+    return (((i * np.uint64(2654435761) + np.uint64(salt)) >> np.uint64(7)) % np.uint64(61)) != 0
+
+
+def verdict_digest(ok):
+    import hashlib
+    return hashlib.sha256(np.packbits(np.asarray(ok, dtype=np.uint8), bitorder="little").tobytes()).hexdigest()
 
 
 def effective_cores():
@@ -614,12 +644,10 @@ def bench_cfg2(args, D):
         elapsed = timed_region(D, run, args.steps, args.warmup)
         rows = np.unpackbits(gathered[-1].reshape(D.world, -1), axis=1, bitorder="little")[:, :items]
         tot = D.sum_ints([int(want_ok.sum())])[0]
-        if D.rank == 0:
-            print(json.dumps({"dry_run": True, "config": 2, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup,
-                              "allgathers_in_step_loop": V.gathers, "gather_rows": int(rows.shape[0]),
-                              "gathered_ok": int(rows.sum()), "sum_of_rank_ok": tot,
-                              "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed}), flush=True)
-        return
+        return {"dry_run": True, "config": 2, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup,
+                "allgathers_in_step_loop": V.gathers, "gather_rows": int(rows.shape[0]),
+                "gathered_ok": int(rows.sum()), "sum_of_rank_ok": tot,
+                "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed} if D.rank == 0 else None
 
     V.run(V.n_ctx)               # one untimed call per verifier context: its arena is allocated at its first call
     elapsed = timed_region(D, V.run, args.steps, args.warmup, V.reset_timing)
@@ -759,14 +787,45 @@ def bench_cfg2(args, D):
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 3: 100k mixed RSA / DSA signed read replies -> maxTimestampedValue per variable
 # ------------------------------------------------------------------------------------------------------------------
+def dry_cfg3(args, D, lo, hi, n_vars_total):
+    """--dry-run of cfg 3's rank split: variables [lo, hi) of this rank, 9..11 replies per variable (by variable index), reply
+    verdicts constructed by GLOBAL reply index; ranks hold DIFFERENT reply counts, so the bitmap rows are sized by the largest
+    (what Verifier does with D.max_int) and each row is cut back to its rank's count when the job's vector is assembled."""
+    per_var = lambda a, b: 9 + (np.arange(a, b, dtype=np.int64) % 3)
+    first = int(per_var(0, lo).sum())                # global index of this rank's first reply
+    n_replies = int(per_var(lo, hi).sum())
+    slots = D.max_int(n_replies)
+    ok = constructed_ok(first, first + n_replies, 3)
+    gathered, gathers = [], [0]
+
+    def run(k):
+        for _ in range(k):
+            gathered.append(dry_exchange(D, ok, slots))
+            gathers[0] += 1
+    elapsed = timed_region(D, run, args.steps, args.warmup)
+    counts = D.gather_ints([lo, hi, n_replies])
+    rows = np.unpackbits(gathered[-1].reshape(D.world, -1), axis=1, bitorder="little")
+    full = np.concatenate([rows[r][:counts[r][2]] for r in range(D.world)])
+    tot = D.sum_ints([int(ok.sum())])[0]
+    if D.rank != 0:
+        return None
+    return {"dry_run": True, "config": 3, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup,
+            "scaling": "strong", "variables_total": n_vars_total, "variable_ranges": [c[:2] for c in counts], "replies_per_rank": [c[2] for c in counts],
+            "replies_total": int(full.size), "slots": slots, "bitmap_bytes_per_rank": (slots + 7) // 8, "allgathers_in_step_loop": gathers[0],
+            "gathered_ok": int(full.sum()), "sum_of_rank_ok": tot, "verdict_sha256": verdict_digest(full), "elapsed_s": elapsed}
+
+
 def bench_cfg3(args, D):
     from corpus import build as cb
-    from bftkv_amd import Context, host as HM
+    from bftkv_amd import dist as BD
+    if not D.dry:
+        from bftkv_amd import Context, host as HM
     n = args.replicas or 64
     n_vars_total = args.items or 10000
-    from bftkv_amd import dist as BD
     lo, hi = BD.shard_range(n_vars_total, D.rank, D.world)      # variables are independent: shard by variable
     n_vars = hi - lo
+    if D.dry:
+        return dry_cfg3(args, D, lo, hi, n_vars_total)
     cl = cb.make_cluster(n, dsa_fraction=0.5)
     ctx0 = Context(D.local_rank)
     rsa_signer, dsa_pow = gpu_signers(ctx0, cl)
@@ -901,18 +960,57 @@ def bench_cfg3(args, D):
 # ------------------------------------------------------------------------------------------------------------------
 # cfg 4: 256 replicas, 1M-write storm sharded over the ranks
 # ------------------------------------------------------------------------------------------------------------------
-def bench_cfg4(args, D):
-    from corpus import build as cb
-    from bftkv_amd import Context
-    torch = D.torch
-    n = args.replicas or 256
+def cfg4_split(args, world):
+    """The storm's split (strong scaling): every rank takes total // world writes and verifies them as `calls` calls over a resident
+    batch of `chunk` = `tiles` x `distinct` writes.  1,000,000 writes: 1 GPU 8 calls of 125,000; 2 GPUs 4; 4 GPUs 2; 8 GPUs 1 -- the
+    all-gather of a call moves chunk / 8 bytes per rank (8 GPUs: 15,625 B each, 125 KB gathered)."""
     total_writes = args.items or 1000000
-    share = total_writes // D.world                      # strong scaling: the storm is split over the ranks
+    share = total_writes // world
     chunk = min(args.chunk, share)
     distinct = min(args.distinct, chunk)
     tiles = chunk // distinct
     chunk = tiles * distinct
     calls = max(1, share // chunk)
+    return total_writes, share, chunk, distinct, tiles, calls
+
+
+def dry_cfg4(args, D):
+    """--dry-run of cfg 4's rank split and exchange: rank r owns the writes [r x share, (r+1) x share) of the storm, call c of a step
+    covers chunk writes of them; verdicts constructed by GLOBAL write index, gathered per call like bftkv_gpu_allgather_errs_dev
+    gathers them (gloo instead of RCCL), assembled in write order."""
+    total_writes, share, chunk, distinct, tiles, calls = cfg4_split(args, D.world)
+    lo = D.rank * chunk * calls
+    gathered, gathers = [], [0]
+
+    def run(k):
+        for _ in range(k):
+            for c in range(calls):
+                gathered.append(dry_exchange(D, constructed_ok(lo + c * chunk, lo + (c + 1) * chunk, 4), chunk))
+                gathers[0] += 1
+    elapsed = timed_region(D, run, args.steps, args.warmup)
+    rows = [np.unpackbits(g.reshape(D.world, -1), axis=1, bitorder="little")[:, :chunk] for g in gathered[-calls:]]
+    full = np.concatenate([rows[c][r] for r in range(D.world) for c in range(calls)])
+    own = np.concatenate([rows[c][D.rank] for c in range(calls)])
+    tot = D.sum_ints([int(constructed_ok(lo, lo + chunk * calls, 4).sum())])[0]
+    own_ok = D.sum_ints([int((own == constructed_ok(lo, lo + chunk * calls, 4)).all())])[0]
+    if D.rank != 0:
+        return None
+    return {"dry_run": True, "config": 4, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong",
+            "writes_requested": total_writes, "writes_per_step": chunk * calls * D.world, "share_per_rank": chunk * calls, "writes_per_call": chunk,
+            "calls_per_step": calls, "tiles": tiles, "distinct": distinct, "bitmap_bytes_per_rank_per_call": (chunk + 7) // 8,
+            "gathered_bytes_per_call": D.world * ((chunk + 7) // 8), "allgathers_in_step_loop": gathers[0],
+            "gathered_ok": int(full.sum()), "sum_of_rank_ok": tot, "ranks_whose_own_rows_match": own_ok,
+            "verdict_sha256": verdict_digest(full), "elapsed_s": elapsed}
+
+
+def bench_cfg4(args, D):
+    if D.dry:
+        return dry_cfg4(args, D)
+    from corpus import build as cb
+    from bftkv_amd import Context
+    torch = D.torch
+    n = args.replicas or 256
+    total_writes, share, chunk, distinct, tiles, calls = cfg4_split(args, D.world)
     cl = cb.make_cluster(n)
     ctx0 = Context(D.local_rank)
     rsa_signer, _ = gpu_signers(ctx0, cl)
@@ -1053,12 +1151,27 @@ def threshold_serving_leg(tc, res, n, threads="1,64,256", seconds=1.0):
 
 def bench_cfg5(args, D):
     from corpus import build as cb
-    from bftkv_amd import Context, dist as BD
-    from bftkv_amd._native import _ints_to_be, _ptr
+    from bftkv_amd import dist as BD
+    if not D.dry:
+        from bftkv_amd import Context
+        from bftkv_amd._native import _ints_to_be, _ptr
     torch = D.torch
     n_total = args.items or 10000
     lo, hi = BD.shard_range(n_total, D.rank, D.world)    # operations are independent: shard by operation, no exchange step
     N = hi - lo
+    if D.dry:
+        # --dry-run: the rank split alone -- contiguous shards that tile [0, n_total), no exchange step (a combine's result goes back
+        # to the one client that asked for it), per-rank corpus seeds
+        def run(k):
+            pass
+        elapsed = timed_region(D, run, args.steps, args.warmup)
+        ranges = D.gather_ints([lo, hi, cb.MASTER_SEED + D.rank])
+        tot = D.sum_ints([3 * N])[0]
+        if D.rank != 0:
+            return None
+        return {"dry_run": True, "config": 5, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong",
+                "ops_per_scheme": n_total, "operation_ranges": [r[:2] for r in ranges], "corpus_seeds": [r[2] for r in ranges],
+                "scheme_ops_per_step": tot, "exchange_steps": 0, "elapsed_s": elapsed}
     gold = os.path.join(ROOT, "tests", "golden")
     kat = json.load(open(os.path.join(gold, "threshold_kat.json")))
     k0 = json.load(open(os.path.join(gold, "keys_dsa2048.json")))["keys"][0]
@@ -1330,24 +1443,86 @@ def other_configs(args, D):
     return res
 
 
+def multi_rank_extras(args, D, emit):
+    """N > 1, default run: BASELINE's actual multi-GPU configs behind the cfg-2 headline, IN this process group -- cfg 4 (the
+    1 M-write storm split over the ranks, one RCCL all-gather of verdict bitmaps per call; strong scaling) and cfg 5 (10 k combines
+    per scheme sharded by operation, no exchange; strong scaling), with short timed regions.  (On one GPU `other_configs` runs every
+    config in a process of its own; ranks of a torchrun group cannot spawn a second group, so here they run in line: cfg 5 then sees
+    the runtime's default 4 hardware queues and keeps 4 steps in flight.)  A failure on any rank is recorded in the entry -- all
+    ranks agree on it before the next config starts -- and never takes the headline down; `emit` prints the line early if the
+    extras do not come back in time."""
+    import threading
+    res = {}
+    plan = [(4, ["--steps", "2", "--warmup", "1"]), (5, ["--steps", "32", "--warmup", "8"])]
+    timer = None
+    if not D.dry and D.rank == 0:
+        def give_up():
+            res.setdefault("error", "the configs behind the headline did not finish within 900 s; line printed by the watchdog")
+            emit(res)
+            os._exit(1)      # ends the torchrun group: the other ranks are stuck in a collective
+        timer = threading.Timer(900.0, give_up)
+        timer.daemon = True
+        timer.start()
+    try:
+        for cfg, extra in plan:
+            key = "cfg%d" % cfg
+            argv = ["--config", str(cfg), "--gpus", str(D.world), "--soak-seconds", "0", "--no-serving", "--no-cpu-baseline"] + extra
+            if D.dry:
+                argv += ["--dry-run"] + (["--items", str(args.items * 64)] if cfg == 4 and args.items else []) + \
+                        (["--distinct", "8", "--chunk", "64"] if cfg == 4 and args.items else [])
+            a2 = parse_args(argv)
+            t0 = time.time()
+            out, err = None, None
+            try:
+                out = {4: bench_cfg4, 5: bench_cfg5}[cfg](a2, D)
+            except Exception as e:          # noqa: BLE001 -- reported in the line
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            bad = D.sum_ints([1 if err else 0])[0]          # every rank learns whether ANY rank failed
+            if D.rank == 0:
+                if bad:
+                    res[key] = {"error": err or "a rank other than 0 failed", "ranks_failed": bad}
+                else:
+                    res[key] = out if D.dry else summarize(out)
+                res[key]["wall_s"] = time.time() - t0
+                res[key]["command"] = "in process, after the headline: bench.py " + " ".join(argv)
+            if bad:
+                break           # the group's state is unknown after a failure: nothing further is attempted
+    finally:
+        if timer:
+            timer.cancel()
+    return res
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args))
-    if args.dry_run and args.config not in (None, 1, 2):
-        sys.exit("--dry-run covers the launcher / exchange path of --config 2")
     D = Dist(args)
     try:
-        everything = args.config is None and D.world == 1 and not args.dry_run and not args.no_other_configs
+        default_run = args.config is None
+        everything = default_run and D.world == 1 and not args.dry_run and not args.no_other_configs
         if args.config is None:
             args.config = 2
         out = {1: bench_cfg1, 2: bench_cfg2, 3: bench_cfg3, 4: bench_cfg4, 5: bench_cfg5}[args.config](args, D)
+        printed = [False]
+
+        def emit(extra=None):
+            if out is not None and D.rank == 0 and not printed[0]:
+                printed[0] = True
+                if extra is not None:
+                    out["other_configs"] = extra
+                print(json.dumps(out), flush=True)
         if out is not None and everything:
             out["other_configs"] = other_configs(args, D)
             out["other_configs_note"] = ("BASELINE.json configs[0] (cfg1, CPU restatement) and configs[2..4] (cfg3/4/5 at full size on this "
                                          "GPU, each `python bench.py --config N` in a process of its own with shorter timed regions); the headline `value` is cfg2's")
-        if out is not None and D.rank == 0:
-            print(json.dumps(out), flush=True)
+        if default_run and D.world > 1 and not args.no_other_configs:
+            extra = multi_rank_extras(args, D, emit)
+            if out is not None:
+                out["other_configs"] = extra
+                out["other_configs_note"] = ("BASELINE.json configs[3] (cfg4: the write storm split over the %d ranks) and configs[4] (cfg5: combines "
+                                             "sharded by operation), run in this process group after the headline; the headline `value` is cfg2's" % D.world)
+        emit()
     finally:
         D.close()
 

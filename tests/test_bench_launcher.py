@@ -51,3 +51,77 @@ def test_torchrun_environment_is_honoured():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["world_size"] == 2 and r["allgathers_in_step_loop"] == 3
+
+
+# ---- the rank split of BASELINE's actual multi-GPU configs (cfg 3 / 4 / 5), worlds 2 and 8: no GPU, no number -----------------
+def _dry(cfg, world, extra=()):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--config", str(cfg), "--gpus", str(world), "--steps", "2",
+                          "--warmup", "1"] + list(extra), capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_cfg4_storm_is_split_and_gathered_in_write_order(world):
+    """1,000,000 writes over `world` ranks (strong scaling): the shares sum to the storm, every call's all-gather moves chunk / 8
+    bytes per rank (8 ranks: 15,625 B each, 125 KB gathered), and the gathered rows, laid out rank by rank and call by call, ARE the
+    storm's verdict vector in write order (rebuilt here from the constructed verdicts of the global write indices)."""
+    import bench
+    r = _dry(4, world)
+    assert r["world_size"] == world and r["scaling"] == "strong"
+    assert r["writes_per_step"] == 1000000 == r["share_per_rank"] * world and r["share_per_rank"] == r["writes_per_call"] * r["calls_per_step"]
+    assert r["calls_per_step"] == 8 // world and r["writes_per_call"] == 125000 and r["tiles"] == 50
+    assert r["bitmap_bytes_per_rank_per_call"] == 15625 and r["gathered_bytes_per_call"] == 15625 * world
+    if world == 8:
+        assert r["gathered_bytes_per_call"] == 125000                       # SURVEY 8(e): "cfg 4: 125 KB total"
+    assert r["allgathers_in_step_loop"] == (2 + 1) * r["calls_per_step"]     # one exchange per call, warm-up included
+    want = bench.constructed_ok(0, 1000000, 4)
+    assert r["gathered_ok"] == r["sum_of_rank_ok"] == int(want.sum()) and 0 < r["gathered_ok"] < 1000000
+    assert r["ranks_whose_own_rows_match"] == world
+    assert r["verdict_sha256"] == bench.verdict_digest(want)
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_cfg5_operations_are_sharded_without_an_exchange(world):
+    r = _dry(5, world)
+    assert r["world_size"] == world and r["scaling"] == "strong" and r["exchange_steps"] == 0
+    rs = r["operation_ranges"]
+    assert rs[0][0] == 0 and rs[-1][1] == 10000 and all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))      # the shards tile [0, 10000)
+    assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+    assert r["scheme_ops_per_step"] == 30000 and len(set(r["corpus_seeds"])) == world
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_cfg3_ranks_with_different_reply_counts_share_one_bitmap_width(world):
+    """cfg 3 shards by variable and its ranks hold DIFFERENT numbers of replies: every rank must contribute the same byte count to
+    the all-gather (the largest shard's), and each row is cut back to its rank's count when the job's verdicts are put together."""
+    import numpy as np
+    import bench
+    r = _dry(3, world)
+    per = r["replies_per_rank"]
+    assert len(set(per)) > 1 and r["slots"] == max(per) and r["bitmap_bytes_per_rank"] == (max(per) + 7) // 8
+    vr = r["variable_ranges"]
+    assert vr[0][0] == 0 and vr[-1][1] == 10000 and all(vr[i][1] == vr[i + 1][0] for i in range(world - 1))
+    total = int((9 + np.arange(10000) % 3).sum())
+    assert r["replies_total"] == total == sum(per)
+    want = bench.constructed_ok(0, total, 3)
+    assert r["gathered_ok"] == r["sum_of_rank_ok"] == int(want.sum()) and r["verdict_sha256"] == bench.verdict_digest(want)
+
+
+@pytest.mark.parametrize("world", (2, 8))
+def test_default_line_of_a_multi_rank_run_carries_cfg4_and_cfg5(world):
+    """`bench.py --gpus N` (N > 1) prints ONE line: cfg 2's, with the storm (cfg 4) and the share combine (cfg 5) behind it as
+    `other_configs`, run in the same process group."""
+    r = _run(["--gpus", str(world)])
+    assert r["world_size"] == world and r["config"] == 2 and r["gather_rows"] == world
+    oc = r["other_configs"]
+    assert set(oc) == {"cfg4", "cfg5"} and "error" not in oc["cfg4"] and "error" not in oc["cfg5"]
+    c4, c5 = oc["cfg4"], oc["cfg5"]
+    assert c4["config"] == 4 and c4["world_size"] == world and c4["writes_per_step"] == c4["share_per_rank"] * world
+    assert c4["gathered_ok"] == c4["sum_of_rank_ok"] and c4["ranks_whose_own_rows_match"] == world
+    assert c5["config"] == 5 and c5["operation_ranges"][-1][1] == 10000 and c5["exchange_steps"] == 0
