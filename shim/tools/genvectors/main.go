@@ -7,9 +7,12 @@
 // (tests/golden/reference_inputs.json, written by tests/golden/make_reference_inputs.py) and writes
 // tests/golden/reference_vectors.json, which tests/test_reference_vectors.py compares with the oracle, strictly.
 //
-//	cd $GOPATH/src/github.com/yahoo/bftkv            # the reference, with shim/patches/0001 applied (Cliques accessor)
-//	mkdir -p cmd/genvectors && cp <bftkv_amd>/shim/tools/genvectors/main.go cmd/genvectors/
-//	go run ./cmd/genvectors -in <bftkv_amd>/tests/golden/reference_inputs.json -out <bftkv_amd>/tests/golden/reference_vectors.json
+//	shim/tools/genvectors/run.sh                                  # needs Go (>= 1.13), git, patch; clones yahoo/bftkv
+//	BFTKV_SRC=/path/to/yahoo/bftkv shim/tools/genvectors/run.sh   # ... or uses a checkout
+//	docker build -t genvectors -f shim/tools/genvectors/Dockerfile . && docker run --rm -v "$PWD":/repo genvectors
+//
+// run.sh puts the reference beside this file (./bftkv, shim/patches/0001 applied for the Cliques accessor) and builds this program
+// as a module of its own whose go.mod requires x/crypto at exactly the reference's pin and whose go.sum is the reference's.
 //
 // What is recorded, per input item:
 //

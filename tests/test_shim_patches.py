@@ -48,3 +48,32 @@ def test_patches_apply_in_order(tmp_path):
     # braces balance (no Go toolchain here: the cheapest structural check there is)
     for src in (w, g, sss, dsa, core, rsa):
         assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="reference tree or patch(1) not available")
+def test_genvectors_run_script_assembles_a_buildable_module(tmp_path):
+    """shim/tools/genvectors/run.sh up to the point where Go takes over (there is no Go here: a stub `go` on PATH looks at what it
+    is handed): main.go + go.mod + go.sum in one directory, the reference beside them with the Cliques accessor patched in, x/crypto
+    required at exactly the reference's pin, go.sum the reference's own."""
+    gv = os.path.join(ROOT, "shim", "tools", "genvectors")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    stub = bindir / "go"
+    stub.write_text("#!/bin/sh\n"
+                    "if [ \"$1\" = env ] || [ \"$1\" = version ]; then echo go1.13; exit 0; fi\n"
+                    "test -f main.go && test -f go.mod && test -f go.sum || exit 11\n"
+                    "grep -q 'func (q \\*wotq) Cliques() \\[\\]Clique' bftkv/quorum/wotqs/wotqs.go || exit 12\n"
+                    "test ! -d bftkv/.git || exit 13\n"
+                    "echo \"STUB_GO $*\"\n")
+    stub.chmod(0o755)
+    env = dict(os.environ, PATH=str(bindir) + os.pathsep + os.environ["PATH"], BFTKV_SRC=REF, GENVECTORS_WORK=str(tmp_path / "work"))
+    r = subprocess.run(["sh", os.path.join(gv, "run.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "STUB_GO run . -in " in out and "reference_inputs.json -out " in out and "WARNING" not in out      # the tree's hashes check out
+    mod = open(os.path.join(gv, "go.mod")).read()
+    ref_mod = open(os.path.join(REF, "go.mod")).read()
+    pin = [ln.strip() for ln in ref_mod.splitlines() if "golang.org/x/crypto" in ln][0]
+    assert pin in mod and "go 1.13" in mod and "go 1.13" in ref_mod and "replace github.com/yahoo/bftkv => ./bftkv" in mod
+    assert open(os.path.join(gv, "go.sum")).read() == open(os.path.join(REF, "go.sum")).read()
+    assert "FROM golang:1.13" in open(os.path.join(gv, "Dockerfile")).read()
