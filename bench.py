@@ -406,10 +406,15 @@ def c_oracle_for(cl):
     return co
 
 
+CPU_SWEEP = {}          # what the last cpu_collective call swept (goes into cpu_baseline.sweep)
+
+
 def cpu_collective(cl, tb, to, sb, so, budget_s=25.0):
     """The reference-shaped CPU path (oracle/c/oracle.c: per-signature re-hash, per-signature IsSufficient, early exit) on
     this box's host cores over the given items: checker of the GPU verdicts and the reported CPU baseline.  Thread counts are
-    swept within a time budget; returns (err, n_verified, public-key ops, best seconds, threads, single-thread ops/s)."""
+    swept within a time budget -- but never fewer than two of them: the usable cores and the next wider candidate are always
+    timed, so that a short budget cannot leave the baseline at an untuned first guess; what was timed and whether the budget cut
+    the sweep short is recorded (CPU_SWEEP).  Returns (err, n_verified, public-key ops, best seconds, threads, single-thread ops/s)."""
     co = c_oracle_for(cl)
     n = len(to) - 1
     m1 = max(1, min(n, n // 50))
@@ -418,19 +423,24 @@ def cpu_collective(cl, tb, to, sb, so, budget_s=25.0):
     t1 = time.perf_counter() - t0
     cores = effective_cores()
     cands = sorted({cores} | {t for t in (16, 32, 64, 128, 256) if t <= (os.cpu_count() or 1)})
+    cands = [t for t in cands if t >= cores] or [cores]          # fewer threads than usable cores are never the best
     best = None
     spent = 0.0
     res = None
-    for nt in cands:
-        if best is not None and spent + best[0] > budget_s:
+    timed = []
+    for k, nt in enumerate(cands):
+        if k >= 2 and spent + best[0] > budget_s:
             break
         t0 = time.perf_counter()
         cerr, cnver, ops = co.collective_verify(tb, to, sb, so, n_threads=nt)
         dt = time.perf_counter() - t0
         spent += dt
+        timed.append({"threads": nt, "seconds": dt})
         if best is None or dt < best[0]:
             best = (dt, nt)
         res = (cerr, cnver, ops)
+    CPU_SWEEP.clear()
+    CPU_SWEEP.update({"candidates": cands, "timed": timed, "truncated_by_budget": len(timed) < len(cands), "budget_s": budget_s})
     return res[0], res[1], res[2], best[0], best[1], ops1 / t1
 
 
@@ -779,7 +789,8 @@ def bench_cfg2(args, D):
                           "Go math/big)" % (items, ops, cl.suff, nt, os.cpu_count() or 1, effective_cores()),
                 "verdicts_per_sec": items / best, "single_thread_verifies_per_sec": st1,
                 "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
-                "reference_op_count_identical_to_cpu": bool(ops == ref_ops)}
+                "reference_op_count_identical_to_cpu": bool(ops == ref_ops),
+                "sweep": dict(CPU_SWEEP)}
     V.close()
     return out if D.rank == 0 else None
 
@@ -952,7 +963,7 @@ def bench_cfg3(args, D):
                           "for %d variables" % (w.n_items, n_replies, ops_w, nt, effective_cores(), t_tally, n_vars),
                 "reply_verdicts_per_sec": w.n_items / best, "single_thread_verifies_per_sec": st1,
                 "gpu_verdicts_identical_to_cpu": bool((cerr == err).all() and (cnver == nver).all()),
-                "read_answers_identical_to_oracle": bool(reads_same), "min_cpu_pubkey_ops_all_replies": ops_all}
+                "read_answers_identical_to_oracle": bool(reads_same), "min_cpu_pubkey_ops_all_replies": ops_all, "sweep": dict(CPU_SWEEP)}
     V.close()
     return out if D.rank == 0 else None
 
@@ -1091,7 +1102,8 @@ def bench_cfg4(args, D):
                           "%.1f KB payload for every signature), best thread count %d (usable per affinity/cgroup: %d); OpenSSL libcrypto" %
                           (distinct, ops, cl.suff, float(z["to"][-1]) / distinct / 1024, nt, effective_cores()),
                 "verdicts_per_sec": distinct / best, "single_thread_verifies_per_sec": st1,
-                "gpu_verdicts_identical_to_cpu": bool((np.tile(cerr, tiles) == err).all() and (np.tile(cnver, tiles) == nver).all())}
+                "gpu_verdicts_identical_to_cpu": bool((np.tile(cerr, tiles) == err).all() and (np.tile(cnver, tiles) == nver).all()),
+                "sweep": dict(CPU_SWEEP)}
     V.close()
     return out if D.rank == 0 else None
 
@@ -1299,9 +1311,12 @@ def bench_cfg5(args, D):
             cores = effective_cores()
             cands = sorted({cores} | {t for t in (16, 32, 64, 128) if t <= (os.cpu_count() or 1)})
             best = None
-            for nt in cands:
-                if best is not None and best[0] * 2 > args.cpu_budget:
+            cands = [t for t in cands if t >= cores] or [cores]
+            timed_nt = []
+            for k_, nt in enumerate(cands):
+                if k_ >= 2 and best[0] * 2 > args.cpu_budget:       # (never fewer than two thread counts: ADVICE r04)
                     break
+                timed_nt.append(nt)
                 t0 = time.perf_counter()
                 c_rsa = ct.rsa_combine(h["rsa_f"], 10, 256, tc.rsa_n, n_threads=nt)
                 t1 = time.perf_counter()
@@ -1329,7 +1344,9 @@ def bench_cfg5(args, D):
                                              "CalculateR; one thread: %.0f us per CalculateR" %
                                              (N, best[1], cores, bt[0] * 1e3, bt[1] * 1e3, bt[2] * 1e3, bt[3] * 1e3, t_r1 * 1e6),
                                    "per_scheme_ops_per_sec": {names[i]: N / bt[i] for i in range(4)},
-                                   "gpu_results_identical_to_cpu": same}
+                                   "gpu_results_identical_to_cpu": same,
+                                   "sweep": {"candidates": cands, "timed": [{"threads": t} for t in timed_nt], "truncated_by_budget": len(timed_nt) < len(cands),
+                                             "budget_s": args.cpu_budget}}
     for cx in reversed(ctxs):
         cx.close()
     return out if D.rank == 0 else None
@@ -1397,6 +1414,9 @@ def summarize(out):
     cb_ = out.get("cpu_baseline")
     if cb_:
         keep["cpu_baseline"] = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
+        if "sweep" in cb_:
+            keep["cpu_baseline"]["threads_timed"] = [t["threads"] for t in cb_["sweep"]["timed"]]
+            keep["cpu_baseline"]["sweep_truncated_by_budget"] = cb_["sweep"]["truncated_by_budget"]
         keep["identity"] = {k: v for k, v in cb_.items() if "identical" in k}
     for k in ("verdicts_match_construction", "kernel_ms", "per_scheme_ops_per_sec_per_gpu", "packets_per_sec", "quorum_verdicts_per_sec",
               "reply_verdicts_per_sec", "read_verdicts_per_sec", "dsa_tables", "single_flight", "serving"):

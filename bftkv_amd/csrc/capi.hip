@@ -120,6 +120,7 @@ struct bftkv_gpu_ctx {
 
   // per-call arena
   DevBuf txt_mid32, txt_mid64, txt_tail, txt_len;     // text-mode hashing state (TextDev)
+  DevBuf forced_iss;      // per-item key ids of certificate checks (signature_verify_entities)
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
@@ -191,7 +192,7 @@ void rccl_release(bftkv_gpu_ctx* c);
 void release_small_pin(bftkv_gpu_ctx* c);
 extern "C" int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
                                          const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class = nullptr,
-                                         uint8_t* fenced_out = nullptr);
+                                         uint8_t* fenced_out = nullptr, const uint64_t* forced_issuer = nullptr);
 
 namespace {
 
@@ -378,7 +379,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
                  const uint32_t* d_msg_slot = nullptr, const uint8_t* d_msg_hash = nullptr,
                  const std::function<int(hipStream_t)>* upload_tbs = nullptr, const QuorumDev* plan_q = nullptr, uint64_t ss_len = 0,
                  const uint32_t* d_mid_in = nullptr, const uint64_t* d_tbs_prefix = nullptr, uint32_t staged_cap = 0,
-                 hipEvent_t ev_input = nullptr, bool mid_prelaunched = false) {
+                 hipEvent_t ev_input = nullptr, bool mid_prelaunched = false, const uint64_t* d_forced_issuer = nullptr) {
   // mid_prelaunched (pieces of a pipelined host-buffer call): the caller has already put k_sha256_mid for these items on the
   // hash stream -- when the payloads arrived, ahead of the signature streams -- so the chain of 134 dependent compressions per
   // payload is under way before the piece is picked up.
@@ -493,7 +494,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     pa.scratch = c->walk_scratch.as<WalkEnt>(); pa.walk_cap = walk_cap; pa.recs = c->recs.as<SigRec>(); pa.n_recs = total; pa.cert_ent = d_cert_ent;
     pa.pk_list = c->pk_list.as<uint32_t>(); pa.pk_list3072 = c->pk_list3072.as<uint32_t>(); pa.pk_list4096 = c->pk_list4096.as<uint32_t>();
     pa.pk_count = c->pk_count.as<uint32_t>(); pa.dsa_list = c->dsa_list.as<uint32_t>(); pa.item_hash_mask = c->hash_mask.as<uint32_t>();
-    pa.sig_class = d_sig_class; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
+    pa.sig_class = d_sig_class; pa.forced_issuer = d_forced_issuer; pa.msg_slot = d_msg_slot; pa.msg_hash = d_msg_hash; pa.item_flags = c->item_flags.as<uint8_t>();
     pa.defer_queue = plan_q ? 1u : 0u;
     pa.n_recs_dev = n_recs_dev;
     pa.chunk_arena = c->chunk_arena.as<uint8_t>(); pa.chunk_cap_units = (uint32_t)std::min<size_t>(c->chunk_arena.cap / 16, 0xFFFFFFF0u);
@@ -1109,6 +1110,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   c->in_pack.release();
+  c->forced_iss.release();
   release_small_pin(c);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->root) c->root->n_forks.fetch_sub(1);
@@ -1772,7 +1774,8 @@ static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
 // Signature.Verify over a batch with the keyring of item i restricted to entity index ent[i] (0xFFFFFFFF: the node
 // keyring).  Shared by bftkv_gpu_signature_verify and the Server.sign site of the host mirror.
 int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off, const uint8_t* sig,
-                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class, uint8_t* fenced_out) {
+                              const uint64_t* sig_off, const uint32_t* ent, uint8_t* err_out, const uint8_t* sig_class, uint8_t* fenced_out,
+                              const uint64_t* forced_issuer) {
   ctx_lock lk(c->mu);
   KtRead kr(c);
   if (kr.rc) return kr.rc;
@@ -1802,8 +1805,14 @@ int signature_verify_entities(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t*
     HIPCHK(c, hipMemcpyAsync(c->sig_class.p, sig_class, n_items, hipMemcpyHostToDevice, c->stream));
     d_cls = c->sig_class.as<uint8_t>();
   }
+  const uint64_t* d_forced = nullptr;
+  if (forced_issuer && sig_class) {     // certificate checks: the key the caller holds for each check (ParseArgs::forced_issuer)
+    HIPCHK(c, c->forced_iss.ensure(sizeof(uint64_t) * n_items + 16));
+    HIPCHK(c, hipMemcpyAsync(c->forced_iss.p, forced_issuer, sizeof(uint64_t) * n_items, hipMemcpyHostToDevice, c->stream));
+    d_forced = c->forced_iss.as<uint64_t>();
+  }
   int rc = run_pipeline(c, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
-                        c->in_ss_off.as<uint64_t>(), d_cert, d_cls, nullptr, nullptr, nullptr, nullptr, sl);
+                        c->in_ss_off.as<uint64_t>(), d_cert, d_cls, nullptr, nullptr, nullptr, nullptr, sl, nullptr, nullptr, 0, nullptr, false, d_forced);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sigverify_fold, dim3((n_items + 255) / 256), dim3(256), 0, c->stream, c->recs.as<SigRec>(),
                      c->base.as<uint32_t>(), c->counts.as<uint32_t>(), c->item_flags.as<uint8_t>(), n_items, c->o_err.as<uint8_t>());

@@ -616,6 +616,11 @@ struct ParseArgs {
   uint32_t* pk_count;          // [0] RSA<=2048, [1] DSA, [2] RSA<=3072, [3] RSA<=4096, [4] some hash other than SHA-256
   uint32_t* dsa_list; uint32_t* item_hash_mask;
   const uint8_t* sig_class;    // per item or null
+  // per item or null, certificate checks only (sig_class >= 1): the id of the key the CALLER holds for this check -- x/crypto's
+  // VerifyUserIdSignature / VerifyKeySignature / VerifyRevocationSignature verify with the key ReadEntity has in hand (the primary
+  // key; the subkey for a cross-signature) and never look at the issuer subpacket.  Non-zero: that id replaces the signature's
+  // issuer in the key lookup, and a signature without issuer subpacket is not an error.
+  const uint64_t* forced_issuer;
   const uint32_t* msg_slot;    // per item or null
   const uint8_t* msg_hash;     // per item, with msg_slot
   const uint8_t* item_flags;
@@ -702,6 +707,10 @@ __device__ __forceinline__ void parse_one(const ParseArgs& a, const KeyTableDev&
     // packets out of the middle of this one -- not followed: fenced.  (One span of <= 4096 bytes is taken by the first fetch.)
     if (parsed && (chunked || rec.body_len > BUFIO_SIZE) && reader_position_after_parse(sig_blob, body_cur, item_end, rec, v3) != body_next)
       fence = true;
+    if (parsed && a.forced_issuer && sig_class && sig_class[rec.item] != 0 && a.forced_issuer[rec.item] != 0) {
+      issuer = a.forced_issuer[rec.item];
+      have_issuer = true;
+    }
     if (!parsed) { st = ST_PARSE_ERROR; fence = too_deep; }
     else if (!have_issuer && !msg_slot) st = ST_NO_ISSUER;
     else {

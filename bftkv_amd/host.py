@@ -418,23 +418,35 @@ class Certificate:
 def certs_verify(ctx: _native.Context, cert: bytes) -> List[Optional[bool]]:
     """Which entities of a certificate blob openpgp.ReadEntity returns: True, False (refused), None (no verdict: a shape left to
     the reference, or a check that met a fenced shape)."""
-    valid = np.zeros(64, dtype=np.uint8)
-    n = C.c_uint32(0)
-    rc = _lib().bftkv_host_certs_verify(ctx.h, cert, len(cert), valid.ctypes.data, len(valid), C.byref(n))
-    if rc:
-        raise _native.NativeError("certs_verify failed: %d" % rc)
-    return [None if v == 2 else bool(v) for v in valid[:n.value]]
+    # sized from the call: the entry point reports how many entities it found (BFTKV_E_NOMEM with *n_out set when the array is
+    # too short), so a certificate of any number of entities is answered in at most two calls
+    cap = 64
+    while True:
+        valid = np.zeros(cap, dtype=np.uint8)
+        n = C.c_uint32(0)
+        rc = _lib().bftkv_host_certs_verify(ctx.h, cert, len(cert), valid.ctypes.data, len(valid), C.byref(n))
+        if rc == -3 and n.value > cap:          # BFTKV_E_NOMEM
+            cap = n.value
+            continue
+        if rc:
+            raise _native.NativeError("certs_verify failed: %d" % rc)
+        return [None if v == 2 else bool(v) for v in valid[:n.value]]
 
 
 def quorum_cert_verify(ctx: _native.Context, q: "Quorum", cert: bytes):
     """CheckQuorumCert of the paper: (IsThreshold over VERIFIED certifiers, their ids)."""
     ok = np.zeros(4, dtype=np.uint8)
-    ids = np.zeros(1024, dtype=np.uint64)
-    n = C.c_uint32(0)
-    rc = _lib().bftkv_host_quorum_cert_verify(ctx.h, q.h, cert, len(cert), ok.ctypes.data, ids.ctypes.data, len(ids), C.byref(n))
-    if rc:
-        raise _native.NativeError("quorum_cert_verify failed: %d" % rc)
-    return bool(ok[0]), [int(x) for x in ids[:n.value]]
+    cap = 1024
+    while True:
+        ids = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint32(0)
+        rc = _lib().bftkv_host_quorum_cert_verify(ctx.h, q.h, cert, len(cert), ok.ctypes.data, ids.ctypes.data, len(ids), C.byref(n))
+        if rc == -3 and n.value > cap:          # BFTKV_E_NOMEM: *n_out says how many verified certifiers there are
+            cap = n.value
+            continue
+        if rc:
+            raise _native.NativeError("quorum_cert_verify failed: %d" % rc)
+        return bool(ok[0]), [int(x) for x in ids[:n.value]]
 
 
 def sha256(data: bytes, mode: int = 0):

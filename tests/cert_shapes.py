@@ -75,8 +75,8 @@ def binding(kp, sk, sig_type=0x18, flags=0x0c, ctime=T0, cross="auto", issuer="p
     unhashed = b""
     fake = k.get("fake", False)
     if cross is not None and flags is not None and (flags & 2):
-        eb = sig_body(sk, 0x19, signed, hashed_area(None if cross == "no-issuer" else (kp.key_id if cross == "wrong-issuer" else sk.key_id), ctime),
-                      spoil=cross == "bad", fake=fake)
+        eb = sig_body(sk, 0x19, signed, hashed_area(None if cross == "no-issuer" else (kp.key_id if cross in ("wrong-issuer", "bad-wrong-issuer") else sk.key_id), ctime),
+                      spoil=cross in ("bad", "bad-wrong-issuer"), fake=fake)
         unhashed = bytes([255]) + struct.pack(">I", 1 + len(eb)) + bytes([32]) + eb
     iss = kp.key_id if issuer == "primary" else issuer
     return sig_pkt(kp, sig_type, signed, hashed_area(iss, ctime, extra), unhashed, **k)
@@ -84,6 +84,28 @@ def binding(kp, sk, sig_type=0x18, flags=0x0c, ctime=T0, cross="auto", issuer="p
 
 def key_revocation(kp, issuer="primary", **k):
     return sig_pkt(kp, 0x20, key_framed(kp), hashed_area(kp.key_id if issuer == "primary" else issuer, T0, sub(29, b"\x00")), **k)
+
+
+def embedded(eb: bytes) -> bytes:
+    """An embedded-signature subpacket (type 32, five-octet length)."""
+    return bytes([255]) + struct.pack(">I", 1 + len(eb)) + bytes([32]) + eb
+
+
+def nested_binding(kp, sk, depth: int) -> bytes:
+    """A signing subkey's binding whose cross-signature (real) carries `depth - 1` further 0x19 signatures nested in its unhashed
+    area (fake values: x/crypto parses embedded signatures recursively but verifies only the outermost one)."""
+    signed = key_framed(kp) + key_framed(sk)
+    inner = b""
+    for _ in range(depth - 1):
+        inner = embedded(sig_body(sk, 0x19, signed, hashed_area(sk.key_id), inner, fake=True))
+    eb = sig_body(sk, 0x19, signed, hashed_area(sk.key_id), inner)
+    return sig_pkt(kp, 0x18, signed, hashed_area(kp.key_id, T0, sub(27, bytes([0x02]))), embedded(eb))
+
+
+def body_over_4096(kp, sk) -> bytes:
+    """A binding-typed signature body of more than 4096 bytes (fake value, bulky unhashed area)."""
+    return sig_body(kp, 0x18, key_framed(kp) + key_framed(sk), hashed_area(kp.key_id, T0, sub(27, bytes([0x0c]))),
+                    b"".join(sub(100, bytes(150)) for _ in range(29)), fake=True)
 
 
 def keys():
@@ -126,16 +148,20 @@ def scenarios():
     add("... unless a later one is the primary user id", K + U + ss + U2 + self_sig(a, uid2, flags=0x0c, primary=True), [True], [], [])
     add("the same uid twice: the later identity replaces the earlier with its signatures",
         K + U + ss + cert_b + U + self_sig(a, uid, ctime=T0 + 2) + certification(d, a, uid), [True], [d.key_id], [a.key_id])
-    add("a certification without issuer subpacket is not a signer (the reference dereferences nil there)",
-        K + U + ss + certification(b, a, uid, issuer=None), [True], [], [a.key_id])
+    add("a certification without issuer subpacket: ReadEntity takes it, PGPCertificateInstance.Signers dereferences nil on it -- no verdict",
+        K + U + ss + certification(b, a, uid, issuer=None), [None])
     add("signing subkey with its cross-signature", K + U + ss + S + binding(a, s, flags=0x02), [True], [], [a.key_id, s.key_id])
     add("signing subkey WITHOUT cross-signature", K + U + ss + S + binding(a, s, flags=0x02, cross=None), [False])
     add("signing subkey, cross-signature does not verify", K + U + ss + S + binding(a, s, flags=0x02, cross="bad"), [False])
-    add("cross-signature naming another issuer: verified under the subkey all the same by the reference -- no verdict here",
-        K + U + ss + S + binding(a, s, flags=0x02, cross="wrong-issuer"), [None])
+    add("cross-signature naming another issuer: verified under the subkey all the same (VerifyKeySignature never reads the issuer)",
+        K + U + ss + S + binding(a, s, flags=0x02, cross="wrong-issuer"), [True], [], [a.key_id, s.key_id])
+    add("cross-signature without issuer subpacket: the same", K + U + ss + S + binding(a, s, flags=0x02, cross="no-issuer"), [True], [], [a.key_id, s.key_id])
+    add("... and one that does not verify under the subkey is refused whatever it names",
+        K + U + ss + S + binding(a, s, flags=0x02, cross="bad-wrong-issuer"), [False])
     add("binding that does not verify", K + U + ss + S + binding(a, s, spoil=True), [False])
-    add("binding without issuer subpacket: verified under the primary key by the reference -- no verdict here",
-        K + U + ss + S + binding(a, s, issuer=None), [None])
+    add("binding without issuer subpacket: verified under the primary key ReadEntity holds", K + U + ss + S + binding(a, s, issuer=None), [True], [], [a.key_id])
+    add("binding naming another issuer: the same", K + U + ss + S + binding(a, s, issuer=b.key_id), [True], [], [a.key_id])
+    add("binding without issuer subpacket that does not verify", K + U + ss + S + binding(a, s, issuer=None, spoil=True), [False])
     add("subkey without any signature", K + U + ss + S, [False])
     add("subkey followed by a certification: wrong type", K + U + ss + S + cert_b, [False])
     add("subkey with two bindings: the newer one's flags", K + U + ss + S + binding(a, s, flags=0x02) + binding(a, s, flags=0x0c, ctime=T0 + 9),
@@ -150,6 +176,8 @@ def scenarios():
         K + U + ss + S + binding(a, s, sig_type=0x28, flags=None, reason=1) + binding(a, s, flags=0x02, ctime=T0 + 20), [True], [], [a.key_id])
     add("key revocation before the uid: verified, the entity's keys are out", K + key_revocation(a) + U + ss, [True], [], [])
     add("key revocation that does not verify refuses the entity", K + key_revocation(a, spoil=True) + U + ss, [False])
+    add("key revocation without issuer subpacket: verified under the primary key all the same", K + key_revocation(a, issuer=None) + U + ss, [True], [], [])
+    add("... one naming another key that does not verify", K + key_revocation(a, issuer=b.key_id, spoil=True) + U + ss, [False])
     add("a 0x20 inside a uid's run is just one of its signatures", K + U + ss + key_revocation(a), [True], [a.key_id], [a.key_id])
     add("a version-3 signature ends the uid's run: what follows is ignored",
         K + U + ss + pkt(2, bytes([3, 5, 0x10]) + struct.pack(">I", T0) + struct.pack(">Q", b.key_id) + bytes([1, 8, 0, 0]) + cb.go_mpi_bytes(b"\x01" * 8)) + cert_b,
@@ -177,6 +205,23 @@ def scenarios():
     add("a stray byte behind the last packet is an error of Next: the entity it ends is refused", K + U + ss + b"\x00", [False])
     add("an unknown packet type cut off by the end of the certificate is skipped like a whole one", K + U + ss + pkt(12, b"abcdef")[:-2], [True], [], [a.key_id])
     add("a second primary key packet that does not parse refuses only its own entity", K + U + ss + pkt(6, a.pub_body[:20]), [True, False], [], [a.key_id])
+    # shapes left to the reference must never turn into a refusal by what they HIDE: the self-signature below is
+    # real and x/crypto accepts the entity -- its 4.4 KB unhashed area is read through bufio like any other
+    big_unhashed = b"".join(sub(100, bytes(150)) for _ in range(29))
+    add("a valid self-signature with a 4.4 KB unhashed area: its body is over 4096 bytes -- no verdict, and NOT 'entity without any identities'",
+        K + U + self_sig(a, uid, unhashed=big_unhashed), [None])
+    add("... the same behind a first, ordinary self-signature", K + U + ss + self_sig(a, uid, ctime=T0 + 3, unhashed=big_unhashed) + cert_b, [None])
+    add("a user id under a partial length, then its self-signature: no verdict (the walk ends at the partial length)",
+        K + bytes([0xCD, 0xE4]) + uid[:16] + bytes([len(uid) - 16]) + uid[16:] + ss, [None])
+    add("a subkey whose binding sits behind a signature body over 4096 bytes: no 'subkey packet not followed by signature'",
+        K + U + ss + S + pkt(2, body_over_4096(a, s)) + binding(a, s), [None])
+    add("a secret-key packet first: ReadEntity takes a private key for the primary key -- no verdict", pkt(5, a.pub_body + b"\x00" + bytes(16)) + U + ss, [None])
+    add("... and the public entity behind it is walked on its own", pkt(5, a.pub_body + b"\x00" + bytes(16)) + U + ss + pkt(6, b.pub_body) + pkt(13, b.name.encode()) + self_sig(b, b.name.encode()),
+        [None, True])
+    add("a secret subkey in mid-entity", K + U + ss + pkt(7, s.pub_body + b"\x00" + bytes(16)) + binding(a, s), [None])
+    add("embedded signatures nested three deep in a binding: x/crypto parses them recursively -- no verdict (the parser here is bounded)",
+        K + U + ss + S + nested_binding(a, s, 3), [None])
+    add("... two deep is followed: the inner ones must be 0x19, the outer cross-signature verifies", K + U + ss + S + nested_binding(a, s, 2), [True], [], [a.key_id, s.key_id])
     add("empty", b"", [])
     add("not a packet", bytes(range(200)), [])
     # a key packet with bytes behind its last MPI: key id, fingerprint and hashes are those of the key without them
@@ -219,6 +264,10 @@ def random_blobs(n: int, seed: int = 7):
         lambda: bytes([0xCD, 0xC0, 0x10]) + bytes(208),                                              # two-octet length, a 208-byte user id
         lambda: bytes([0xC2, 0xE0]) + b"\x04",                          # partial length
         lambda: pkt(2, self_sig(a, uid, **fake)[3:] + bytes(4200)),      # a signature body over 4096 bytes
+        lambda: self_sig(a, uid, unhashed=b"".join(sub(100, bytes(150)) for _ in range(29)), **fake),      # ... a well-formed one
+        lambda: bytes([0xCD, 0xE4]) + uid[:16] + bytes([len(uid) - 16]) + uid[16:],                        # a user id under a partial length
+        lambda: nested_binding(a, s, rnd.choice([2, 3, 3, 4])),                                             # embedded signatures 2 / 3 / 4 deep
+        lambda: sig_pkt(b, 0x10, key_framed(a) + uid_framed(uid), hashed_area(b.key_id), embedded(sig_body(s, 0x19, b"", hashed_area(s.key_id), embedded(sig_body(s, 0x19, b"", hashed_area(s.key_id), embedded(sig_body(s, 0x19, b"", hashed_area(s.key_id), fake=True)), fake=True)), fake=True)), fake=True),
     ]
     out = []
     for i in range(n):

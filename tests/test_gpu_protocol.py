@@ -1113,11 +1113,31 @@ def test_read_entity_shape_by_shape_on_the_gpu(gpu_ctx):
         "the key is revoked": CS.pkt(6, a.pub_body) + CS.key_revocation(a) + CS.pkt(13, uid) + CS.self_sig(a, uid) + CS.pkt(14, s.pub_body) + CS.binding(a, s, flags=0x02),
         "a user attribute: left to the reference": head + CS.binding(a, s, flags=0x02) + CS.pkt(17, b"\x01\x01"),
     }
+    # shapes the walk leaves to the reference must come out FENCED, never as "certificate not found" (what an unknown shape
+    # hides -- the self-signature, the binding -- must not turn into a refusal), and the checks ReadEntity makes with the key it HOLDS
+    # (binding / cross-signature / revocation that name another issuer or none) get their verdict on the device
+    big_unhashed = b"".join(CS.sub(100, bytes(150)) for _ in range(29))
+    certs.update({
+        "self-signature body over 4096 bytes: left to the reference": CS.pkt(6, a.pub_body) + CS.pkt(13, uid) + CS.self_sig(a, uid, unhashed=big_unhashed),
+        "user id under a partial length: left to the reference": CS.pkt(6, a.pub_body) + bytes([0xCD, 0xE4]) + uid[:16] + bytes([len(uid) - 16]) + uid[16:] + CS.self_sig(a, uid),
+        "embedded signatures three deep: left to the reference": head + CS.nested_binding(a, s, 3),
+        "binding and cross-signature without issuer subpackets": head + CS.binding(a, s, flags=0x02, issuer=None, cross="no-issuer"),
+        "binding naming a stranger, forged": head + CS.binding(a, s, flags=0x02, issuer=b_.key_id, spoil=True),
+    })
+    # a certificate of more entities than the wrapper's first guess (bftkv_amd.host.certs_verify sizes its answer from the call)
+    many = b"".join(CS.pkt(6, a.pub_body) + CS.pkt(13, uid) + (CS.self_sig(a, uid) if i % 3 else CS.self_sig(a, uid, spoil=True)) for i in range(70))
+    assert host.certs_verify(gpu_ctx, many) == [bool(i % 3) for i in range(70)]
     bt = Batcher(gpu_ctx, max_items=16)
     try:
         outcomes, bad = set(), []
         for name, cert in certs.items():
             ent = pgp.entity_checks(cert)[0]
+            if "left to the reference" in name:
+                assert ent["valid"] is None, name
+            if "without issuer subpackets" in name:
+                assert ent["valid"] is True, name
+            if "forged" in name:
+                assert ent["valid"] is False, name
             for who, sig in (("subkey", by_sub), ("primary", by_primary)):
                 err, fenced, got_id, _ = bt.cert_verify(cert, tbs, sig)
                 if ent["valid"] is None:
