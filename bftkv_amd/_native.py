@@ -46,7 +46,7 @@ EXPORTS = [
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
     "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_host_pipeline_trace",
-    "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r", "bftkv_gpu_batcher_modexp",
+    "bftkv_gpu_batcher_cert_entity", "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r", "bftkv_gpu_batcher_modexp",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p]
     lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p, u8p]
     lib.bftkv_gpu_batcher_cert_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p]
+    lib.bftkv_gpu_batcher_cert_entity.argtypes = [vp, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p, vp, vp, vp, u32, vp]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.bftkv_gpu_batcher_modmul_product.argtypes = [vp, u32, u8p, u32, u8p, u8p, u8p]
@@ -568,6 +569,21 @@ class Batcher:
         if rc:
             raise NativeError("batcher cert_verify failed: %d" % rc)
         return int(err[0]), int(fenced[0]), int(iid[0]), fp.tobytes()
+
+    def cert_entity(self, cert: bytes, cap: int = 256):
+        """bftkv_gpu_batcher_cert_entity: Issuer(sig) without ReadEntity on the CPU.  Returns (rc, err, fenced, issuer_key_id,
+        fingerprint, entity_off, entity_len, roles) with roles = [(role number, index, chosen)]."""
+        err, fenced = np.zeros(1, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        iid, rng = np.zeros(1, dtype=np.uint64), np.zeros(2, dtype=np.uint64)
+        fp = np.zeros(20, dtype=np.uint8)
+        while True:
+            roles, n = np.zeros(max(1, cap), dtype=np.uint32), np.zeros(1, dtype=np.uint32)
+            rc = self.lib.bftkv_gpu_batcher_cert_entity(self.h, cert, len(cert), _ptr(err), _ptr(fenced), iid.ctypes.data, _ptr(fp), rng.ctypes.data,
+                                                        rng.ctypes.data + 8, roles.ctypes.data, cap, n.ctypes.data)
+            if rc == -3 and int(n[0]) > cap:
+                cap = int(n[0])
+                continue
+            return rc, int(err[0]), int(fenced[0]), int(iid[0]), fp.tobytes(), int(rng[0]), int(rng[1]), [(int(r) & 0xFF, (int(r) >> 8) & 0xFFFF, bool(int(r) >> 24)) for r in roles[:int(n[0])]]
 
     def message_verify(self, msg: bytes):
         """One transport message through the batcher: (status, signer_key_id, peer_id, plain, file_name)."""

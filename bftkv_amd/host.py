@@ -80,7 +80,7 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_max_timestamped_value_masked", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
-    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key", "bftkv_host_certs_structure", "bftkv_host_certs_check",
+    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key", "bftkv_host_certs_structure", "bftkv_host_certs_check", "bftkv_host_certs_roles",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
     "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256", "bftkv_host_cert_fingerprint",
@@ -138,6 +138,7 @@ def _lib():
         lib.bftkv_host_certs_n_entities.restype = C.c_uint32
         lib.bftkv_host_certs_entity.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_key.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(_native.PubKey)]
+        lib.bftkv_host_certs_roles.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_structure.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]
         lib.bftkv_host_certs_check.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint64),
                                                C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -376,6 +377,9 @@ def _cat(parts: Sequence[bytes]):
     return blob, off
 
 
+ROLE_NAMES = ["ignored", "primary", "uid", "self", "ident_sig", "subkey", "subkey_sig", "revocation"]      # BFTKV_ROLE_* (bftkv_gpu.h)
+
+
 class Certificate:
     """PGPCertificate.Parse / Signers reduced to what the path reads (crypto_pgp.go:236-272, 80-88)."""
 
@@ -408,8 +412,12 @@ class Certificate:
                     lib.bftkv_host_certs_check(h, e, i, C.byref(kind), C.byref(ki), C.byref(sp), C.byref(sl), C.byref(gp), C.byref(gl))
                     checks.append({"kind": kind.value, "key_index": ki.value, "signed": C.string_at(sp.value, sl.value) if sl.value else b"",
                                    "sig": C.string_at(gp.value, gl.value) if gl.value else b""})
+                st, ln, rp, nr = C.c_uint64(0), C.c_uint64(0), C.c_void_p(), C.c_uint32(0)
+                lib.bftkv_host_certs_roles(h, e, C.byref(st), C.byref(ln), C.byref(rp), C.byref(nr))
+                raw = [int(x) for x in (C.c_uint32 * nr.value).from_address(rp.value)] if nr.value else []
                 out.append({"id": eid.value, "keys": keys, "certifiers": certifiers, "refused": bool(refused.value), "unknown": bool(unknown.value),
-                            "why": (why.value or b"").decode(), "checks": checks})
+                            "why": (why.value or b"").decode(), "checks": checks, "start": st.value, "len": ln.value,
+                            "roles": [(ROLE_NAMES[r & 0xFF], (r >> 8) & 0xFFFF, bool(r >> 24)) for r in raw]})
         finally:
             lib.bftkv_host_certs_free(h)
         return out

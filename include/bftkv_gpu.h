@@ -288,6 +288,28 @@ int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs,
 int bftkv_gpu_batcher_cert_verify(bftkv_gpu_batcher* b, const uint8_t* cert, uint64_t cert_len, const uint8_t* tbs, uint64_t tbs_len,
                                   const uint8_t* sig, uint64_t sig_len, uint8_t* err_out, uint8_t* fenced_out,
                                   uint64_t* issuer_id_out, uint8_t* fingerprint_out);
+/* Signature.Issuer(sig) WITHOUT openpgp.ReadEntity on the CPU (crypto_pgp.go:392-405 -> 236-249): the ReadEntity verdict of the
+ * first entity of sig.Cert as bftkv_gpu_batcher_cert_verify(sig = NULL) gives it -- its signature checks on the GPU, once per
+ * distinct certificate -- plus what a caller needs to ASSEMBLE the entity ReadEntity would have returned from packets it
+ * parses itself (x/crypto's packet.Read: no cryptography): for each packet packet.Reader.Next() yields inside the entity, in
+ * order, what ReadEntity does with it:
+ *   roles_out[i] = BFTKV_ROLE_* | index << 8 | chosen << 24   (index: ordinal of the identity / subkey the packet belongs to;
+ *                  chosen, on a subkey signature: it is the one ReadEntity leaves in Subkey.Sig)
+ *   *entity_off_out, *entity_len_out   the entity's bytes inside cert (packet types unknown to x/crypto may precede it)
+ * err / fenced / issuer id / fingerprint as for bftkv_gpu_batcher_cert_verify.  Only *err_out == BFTKV_ERR_NONE with
+ * *fenced_out == 0 says "ReadEntity returns this entity, built like this"; everything else: take the reference path.
+ * BFTKV_E_NOMEM with *n_roles_out set when roles_cap is too small. */
+#define BFTKV_ROLE_IGNORED 0u             /* read and dropped (a version-3 signature, a stray signature outside any run) */
+#define BFTKV_ROLE_PRIMARY_KEY 1u
+#define BFTKV_ROLE_USER_ID 2u             /* starts identity `index` */
+#define BFTKV_ROLE_SELF_SIGNATURE 3u      /* identity.SelfSignature (the last one counts) and e.Identities[name] = identity */
+#define BFTKV_ROLE_IDENTITY_SIGNATURE 4u  /* appended to identity.Signatures, unverified */
+#define BFTKV_ROLE_SUBKEY 5u              /* starts subkey `index` */
+#define BFTKV_ROLE_SUBKEY_SIGNATURE 6u    /* verified binding / revocation of subkey `index`; chosen = Subkey.Sig */
+#define BFTKV_ROLE_REVOCATION 7u          /* appended to e.Revocations */
+int bftkv_gpu_batcher_cert_entity(bftkv_gpu_batcher* b, const uint8_t* cert, uint64_t cert_len, uint8_t* err_out, uint8_t* fenced_out,
+                                  uint64_t* issuer_id_out, uint8_t* fingerprint_out, uint64_t* entity_off_out, uint64_t* entity_len_out,
+                                  uint32_t* roles_out, uint32_t roles_cap, uint32_t* n_roles_out);
 /* stats[0] calls served, stats[1] device calls made, stats[2] largest batch, stats[3] lanes */
 /* One transport message (bftkv_gpu_message_verify for a single caller): blocks until its batch has run.  plain_out
  * receives the literal body (BFTKV_E_NOMEM if plain_cap is too small; msg_len always suffices), fname_out[256] the

@@ -156,12 +156,19 @@ int bftkv_host_certs_key(const bftkv_certs* c, uint32_t e, uint32_t k, bftkv_gpu
 /* What the walk alone says about entity e.  *refused_out: ReadEntity returns an error whatever the signatures say
  * (no identity with a self-signature, a subkey without or with a wrong-typed signature, a signing subkey without
  * cross-signature, a packet that does not parse, a primary key that cannot sign, ...).  *unknown_out: the entity has
- * a shape this library does not follow (elliptic-curve or version-3 keys, user attributes and other packet types
- * whose parsers are not restated, bodies over 4096 bytes, partial lengths, binding / revocation / cross signatures
- * that do not name the key they are verified with): no verdict, the reference decides.  *why_out: the reference's
+ * a shape this library does not follow (elliptic-curve or version-3 keys, secret-key packets, user attributes and
+ * other packet types whose parsers are not restated, bodies over 4096 bytes, partial lengths, embedded signatures
+ * nested beyond the parser's bound, a certification without issuer subpacket -- on which the reference's Signers()
+ * dereferences nil): no verdict, the reference decides.  Nothing is refused BEHIND such a shape: what it hides may be
+ * exactly the self-signature or binding whose absence would be the refusal.  *why_out: the reference's
  * message or the shape (a string owned by c).  *n_checks_out: the signatures ReadEntity verifies. */
 int bftkv_host_certs_structure(const bftkv_certs* c, uint32_t e, uint8_t* refused_out, uint8_t* unknown_out,
                                const char** why_out, uint32_t* n_checks_out);
+/* What ReadEntity does with each packet that packet.Reader.Next() hands it inside entity e, in order (packet types
+ * unknown to x/crypto are skipped by Next and have no entry): roles_out[i] = BFTKV_ROLE_* | index << 8 | chosen << 24
+ * (bftkv_gpu.h).  *start_out / *len_out: the entity's bytes within the certificate.  Pointers into c. */
+int bftkv_host_certs_roles(const bftkv_certs* c, uint32_t e, uint64_t* start_out, uint64_t* len_out,
+                           const uint32_t** roles_out, uint32_t* n_out);
 /* check i of entity e, in the order ReadEntity meets them (third-party certifications, which it does not verify,
  * come last but for key revocations).  kind: 0 user-id self-signature, 1 subkey binding / subkey revocation,
  * 2 third-party certification (CheckQuorumCert only), 3 cross-signature of a signing subkey, 4 key revocation;

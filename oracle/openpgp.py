@@ -1152,6 +1152,9 @@ class EntityWalk:
     revocations: list = field(default_factory=list)
     checks: List[CertCheck] = field(default_factory=list)
     key_hash: bytes = b""
+    # what ReadEntity does with each packet Reader.Next() hands it inside the entity, in order: (role, index, chosen) with role in
+    # "primary" | "uid" | "self" | "ident_sig" | "subkey" | "subkey_sig" | "revocation" | "ignored" (include/bftkv_gpu.h BFTKV_ROLE_*)
+    roles: list = field(default_factory=list)
 
 
 def _read_mpi_strict(body: bytes, p: int) -> Tuple[int, bytes, int]:
@@ -1289,6 +1292,7 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
             close(at)
             cur = EntityWalk(start=at)
             out.append(cur)
+            cur.roles.append(["primary", 0, False])
             if leading_junk:
                 cur.error = "first packet was not a public/private key"
             leading_junk = False
@@ -1339,6 +1343,7 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
         if tag == 13:
             ident = {"name": body, "self_sig": None, "sigs": [], "framed": b"\xb4" + struct.pack(">I", len(body)) + body, "at": at}
             cur.identities.append(ident)
+            cur.roles.append(["uid", len(cur.identities) - 1, False])
             run = ("uid", ident)
             continue
         if tag == 14:
@@ -1360,6 +1365,8 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
                     fail("subkey")
                 continue
             cur.subkeys.append(sk)
+            sk["chosen_role"] = None
+            cur.roles.append(["subkey", len(cur.subkeys) - 1, False])
             run = ("sub", sk)
             continue
         if tag == 2:
@@ -1374,6 +1381,7 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
                 continue
             raw = blob[at:pos]
             if v3:
+                cur.roles.append(["ignored", 0, False])
                 run = None                         # a SignatureV3 is not a *packet.Signature: it ends the run and is ignored
                 continue
             if run is not None and run[0] == "dead":
@@ -1383,7 +1391,10 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
                 if sig.sig_type in (0x10, 0x13) and sig.issuer is not None and sig.issuer == cur.primary.key_id:
                     cur.checks.append(CertCheck("uid", cur.primary, cur.key_hash + ident["framed"], sig, raw))
                     ident["self_sig"] = sig
+                    cur.roles.append(["self", len(cur.identities) - 1, False])
                 else:
+                    if sig.issuer is not None:
+                        cur.roles.append(["ident_sig", len(cur.identities) - 1, False])
                     if sig.issuer is None:
                         # one of identity.Signatures without issuer subpacket: PGPCertificateInstance.Signers dereferences nil
                         # (crypto_pgp.go:80-88) -- the reference panics where this walk would silently drop a signer
@@ -1403,11 +1414,16 @@ def walk_certificate(blob: bytes) -> List[EntityWalk]:
                         fail("signing subkey is missing cross-signature")
                         continue
                     cur.checks.append(CertCheck("cross", sk["key"], signed, sig.embedded, _frame_sig(sig.embedded_body)))
-                if sig.sig_type == 0x28:
-                    sk["sig"] = sig
-                elif sk["sig"] is None or (sk["sig"].sig_type != 0x28 and sig.creation_time > sk["sig"].creation_time):
+                take = sig.sig_type == 0x28 or sk["sig"] is None or (sk["sig"].sig_type != 0x28 and sig.creation_time > sk["sig"].creation_time)
+                cur.roles.append(["subkey_sig", len(cur.subkeys) - 1, False])
+                if take:
+                    if sk["chosen_role"] is not None:
+                        cur.roles[sk["chosen_role"]][2] = False
+                    sk["chosen_role"] = len(cur.roles) - 1
+                    cur.roles[-1][2] = True
                     sk["sig"] = sig
                 continue
+            cur.roles.append(["revocation" if sig.sig_type == 0x20 else "ignored", 0, False])
             if sig.sig_type == 0x20:
                 cur.revocations.append((sig, raw))
             continue

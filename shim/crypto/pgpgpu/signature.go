@@ -14,10 +14,9 @@ import (
 )
 
 // Signature replaces pgp.PGPSignature's verifying half (crypto/pgp/crypto_pgp.go:319-344), for keyring entities and for the
-// principals whose certificate travels in the request; Sign uses the private key and stays with crypto/pgp, and so do Signers,
-// Issuer and Certs: they must hand back x/crypto's own *openpgp.Entity objects, which only openpgp.ReadEntity builds (it
-// verifies the entity's self-signature and subkey bindings while it reads; third-party certifications are only collected).
-// bftkv_gpu_batcher_cert_verify with sig == NULL is the issuer check for callers that do not need that object.
+// principals whose certificate travels in the request; Sign uses the private key and stays with crypto/pgp, and so do Signers and
+// Certs.  Issuer (issuer.go) has the device make the checks openpgp.ReadEntity makes and assembles the *openpgp.Entity from
+// parsed packets, so that a request's certificate is verified once, not on the CPU in Issuer and again in VerifyWithCertificate.
 type Signature struct {
 	g       *gpu
 	inner   crypto.Signature
@@ -103,7 +102,5 @@ func (s *Signature) VerifyWithCertificate(tbs []byte, sig *packet.SignaturePacke
 	return nil
 }
 
-func (s *Signature) Sign(tbs []byte) (*packet.SignaturePacket, error)        { return s.inner.Sign(tbs) }
-func (s *Signature) Signers(sig *packet.SignaturePacket) []node.Node         { return s.inner.Signers(sig) }
-func (s *Signature) Issuer(sig *packet.SignaturePacket) node.Node            { return s.inner.Issuer(sig) }
-func (s *Signature) Certs(sig *packet.SignaturePacket) ([]node.Node, error)  { return s.inner.Certs(sig) }
+func (s *Signature) Sign(tbs []byte) (*packet.SignaturePacket, error) { return s.inner.Sign(tbs) }
+func (s *Signature) Signers(sig *packet.SignaturePacket) []node.Node  { return s.inner.Signers(sig) }

@@ -65,6 +65,10 @@ def compare_with_mirror(host, blob, label=""):
         if w.error is not None:
             continue          # refused: both stop looking at the entity's packets there
         assert g["certifiers"] == pgp.walk_signers(w), ctx
+        if w.unknown is None:
+            # what ReadEntity does with each packet of the entity (bftkv_host_certs_roles): the shim assembles *openpgp.Entity from it
+            assert (g["start"], g["len"]) == (w.start, w.end - w.start), ctx
+            assert g["roles"] == [tuple(r) for r in w.roles], ctx
         own = [c for c in g["checks"] if c["kind"] != 2]
         assert [(c["kind"], c["signed"], c["sig"]) for c in own] == [(KIND[c.kind], c.signed, c.raw) for c in w.checks], ctx
         for c, oc in zip(own, w.checks):
@@ -199,3 +203,77 @@ def test_md5_self_signature_follows_the_availability_policy():
         assert [pgp.walk_valid(w) for w in pgp.walk_certificate(bytes(spoiled))] == [False]
     finally:
         pgp.HASH_POLICY.update(saved)
+
+
+def assemble_from_roles(blob, start, ln, roles):
+    """What shim/crypto/pgpgpu/issuer.go does with the role list of bftkv_gpu_batcher_cert_entity, in Python: the packets
+    packet.Reader.Next() yields inside the entity (unknown packet types skipped), one role each -> Entity.Identities (a map: a later
+    identity of the same name replaces the earlier), identity.Signatures, Subkeys with their Subkey.Sig, Revocations."""
+    ent = blob[start:start + ln]
+    pkts, pos = [], 0
+    while pos < len(ent):
+        tag, s0, n = pgp.read_header(ent, pos)
+        body = ent[s0:s0 + n]
+        pos = s0 + n
+        if tag in pgp._KNOWN_TAGS:
+            if tag in (2, 6, 14) and len(body) == 0:
+                break
+            pkts.append((tag, body))
+    assert len(pkts) == len(roles), (len(pkts), len(roles))
+    idents, by_name, subkeys, revocations, primary = [], {}, [], [], None
+    for (tag, body), (role, idx, chosen) in zip(pkts, roles):
+        if role == "primary":
+            assert tag in (6, 14)
+            primary = body
+        elif role == "uid":
+            assert tag == 13 and idx == len(idents)
+            idents.append({"name": body, "self": None, "sigs": []})
+        elif role == "self":
+            assert tag == 2
+            idents[idx]["self"] = body
+            by_name[idents[idx]["name"]] = idents[idx]
+        elif role == "ident_sig":
+            idents[idx]["sigs"].append(body)
+        elif role == "subkey":
+            assert tag == 14 and idx == len(subkeys)
+            subkeys.append({"key": body, "sig": None})
+        elif role == "subkey_sig":
+            if chosen:
+                subkeys[idx]["sig"] = body
+        elif role == "revocation":
+            revocations.append(body)
+        else:
+            assert role == "ignored" and tag == 2
+    return primary, by_name, subkeys, revocations
+
+
+def test_entity_assembled_from_roles_is_the_entity_read_entity_returns(host, shapes):
+    """The role list is enough to build what ReadEntity returns: over every hand-worked shape and gpg-made certificate whose first
+    entity is accepted, the assembly has the identities (by name, with the self-signature that counts), the Signers(), the
+    subkeys with the Subkey.Sig that decides their usability, and the revocations the oracle's walk has."""
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "gpg_cert_vectors.json")))
+    blobs = [(n, b) for n, b, _, _, _ in shapes] + [(c["name"], bytes.fromhex(c["blob"])) for c in vec["certificates"]]
+    n_done = 0
+    for name, blob in blobs:
+        ws = pgp.walk_certificate(blob)
+        if not ws or pgp.walk_valid(ws[0]) is not True:
+            continue
+        w, g = ws[0], host.Certificate.Parse(blob)[0]
+        primary, by_name, subkeys, revocations = assemble_from_roles(blob, g["start"], g["len"], g["roles"])
+        assert pgp.parse_public_key_strict(primary, False)[0].key_id == w.primary.key_id, name
+        want_names = {}
+        for ident in w.identities:
+            if ident["self_sig"] is not None:
+                want_names[ident["name"]] = ident
+        assert set(by_name) == set(want_names), name
+        for nm, ident in by_name.items():
+            assert pgp.parse_signature_body(ident["self"]).hash_suffix == want_names[nm]["self_sig"].hash_suffix, name
+            assert [pgp.parse_signature_body(b).issuer for b in ident["sigs"]] == [s_.issuer for s_, _, _ in want_names[nm]["sigs"]], name
+        assert sorted(i for ident in by_name.values() for i in (pgp.parse_signature_body(b).issuer for b in ident["sigs"])) == sorted(pgp.walk_signers(w)), name
+        assert len(subkeys) == len(w.subkeys), name
+        for sk, wk in zip(subkeys, w.subkeys):
+            assert pgp.parse_public_key_strict(sk["key"], True)[0].key_id == wk["key"].key_id, name
+            assert pgp.parse_signature_body(sk["sig"]).hash_suffix == wk["sig"].hash_suffix, name
+        assert len(revocations) == len(w.revocations), name
+        n_done += 1
+    assert n_done >= 40

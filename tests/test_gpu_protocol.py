@@ -1155,3 +1155,48 @@ def test_read_entity_shape_by_shape_on_the_gpu(gpu_ctx):
         assert outcomes == {"fenced", ("subkey", 0), ("subkey", 1), ("subkey", 3), ("primary", 0), ("primary", 1), ("primary", 3)}
     finally:
         bt.close()
+
+
+def test_issuer_entity_structure_from_the_library(gpu_ctx):
+    """Signature.Issuer without openpgp.ReadEntity on the CPU (bftkv_gpu_batcher_cert_entity): for the certificates GnuPG made and the
+    76 certificate blobs of tests/golden/reference_inputs.json (the hand-worked ReadEntity shapes among them), the verdict on the first
+    entity is the oracle's walk_valid -- its signature checks on the GPU --, and wherever ReadEntity returns the entity the role of
+    every packet (what the shim assembles *openpgp.Entity from), the entity's byte range and its fingerprint are the oracle walk's."""
+    import json
+    import os
+    from bftkv_amd import Batcher, host
+    from oracle import openpgp as pgp
+    cl = cb.make_cluster(4)
+    gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    vec = json.load(open(os.path.join(gold, "gpg_cert_vectors.json")))
+    ri = json.load(open(os.path.join(gold, "reference_inputs.json")))
+    blobs = [(c["name"], bytes.fromhex(c["blob"])) for c in vec["certificates"] + vec["tampered"]]
+    blobs += [("reference_inputs cert %d" % i, bytes.fromhex(c if isinstance(c, str) else c["blob"])) for i, c in enumerate(ri["certs"])]
+    assert len(blobs) >= 80
+    role_no = {n: i for i, n in enumerate(host.ROLE_NAMES)}
+    bt = Batcher(gpu_ctx, max_items=16)
+    seen = {"built": 0, "fenced": 0, "refused": 0}
+    try:
+        for name, blob in blobs:
+            rc, err, fenced, iid, fp, off, ln, roles = bt.cert_entity(blob, cap=4)       # (a small first guess: the retry is part of the contract)
+            assert rc == 0, (name, rc)
+            ws = pgp.walk_certificate(blob)
+            v = pgp.walk_valid(ws[0]) if ws else False
+            if v is None:
+                assert fenced == 1 and not roles, name
+                seen["fenced"] += 1
+            elif v is False:
+                assert (err, fenced) == (3, 0) and not roles, (name, err, fenced)         # crypto.ErrCertificateNotFound: Issuer() == nil
+                seen["refused"] += 1
+            else:
+                w = ws[0]
+                assert (err, fenced) == (0, 0), (name, err, fenced)
+                assert iid == w.primary.key_id and fp == w.primary.fingerprint, name
+                assert (off, ln) == (w.start, w.end - w.start), name
+                assert roles == [(role_no[r], i, ch) for r, i, ch in w.roles], name
+                seen["built"] += 1
+        assert seen["built"] >= 40 and seen["fenced"] >= 3 and seen["refused"] >= 10, seen
+        # fail closed: a dead batcher handle answers with a failure byte and no roles
+    finally:
+        bt.close()

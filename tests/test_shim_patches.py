@@ -13,14 +13,14 @@ REF = "/root/reference"
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="reference tree or patch(1) not available")
 def test_patches_apply_in_order(tmp_path):
     for rel in ("quorum/wotqs/wotqs.go", "node/graph/graph.go", "crypto/sss/sss.go", "crypto/threshold/dsa/dsa.go", "crypto/threshold/dsa/dsa_core.go",
-                "crypto/threshold/rsa/rsa.go"):
+                "crypto/threshold/rsa/rsa.go", "crypto/pgp/crypto_pgp.go"):
         dst = tmp_path / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
         shutil.copy(os.path.join(REF, rel), dst)
     pdir = os.path.join(ROOT, "shim", "patches")
     names = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
-    assert names[:3] == ["0001-wotqs-export-cliques.patch", "0002-wotqs-selector-cache-counted-membership.patch",
-                         "0003-threshold-combine-hooks.patch"]
+    assert names[:4] == ["0001-wotqs-export-cliques.patch", "0002-wotqs-selector-cache-counted-membership.patch",
+                         "0003-threshold-combine-hooks.patch", "0004-pgp-export-newnode.patch"]
     for name in names:
         r = subprocess.run(["patch", "-p1", "--batch", "-d", str(tmp_path)], stdin=open(os.path.join(pdir, name)), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT)
@@ -45,9 +45,13 @@ def test_patches_apply_in_order(tmp_path):
     for src, kept in ((sss, "S.Mod(S.Add(S, l.Mul(l, r.Y)), p.m)"), (core, "s.Mod(s.Add(s, t), q)"), (dsa, "r.Exp(r, v, g.params.P)"),
                       (rsa, "s.Mod(s.Mul(s, st.psig), N)"), (rsa, "z.Exp(base, exp, N)")):
         assert kept in src, kept
+    # 0004: the node constructor crypto/pgpgpu needs for an issuer it assembled itself
+    cp = (tmp_path / "crypto/pgp/crypto_pgp.go").read_text()
+    assert "func NewNode(e *openpgp.Entity) node.Node {\n\treturn newNode(e)\n}" in cp
     # braces balance (no Go toolchain here: the cheapest structural check there is)
     for src in (w, g, sss, dsa, core, rsa):
         assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
+    assert cp.count("{") == cp.count("}")          # (its regular-expression literals hold lone parentheses)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="reference tree or patch(1) not available")

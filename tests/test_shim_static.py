@@ -121,7 +121,7 @@ def test_c_calls_match_the_header():
             assert t in structs or t in ("bftkv_gpu_ctx", "bftkv_gpu_batcher") or t in protos, (path, t)
     # the seam of the path: every verifying call of the shim is among them
     assert {"bftkv_gpu_init", "bftkv_gpu_keyring_set", "bftkv_gpu_quorum_create", "bftkv_gpu_quorum_destroy",
-            "bftkv_gpu_batcher_collective_verify", "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_cert_verify",
+            "bftkv_gpu_batcher_collective_verify", "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_batcher_cert_entity",
             "bftkv_gpu_batcher_message_verify", "bftkv_gpu_signers_fenced", "bftkv_gpu_set_hash_policy",
             # config 5 behind crypto.Threshold (shim/crypto/thresholdgpu)
             "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r",
@@ -186,6 +186,8 @@ REFERENCE_NAMES = [
     "SignaturePacket", "SignatureTypeNil", "SignatureTypePGP", "TBS", "TBSS", "Type", "Clique", "Threshold", "Suff", "Min", "Nodes",
     # crypto/thresholdgpu: the hooks of shim/patches/0003 and the reference types they carry
     "CombineHook", "CalculateRHook", "ModExpHook", "Coordinate", "PartialR", "Ri", "Vi",
+    # Issuer without ReadEntity on the CPU: the node constructor shim/patches/0004 exports
+    "NewNode",
 ]
 
 
