@@ -423,6 +423,15 @@ class Certificate:
         return out
 
 
+def cert_fingerprint(cert: bytes) -> Optional[bytes]:
+    """v4 fingerprint of the primary key of the first entity (bftkv_host_cert_fingerprint), None when no key packet leads the
+    certificate (packet types x/crypto skips may precede it)."""
+    out = np.zeros(20, dtype=np.uint8)
+    lib = _lib()
+    lib.bftkv_host_cert_fingerprint.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p]
+    return out.tobytes() if lib.bftkv_host_cert_fingerprint(cert, len(cert), out.ctypes.data) == 0 else None
+
+
 def certs_verify(ctx: _native.Context, cert: bytes) -> List[Optional[bool]]:
     """Which entities of a certificate blob openpgp.ReadEntity returns: True, False (refused), None (no verdict: a shape left to
     the reference, or a check that met a fenced shape)."""
