@@ -841,7 +841,18 @@ def bench_cfg3(args, D):
     ctx0 = Context(D.local_rank)
     rsa_signer, dsa_pow = gpu_signers(ctx0, cl)
     t0 = time.time()
-    rc = cb.make_read_corpus(cl, n_vars, seed=cb.MASTER_SEED + D.rank, batch_signer=rsa_signer, dsa_batch_pow=dsa_pow)
+    rc = None
+    cache = "%s.cfg3.n%d.v%d.r%d.pickle" % (args.corpus_cache, n, n_vars, D.rank) if args.corpus_cache else None
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as fh:
+            rc = pickle.load(fh)
+    if rc is None:
+        rc = cb.make_read_corpus(cl, n_vars, seed=cb.MASTER_SEED + D.rank, batch_signer=rsa_signer, dsa_batch_pow=dsa_pow)
+        if cache:
+            import pickle
+            with open(cache, "wb") as fh:
+                pickle.dump(rc, fh, protocol=4)
     t_corpus = time.time() - t0
     n_replies = len(rc.reply_var)
     V = Verifier(D, cl, n_replies, rc.tbss_blob, rc.tbss_off, rc.ss_blob, rc.ss_off, n_ctx=max(1, args.inflight), ctx0=ctx0)
@@ -925,7 +936,11 @@ def bench_cfg3(args, D):
             "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * macs_per_dsa_verify(dsa_bits), elapsed / args.steps * 1e3,
                                      rsa_ms + dsa_ms, None, sclk, V.n_ctx),
             "dsa_tables": {"window_bits": dsa_bits, "products_per_verify": macs_per_dsa_verify(dsa_bits) // 11552,
-                           "note": "width chosen by the library for this keyring and the free HBM (bftkv_gpu_dsa_window_bits); BFTKV_DSA_WBITS pins it"},
+                           "dsa_keys": sum(1 for r in cl.replicas if r.algo == cb.PK_DSA),
+                           "gb_pinned": (sum(1 for r in cl.replicas if r.algo == cb.PK_DSA) * 2 * ((256 + dsa_bits - 1) // dsa_bits) *
+                                         ((1 << dsa_bits) - 1) * 304 / 1e9) if dsa_bits else 0.0,
+                           "note": "width chosen by the library for this keyring and the free HBM (bftkv_gpu_dsa_window_bits: the widest of 18 / 16 / "
+                                   "15 / 14 / 13 / 12 / 10 / 8 bits whose tables fit the budget); BFTKV_DSA_WBITS pins it"},
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:

@@ -643,11 +643,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   auto launch_dsa = [&](const uint32_t* start) {
     hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
-    static const bool dsa_dma = getenv("BFTKV_DSA_DMA") && atoi(getenv("BFTKV_DSA_DMA")) != 0;      // A/B: table rows by LDS-DMA
-    if (dsa_dma)
-      hipLaunchKernelGGL(k_dsa_modexp_dma, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
-                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
-    else
+    // (the LDS-DMA form of this kernel measured the same and spilled: removed in round 5, profiles/r04_cfg3_ab_dsa_dma*.json)
     hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
                        c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
   };
@@ -773,7 +769,9 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   *bits_changed = false;
   auto assign = [&](std::vector<uint32_t>& new_slots, std::vector<uint32_t>& new_rows) {
     new_slots.clear(); new_rows.clear();
-    const size_t cert_cap = c->dsa_wbits >= 16 ? 8 : 1024;
+    // certificate-only DSA keys (they arrive in unauthenticated requests) share a bounded set of table slots, recycled by recency:
+    // 8 at the widths of 16 bits and more, below that about 8 GB of them (14 bits: 45, 12 bits: 156), at most 1024
+    const size_t cert_cap = c->dsa_wbits >= 16 ? 8 : std::min<size_t>(1024, std::max<size_t>(8, (8ull << 30) / (dsa_slot_stride(c->dsa_wbits) * sizeof(uint32_t))));
     for (size_t i = 0; i < rows.size(); ++i) {
       if (algo[i] != PK_DSA || bits[i] == 0xFFFFFFFFu) continue;
       auto it = c->dsa_comb_slot.find(rows[i]->material);
@@ -816,24 +814,32 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   std::vector<uint32_t> new_slots, new_rows;
   assign(new_slots, new_rows);
   const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
-  // window width by DSA population and free HBM: 18 bits (2.39 GB per key, 29 table multiplications per signature) while the
-  // tables of all keys -- with the half again the buffer grows by -- fit 45 % of what is free, 16 bits (637 MB, 31) while they
-  // fit a quarter; both only up to 64 keys; 8 bits (4.96 MB, <= 63) up to 4096 keys, 4 beyond
+  // Window width by DSA population and free HBM -- HBM capacity traded for multiplications, GRADED (round 5: the policy used to
+  // fall from 16 bits straight to 8 at 65 keys, 31 -> 63 products per signature).  2 * ceil(256 / w) - 1 products and
+  // 2 * ceil(256 / w) * (2^w - 1) * 304 bytes per key:
+  //     w   18      16      15      14      13      12      10      8
+  //   prod  29      31      35      37      39      43      51      63
+  //   /key  2.39 GB 637 MB  358 MB  189 MB  100 MB  55 MB   16 MB   5 MB
+  // The widest width whose tables for every key of the ring -- with the half again the buffer grows by -- fit the budget: 45 % of
+  // the free HBM for 18 bits (as since round 3), a quarter for the others.  (17 bits has 16 windows like 16; 19 / 20 can be
+  // pinned, never chosen.)  4 bits beyond 4096 keys.
   auto policy = [&](size_t n_keys) -> uint32_t {
     if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
     if (const char* e = getenv("BFTKV_DSA_WBITS")) {            // experiments: the width without touching the caller
       const uint32_t b = (uint32_t)atoi(e);
-      if (b == 4 || b == 8 || (b >= 16 && b <= 20)) return b;
+      if (b == 4 || (b >= 8 && b <= 20)) return b;
     }
-    if (n_keys <= 64) {
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const size_t room = free_b + c->dsa_comb.cap;
-        if ((n_keys + 1) * dsa_slot_stride(18) * sizeof(uint32_t) * 3 / 2 < room / 100 * 45) return 18u;
-        if ((n_keys + 1) * dsa_slot_stride(16) * sizeof(uint32_t) * 3 / 2 < room / 4) return 16u;
+    if (n_keys > 4096) return 4u;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t room = free_b + c->dsa_comb.cap;
+      static const uint32_t widths[] = {18, 16, 15, 14, 13, 12, 10};
+      for (uint32_t w : widths) {
+        const size_t need = (n_keys + 1) * dsa_slot_stride(w) * sizeof(uint32_t) * 3 / 2;
+        if (need < (w == 18 ? room / 100 * 45 : room / 4)) return w;
       }
     }
-    return n_keys > 4096 ? 4u : 8u;
+    return 8u;
   };
   if (c->dsa_ring_epoch_seen != c->ring_epoch || c->dsa_wbits_want == 0) {      // the node keyring changed (or first upload)
     size_t ring_dsa = 0;
@@ -846,7 +852,7 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
   // tables of keys that left the keyring stay cached by key material (a key that comes back costs nothing) -- as long as they
   // are few and the wide layouts do not crowd the HBM: past 45 % of what is free (with the buffer's growth margin) they go
   bool crowded = false;
-  if (want_wbits >= 16 && c->dsa_comb_slot.size() > live) {
+  if (want_wbits >= 12 && c->dsa_comb_slot.size() > live) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
       crowded = c->dsa_comb_slot.size() * dsa_slot_stride(want_wbits) * sizeof(uint32_t) * 3 / 2 > (free_b + c->dsa_comb.cap) / 100 * 45;
@@ -890,7 +896,7 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
                              rows[new_rows[k]]->qpow.data(), DSA_QTAIL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   DevBuf d_slots, d_rows;
   if ((rc = upload(c, d_slots, new_slots)) || (rc = upload(c, d_rows, new_rows))) { d_slots.release(); d_rows.release(); return rc; }
-  const uint32_t parts = c->dsa_wbits >= 16 ? 1u << (c->dsa_wbits - 12u) : 1u;       // 4,096 entries per quad at the wide widths
+  const uint32_t parts = c->dsa_wbits > 12 ? 1u << (c->dsa_wbits - 12u) : 1u;        // at most 4,096 entries per quad
   const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * dsa_nwin(c->dsa_wbits) * parts;
   hipLaunchKernelGGL(k_dsa_build_comb, dim3((n_quads + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
                      (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
@@ -1195,9 +1201,9 @@ int bftkv_gpu_set_hash_policy(bftkv_gpu_ctx* c, int hash_id, int state) {
   return 0;
 }
 
-// widths the tables can be built at: the policy's four, and 17 / 19 / 20 for callers that pin them (19: 4.46 GB per key and 27
-// table multiplications, 20: 8.3 GB and 25 -- never chosen by the policy)
-static bool dsa_width_ok(uint32_t bits) { return bits == 4 || bits == 8 || (bits >= 16 && bits <= 20); }
+// widths the tables can be built at: 4 and every width from 8 to 20 (windows may straddle words); 17, 19 and 20 are for callers
+// that pin them (19: 4.46 GB per key and 27 table multiplications, 20: 8.3 GB and 25 -- never chosen by the policy)
+static bool dsa_width_ok(uint32_t bits) { return bits == 4 || (bits >= 8 && bits <= 20); }
 
 int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && !dsa_width_ok(bits))) return BFTKV_E_INVALID;

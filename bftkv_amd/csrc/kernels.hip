@@ -2026,172 +2026,6 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   if (live && qlane == 0) recs[ri].status = (diff != 0 && u256_cmp(acc, rr) == 0) ? ST_OK : ST_BAD_SIG;
 }
 
-// k_dsa_modexp with the table rows brought in by LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing through VGPRs),
-// double-buffered: the 16 rows a wave needs for step s+1 (16 x 304 bytes = 304 chunks of 16 bytes, five wave instructions) are
-// issued BEFORE the Montgomery product of step s and land in the other half of the LDS while it runs.  The DMA writes a
-// wave-uniform base + lane x 16 bytes, which is exactly the row-major [quad][76 limbs] layout mont_mul reads its operand from,
-// so chunk g = 64 i + lane of instruction i is chunk g % 19 of the row of quad g / 19: every lane fetches the entry index of THAT
-// quad from its lanes (one ds_bpermute per instruction) and adds it to the slot base it looked up before the loop.  Against the
-// plain kernel: 19 global loads + 19 LDS stores per lane and step become 5 DMA instructions per wave, the row latency leaves
-// the critical path, no VGPR is spent on the prefetch; u1 / u2 live in LDS, so a step's digits cost no memory latency either.
-__global__ void __launch_bounds__(RSA_BLOCK, 3) k_dsa_modexp_dma(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
-                                                              const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
-                                                              const uint32_t* __restrict__ dsa_u) {
-  __shared__ __attribute__((aligned(16))) uint32_t a_sh2[2][QUADS_PER_BLOCK * MONT_N];
-  __shared__ uint32_t u_sh[QUADS_PER_BLOCK * 16];
-  constexpr int L = MONT_L;
-  constexpr uint32_t ROW_BYTES = MONT_N * 4, CHUNKS = 16 * (ROW_BYTES / 16);      // 304 bytes per row, 304 chunks per wave
-  const uint32_t count = pk_count[1], start = pk_start[1];
-  if (start + blockIdx.x * QUADS_PER_BLOCK >= count) return;
-  const uint32_t quad = threadIdx.x >> 2;
-  const int qlane = threadIdx.x & 3;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t gq = start + blockIdx.x * QUADS_PER_BLOCK + quad;
-  const bool active = gq < count;
-  const uint32_t di = active ? gq : (count - 1);
-  const uint32_t ri = dsa_list[di];
-  const SigRec rec = recs[ri];
-  const uint32_t key = (uint32_t)rec.key_slot;
-  uint32_t n[L], y[L], t[L];
-  const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t wbits = kt.dsa_wbits, nwin = dsa_nwin(wbits), nent = (1u << wbits) - 1u;
-  const uint32_t* slot_base = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(wbits);
-#pragma unroll
-  for (int k = 0; k < L; ++k) n[k] = np[k];
-  const uint32_t n0inv = kt.n0inv[key];
-  const uint32_t* up = dsa_u + (uint64_t)di * DSA_U_WORDS;
-  const bool live = active && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
-  // u1 | u2 (eight words each) of this quad into LDS: lane ql stores words 4 ql .. 4 ql + 3
-#pragma unroll
-  for (int k = 0; k < 4; ++k) u_sh[quad * 16 + qlane * 4 + k] = live ? up[qlane * 4 + k] : 0u;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const uint32_t* const uq = u_sh + quad * 16;
-  auto digit = [&](uint32_t step) -> uint32_t {
-    const uint32_t bitpos = (step >> 1) * wbits, wi = bitpos >> 5, sh = bitpos & 31u;
-    const uint32_t* e = uq + (step & 1u) * 8;                       // u1 or u2: eight 32-bit words
-    const uint32_t lo = e[wi], hi = (wi < 7u && sh + wbits > 32u) ? e[wi + 1] : 0u;     // (a window may straddle two words)
-    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & nent;
-  };
-  auto entry_index = [&](uint32_t step, uint32_t d) -> uint32_t { return ((step & 1u) * nwin + (step >> 1)) * nent + (d ? d - 1 : 0); };
-  // the five DMA instructions of a wave: which quad's row and which 16-byte chunk of it this lane fetches in each.  Kept small
-  // (one packed register per instruction: table slot of that quad's key << 5 | chunk) so that the kernel stays at three waves per
-  // SIMD; g / 19 = (27 g) >> 9 for g < 304.
-  const uint32_t my_slot = kt.dsa_slot[key];
-  uint32_t src_pk[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const uint32_t g = (uint32_t)i * 64u + lane;
-    const uint32_t qw = (g < CHUNKS) ? (g * 27u) >> 9 : 0u, ch = (g < CHUNKS) ? g - qw * (ROW_BYTES / 16) : 0u;
-    src_pk[i] = ((uint32_t)__shfl((int)my_slot, (int)(qw * 4u)) << 5) | ch;
-  }
-  const uint64_t slot_bytes = dsa_slot_stride(wbits) * sizeof(uint32_t);
-  const uint8_t* const comb_bytes = (const uint8_t*)kt.dsa_comb;
-  auto issue_rows = [&](uint32_t step, uint32_t d, uint32_t buf) {
-    const uint32_t ent = entry_index(step, d);
-    uint32_t* const wave_dst = &a_sh2[buf][wave * 16 * MONT_N];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const uint32_t g = (uint32_t)i * 64u + lane;
-      const uint32_t qw = (g < CHUNKS) ? (g * 27u) >> 9 : 0u;
-      const uint32_t e = (uint32_t)__shfl((int)ent, (int)(qw * 4u));
-      const uint8_t* src = comb_bytes + (uint64_t)(src_pk[i] >> 5) * slot_bytes + (uint64_t)e * ROW_BYTES + 16u * (src_pk[i] & 31u);
-      if (g < CHUNKS)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(wave_dst + i * 256), 16, 0, 0);
-    }
-  };
-  const uint32_t last = 2u * nwin - 1u;
-  bool started = false;
-#pragma unroll
-  for (int k = 0; k < L; ++k) y[k] = 0;
-  uint32_t d = digit(0);
-  issue_rows(0, d, 0);
-  for (uint32_t step = 0; step <= last; ++step) {
-    const uint32_t buf = step & 1u;
-    const bool need = (step == last) || d != 0;      // the last product always happens: a zero digit multiplies by the plain 1
-    // rows of this step have landed (the DMA counts on vmcnt); then the next step's rows go out, into the half nobody reads
-    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)  (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    uint32_t dn = 0;
-    if (step < last) { dn = digit(step + 1); issue_rows(step + 1, dn, buf ^ 1u); }
-    uint32_t* a_lds = &a_sh2[buf][quad * MONT_N + qlane * L];
-    const uint32_t* a_rd = &a_sh2[buf][quad * MONT_N];
-    if (step == last && __any(d == 0)) {
-      if (d == 0) {
-#pragma unroll
-        for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    if (__any(need && started)) {
-      mont_mul(t, a_rd, y, n, n0inv, qlane);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    if (__any(need && !started)) {                   // first non-zero digit of some signature: the entry is its starting value
-      if (need) {
-#pragma unroll
-        for (int k = 0; k < L; ++k) y[k] = started ? t[k] : a_lds[k];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    } else if (need) {
-#pragma unroll
-      for (int k = 0; k < L; ++k) y[k] = t[k];
-    }
-    started = started || need;
-    d = dn;
-  }
-  // y = g^u1 y^u2 mod p, possibly + p (mont_mul leaves values below p(1 + 2^-79)): the mod-q fold below needs the residue
-#pragma unroll
-  for (int k = 0; k < L; ++k) t[k] = y[k];
-  canonicalize(t, qlane);
-  reduce_once(t, n, qlane);
-  uint32_t diff = 0;
-#pragma unroll
-  for (int k = 0; k < L; ++k) diff |= t[k];
-  diff = quad_or(diff);                      // 0: v = 0, and r > 0 can never match
-  // v mod q: sum_j v_j * (2^(28 j) mod q) over 10 radix-2^28 columns (76 terms of < 2^56 each)
-  uint64_t col[10];
-#pragma unroll
-  for (int j = 0; j < 10; ++j) col[j] = 0;
-  const uint32_t* pw = slot_base + dsa_comb_limbs_per_key(wbits) + (qlane * L) * 10;
-#pragma unroll
-  for (int k = 0; k < L; ++k) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) col[j] = mad64(t[k], pw[k * 10 + j], col[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 10; ++j) col[j] = quad_sum64(col[j]);
-  // columns -> 32-bit words W (value < q * 2^34.3)
-  uint32_t W[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) W[i] = 0;
-  uint64_t carry = 0;
-#pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    const uint64_t sacc = (j < 10 ? col[j] : 0ull) + carry;
-    const uint32_t limb = (uint32_t)sacc & MONT_MASK;
-    carry = sacc >> MONT_W;
-    const int bit = MONT_W * j, wi = bit >> 5, sh = bit & 31;
-    W[wi] |= limb << sh;
-    if (sh > 4 && wi + 1 < 12) W[wi + 1] |= limb >> (32 - sh);
-  }
-  U256 q, rr, acc;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { q.w[i] = kt.q_words[(uint64_t)key * 8 + i]; rr.w[i] = up[16 + i]; }
-  // acc = top part (value >> 35 < 2^bits(q) <= 2q), then 35 double-and-reduce steps for the low bits
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc.w[i] = (W[i + 1] >> 3) | (W[i + 2] << 29);
-  if (u256_cmp(acc, q) >= 0) u256_sub(acc, q);
-  const uint64_t low = ((uint64_t)(W[1] & 7u) << 32) | W[0];
-#pragma unroll 1
-  for (int bit = 34; bit >= 0; --bit) {
-    uint32_t cbit = u256_shl1(acc);
-    acc.w[0] |= (uint32_t)(low >> bit) & 1u;
-    if (cbit || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
-  }
-  if (live && qlane == 0) recs[ri].status = (diff != 0 && u256_cmp(acc, rr) == 0) ? ST_OK : ST_BAD_SIG;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // generic modular exponentiation  out = base^exp mod n   (corpus signing; threshold-RSA partials,

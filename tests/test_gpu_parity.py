@@ -686,14 +686,15 @@ def test_cfg3_shape_mixed_rsa_dsa(gpu_ctx, exit_mode):
 
 
 def test_dsa_fixed_base_tables_both_widths(gpu_ctx):
-    """DSA verifies from per-key window tables (k_dsa_build_comb): the 18-, 16-, 8- and 4-bit layouts give the oracle's statuses,
-    and re-uploading the keyring (tables cached by key material) changes nothing."""
+    """DSA verifies from per-key window tables (k_dsa_build_comb): the 18-, 16-, 8- and 4-bit layouts and the graded widths between
+    (14, 13, 12, 10 bits: windows that straddle words, a narrow top window) give the oracle's statuses, and re-uploading the keyring
+    (tables cached by key material) changes nothing."""
     cl = cb.make_cluster(12, dsa_fraction=1.0)
     c = cb.make_write_corpus(cl, 48, seed=21, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.2})
     q = H.clique_quorum(cl)
     want = None
     try:
-        for bits in (8, 4, 4, 16, 18, 0):
+        for bits in (8, 4, 4, 10, 12, 13, 14, 15, 16, 18, 0):
             gpu_ctx.set_dsa_window_bits(bits)
             kr = _ring_and_ctx(gpu_ctx, cl)
             qh = gpu_ctx.quorum_create(H.abi_qcs(q))
