@@ -110,7 +110,7 @@ def parse_args(argv=None):
     if args.steps is None:
         args.steps = 200 if (args.config in (None, 2) and not args.dry_run) else 64 if args.config == 5 else 10
     if args.config == 5 and not args.dry_run:
-        # Steps of cfg 5 are chains on too few waves to fill the chip: what buys throughput is MANY steps in
+        # Steps of cfg 5 are chains on too few waves to fill the chip (docs/history.md, round 4): what buys throughput is MANY steps in
         # flight, each on its own context, and their streams on hardware queues of their own.  The HIP runtime multiplexes all streams
         # onto GPU_MAX_HW_QUEUES queues (4 by default; read when the runtime starts, so it is set here, before torch / HIP are
         # loaded).  Measured (tools/runs/r04/gpu_r4z.sh): 4 queues x 4 steps in flight 7.6 ms per step, 16 x 8: 6.2, 16 x 12: 5.8, 16 x 16:
