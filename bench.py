@@ -1488,7 +1488,8 @@ def multi_rank_extras(args, D, emit):
     extras do not come back in time."""
     import threading
     res = {}
-    plan = [(4, ["--steps", "2", "--warmup", "1"]), (5, ["--steps", "32", "--warmup", "8"])]
+    # (cfg 5: the HIP runtime of this process started with its default 4 hardware queues -- 4 steps in flight is their optimum)
+    plan = [(4, ["--steps", "2", "--warmup", "1"]), (5, ["--steps", "32", "--warmup", "8", "--inflight", "4"])]
     timer = None
     if not D.dry and D.rank == 0:
         def give_up():
@@ -1535,7 +1536,8 @@ def main():
     D = Dist(args)
     try:
         default_run = args.config is None
-        everything = default_run and D.world == 1 and not args.dry_run and not args.no_other_configs
+        everything = (default_run and D.world == 1 and not args.dry_run and not args.no_other_configs and
+                      os.environ.get("BFTKV_BENCH_EXTRAS_IN_PROCESS") != "1")
         if args.config is None:
             args.config = 2
         out = {1: bench_cfg1, 2: bench_cfg2, 3: bench_cfg3, 4: bench_cfg4, 5: bench_cfg5}[args.config](args, D)
@@ -1551,7 +1553,13 @@ def main():
             out["other_configs"] = other_configs(args, D)
             out["other_configs_note"] = ("BASELINE.json configs[0] (cfg1, CPU restatement) and configs[2..4] (cfg3/4/5 at full size on this "
                                          "GPU, each `python bench.py --config N` in a process of its own with shorter timed regions); the headline `value` is cfg2's")
-        if default_run and D.world > 1 and not args.no_other_configs:
+        # (BFTKV_BENCH_EXTRAS_IN_PROCESS=1: the N > 1 form of the extras on ONE rank -- the rehearsal of exactly what the driver's
+        # multi-GPU run executes after the headline, on the 1-GPU box; with BFTKV_FORCE_RCCL=1 its exchanges go through real
+        # one-rank communicators)
+        rehearse = os.environ.get("BFTKV_BENCH_EXTRAS_IN_PROCESS") == "1" and not args.dry_run
+        if rehearse and out is not None:
+            out.pop("other_configs", None)
+        if default_run and (D.world > 1 or rehearse) and not args.no_other_configs:
             extra = multi_rank_extras(args, D, emit)
             if out is not None:
                 out["other_configs"] = extra
