@@ -1533,6 +1533,12 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args))
+    # stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version banner on stdout when the first
+    # communicator is created -- seen on the GPU box), so file descriptor 1 is pointed at stderr for the life of the process and the
+    # line goes to the descriptor stdout had.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     D = Dist(args)
     try:
         default_run = args.config is None
@@ -1548,7 +1554,7 @@ def main():
                 printed[0] = True
                 if extra is not None:
                     out["other_configs"] = extra
-                print(json.dumps(out), flush=True)
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
         if out is not None and everything:
             out["other_configs"] = other_configs(args, D)
             out["other_configs_note"] = ("BASELINE.json configs[0] (cfg1, CPU restatement) and configs[2..4] (cfg3/4/5 at full size on this "

@@ -24,6 +24,9 @@ def _run(extra, env=None):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout          # exactly ONE JSON line, from rank 0
+    # ... and nothing else on stdout: whatever libraries print (gloo's connection notes here, RCCL's version banner on the GPU box)
+    # goes to stderr -- bench.py points file descriptor 1 there and writes its line to the descriptor stdout had
+    assert out.stdout.strip() == lines[0], out.stdout[:400]
     return json.loads(lines[0])
 
 
