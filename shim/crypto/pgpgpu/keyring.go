@@ -67,6 +67,13 @@ func (k *keyring) holds(e *openpgp.Entity) bool {
 	return found
 }
 
+// upsert mirrors crypto/pgp's replace (crypto_pgp.go:125-140): an entity whose primary key id the ring already holds takes that
+// entry's place (the first such entry), the others are appended.  NOT the same order in one respect: replace collects the new
+// nodes in a Go MAP and appends what is left of it in map-iteration order, i.e. in a random order that differs from run to run;
+// here they are appended in argument order.  Ring order is observable only through which candidate is asked first under one
+// 64-bit key id (KeysByIdUsage walks the ring), so for distinct key ids the two cannot be told apart, and with id twins
+// registered in ONE call the reference is itself nondeterministic -- which is one more reason holds() sends certificates with an
+// id twin to crypto/pgp instead of answering for them.
 func upsert(ring openpgp.EntityList, nodes []node.Node) openpgp.EntityList {
 	for _, n := range nodes {
 		e := n.Instance().(*openpgp.Entity)
@@ -94,9 +101,9 @@ func (k *keyring) Register(nodes []node.Node, priv bool, self bool) error {
 		return err
 	}
 	if priv {
-		k.secring = upsert(k.secring, nodes) // crypto_pgp.go:153-155
+		k.secring = upsert(k.secring, nodes) // crypto_pgp.go:144-145 (replace; see upsert for the one difference)
 	} else {
-		k.pubring = upsert(k.pubring, nodes) // crypto_pgp.go:156-158
+		k.pubring = upsert(k.pubring, nodes) // crypto_pgp.go:146-147
 	}
 	return k.syncLocked()
 }
