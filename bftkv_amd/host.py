@@ -80,7 +80,7 @@ HOST_EXPORTS = [
     "bftkv_host_quorum_is_quorum", "bftkv_host_quorum_is_threshold", "bftkv_host_quorum_is_sufficient", "bftkv_host_quorum_reject",
     "bftkv_host_quorum_get_threshold", "bftkv_host_quorum_gpu_handle", "bftkv_host_collect_signatures",
     "bftkv_host_server_write_verify", "bftkv_host_max_timestamped_value", "bftkv_host_max_timestamped_value_masked", "bftkv_host_vote_fold", "bftkv_host_certs_parse",
-    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key", "bftkv_host_certs_structure", "bftkv_host_certs_check", "bftkv_host_certs_roles",
+    "bftkv_host_certs_free", "bftkv_host_certs_n_entities", "bftkv_host_certs_entity", "bftkv_host_certs_key", "bftkv_host_certs_structure", "bftkv_host_certs_check", "bftkv_host_certs_roles", "bftkv_host_signers_walk",
     "bftkv_host_server_sign_verify", "bftkv_host_server_read_proof_verify", "bftkv_host_server_register_verify", "bftkv_host_equivocation_signers", "bftkv_host_emsa_encode", "bftkv_host_certs_verify",
     "bftkv_host_quorum_cert_verify", "bftkv_host_graph_set_caching", "bftkv_host_graph_cache_stats", "bftkv_host_message_frame",
     "bftkv_host_parse_signature", "bftkv_host_walk_stream", "bftkv_host_scan_stream", "bftkv_host_sha256", "bftkv_host_cert_fingerprint",
@@ -421,6 +421,19 @@ class Certificate:
         finally:
             lib.bftkv_host_certs_free(h)
         return out
+
+
+def signers_walk(ss: bytes):
+    """bftkv_host_signers_walk: (issuer ids of the v4 signatures Signers() walks, in packet order, unfiltered; fenced)."""
+    lib = _lib()
+    lib.bftkv_host_signers_walk.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+    cap = len(ss) // 12 + 1
+    ids = np.zeros(cap, dtype=np.uint64)
+    n, fenced = C.c_uint32(0), C.c_uint8(0)
+    rc = lib.bftkv_host_signers_walk(ss, len(ss), ids.ctypes.data, cap, C.byref(n), C.byref(fenced))
+    if rc:
+        raise _native.NativeError("signers_walk failed: %d" % rc)
+    return [int(x) for x in ids[:n.value]], bool(fenced.value)
 
 
 def cert_fingerprint(cert: bytes) -> Optional[bytes]:

@@ -243,6 +243,14 @@ int bftkv_host_parse_signature(const uint8_t* body, uint32_t len, bftkv_sig_pars
  * length; *n_out = number of events (may exceed cap).  Unknown packet types raise no event (Reader.Next skips them). */
 int bftkv_host_walk_stream(const uint8_t* data, uint64_t len, uint32_t cap, uint8_t* status_out, uint64_t* body_off_out,
                            uint32_t* body_len_out, uint32_t* n_out);
+/* PGPSignature.Signers' walk over ONE stream on the HOST (crypto/pgp/crypto_pgp.go:373-390), for callers that hold a single ss.Data:
+ * CollectiveSignature.Combine asks for the signers after every signature it appends (protocol/client.go:153), and a parse-only walk
+ * of a few dozen packets is microseconds on the caller's thread -- no device round trip, no context.  The code is the device
+ * kernel's (k_signers: shared __host__ __device__ helpers).  issuers_out: the issuer key id of every version-4 signature packet
+ * Reader.Next yields before its first error, in packet order, NOT filtered by a keyring (the reference looks each up with
+ * getCertById: the caller does); *fenced_out as bftkv_gpu_signers_fenced (a shape on which the walk does not follow the reference's
+ * reader, or a v4 signature without issuer: take the reference path).  BFTKV_E_NOMEM with *n_out set when cap is too small. */
+int bftkv_host_signers_walk(const uint8_t* ss, uint64_t len, uint64_t* issuers_out, uint32_t cap, uint32_t* n_out, uint8_t* fenced_out);
 /* Diagnostic: what the kernels decide about one signature stream before any key or hash is involved (framing, partial-length
  * bodies linearised, Signature.parse / SignatureV3.parse, where the reference's reader stands after each parsed signature), on
  * the host through the same code.  status_out[i]: BFTKV_ST_NOT_SIGNATURE, BFTKV_ST_PARSE_ERROR, BFTKV_ST_UNSUPPORTED, or 99 for a

@@ -2,6 +2,7 @@ package pgpgpu
 
 /*
 #include "bftkv_gpu.h"
+#include "bftkv_host.h"
 */
 import "C"
 
@@ -62,7 +63,8 @@ func (cs *CollectiveSignature) Combine(ss, s *packet.SignaturePacket, q quorum.Q
 func (cs *CollectiveSignature) Sign(tbs []byte) (*packet.SignaturePacket, error) { return cs.inner.Sign(tbs) }
 
 // Signers replaces crypto_pgp.go:517-519 -> PGPSignature.Signers (:373-390): parse-only walk, issuers looked up among the
-// primary key ids of the keyring (getCertById).
+// primary key ids of the keyring (getCertById).  Batches of streams (revoke's history walk, client.go:304-353) have
+// bftkv_gpu_signers_fenced; one stream at a time is walked on the host.
 func (cs *CollectiveSignature) Signers(ss *packet.SignaturePacket) []node.Node {
 	return signers(cs.g, cs.keyring, ss, cs.inner.Signers)
 }
@@ -71,18 +73,21 @@ func signers(g *gpu, kr *keyring, ss *packet.SignaturePacket, fallback func(*pac
 	if ss == nil || len(ss.Data) == 0 {
 		return nil
 	}
-	off := [2]C.uint64_t{0, C.uint64_t(len(ss.Data))}
+	// One stream, parse only: walked on this goroutine's thread by the library's HOST build of its signer walk
+	// (bftkv_host_signers_walk: the code of the device kernel; no device round trip, no context lock) -- Combine asks for the
+	// signers after every signature it appends (client.go:153), a few dozen packets each time.  The walk returns the issuer of
+	// every version-4 signature Reader.Next yields before its first error; getCertById is the mirror keyring's, as in the reference.
 	capIds := len(ss.Data)/12 + 1 // a signature packet is never shorter than 12 bytes
 	ids := make([]C.uint64_t, capIds)
-	var idsOff [2]C.uint64_t
+	var n C.uint32_t
 	var fenced C.uint8_t
-	if rc := C.bftkv_gpu_signers_fenced(g.ctx, 1, ptr(ss.Data), &off[0], &ids[0], &idsOff[0], C.uint64_t(capIds), &fenced); rc != 0 || fenced != 0 || !kr.fresh() {
-		return fallback(ss) // infrastructure error, a shape the walk does not follow, or a stale device table: crypto/pgp decides
+	if rc := C.bftkv_host_signers_walk(ptr(ss.Data), C.uint64_t(len(ss.Data)), &ids[0], C.uint32_t(capIds), &n, &fenced); rc != 0 || fenced != 0 {
+		return fallback(ss) // a shape the walk does not follow (or a v4 signature without issuer, on which the reference dereferences nil): crypto/pgp decides
 	}
 	var nodes []node.Node
-	for _, id := range ids[:int(idsOff[1])] {
-		if n := kr.GetCertById(uint64(id)); n != nil {
-			nodes = append(nodes, n)
+	for _, id := range ids[:int(n)] {
+		if nd := kr.GetCertById(uint64(id)); nd != nil {
+			nodes = append(nodes, nd)
 		}
 	}
 	return nodes

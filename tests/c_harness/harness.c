@@ -60,6 +60,20 @@ int main(int argc, char** argv) {
   bftkv_host_quorum_free(q);
   bftkv_host_graph_free(g);
 
+  /* PGPSignature.Signers over one ss.Data on the host (what Combine asks after every appended signature): every packet of the
+   * fixture's first write names a replica of the ring, nothing fenced; cut in mid-packet the walk ends one signer short */
+  {
+    uint64_t iss[64];
+    uint32_t ns = 0, in_ring = 0;
+    uint8_t sfen = 0xEE;
+    int rcs = bftkv_host_signers_walk(fx_ss, fx_ss_off[1], iss, 64, &ns, &sfen);
+    for (uint32_t i = 0; i < ns; ++i) for (int k = 0; k < FX_N_KEYS; ++k) in_ring += iss[i] == fx_key_id[k];
+    uint32_t ns_cut = 0;
+    uint8_t sfen_cut = 0xEE;
+    int rcc = bftkv_host_signers_walk(fx_ss, fx_ss_off[1] - 5, iss, 64, &ns_cut, &sfen_cut);
+    printf("host_signers_walk=%d,%u,%u,%u cut=%d,%u,%u\n", rcs, ns, in_ring, (unsigned)sfen, rcc, ns_cut, (unsigned)sfen_cut);
+  }
+
   if (argc > 1 && strcmp(argv[1], "gpu") == 0 && ctx) {
     /* keyring: the replicas in order (secring-first order is the caller's business, crypto_pgp.go:195-197) */
     bftkv_gpu_pubkey keys[FX_N_KEYS];

@@ -75,3 +75,21 @@ def test_c_caller_links_and_runs(tmp_path):
     assert out["err_insufficient"] == "crypto: insufficient number of signatures"
     assert out["packet"].startswith("0,0,0 len=32 x_len=3 v_len=5 t=42 tbs=32 has_sig=0")
     assert out["quorum n_qcs"] == "1 f=1 min=4 threshold=3 suff=3 n_nodes=4 suff3=1 suff_dup=0 thr3=1 reject2=1"
+    # PGPSignature.Signers' walk on the host, from plain C (bftkv_host_signers_walk), against the oracle's walk of the same stream
+    import importlib.util
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    from tests import helpers as H
+    spec = importlib.util.spec_from_file_location("make_fixture", os.path.join(ROOT, "tests", "c_harness", "make_fixture.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cl, c = m.corpus()
+
+    class Everyone:
+        def get_cert_by_id(self, i):
+            return type("E", (), {"id": i})()
+    s0 = c.ss_data(0)
+    every = col.signers(Everyone(), SignaturePacket(1, 0, False, s0, None))
+    ring = col.signers(H.oracle_keyring(cl), SignaturePacket(1, 0, False, s0, None))
+    cut = col.signers(Everyone(), SignaturePacket(1, 0, False, s0[:-5], None))
+    assert out["host_signers_walk"] == "0,%d,%d,0 cut=0,%d,0" % (len(every), len(ring), len(cut)) and len(cut) == len(every) - 1

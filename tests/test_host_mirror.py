@@ -628,3 +628,40 @@ def test_host_sha256_matches_hashlib_on_both_code_paths(H):
         for mode in (0, 1):
             got, _ = H.sha256(data[:ln], mode)
             assert got == want, (ln, mode)
+
+
+def test_signers_walk_on_the_host_follows_the_oracle(H):
+    """PGPSignature.Signers' walk (crypto_pgp.go:373-390) on the caller's thread (bftkv_host_signers_walk: the loop and helpers of the
+    device kernel k_signers, built for the host): over quorum signatures with every mutation class, hand-made endings and random
+    packet framings the issuer list is the oracle's walk and the fence goes up exactly where the oracle says the reference's
+    reader is not followed (or a v4 signature carries no issuer: the reference dereferences nil there)."""
+    from corpus import build as cb
+    from oracle import openpgp as pgp, collective as col
+    from oracle.packet import SignaturePacket
+    from tests import helpers as TH
+
+    class Everyone:                                    # getCertById that knows every id: the walk itself, unfiltered
+        def get_cert_by_id(self, i):
+            return type("E", (), {"id": i})()
+    cl = cb.make_cluster(10, dsa_fraction=0.3)
+    c = cb.make_write_corpus(cl, 40, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_UNKNOWN_ISSUER: 0.3, cb.MUT_DUP_SIGNER: 0.2})
+    streams = [c.ss_data(i) for i in range(40)]
+    streams[3] = b""
+    streams[4] = streams[4][:300] + b"\x00garbage" + streams[4][300:]      # a bad tag byte ends the walk
+    streams[5] = b"\xd4\x02\x01\x02" + streams[5]                          # an unknown packet type is skipped
+    streams[6] = streams[6][:287 + 100]                                    # a truncated second packet
+    streams += TH.random_framing_streams(cl, 600, seed=91)[1]
+    n_ids = n_fenced = 0
+    for i, s in enumerate(streams):
+        ids, fenced = H.signers_walk(s)
+        want_fence = bool(pgp.position_is_type_dependent(s, stop_at_error=True))
+        want = col.signers(Everyone(), SignaturePacket(1, 0, False, s or None, None))
+        # (a v4 signature without issuer ends the oracle's walk and raises the fence here)
+        if not want_fence:
+            assert ids == want or fenced, (i, ids[:4], want[:4])
+        if fenced != want_fence:
+            # the only other fence: an issuer-less v4 signature at the point where the oracle's walk ended
+            assert fenced and ids == want, (i, fenced, want_fence)
+        n_ids += len(ids)
+        n_fenced += fenced
+    assert n_ids > 2000 and 10 < n_fenced < len(streams) // 2

@@ -84,10 +84,10 @@ def call_args(src, open_paren):
 
 
 def header():
-    h = open(os.path.join(ROOT, "include", "bftkv_gpu.h")).read()
+    h = open(os.path.join(ROOT, "include", "bftkv_gpu.h")).read() + open(os.path.join(ROOT, "include", "bftkv_host.h")).read()
     h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(bftkv_gpu_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", h):
+    for m in re.finditer(r"\b(bftkv_(?:gpu|host)_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", h):
         params = m.group(2).strip()
         protos[m.group(1)] = 0 if params in ("", "void") else len(split_args(params))
     consts = set(re.findall(r"#define\s+(BFTKV_[A-Z_0-9]+)\b", h))
@@ -109,9 +109,11 @@ def test_c_calls_match_the_header():
     seen = set()
     for path in go_files():
         src = strip_go(open(path).read())
-        for m in re.finditer(r"\bC\.(bftkv_gpu_[a-z_0-9]+)\s*\(", src):
+        for m in re.finditer(r"\bC\.(bftkv_(?:gpu|host)_[a-z_0-9]+)\s*\(", src):
             name = m.group(1)
-            assert name in protos, "%s: %s is not declared in include/bftkv_gpu.h" % (path, name)
+            assert name in protos, "%s: %s is not declared in include/bftkv_gpu.h / bftkv_host.h" % (path, name)
+            if name.startswith("bftkv_host_"):
+                assert '#include "bftkv_host.h"' in open(path).read(), "%s calls %s without including bftkv_host.h" % (path, name)
             got = len(call_args(src, m.end() - 1))
             assert got == protos[name], "%s: %s called with %d arguments, the prototype takes %d" % (path, name, got, protos[name])
             seen.add(name)
@@ -122,7 +124,7 @@ def test_c_calls_match_the_header():
     # the seam of the path: every verifying call of the shim is among them
     assert {"bftkv_gpu_init", "bftkv_gpu_keyring_set", "bftkv_gpu_quorum_create", "bftkv_gpu_quorum_destroy",
             "bftkv_gpu_batcher_collective_verify", "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_batcher_cert_entity",
-            "bftkv_gpu_batcher_message_verify", "bftkv_gpu_signers_fenced", "bftkv_gpu_set_hash_policy",
+            "bftkv_gpu_batcher_message_verify", "bftkv_host_signers_walk", "bftkv_gpu_set_hash_policy",
             # config 5 behind crypto.Threshold (shim/crypto/thresholdgpu)
             "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r",
             "bftkv_gpu_batcher_modexp"} <= seen
