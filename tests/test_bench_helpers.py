@@ -78,3 +78,41 @@ def test_summarize_keeps_what_the_default_line_shows_per_config():
     assert set(s["int_mac"]) == {"achieved", "frac", "frac_of_theoretical", "basis"} and s["roofline"]["kernel"] == "k_dsa_modexp"
     assert all(isinstance(v, (int, float)) for v in s["kernel_ms"].values())
     assert bench.summarize(None) is None
+
+
+def test_verifier_gather_check_with_unequal_shards():
+    """cfg 3's ranks hold different numbers of replies: every rank contributes the LARGEST shard's byte count to the all-gather
+    (Verifier.slots = max over ranks) and check_gather compares this rank's row on its own length and the population count of ALL
+    rows -- padding bits are zero -- with the all-reduced count.  Two fake ranks, 13 and 21 replies."""
+    import torch
+    from bftkv_amd import dist as BD
+    n_items = [13, 21]
+    rng = np.random.default_rng(3)
+    errs = [np.where(rng.random(n) < 0.3, 2, 0).astype(np.uint8) for n in n_items]
+    slots = max(n_items)
+    rows = [BD.pack_verdicts(torch.from_numpy((e == 0).astype(np.uint8)), slots).numpy() for e in errs]
+    gathered = np.concatenate(rows)
+    total_ok = int(sum((e == 0).sum() for e in errs))
+
+    torch_mod = torch
+
+    class FakeDist:
+        dry, world, torch = True, 2, torch_mod
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def max_int(self, v):
+            return slots
+
+        def sum_ints(self, vals):
+            return [total_ok]
+    for r in range(2):
+        D = FakeDist(r)
+        V = bench.Verifier(D, None, n_items[r], None, None, None, np.zeros(1, dtype=np.uint64), n_ctx=1)
+        assert V.slots == slots and (V.slots + 7) // 8 == rows[0].size
+        assert V.check_gather(errs[r], gathered)
+        # a flipped bit in the OTHER rank's row, or this rank's row shifted by one, is noticed
+        bad = gathered.copy(); bad[(1 - r) * rows[0].size] ^= 1
+        assert not V.check_gather(errs[r], bad)
+        assert not V.check_gather(np.roll(errs[r], 1) if errs[r].any() and not (np.roll(errs[r], 1) == errs[r]).all() else 1 - errs[r], gathered)
