@@ -1478,6 +1478,36 @@ def other_configs(args, D):
     return res
 
 
+def line_summary(out):
+    """The line's figures in one small object (placed last in the line): headline, the legs measured beside it, every other config."""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    s = {"metric": out.get("metric"), "value": out.get("value"), "ms_per_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus"),
+         "roofline_frac": g(out, "roofline", "frac"), "int_mac_frac": g(out, "int_mac", "frac"),
+         "cpu_baseline": g(out, "cpu_baseline", "value"), "identity": {k: v for k, v in (out.get("cpu_baseline") or {}).items() if "identical" in k}}
+    if "end_to_end" in out:
+        s["host_buffers_ms_per_call"] = {"alone": g(out, "end_to_end", "ms_per_step"), "three_callers": g(out, "end_to_end", "three_callers", "ms_per_call"),
+                                         "pcie_floor": g(out, "end_to_end", "pcie_floor_ms_at_63GBps")}
+    runs = g(out, "serving", "runs")
+    if runs:
+        s["serving_verify_calls_per_s"] = {str(r["caller_threads"]): r["verify_calls_per_s"] for r in runs}
+        s["serving_p99_ms"] = {str(r["caller_threads"]): r["latency_ms"]["p99"] for r in runs}
+    for k, v in (out.get("other_configs") or {}).items():
+        if isinstance(v, dict):
+            e = {x: v.get(x) for x in ("value", "unit", "ms_per_step", "error") if v.get(x) is not None}
+            if v.get("single_flight"):
+                e["single_flight_ms_per_step"] = v["single_flight"].get("ms_per_step")
+            th = [r for r in g(v, "serving", "runs") or [] if r.get("caller_threads") == 256]
+            if th:
+                e["one_op_per_call_256_callers_ops_per_s"] = {r["scheme"]: r["ops_per_s"] for r in th}
+            s[k] = e
+    return s
+
+
 def multi_rank_extras(args, D, emit):
     """N > 1, default run: BASELINE's actual multi-GPU configs behind the cfg-2 headline, IN this process group -- cfg 4 (the
     1 M-write storm split over the ranks, one RCCL all-gather of verdict bitmaps per call; strong scaling) and cfg 5 (10 k combines
@@ -1554,6 +1584,8 @@ def main():
                 printed[0] = True
                 if extra is not None:
                     out["other_configs"] = extra
+                if not args.dry_run:
+                    out["summary"] = line_summary(out)        # LAST key: the few numbers a reader of the line's tail should see
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
         if out is not None and everything:
             out["other_configs"] = other_configs(args, D)
