@@ -26,7 +26,7 @@ def main(tag, rnd):
     # The public-key kernels are launched twice per call (two-phase planning); the phase-2 launch normally has nothing to do
     # and lasts ~5 us, which halves the --stats average.  Per-dispatch durations from the kernel trace give the average over
     # the launches that did work (>= 10 % of the kernel's longest launch) -- the figure bench.py's HIP events measure.
-    nonempty = {}
+    nonempty, in_order = {}, {}
     tp = os.path.join(src, "trace", "t_kernel_trace.csv")
     if os.path.exists(tp):
         per = collections.defaultdict(list)
@@ -35,6 +35,7 @@ def main(tag, rnd):
         for k, v in per.items():
             big = [x for x in v if x >= 0.1 * max(v)]
             nonempty[k] = (sum(big) / len(big), len(big), len(v))
+        in_order = {k: [round(x / 1e6, 3) for x in v] for k, v in per.items() if max(v) >= 1e6 and len(v) <= 200}   # ms, launch order
     with open(os.path.join(dst, "%s_kernel_stats.csv" % rnd), "a") as f:
         pass
     # 2. HBM counters, one pass each
@@ -81,6 +82,12 @@ def main(tag, rnd):
                                  "avg_ns_working_launches": nonempty.get(k, (avg_ns.get(k, 0), 0, 0))[0],
                                  "working_launches": "%d of %d" % nonempty.get(k, (0, 0, 0))[1:], "fetch_kib_raw": fetch.get(k, 0), "write_kib_raw": write.get(k, 0),
                                  "hbm_bytes_corrected": b, "sq": sq.get(k, {})}
+            if k in in_order:
+                # every launch of the profiled command in order (ms): warm-up, the timed region's launches (batches in flight: a launch
+                # queued behind the turnstile starts as its predecessor drains and its span is not the kernel alone), and -- cfg 2 --
+                # the three NON-OVERLAPPED calls bench.py makes after the timed region, whose durations are the kernel's own and are what
+                # `kernel_ms.single_flight.rsa` (HIP events) reports
+                out["kernels"][k]["launch_ms_in_order"] = in_order[k]
     with open(os.path.join(dst, "%s_pmc_summary.json" % rnd), "w") as f:
         json.dump(out, f, indent=1)
     for n in ("bench_plain.json", "bench_trace.json"):
