@@ -40,6 +40,7 @@ import (
 	"fmt"
 	"io/ioutil"
 	"log"
+	"sort"
 	"strings"
 
 	"golang.org/x/crypto/openpgp"
@@ -123,6 +124,63 @@ type certOut struct {
 	Signers []string `json:"signers"`
 	Panic   bool     `json:"signers_panic,omitempty"`
 	Usable  []string `json:"usable"`
+	// the first entity as openpgp.ReadEntity built it -- what shim/crypto/pgpgpu/issuer.go assembles from the library's packet
+	// roles instead (bftkv_gpu_batcher_cert_entity): identities by name with the self-signature that counts and the signatures
+	// collected on them, subkeys with their Subkey.Sig, the number of revocations
+	Structure *entityOut `json:"structure,omitempty"`
+}
+
+type identityOut struct {
+	Name         string   `json:"name"` // hex
+	SelfType     int      `json:"self_type"`
+	SelfCreation int64    `json:"self_creation"`
+	Signatures   []string `json:"signatures"` // issuer key ids in order ("nil": no issuer subpacket)
+}
+
+type subkeyOut struct {
+	KeyId       string `json:"key_id"`
+	SigType     int    `json:"sig_type"`
+	SigCreation int64  `json:"sig_creation"`
+}
+
+type entityOut struct {
+	Identities  []identityOut `json:"identities"` // sorted by name
+	Subkeys     []subkeyOut   `json:"subkeys"`
+	Revocations int           `json:"revocations"`
+}
+
+func entityStructure(e *openpgp.Entity) *entityOut {
+	eo := &entityOut{Identities: []identityOut{}, Subkeys: []subkeyOut{}, Revocations: len(e.Revocations)}
+	var names []string
+	for name := range e.Identities {
+		names = append(names, name)
+	}
+	sort.Strings(names)
+	for _, name := range names {
+		id := e.Identities[name]
+		ido := identityOut{Name: hex.EncodeToString([]byte(name)), Signatures: []string{}}
+		if id.SelfSignature != nil {
+			ido.SelfType = int(id.SelfSignature.SigType)
+			ido.SelfCreation = id.SelfSignature.CreationTime.Unix()
+		}
+		for _, sg := range id.Signatures {
+			if sg.IssuerKeyId == nil {
+				ido.Signatures = append(ido.Signatures, "nil")
+			} else {
+				ido.Signatures = append(ido.Signatures, fmt.Sprintf("%016x", *sg.IssuerKeyId))
+			}
+		}
+		eo.Identities = append(eo.Identities, ido)
+	}
+	for _, sk := range e.Subkeys {
+		so := subkeyOut{KeyId: fmt.Sprintf("%016x", sk.PublicKey.KeyId)}
+		if sk.Sig != nil {
+			so.SigType = int(sk.Sig.SigType)
+			so.SigCreation = sk.Sig.CreationTime.Unix()
+		}
+		eo.Subkeys = append(eo.Subkeys, so)
+	}
+	return eo
 }
 
 func firstEntityFacts(n node.Node, co *certOut) {
@@ -132,6 +190,7 @@ func firstEntityFacts(n node.Node, co *certOut) {
 		}
 	}()
 	e := n.Instance().(*openpgp.Entity)
+	co.Structure = entityStructure(e)
 	l := openpgp.EntityList{e}
 	ids := []uint64{e.PrimaryKey.KeyId}
 	for _, sk := range e.Subkeys {

@@ -82,6 +82,21 @@ def oracle_packet(b):
     return tuple(res)
 
 
+def oracle_structure(w):
+    """The entity ReadEntity returns, as genvectors writes it (`structure`): identities by name -- a later one of the same name in the
+    place of the earlier -- with the self-signature that counts and the issuers of the signatures collected on them, subkeys with
+    their Subkey.Sig, the number of revocations.  It is also what the library's packet roles assemble (tests/test_cert_walk.py)."""
+    by_name = {}
+    for ident in w.identities:
+        if ident["self_sig"] is not None:
+            by_name[bytes(ident["name"])] = ident
+    # Go sorts the names as strings (bytes): the same order
+    idents = [{"name": nm.hex(), "self_type": i["self_sig"].sig_type, "self_creation": i["self_sig"].creation_time,
+               "signatures": ["nil" if s_.issuer is None else "%016x" % s_.issuer for s_, _, _ in i["sigs"]]} for nm, i in sorted(by_name.items())]
+    subs = [{"key_id": "%016x" % sk["key"].key_id, "sig_type": sk["sig"].sig_type, "sig_creation": sk["sig"].creation_time} for sk in w.subkeys]
+    return {"identities": idents, "subkeys": subs, "revocations": len(w.revocations)}
+
+
 def oracle_cert(blob):
     """crypto.Certificate.Parse: the entities ReadEntity accepts, in order, up to the first one it refuses (crypto_pgp.go:236-249);
     for the first one Signers() and the key ids KeysByIdUsage(id, KeyFlagSign) returns.  None in place of an entity: a shape the
@@ -91,6 +106,7 @@ def oracle_cert(blob):
     if ws and ws[0] is not None:
         e = [x for x in pgp.read_entities(blob) if x.serialized == blob[ws[0].start:ws[0].end]][0]
         out["signers"] = e.certifiers
+        out["structure"] = oracle_structure(ws[0])
         out["usable"] = [k for k in [e.primary.key_id] + [sk.key_id for sk, _, _, _ in e.subkeys] if pgp.keys_by_id_usage_sign([e], k)]
     return out
 
@@ -211,6 +227,8 @@ def _same_cert(n, a, b):
     # Signers() walks a Go map: the order across identities is not defined
     if "signers" in b and not b.get("signers_panic"):
         assert sorted("%016x" % i for i in a["signers"]) == sorted(b["signers"]), ("cert", n, "Signers()", a, b)
+    if b.get("structure") is not None and a.get("structure") is not None:
+        assert a["structure"] == b["structure"], ("cert", n, "the entity ReadEntity built", a["structure"], b["structure"])
 
 
 def _same_packet(tag, ours, ref):
@@ -260,11 +278,16 @@ def test_comparison_accepts_the_oracles_own_answers_and_refuses_a_flipped_one(re
     for n, c in enumerate(replayed["certs"]):
         if None in c["ids"]:
             continue
-        as_ref = {"ids": ["%016x" % i for i in c["ids"]], "signers": ["%016x" % i for i in reversed(c["signers"])], "usable": ["%016x" % i for i in c["usable"]]}
+        import copy
+        as_ref = {"ids": ["%016x" % i for i in c["ids"]], "signers": ["%016x" % i for i in reversed(c["signers"])], "usable": ["%016x" % i for i in c["usable"]],
+                  "structure": copy.deepcopy(c.get("structure"))}
         _same_cert(n, c, as_ref)
         n_cmp += 1
+        other_entity = copy.deepcopy(as_ref["structure"]) if as_ref["structure"] else None
+        if other_entity and other_entity["identities"]:
+            other_entity["identities"][0]["self_creation"] += 1
         for tampered in (dict(as_ref, ids=as_ref["ids"] + ["00" * 8]), dict(as_ref, usable=as_ref["usable"][1:] if as_ref["usable"] else ["00" * 8]),
-                         dict(as_ref, signers=as_ref["signers"] + ["00" * 8])):
+                         dict(as_ref, signers=as_ref["signers"] + ["00" * 8])) + ((dict(as_ref, structure=other_entity),) if other_entity else ()):
             with pytest.raises(AssertionError):
                 _same_cert(n, c, tampered)
     assert n_cmp > 50
