@@ -1493,9 +1493,13 @@ def line_summary(out):
         s["host_buffers_ms_per_call"] = {"alone": g(out, "end_to_end", "ms_per_step"), "three_callers": g(out, "end_to_end", "three_callers", "ms_per_call"),
                                          "pcie_floor": g(out, "end_to_end", "pcie_floor_ms_at_63GBps")}
     runs = g(out, "serving", "runs")
-    if runs:
+    if runs and "verify_calls_per_s" in runs[0]:          # cfg 2: one Verify per call
         s["serving_verify_calls_per_s"] = {str(r["caller_threads"]): r["verify_calls_per_s"] for r in runs}
         s["serving_p99_ms"] = {str(r["caller_threads"]): r["latency_ms"]["p99"] for r in runs}
+    elif runs:                                            # cfg 5: one share-combine per call, per scheme
+        s["serving_ops_per_s_256_callers"] = {r["scheme"]: r["ops_per_s"] for r in runs if r.get("caller_threads") == 256}
+    if out.get("single_flight"):
+        s["single_flight_ms_per_step"] = g(out, "single_flight", "ms_per_step")
     for k, v in (out.get("other_configs") or {}).items():
         if isinstance(v, dict):
             e = {x: v.get(x) for x in ("value", "unit", "ms_per_step", "error") if v.get(x) is not None}
@@ -1585,7 +1589,10 @@ def main():
                 if extra is not None:
                     out["other_configs"] = extra
                 if not args.dry_run:
-                    out["summary"] = line_summary(out)        # LAST key: the few numbers a reader of the line's tail should see
+                    try:
+                        out["summary"] = line_summary(out)    # LAST key: the few numbers a reader of the line's tail should see
+                    except Exception as e:                    # noqa: BLE001 -- a digest must never take the line down
+                        out["summary"] = {"error": repr(e)[:200]}
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
         if out is not None and everything:
             out["other_configs"] = other_configs(args, D)

@@ -116,3 +116,23 @@ def test_verifier_gather_check_with_unequal_shards():
         bad = gathered.copy(); bad[(1 - r) * rows[0].size] ^= 1
         assert not V.check_gather(errs[r], bad)
         assert not V.check_gather(np.roll(errs[r], 1) if errs[r].any() and not (np.roll(errs[r], 1) == errs[r]).all() else 1 - errs[r], gathered)
+
+
+def test_line_summary_digests_every_committed_line_shape():
+    """The digest at the end of the line (bench.line_summary) over real lines of every config: cfg 2's default line with its
+    other_configs, cfg 3's, cfg 5's with its own `serving` shape (one share-combine per call, per scheme) -- and it never raises."""
+    import glob
+    import json
+    import os
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    lines = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(prof, "r05_*bench*.json")))]
+    lines += [json.load(open(os.path.join(prof, "r05_cfg3_dsa64.json")))["policy_run_line"]]
+    assert len(lines) >= 6
+    seen = set()
+    for d in lines:
+        s = bench.line_summary(d)
+        assert s["value"] == d["value"] and s["metric"] == d["metric"]
+        seen.update(s)
+        json.dumps(s)
+    assert {"serving_verify_calls_per_s", "serving_ops_per_s_256_callers", "single_flight_ms_per_step", "host_buffers_ms_per_call", "cfg4", "cfg5"} <= seen
+    assert "error" not in bench.line_summary({"metric": "m", "value": 1.0, "serving": {"runs": []}, "other_configs": {"cfg9": "text"}})
