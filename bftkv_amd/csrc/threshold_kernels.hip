@@ -214,6 +214,191 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
   }
 }
 
+// ---- Lagrange: the BIG-integer side (round 5) ----------------------------------------------------------------------
+// k_lagrange_inv works on exact 31-bit products: enough for the reference's own parameters (n = 10 nodes: k = 7, 2t = 8), not
+// for the clusters BASELINE names -- at n = 64, k = 22 the numerator alone is 64^21 -- and big.Int has no such bound
+// (sss.Lagrange, crypto/sss/sss.go:94-107).  Operations k_lagrange_inv flagged (status bit 2: a product past 2^31, or a negative
+// x) are redone here:
+//   k_lagrange_big     thread / term: |a_j| = prod |x_i|, |b_j| = prod |x_i - x_j| (i != j, every x_i == x_j skipped as
+//                      sss.Lagrange skips them) as EXACT integers of up to 2128 bits -- a limb row times a 32-bit factor is
+//                      76 MACs, nothing next to a Montgomery product -- and the sign of a_j / b_j; a product beyond 2128 bits
+//                      stays fenced (256 nodes with ids up to 255: k up to ~260 terms fit)
+//   k_lagrange_prep    quad / op: B_j = b_j R mod m, the prefix products Pre_j = B_0 ... B_(j-1), and D = prod_j b_j mod m
+//   k_modinv           D^-1 mod m -- ONE big inverse per operation (Montgomery's trick).  The reference inverts every b_j
+//                      (ModInverse returns nil for one without inverse and the next Mul dereferences it): all b_j are
+//                      invertible exactly when their product is, so "no inverse" is the same outcome for the operation
+//   k_lagrange_finish  quad / op: lambda_j = +-a_j Pre_j Suf_j D^-1 mod m (Suf_j = B_(j+1) ... B_(k-1), built backwards),
+//                      written out and / or folded into S = sum_j lambda_j y_j mod m; sets the operation's final status
+__device__ __forceinline__ bool limbs_mul_small(uint32_t* v, uint32_t& len, uint64_t f) {      // v *= f (f < 2^32); false: beyond 76 limbs
+  uint64_t carry = 0;
+  for (uint32_t i = 0; i < len; ++i) { const uint64_t w = (uint64_t)v[i] * f + carry; v[i] = (uint32_t)w & MONT_MASK; carry = w >> MONT_W; }
+  while (carry) {
+    if (len == (uint32_t)MONT_N) return false;
+    v[len++] = (uint32_t)carry & MONT_MASK;
+    carry >>= MONT_W;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void status_byte_set(uint8_t* status, uint32_t op, uint8_t v) {      // bytes are packed four to an atomic word
+  unsigned int* w = (unsigned int*)(status + (op & ~3u));
+  const unsigned int sh = 8u * (op & 3u);
+  atomicAnd(w, ~(0xFFu << sh));
+  atomicOr(w, (unsigned int)v << sh);
+}
+
+__global__ void __launch_bounds__(64) k_lagrange_big(uint32_t n_ops, uint32_t k_shares, const int32_t* __restrict__ xs, const uint8_t* __restrict__ status,
+                                                     uint32_t* __restrict__ a_big /*[n_ops][k][76]*/, uint32_t* __restrict__ b_big, uint8_t* __restrict__ sign /*[n_ops][k]*/,
+                                                     uint8_t* __restrict__ big_st /*[n_ops]: 2 = a product beyond 2128 bits*/) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_ops * k_shares) return;
+  const uint32_t op = t / k_shares, j = t % k_shares;
+  if (!(status[op] & 2u)) return;
+  const int32_t* x = xs + (uint64_t)op * k_shares;
+  uint32_t A[MONT_N], B[MONT_N];
+  for (int i = 0; i < MONT_N; ++i) { A[i] = 0; B[i] = 0; }
+  A[0] = 1; B[0] = 1;
+  uint32_t la = 1, lb = 1;
+  bool neg = false, ok = true;
+  for (uint32_t i = 0; i < k_shares && ok; ++i) {
+    if (x[i] == x[j]) continue;
+    const int64_t xi = x[i], d = (int64_t)x[i] - x[j];
+    neg ^= (xi < 0) ^ (d < 0);
+    ok = limbs_mul_small(A, la, (uint64_t)(xi < 0 ? -xi : xi)) && limbs_mul_small(B, lb, (uint64_t)(d < 0 ? -d : d));
+  }
+  if (!ok) { big_st[op] = 2; return; }          // (every thread that writes, writes the same value)
+  uint32_t* ao = a_big + (uint64_t)t * MONT_N;
+  uint32_t* bo = b_big + (uint64_t)t * MONT_N;
+  for (int i = 0; i < MONT_N; ++i) { ao[i] = A[i]; bo[i] = B[i]; }
+  sign[t] = neg ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_prep(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ b_big, const uint8_t* __restrict__ status,
+                                                             const uint8_t* __restrict__ big_st, const uint32_t* __restrict__ mod_idx, ModTab mt,
+                                                             uint32_t* __restrict__ pre /*[n_ops][k][76], Montgomery form*/, uint32_t* __restrict__ d_plain /*[n_ops][76]*/) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const bool mine = active && (status[op] & 2u) && !big_st[op];
+  if (!__any(mine)) return;
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], acc[L], t[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  const uint32_t n0inv = mt.n0inv[mi];
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(acc, r2);                                                     // R mod m: the empty product
+  for (uint32_t j = 0; j < k_shares; ++j) {
+    const uint64_t sj = (uint64_t)op * k_shares + j;
+    if (mine) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) pre[sj * MONT_N + qlane * L + k] = acc[k];
+    }
+    const uint32_t* bp = b_big + sj * MONT_N + qlane * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = mine ? bp[k] : 0u;
+    MONT(t, r2);                                                     // B_j = b_j R
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+    MONT(t, acc);                                                    // Pre_(j+1)
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = t[k];
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(t, acc);                                                      // D = prod b_j mod m, plain
+  canonicalize(t, qlane);
+  if (mine) store_mod_result(d_plain + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
+}
+
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_finish(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ a_big, const uint32_t* __restrict__ b_big,
+                                                               const uint8_t* __restrict__ sign, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ d_inv /*[n_ops][76] plain*/,
+                                                               const uint8_t* __restrict__ inv_st /*[n_ops]: 1 = D has no inverse*/, const uint8_t* __restrict__ big_st,
+                                                               const uint32_t* __restrict__ y_limbs, const uint32_t* __restrict__ mod_idx, ModTab mt,
+                                                               uint32_t* __restrict__ lambda_out, uint32_t* __restrict__ sum_out, uint8_t* __restrict__ status) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const bool flagged = active && (status[op] & 2u);
+  if (!__any(flagged)) return;
+  const uint8_t bad = flagged ? (big_st[op] ? 2 : (inv_st[op] ? 1 : 0)) : 0;
+  const bool mine = flagged && !bad;
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], di[L], suf[L], acc[L], t[L], u[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; acc[k] = 0; }
+  const uint32_t n0inv = mt.n0inv[mi];
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = mine ? d_inv[(uint64_t)op * MONT_N + qlane * L + k] : 0u;
+  MONT(di, r2);                                                      // D^-1 R
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(suf, r2);                                                     // R mod m
+  for (uint32_t jj = 0; jj < k_shares; ++jj) {
+    const uint32_t j = k_shares - 1 - jj;
+    const uint64_t sj = (uint64_t)op * k_shares + j;
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = mine ? a_big[sj * MONT_N + qlane * L + k] : 0u;
+    MONT(t, r2);                                                     // |a_j| R
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = mine ? pre[sj * MONT_N + qlane * L + k] : 0u;
+    MONT(u, t);                                                      // |a_j| Pre_j R
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = u[k];
+    MONT(t, suf);                                                    // ... Suf_j
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+    MONT(u, di);                                                     // |lambda_j| R
+    // leave the domain WITH the sign: times 1, or times m - 1 = -1 (m is odd: m - 1 is m with its lowest bit cleared)
+    const bool neg = mine && sign[sj];
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = neg ? (n[k] & ~((qlane == 0 && k == 0) ? 1u : 0u)) : ((qlane == 0 && k == 0) ? 1u : 0u);
+    MONT(t, u);                                                      // lambda_j, plain, < 2m
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+    MONT(u, r2);                                                     // lambda_j R
+    if (lambda_out) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+      uint32_t c[L];
+      MONT(c, u);
+      canonicalize(c, qlane);
+      if (mine) store_mod_result(lambda_out + sj * MONT_N + qlane * L, c, n, qlane);
+    }
+    if (sum_out) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) a_lds[k] = mine ? y_limbs[sj * MONT_N + qlane * L + k] : 0u;
+      MONT(t, u);                                                    // lambda_j y_j (plain, < 2m)
+#pragma unroll
+      for (int k = 0; k < L; ++k) acc[k] += t[k];
+      canonicalize(acc, qlane);
+    }
+    // Suf_(j-1) = Suf_j B_j
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = mine ? b_big[sj * MONT_N + qlane * L + k] : 0u;
+    MONT(t, r2);
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+    MONT(t, suf);
+#pragma unroll
+    for (int k = 0; k < L; ++k) suf[k] = t[k];
+  }
+  if (sum_out) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = acc[k];
+    MONT(t, r2);
+#pragma unroll
+    for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+    MONT(u, t);
+    canonicalize(u, qlane);
+    if (mine) store_mod_result(sum_out + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
+    else if (flagged) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) sum_out[(uint64_t)op * MONT_N + qlane * L + k] = 0;
+    }
+  }
+  if (flagged && qlane == 0) status_byte_set(status, op, bad);
+}
+
 // r = prod_j base_j ^ e_j mod p, e_j up to 256 bits (radix-2^28 limbs; 10 limbs = 280 bits cover them).
 // Straus' simultaneous exponentiation with 4-bit windows: per base the multiples b^1 .. b^15 (Montgomery form) go to a
 // global table (4.5 KB per base, written and re-read by the same quad), then 70 windows of 4 shared squarings and at
@@ -472,10 +657,14 @@ __device__ __forceinline__ void bw_add(BigW& a, const BigW& b) { uint64_t c = 0;
 __device__ __forceinline__ uint32_t bw_sub(BigW& a, const BigW& b) { uint64_t br = 0; for (int i = 0; i < INV_W; ++i) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; } return (uint32_t)br; }
 __device__ __forceinline__ void bw_shr1(BigW& a) { for (int i = 0; i < INV_W - 1; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 31); a.w[INV_W - 1] >>= 1; }
 
+// `gate` / `gate_not` (the big Lagrange path): only operations whose gate byte has bit 2 set and whose gate_not byte is zero are
+// inverted; `status` is then a plain byte per operation (1 = no inverse), not the packed array of the public entry point.
 __global__ void __launch_bounds__(64) k_modinv(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx, ModTab mt,
-                                               uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status) {
+                                               uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status, const uint8_t* __restrict__ gate = nullptr,
+                                               const uint8_t* __restrict__ gate_not = nullptr) {
   const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
   if (op >= n_ops) return;
+  if (gate && (!(gate[op] & 2u) || gate_not[op])) return;
   auto load = [](const uint32_t* l, BigW& o) {
     for (int i = 0; i < INV_W; ++i) o.w[i] = 0;
     for (int j = 0; j < MONT_N; ++j) {
@@ -502,7 +691,7 @@ __global__ void __launch_bounds__(64) k_modinv(uint32_t n_ops, const uint32_t* _
     if (bw_cmp(u, v) >= 0) { bw_sub(u, v); if (bw_sub(x1, x2)) bw_add(x1, q); }
     else { bw_sub(v, u); if (bw_sub(x2, x1)) bw_add(x2, q); }
   }
-  if (!ok) atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3)));
+  if (!ok) { if (gate) status[op] = 1; else atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3))); }
   uint32_t* o = out_limbs + (uint64_t)op * MONT_N;
   for (int j = 0; j < MONT_N; ++j) {
     const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;

@@ -324,7 +324,7 @@ int bftkv_gpu_batcher_message_verify(bftkv_gpu_batcher* b, const uint8_t* msg, u
  * request) are gathered like the verify calls above: operations of one shape (kind, k, widths) share a device call on a
  * lane, whatever their moduli; each caller blocks until its batch has run.  Numbers are big-endian, fixed width.
  *   *status_out   BFTKV_TH_OK; BFTKV_TH_NO_INVERSE (math/big's ModInverse would return nil and the reference would
- *                 dereference it: take the reference path); BFTKV_TH_FENCED (Lagrange integers beyond 2^31: the reference
+ *                 dereference it: take the reference path); BFTKV_TH_FENCED (Lagrange integers beyond 2128 bits: the reference
  *                 path decides); BFTKV_TH_FAILED whenever the return code is not 0 -- the byte starts out as a failure and
  *                 `out` as zeroes (fail closed: no caller reads a result out of an infrastructure error).
  * An even modulus or one wider than 2048 bits returns BFTKV_E_UNSUPPORTED for that caller alone. */
@@ -417,7 +417,10 @@ int bftkv_gpu_allgather_errs_dev(bftkv_gpu_ctx* ctx, const uint8_t* err_dev, uin
 
 /* ---- threshold-signature share combine (BASELINE config 5) ------------------------------------ */
 /* Numbers are big-endian, nbytes each (<= 256); moduli must be odd; mod_idx[op] selects the modulus.
- * status_out[op] (where present): 0 ok, 1 no modular inverse, 2 Lagrange integers beyond 2^31 (fenced). */
+ * status_out[op] (where present): 0 ok, 1 no modular inverse, 2 fenced -- a Lagrange numerator prod x_i or denominator
+ * prod (x_i - x_j) beyond 2128 bits as an exact integer (256 nodes with ids below 256: about 260 terms fit; the reference's
+ * big.Int has no bound).  Coefficients within 31 bits -- the reference's own n = 10 -- take a small-integer fast path, larger
+ * ones (64 or 256 nodes) exact big integers and ONE modular inverse per operation. */
 
 /* S = prod_j factors[op][j] mod N -- calculateSignature (crypto/threshold/rsa/rsa.go:318-329). */
 int bftkv_gpu_modmul_product(bftkv_gpu_ctx* ctx, uint32_t n_ops, uint32_t k, const uint8_t* factors, uint32_t nbytes,

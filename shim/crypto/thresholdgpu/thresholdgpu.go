@@ -12,7 +12,7 @@
 // One goroutine per DistSign (protocol/client.go:509-546) and per distSign request (protocol/server.go:528-541) calls them;
 // the batcher gathers the concurrent callers of one shape into a device call.  Every hook answers nil whenever the library
 // makes no claim -- an infrastructure error (the library fails closed: the status byte starts out as BFTKV_TH_FAILED), an
-// input it fences (status != BFTKV_TH_OK: no modular inverse, Lagrange integers beyond 2^31), an even or over-wide modulus,
+// input it fences (status != BFTKV_TH_OK: no modular inverse, Lagrange integers beyond 2128 bits), an even or over-wide modulus,
 // a negative or over-long operand -- and the reference's arithmetic then runs exactly as it always did.
 //
 //	crypt := pgpgpu.New(0)

@@ -371,3 +371,149 @@ def test_one_combine_per_call_through_the_micro_batcher(gpu_ctx):
     b.close()
     rc, st_, got = Batcher.modmul_product(type("Dead", (), {"lib": gpu_ctx.lib, "h": None})(), [3, 5], n_kat)
     assert rc != 0 and st_ == 0xFF and got == 0
+
+
+def test_one_op_entries_on_random_shapes_and_unreduced_operands(gpu_ctx):
+    """The one-operation entries over shapes nobody tuned for -- k from 1 to 12, numbers of 20 / 32 / 128 / 256 bytes, odd moduli that
+    are prime or composite and narrower than their byte width, operands ANYWHERE below 2^(8 nbytes) (the reference reduces every
+    product and sum mod m, so an unreduced operand must give the residue's result) -- against Python integers through the
+    oracle's own functions.  A combine whose Lagrange denominator shares a factor with the modulus must come back as
+    BFTKV_TH_NO_INVERSE with zeroes, never as a number."""
+    from bftkv_amd import Batcher
+    rng = np.random.default_rng(2026)
+    rnd = lambda nb: int.from_bytes(rng.bytes(nb), "big")
+    b = Batcher(gpu_ctx, max_items=64, n_lanes=2)
+    kg = KAT["dsa_group"]
+    p2, q2 = int(kg["p"], 16), int(kg["q"], 16)
+    g_ = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keys_dsa2048.json")))["keys"][1]
+    as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
+    p1, q1 = as_int(g_["p"]), as_int(g_["q"])
+    n_no_inverse = 0
+    try:
+        for trial in range(160):
+            nb = int(rng.choice([20, 32, 128, 256]))
+            k = int(rng.integers(1, 13))
+            m = (rnd(nb) >> int(rng.integers(0, 8 * nb - 9))) | 1          # odd, anything from 9 bits to the full width
+            if m < 3:
+                m = 3
+            kind = trial % 4
+            if kind == 0:
+                f = [rnd(nb) for _ in range(k)]
+                rc, st, got = b.modmul_product(f, m, nbytes=nb)
+                assert (rc, st) == (0, 0) and got == T.calculate_signature(f, m), (trial, nb, k, hex(m)[:20])
+            elif kind == 1:
+                xs = [int(v) for v in rng.choice(np.arange(1, 40), size=k, replace=False)]
+                ys = [rnd(nb) for _ in range(k)]
+                rc, st, got = b.lagrange_combine(xs, ys, m, nbytes=nb)
+                try:
+                    want = T.calculate_secret(list(zip(xs, ys)), m)
+                except ValueError:
+                    want = None
+                if want is None:
+                    assert (rc, st, got) == (0, 1, 0), (trial, xs, hex(m)[:20])
+                    n_no_inverse += 1
+                else:
+                    assert (rc, st) == (0, 0) and got == want, (trial, nb, k, xs, hex(m)[:20])      # (x up to 39: the big-integer path too)
+            elif kind == 2:
+                base, e = rnd(nb), rnd(int(rng.integers(1, 40)))
+                el = int(rng.integers((e.bit_length() + 7) // 8 or 1, 48))
+                rc, st, got = b.modexp(base, e, m, nbytes=nb, exp_len=el)
+                assert (rc, st) == (0, 0) and got == pow(base, e, m), (trial, nb, el, hex(m)[:20])
+            else:
+                p, q, pb, qb = ((p1, q1, 256, 32) if trial % 8 == 3 else (p2, q2, 128, 20))
+                kk = int(rng.integers(1, 9))
+                xs = [int(v) for v in rng.choice(np.arange(1, 30), size=kk, replace=False)]
+                ri = [rnd(pb) for _ in range(kk)]                     # anywhere below 2^(8 pbytes): Exp reduces its base mod p
+                vi = [rnd(qb) for _ in range(kk)]                     # ... and Vi * l is reduced mod q
+                rc, st, got = b.dsa_calculate_r(xs, ri, vi, p, q, pbytes=pb, qbytes=qb)
+                try:
+                    want = T.calculate_r([(x, r.to_bytes(pb, "big"), v) for x, r, v in zip(xs, ri, vi)], p, q)
+                except ValueError:
+                    want = None
+                if want is None:
+                    assert (rc, st, got) == (0, 1, 0), trial
+                else:
+                    assert (rc, st) == (0, 0) and got == want, (trial, kk, xs)
+        assert n_no_inverse >= 3          # the composite moduli did meet denominators they share a factor with
+    finally:
+        b.close()
+
+
+def test_lagrange_coefficients_beyond_31_bits(gpu_ctx):
+    """sss.Lagrange has no bound on its integers (big.Int); the kernels' fast path holds them in 31 bits -- enough for the
+    reference's own n = 10, not for the clusters BASELINE names.  64 and 256 nodes: real dealings recovered through the
+    big-integer path (exact products of up to 2128 bits, ONE modular inverse per operation), mixed in one call with operations that
+    stay on the fast path; negative x; a denominator that shares a factor with a composite modulus (status 1, as the reference's nil
+    dereference); products beyond 2128 bits stay fenced (status 2); CalculateR with 2t = 22 of 64 nodes; one operation per call."""
+    from bftkv_amd import Batcher
+    m = int(KAT["sss"]["pb"], 16)
+    kg = KAT["dsa_group"]
+    p, q, g = int(kg["p"], 16), int(kg["q"], 16), int(kg["g"], 16)
+    rng = np.random.default_rng(64)
+    rnd = lambda mod: int.from_bytes(rng.bytes(264), "big") % mod
+    secret = int.from_bytes(b"a secret shared among 64 and 256 nodes", "big")
+    # ---- SSS: n = 64, k = 22 and n = 256, k = 171 (real dealings); a fast-path operation and a fenced one in the same call
+    cases, want, want_st = [], [], []
+    for n, k in ((64, 22), (256, 171), (64, 43), (10, 7)):
+        shares = T.distribute(secret, n, k, m, [rnd(m) for _ in range(k - 1)])
+        pick = [shares[i] for i in rng.choice(n, size=k, replace=False)]
+        cases.append(pick); want.append(secret); want_st.append(0)
+    assert T.calculate_secret(cases[0], m) == secret
+    for pick, w, ws in zip(cases, want, want_st):
+        xs, ys = [[s_[0] for s_ in pick]], [[s_[1] for s_ in pick]]
+        got, st = gpu_ctx.lagrange_combine(xs, ys, [m], [0])
+        assert (int(st[0]), got[0]) == (ws, w), (len(pick), int(st[0]))
+    # one call, k = 22: big path / fast path (x in 1..8 padded with repeats is not possible: distinct small x instead) / negative x /
+    # no inverse under a composite modulus / fenced
+    k = 22
+    comp = 3 * 5 * 7 * 11 * 13 * (2**89 - 1)
+    rows = [
+        ([int(v) for v in rng.choice(np.arange(1, 65), size=k, replace=False)], m),
+        ([int(v) for v in rng.choice(np.arange(-40, 0), size=k, replace=False)], q),
+        ([int(v) for v in rng.choice(np.arange(1, 65), size=k, replace=False)], comp),          # differences of 3, 5, 7 ... share factors with it
+        ([int(v) for v in rng.choice(np.arange(2**30, 2**31 - 1), size=k, replace=False)], m),  # 21 x 31 bits: fits
+    ]
+    xs, ys, mods = [r_[0] for r_ in rows], [[rnd(r_[1]) for _ in range(k)] for r_ in rows], [r_[1] for r_ in rows]
+    got, st = gpu_ctx.lagrange_combine(xs, ys, mods, list(range(len(rows))))
+    for i, (x, mod) in enumerate(rows):
+        try:
+            w = T.calculate_s(list(zip(x, ys[i])), mod)
+        except ValueError:
+            w = None
+        if w is None:
+            assert int(st[i]) == 1, i
+        else:
+            assert (int(st[i]), got[i]) == (0, w), (i, int(st[i]))
+    assert int(st[2]) == 1
+    # 120 factors of 31 bits: 3,720 bits, beyond the exact integers the big path holds -- fenced, never a number
+    x_huge = [int(v) for v in rng.choice(np.arange(2**30, 2**31 - 1), size=120, replace=False)]
+    got, st = gpu_ctx.lagrange_combine([x_huge], [[rnd(m) for _ in range(120)]], [m], [0])
+    assert int(st[0]) == 2
+    # ---- CalculateR: 2t = 22 of n = 64 nodes (the exponents are the big-path coefficients mod q)
+    n, t = 64, 11
+    rq = lambda: int.from_bytes(rng.bytes(40), "big") % q
+    xs_r, ri, vi, want_r = [], [], [], []
+    for trial in range(6):
+        kk, aa = rq(), rq()
+        ks = T.distribute(kk, n, t, q, [rq() for _ in range(t - 1)])
+        as_ = T.distribute(aa, n, t, q, [rq() for _ in range(t - 1)])
+        zs = T.distribute(0, n, 2 * t, q, [rq() for _ in range(2 * t - 1)])
+        pick = [int(i) for i in rng.choice(n, size=2 * t, replace=False)]
+        rs = [(as_[i][0], T.calculate_partial_r(g, as_[i][1], p), (ks[i][1] * as_[i][1] + zs[i][1]) % q) for i in pick]
+        xs_r.append([r_[0] for r_ in rs]); ri.append([int.from_bytes(r_[1], "big") for r_ in rs]); vi.append([r_[2] for r_ in rs])
+        want_r.append(T.calculate_r(rs, p, q))
+        assert want_r[-1] == pow(g, pow(kk, -1, q), p) % q
+    got, st = gpu_ctx.dsa_calculate_r(xs_r, ri, vi, [(p, q)], [0] * len(xs_r), pbytes=128, qbytes=20)
+    assert list(st) == [0] * len(xs_r) and got == want_r
+    # ---- the same shapes, one operation per call
+    b = Batcher(gpu_ctx, max_items=16, n_lanes=2)
+    try:
+        pick = cases[0]
+        assert b.lagrange_combine([s_[0] for s_ in pick], [s_[1] for s_ in pick], m) == (0, 0, secret)
+        assert b.dsa_calculate_r(xs_r[0], ri[0], vi[0], p, q, pbytes=128, qbytes=20) == (0, 0, want_r[0])
+        rc, st_, got1 = b.lagrange_combine(rows[2][0], ys[2], comp)
+        assert (rc, st_, got1) == (0, 1, 0)
+        rc, st_, got1 = b.lagrange_combine(x_huge, [1] * 120, m)
+        assert (rc, st_, got1) == (0, 2, 0)
+    finally:
+        b.close()
