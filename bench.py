@@ -1214,6 +1214,8 @@ def bench_cfg5(args, D):
     n_ctx = max(1, args.inflight)
     ctxs = [ctx] + [Context(D.local_rank) for _ in range(n_ctx - 1)]
     lib, dev = ctx.lib, D.dev
+    for cx in ctxs:         # the corpus deals to n = 10 nodes (x = 1..10, as sss.Distribute numbers them): 10^7 stays within the Lagrange fast path
+        cx._check(lib.bftkv_gpu_set_lagrange_x_bound(cx.h, 10), "set_lagrange_x_bound")
     flat = lambda rows: [v for r in rows for v in r]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # inputs resident in HBM: big-endian numbers as the reference serialises them (big.Int.Bytes, left-padded)

@@ -46,7 +46,7 @@ EXPORTS = [
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
     "bftkv_gpu_collective_verify_small", "bftkv_gpu_signature_verify_small", "bftkv_gpu_set_hash_policy", "bftkv_gpu_signers_fenced",
     "bftkv_gpu_set_host_pipeline", "bftkv_gpu_batcher_cert_verify", "bftkv_gpu_host_pipeline_trace",
-    "bftkv_gpu_batcher_cert_entity", "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r", "bftkv_gpu_batcher_modexp",
+    "bftkv_gpu_batcher_cert_entity", "bftkv_gpu_set_lagrange_x_bound", "bftkv_gpu_batcher_modmul_product", "bftkv_gpu_batcher_lagrange_combine", "bftkv_gpu_batcher_dsa_calculate_r", "bftkv_gpu_batcher_modexp",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_batcher_collective_verify.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p]
     lib.bftkv_gpu_batcher_signature_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, vp, u8p, u8p]
     lib.bftkv_gpu_batcher_cert_verify.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p]
+    lib.bftkv_gpu_set_lagrange_x_bound.argtypes = [vp, u32]
     lib.bftkv_gpu_batcher_cert_entity.argtypes = [vp, C.c_char_p, C.c_uint64, u8p, u8p, vp, u8p, vp, vp, vp, u32, vp]
     lib.bftkv_gpu_batcher_message_verify.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_batcher_stats.argtypes = [vp, C.POINTER(C.c_uint64)]

@@ -131,6 +131,7 @@ struct bftkv_gpu_ctx {
   uint32_t multiexp_lanes = 0;        // experiment knob (BFTKV_MULTIEXP_LANES = 4 | 8): lanes per number in k_multiexp, 0 = by call size
   uint32_t dsa_inv_mode = 0;          // experiment knob (BFTKV_DSA_INV = single | batched): 1 / 2, 0 = by batch shape
   uint32_t n_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  uint32_t lagrange_x_bound = 0;      // bftkv_gpu_set_lagrange_x_bound: device-resident callers promise 0 <= x <= bound (0: no promise)
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
   std::map<std::string, std::array<DevBuf, 4>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes

@@ -452,6 +452,13 @@ int bftkv_gpu_modinv(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, 
 int bftkv_gpu_selftest_reduce(bftkv_gpu_ctx* ctx, uint32_t n_ops, const uint8_t* values, uint32_t nbytes, const uint32_t* mod_idx,
                               uint32_t n_mods, const uint8_t* mods, uint32_t lanes, uint8_t* out);
 
+/* The *_dev forms below cannot look at their x's (they are in HBM), so they always enqueue the big-integer Lagrange kernels
+ * behind the fast path (their grids return at once for operations that did not need them: a few launches per call).  A caller
+ * that KNOWS its share indices -- sss.Distribute hands out x = 1..n (crypto/sss/sss.go:36-44) -- promises 0 <= x <= bound here
+ * and the kernels are enqueued only when bound^(k-1) leaves the fast path's 31 bits.  0 = no promise (the default).  A promise
+ * that does not hold costs nothing but speed: an operation outside the fast path then comes back fenced (status 2). */
+int bftkv_gpu_set_lagrange_x_bound(bftkv_gpu_ctx* ctx, uint32_t bound);
+
 /* The same five with the PER-OPERATION arrays (factors / xs / ys / ri / vi / coeffs / values / mod_idx / outputs / status)
  * already resident in HBM and the results left there: asynchronous on the context's stream until bftkv_gpu_sync.
  * mods / p / q stay HOST pointers (a few hundred bytes per distinct modulus, cached per context by value); mod_idx /

@@ -160,6 +160,20 @@ def test_partial_sign_with_negative_fragments(gpu_ctx):
     assert list(st) == [1, 1, 1, 0, 0] and vals[3] == pow(5, -1, n) and vals[4] == pow(7, -1, n)
 
 
+def bench_needs_big(x):
+    """k_lagrange_inv's rule for one operation: does any term's numerator or denominator leave 31 bits?"""
+    x = [int(v) for v in x]
+    for j in range(len(x)):
+        a = b = 1
+        for i in range(len(x)):
+            if x[i] == x[j]:
+                continue
+            a *= x[i]; b *= x[i] - x[j]
+            if abs(a) >= 1 << 31 or abs(b) >= 1 << 31:
+                return True
+    return False
+
+
 def test_device_resident_entry_points_match_the_host_ones(gpu_ctx):
     """The *_dev forms (inputs already in HBM, results left there, asynchronous until bftkv_gpu_sync) compute what the
     host-pointer forms compute: they share one body, the difference is only who moves the bytes."""
@@ -170,6 +184,7 @@ def test_device_resident_entry_points_match_the_host_ones(gpu_ctx):
     as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
     N = 300
     tc = cb.make_threshold_corpus(N, int(KAT["rsa"]["n"], 16), int(KAT["sss"]["pb"], 16), as_int(g_["p"]), as_int(g_["q"]), seed=77)
+    rng_x = np.random.default_rng(771)
     lib, h = gpu_ctx.lib, gpu_ctx.h
     flat = lambda rows: [v for r in rows for v in r]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
@@ -195,6 +210,27 @@ def test_device_resident_entry_points_match_the_host_ones(gpu_ctx):
         gpu_ctx.sync()
         want = [T.calculate_s(list(zip([int(v) for v in xs[i]], ys[i])), mod) for i in range(N)]
         assert [toi(r) for r in o.cpu().numpy()] == want and not st.cpu().numpy()[:N].any()
+    # The device forms cannot see their x's: without a promise they enqueue the big-integer Lagrange kernels behind the fast path
+    # (above: no-ops); with bftkv_gpu_set_lagrange_x_bound they skip them -- and a promise that does not hold costs a fence, never
+    # a wrong number
+    xs_big = np.ascontiguousarray(np.stack([rng_x.permutation(60)[:8] + 1 for _ in range(N)]).astype(np.int32))
+    ys_big = [[int.from_bytes(rng_x.bytes(40), "big") % tc.dsa_q for _ in range(8)] for _ in range(N)]
+    want_big = [T.calculate_s(list(zip([int(v) for v in xs_big[i]], ys_big[i])), tc.dsa_q) for i in range(N)]
+    mb = _ints_to_be([tc.dsa_q], 32)
+    d_x, d_y = up(xs_big), up(_ints_to_be(flat(ys_big), 32))
+    for bound, ok in ((0, True), (10, False), (60, True), (0, True)):
+        gpu_ctx._check(lib.bftkv_gpu_set_lagrange_x_bound(h, bound), "set_lagrange_x_bound")
+        o = torch.zeros((N, 32), dtype=torch.uint8, device="cuda:0")
+        st = torch.zeros(N + 8, dtype=torch.uint8, device="cuda:0")
+        gpu_ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, 8, P(d_x), P(d_y), 32, None, 1, _ptr(mb), P(o), P(st)), "lagrange_dev")
+        gpu_ctx.sync()
+        stn = st.cpu().numpy()[:N]
+        if ok:
+            assert not stn.any() and [toi(r) for r in o.cpu().numpy()] == want_big, bound
+        else:
+            big = np.array([bench_needs_big(xs_big[i]) for i in range(N)])
+            assert big.sum() > N // 2 and (stn[big] == 2).all() and not stn[~big].any()
+            assert [toi(r) for r, b_ in zip(o.cpu().numpy(), big) if not b_] == [w for w, b_ in zip(want_big, big) if not b_]
     # CalculateR
     o = torch.zeros((N, 32), dtype=torch.uint8, device="cuda:0")
     st = torch.zeros(N + 8, dtype=torch.uint8, device="cuda:0")
