@@ -572,15 +572,24 @@ __device__ __forceinline__ void u256_to_limbs(const U256& a, uint32_t* l) {
     l[j] = (wi < 8) ? ((uint32_t)(v >> sh) & MONT_MASK) : 0u;
   }
 }
+// `gate` / `gate_not`: as k_modinv (the big Lagrange path under a modulus of at most 256 bits: the order q of calculateS and
+// CalculateR); `status` is then a plain byte per operation.
 __global__ void __launch_bounds__(64) k_u256_inv_modq(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,
-                                                      ModTab mt, uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status) {
+                                                      ModTab mt, uint32_t* __restrict__ out_limbs, uint8_t* __restrict__ status,
+                                                      const uint8_t* __restrict__ gate = nullptr, const uint8_t* __restrict__ gate_not = nullptr) {
   const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
   if (op >= n_ops) return;
+  // (u256_modinv_odd votes across the wave: gated-out lanes run it on a harmless value instead of leaving)
+  const bool skip = gate && (!(gate[op] & 2u) || gate_not[op]);
   const U256 q = u256_from_limbs(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N);
-  const U256 v = u256_from_limbs(in_limbs + (uint64_t)op * MONT_N);
+  U256 v = u256_from_limbs(in_limbs + (uint64_t)op * MONT_N);
+  if (skip) { v = u256_zero(); v.w[0] = 1; }
   U256 w = u256_zero();
-  if (u256_is_zero(v) || !u256_modinv_odd(v, q, w)) { atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3))); w = u256_zero(); }
-  u256_to_limbs(w, out_limbs + (uint64_t)op * MONT_N);
+  if (u256_is_zero(v) || !u256_modinv_odd(v, q, w)) {
+    if (gate) { if (!skip) status[op] = 1; } else atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3)));
+    w = u256_zero();
+  }
+  if (!skip) u256_to_limbs(w, out_limbs + (uint64_t)op * MONT_N);
 }
 // thread per op: out = in mod q  (in: 76 limbs, q <= 256 bits)
 __global__ void __launch_bounds__(64) k_limbs_mod_q(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,

@@ -38,6 +38,9 @@ def timed(fn, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ops", type=int, default=10000)
+    ap.add_argument("--nodes", type=int, default=10, help="share indices are drawn from 1..nodes (10: the reference's own parameters)")
+    ap.add_argument("--k", type=int, default=0, help="shares per combine (default: 7 for SSS, 8 for threshold DSA, the reference's); with "
+                    "--nodes 64 --k 22 the Lagrange coefficients leave the 31-bit fast path: the big-integer kernels")
     a = ap.parse_args()
     kat = json.load(open(os.path.join(GOLD, "threshold_kat.json")))
     dsa = json.load(open(os.path.join(GOLD, "keys_dsa2048.json")))
@@ -64,8 +67,8 @@ def main():
     res["rsa_combine_n10"] = {"gpu_ops_per_s": N / dt, "ms": dt * 1e3, "oracle_ops_per_s": 1 / cpu}
 
     # --- SSS calculateSecret k=7 mod the 2048-bit prime (sss.go:69-92) and calculateS 2t=8 mod q (dsa_core.go:389-403)
-    for name, kk, mod, nbytes in (("sss_calculate_secret_k7_2048", 7, pb, 256), ("dsa_calculate_s_2t8_q256", 8, q256, 256)):
-        xs = np.stack([rng.choice(np.arange(1, 11), size=kk, replace=False) for _ in range(N)]).astype(np.int32)
+    for name, kk, mod, nbytes in (("sss_calculate_secret_k%d_2048" % (a.k or 7), a.k or 7, pb, 256), ("dsa_calculate_s_2t%d_q256" % (a.k or 8), a.k or 8, q256, 256)):
+        xs = np.stack([rng.choice(np.arange(1, a.nodes + 1), size=kk, replace=False) for _ in range(N)]).astype(np.int32)
         ys = rand_ints(rng, N * kk, mod)
         y = _ints_to_be(ys, nbytes); m = _ints_to_be([mod], nbytes); out = np.zeros((N, nbytes), dtype=np.uint8); st = np.zeros(N + 8, dtype=np.uint8)
         xs = np.ascontiguousarray(xs)
@@ -79,8 +82,8 @@ def main():
         res[name] = {"gpu_ops_per_s": N / dt, "ms": dt * 1e3, "oracle_ops_per_s": 1 / cpu}
 
     # --- threshold DSA CalculateR over 2t=8 partial r's, 2048/256-bit group (dsa.go:33-52)
-    kk = 8
-    xs = np.ascontiguousarray(np.stack([rng.choice(np.arange(1, 11), size=kk, replace=False) for _ in range(N)]).astype(np.int32))
+    kk = a.k or 8
+    xs = np.ascontiguousarray(np.stack([rng.choice(np.arange(1, a.nodes + 1), size=kk, replace=False) for _ in range(N)]).astype(np.int32))
     ri = rand_ints(rng, N * kk, p2048)
     vi = rand_ints(rng, N * kk, q256)
     r = _ints_to_be(ri, 256); v = _ints_to_be(vi, 32); p = _ints_to_be([p2048], 256); q = _ints_to_be([q256], 32)
@@ -101,7 +104,8 @@ def main():
     for i in range(S2):
         if want[i] is not None:
             assert st[i] == 0 and int.from_bytes(out[i].tobytes(), "big") == want[i]
-    res["dsa_calculate_r_2t8_2048_256"] = {"gpu_ops_per_s": N / dt, "ms": dt * 1e3, "oracle_ops_per_s": 1 / cpu}
+    res["dsa_calculate_r_2t%d_2048_256" % kk] = {"gpu_ops_per_s": N / dt, "ms": dt * 1e3, "oracle_ops_per_s": 1 / cpu}
+    res["nodes"], res["k"] = a.nodes, a.k
     print(json.dumps(res))
 
 
