@@ -231,14 +231,15 @@ def scenarios():
     return out
 
 
-def random_blobs(n: int, seed: int = 7):
-    """Random packet sequences over the building blocks above (fake signature values: the walk's structure only), some with a
-    byte changed afterwards."""
+def random_blobs(n: int, seed: int = 7, real: bool = False):
+    """Random packet sequences over the building blocks above (fake signature values: the walk's structure only -- or, `real`, true
+    signatures, so that entities can come out VALID and the checks ReadEntity makes are decided by arithmetic), some with a byte
+    changed afterwards."""
     import random
     rnd = random.Random(seed)
     a, b, s, s2, d = keys()
     uid, uid2 = a.name.encode(), b"other"
-    fake = dict(fake=True)
+    fake = dict(fake=not real)
     body_of = lambda p: p[2 if p[1] < 192 else 3 if p[1] < 224 else 6:]      # a new-format packet without its header
     blocks = [
         lambda: pkt(6, a.pub_body), lambda: pkt(6, b.pub_body), lambda: pkt(6, d.pub_body),
@@ -274,6 +275,8 @@ def random_blobs(n: int, seed: int = 7):
         seq = [rnd.choice(blocks)() for _ in range(rnd.randrange(1, 12))]
         if rnd.random() < 0.7:
             seq = [pkt(6, a.pub_body), pkt(13, uid), self_sig(a, uid, **fake)] + seq
+        if real and rnd.random() < 0.5:          # (true signatures: keep half of the sequences short enough to come out valid)
+            seq = seq[:3 + rnd.randrange(3)]
         blob = b"".join(seq)
         r = rnd.random()
         if r < 0.25 and blob:
