@@ -1204,8 +1204,13 @@ def bench_cfg5(args, D):
     k0 = json.load(open(os.path.join(gold, "keys_dsa2048.json")))["keys"][0]
     as_int = lambda v: int(v, 16) if isinstance(v, str) else int(v)
     t0 = time.time()
+    # shares per combine: the reference's own parameters (n = 10 nodes: SSS k = 7, threshold DSA 2t = 8) -- or, with --replicas n, a
+    # dealing to n nodes with k = f + 1 = 2t shares (wot.newQC's READ threshold, wotqs.go:36-70), whose Lagrange coefficients leave
+    # the kernels' 31-bit fast path (64 nodes: k = 22); the RSA tree stays at 10 partial signatures
+    n_nodes = args.replicas or 10
+    K_SSS, K_DSA = (7, 8) if n_nodes == 10 else ((n_nodes - 1) // 3 + 1,) * 2
     tc = cb.make_threshold_corpus(N, int(kat["rsa"]["n"], 16), int(kat["sss"]["pb"], 16), as_int(k0["p"]), as_int(k0["q"]),
-                                  seed=cb.MASTER_SEED + D.rank)
+                                  seed=cb.MASTER_SEED + D.rank, n_shares=n_nodes, sss_k=K_SSS, dsa_2t=K_DSA)
     t_corpus = time.time() - t0
     ctx = Context(D.local_rank)
     # CalculateR is a chain of ~900 dependent products per operation: 10,000 operations are 625 waves on 1,024 SIMDs, so ONE step
@@ -1214,8 +1219,8 @@ def bench_cfg5(args, D):
     n_ctx = max(1, args.inflight)
     ctxs = [ctx] + [Context(D.local_rank) for _ in range(n_ctx - 1)]
     lib, dev = ctx.lib, D.dev
-    for cx in ctxs:         # the corpus deals to n = 10 nodes (x = 1..10, as sss.Distribute numbers them): 10^7 stays within the Lagrange fast path
-        cx._check(lib.bftkv_gpu_set_lagrange_x_bound(cx.h, 10), "set_lagrange_x_bound")
+    for cx in ctxs:         # the corpus deals to n nodes (x = 1..n, as sss.Distribute numbers them); n = 10: 10^7 stays within the Lagrange fast path
+        cx._check(lib.bftkv_gpu_set_lagrange_x_bound(cx.h, n_nodes), "set_lagrange_x_bound")
     flat = lambda rows: [v for r in rows for v in r]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # inputs resident in HBM: big-endian numbers as the reference serialises them (big.Int.Bytes, left-padded)
@@ -1246,13 +1251,13 @@ def bench_cfg5(args, D):
         ctx._check(lib.bftkv_gpu_modmul_product_dev(h, N, 10, P(d["rsa_f"]), 256, None, 1, _ptr(m_rsa), P(o["rsa"])), "modmul_product_dev")
         e[1].record(stream)
         # SSS: calculateSecret over k = 7 shares mod the 2048-bit prime (sss.go:69-107)
-        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, 7, P(d["sss_x"]), P(d["sss_y"]), 256, None, 1, _ptr(m_sss), P(o["sss"]), P(o["st_sss"])), "lagrange_dev")
+        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, K_SSS, P(d["sss_x"]), P(d["sss_y"]), 256, None, 1, _ptr(m_sss), P(o["sss"]), P(o["st_sss"])), "lagrange_dev")
         e[2].record(stream)
         # threshold DSA: calculateS over 2t = 8 shares mod q (dsa_core.go:389-403) ...
-        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, 8, P(d["s_x"]), P(d["s_y"]), 32, None, 1, _ptr(m_q), P(o["s"]), P(o["st_s"])), "lagrange_dev")
+        ctx._check(lib.bftkv_gpu_lagrange_combine_dev(h, N, K_DSA, P(d["s_x"]), P(d["s_y"]), 32, None, 1, _ptr(m_q), P(o["s"]), P(o["st_s"])), "lagrange_dev")
         e[3].record(stream)
         # ... and CalculateR over 2t = 8 partial r's (dsa.go:33-52)
-        ctx._check(lib.bftkv_gpu_dsa_calculate_r_dev(h, N, 8, P(d["r_x"]), P(d["r_ri"]), 256, P(d["r_vi"]), 32, None, 1, _ptr(m_p), _ptr(m_q),
+        ctx._check(lib.bftkv_gpu_dsa_calculate_r_dev(h, N, K_DSA, P(d["r_x"]), P(d["r_ri"]), 256, P(d["r_vi"]), 32, None, 1, _ptr(m_p), _ptr(m_q),
                                                      P(o["r"]), P(o["st_r"])), "calculate_r_dev")
         e[4].record(stream)
         return e
@@ -1284,17 +1289,19 @@ def bench_cfg5(args, D):
     single_r_ms = float(np.mean(np.array(spans), axis=0)[3])
     if D.rank == 0:
         sp = np.mean(np.array(spans_timed), axis=0)
-        names = ["rsa_combine_n10", "sss_calculate_secret_k7_2048", "dsa_calculate_s_2t8_q256", "dsa_calculate_r_2t8_2048_256"]
+        names = ["rsa_combine_n10", "sss_calculate_secret_k%d_2048" % K_SSS, "dsa_calculate_s_2t%d_q256" % K_DSA, "dsa_calculate_r_2t%d_2048_256" % K_DSA]
         # dominant: CalculateR.  Algorithmic bytes per op: 2t x (|p| + |q|) in, |q| out
-        alg_r = N * (8 * (256 + 32) + 32)
-        alg_all = N * ((10 + 1) * 256 + (7 + 1) * 256 + 7 * 4 + (8 + 1) * 32 + 8 * 4 + 8 * (256 + 32) + 8 * 4 + 32)
+        alg_r = N * (K_DSA * (256 + 32) + 32)
+        alg_all = N * ((10 + 1) * 256 + (K_SSS + 1) * 256 + K_SSS * 4 + (K_DSA + 1) * 32 + K_DSA * 4 + K_DSA * (256 + 32) + K_DSA * 4 + 32)
         out = base_line(args, D, "threshold_share_combine_ops_per_sec", "ops/s", tot_ops * args.steps / elapsed, elapsed, "u32",
                         "threshold share-combine (cfg5 of BASELINE.json): per step %d operations of each scheme over %d GPU(s) -- RSA calculateSignature "
                         "(product of 10 partial signatures mod the 2048-bit N of rsa/test.pkcs8), SSS calculateSecret (k=7 of n=10, mod the 2048-bit "
                         "prime of sss_test.go), threshold-DSA combine = calculateS (2t=8, 256-bit q) + CalculateR (2t=8, 2048/256-bit group); one "
                         "operation = one scheme-level combine (3 per index); %d independent steps in flight on %d contexts with GPU_MAX_HW_QUEUES=%s "
-                        "(set before the HIP runtime loads: a service must export it itself) -- ONE step at a time is `single_flight`"
-                        % (n_total, D.world, n_ctx, n_ctx, os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")),
+                        "(set before the HIP runtime loads: a service must export it itself) -- ONE step at a time is `single_flight`%s"
+                        % (n_total, D.world, n_ctx, n_ctx, os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
+                           "" if n_nodes == 10 else "; THIS RUN (--replicas %d): dealings to %d nodes, SSS k = %d and threshold DSA 2t = %d shares per "
+                           "combine instead of 7 / 8 -- Lagrange coefficients on exact big integers" % (n_nodes, n_nodes, K_SSS, K_DSA)),
                         {"ops_per_scheme": n_total, "ops_per_scheme_per_gpu": N, "schemes": 3, "steps_in_flight": n_ctx,
                          "parallelism": "shard-by-operation x%d, no exchange step (results go back to the one client that asked)" % D.world},
                         scaling="strong")
@@ -1304,20 +1311,20 @@ def bench_cfg5(args, D):
             "roofline": roofline(5, "k_multiexp", alg_r, float(sp[3]),
                                  "launch span of the CalculateR call (k_lagrange_inv/terms, 2 x k_multiexp, k_u256_inv_modq, k_limbs_mod_q); "
                                  "10k operations are 625 waves: latency-, not bandwidth- or MAC-bound"),
-            "int_mac": int_mac_block(N * macs_per_calculate_r(8, 64), elapsed / args.steps * 1e3, float(sp[3]), None, None, n_ctx),
+            "int_mac": int_mac_block(N * macs_per_calculate_r(K_DSA, 64), elapsed / args.steps * 1e3, float(sp[3]), None, None, n_ctx),
             "int_mac_counts": "CalculateR only (the dominant call): %d limb MACs per operation = 2 x k_multiexp (8 bases then the final "
-                              "power; 4-bit windows over the 64 windows of a 256-bit q: 715 general products and 512 squarings)" % macs_per_calculate_r(8, 64),
+                              "power; 4-bit windows over the 64 windows of a 256-bit q: 715 general products and 512 squarings)" % macs_per_calculate_r(K_DSA, 64),
             "algorithmic_bytes_per_step": alg_all,
             "sustained": sustained,
             "corpus_build_s": t_corpus,
         })
-        sf = int_mac(N * macs_per_calculate_r(8, 64), single_ms)
+        sf = int_mac(N * macs_per_calculate_r(K_DSA, 64), single_ms)
         out["single_flight"] = {"what": "the same step with ONE batch of %d operations per scheme on the device at a time (no steps in flight): "
                                         "what a lone caller of the batched entry points sees" % N,
                                 "steps": n_single, "ms_per_step": single_ms, "value": tot_ops / (single_ms * 1e-3), "unit": "ops/s",
                                 "calculate_r_ms": single_r_ms,
                                 "int_mac": {"achieved": sf["achieved"], "frac": sf["frac"], "frac_of_theoretical": sf["frac_of_theoretical"]}}
-        if D.world == 1 and not args.no_serving:
+        if D.world == 1 and not args.no_serving and n_nodes == 10:      # (the load generator's file layout is the reference's k = 7 / 2t = 8)
             out["serving"] = threshold_serving_leg(tc, res, min(N, 2048))
         if D.world == 1 and not args.no_cpu_baseline:
             # the reference's combine arithmetic restated in C on OpenSSL bignums (oracle/c/threshold.c), threads over operations:
@@ -1347,7 +1354,7 @@ def bench_cfg5(args, D):
                     best = (t4 - t0, nt, (t1 - t0, t2 - t1, t3 - t2, t4 - t3))
             t0 = time.perf_counter()
             S1 = min(N, 500)
-            ct.dsa_calculate_r(tc.r_xs[:S1], h["r_ri"][:S1 * 8], 256, h["r_vi"][:S1 * 8], 32, tc.dsa_p, tc.dsa_q, n_threads=1)
+            ct.dsa_calculate_r(tc.r_xs[:S1], h["r_ri"][:S1 * K_DSA], 256, h["r_vi"][:S1 * K_DSA], 32, tc.dsa_p, tc.dsa_q, n_threads=1)
             t_r1 = (time.perf_counter() - t0) / S1
             ok_r = c_st_r == 0
             same = bool((c_rsa == res["rsa"]).all() and (c_sss == res["sss"]).all() and (c_s == res["s"]).all() and
