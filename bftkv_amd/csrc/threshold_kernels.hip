@@ -655,16 +655,12 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_sss_distribute(uint32_t n_ops_tot
   if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
 }
 
-// ---- modular inverse of up to 2048-bit numbers, odd modulus, by binary extended GCD (thread per op) -------------
-// big.Int.ModInverse inside rsaContext.Sign for negative key fragments (crypto/threshold/rsa/rsa.go:164-167).
-constexpr int INV_W = 68;   // 32-bit words: 2176 bits, headroom for x + n
-struct BigW { uint32_t w[INV_W]; };
-__device__ __forceinline__ bool bw_is_zero(const BigW& a) { uint32_t o = 0; for (int i = 0; i < INV_W; ++i) o |= a.w[i]; return o == 0; }
-__device__ __forceinline__ bool bw_is_one(const BigW& a) { uint32_t o = a.w[0] ^ 1u; for (int i = 1; i < INV_W; ++i) o |= a.w[i]; return o == 0; }
-__device__ __forceinline__ int bw_cmp(const BigW& a, const BigW& b) { int r = 0; for (int i = 0; i < INV_W; ++i) if (a.w[i] != b.w[i]) r = a.w[i] < b.w[i] ? -1 : 1; return r; }
-__device__ __forceinline__ void bw_add(BigW& a, const BigW& b) { uint64_t c = 0; for (int i = 0; i < INV_W; ++i) { c += (uint64_t)a.w[i] + b.w[i]; a.w[i] = (uint32_t)c; c >>= 32; } }
-__device__ __forceinline__ uint32_t bw_sub(BigW& a, const BigW& b) { uint64_t br = 0; for (int i = 0; i < INV_W; ++i) { uint64_t d = (uint64_t)a.w[i] - b.w[i] - br; a.w[i] = (uint32_t)d; br = (d >> 63) & 1; } return (uint32_t)br; }
-__device__ __forceinline__ void bw_shr1(BigW& a) { for (int i = 0; i < INV_W - 1; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 31); a.w[INV_W - 1] >>= 1; }
+// ---- modular inverse of up to 2048-bit numbers, odd modulus, by division steps (thread per op) ------------------
+// big.Int.ModInverse inside rsaContext.Sign for negative key fragments (crypto/threshold/rsa/rsa.go:164-167), and the one inverse
+// per operation of the big Lagrange path.  The arithmetic is safegcd.inc (its header has the algorithm and the step bound; the CPU
+// suite runs the same text against Python's inverse): at most 208 rounds of 30 steps whatever the operands, no reduction loop.
+#define SG_FN __device__
+#include "safegcd.inc"
 
 // `gate` / `gate_not` (the big Lagrange path): only operations whose gate byte has bit 2 set and whose gate_not byte is zero are
 // inverted; `status` is then a plain byte per operation (1 = no inverse), not the packed array of the public entry point.
@@ -674,40 +670,14 @@ __global__ void __launch_bounds__(64) k_modinv(uint32_t n_ops, const uint32_t* _
   const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
   if (op >= n_ops) return;
   if (gate && (!(gate[op] & 2u) || gate_not[op])) return;
-  auto load = [](const uint32_t* l, BigW& o) {
-    for (int i = 0; i < INV_W; ++i) o.w[i] = 0;
-    for (int j = 0; j < MONT_N; ++j) {
-      const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
-      const uint64_t v = (uint64_t)l[j] << sh;
-      o.w[wi] |= (uint32_t)v;
-      if (wi + 1 < INV_W) o.w[wi + 1] |= (uint32_t)(v >> 32);
-    }
-  };
-  BigW u, v, x1, x2, q;
-  load(in_limbs + (uint64_t)op * MONT_N, u);
-  load(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N, q);
-  v = q;
-  while (bw_cmp(u, q) >= 0) bw_sub(u, q);            // ModInverse reduces its argument first (at most a few rounds for < R)
-  for (int i = 0; i < INV_W; ++i) { x1.w[i] = 0; x2.w[i] = 0; }
-  x1.w[0] = 1;
-  bool ok = false, done = false;
-  for (int guard = 0; guard < 2 * 2176 + 8 && !done; ++guard) {
-    if (bw_is_one(u)) { ok = true; done = true; break; }
-    if (bw_is_one(v)) { x1 = x2; ok = true; done = true; break; }
-    if (bw_is_zero(u) || bw_is_zero(v)) { done = true; break; }
-    while (!(u.w[0] & 1u)) { bw_shr1(u); if (x1.w[0] & 1u) bw_add(x1, q); bw_shr1(x1); }
-    while (!(v.w[0] & 1u)) { bw_shr1(v); if (x2.w[0] & 1u) bw_add(x2, q); bw_shr1(x2); }
-    if (bw_cmp(u, v) >= 0) { bw_sub(u, v); if (bw_sub(x1, x2)) bw_add(x1, q); }
-    else { bw_sub(v, u); if (bw_sub(x2, x1)) bw_add(x2, q); }
-  }
+  sg_num x, m, inv;
+  sg_from28(in_limbs + (uint64_t)op * MONT_N, MONT_N, &x);
+  sg_from28(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N, MONT_N, &m);
+  const bool ok = sg_modinv(&x, &m, &inv) != 0;
   if (!ok) { if (gate) status[op] = 1; else atomicOr((unsigned int*)(status + (op & ~3u)), 1u << (8 * (op & 3))); }
   uint32_t* o = out_limbs + (uint64_t)op * MONT_N;
-  for (int j = 0; j < MONT_N; ++j) {
-    const uint32_t bit = 28u * j, wi = bit >> 5, sh = bit & 31;
-    uint64_t w = x1.w[wi];
-    if (wi + 1 < INV_W) w |= (uint64_t)x1.w[wi + 1] << 32;
-    o[j] = ok ? ((uint32_t)(w >> sh) & MONT_MASK) : 0u;
-  }
+  if (ok) sg_to28(&inv, o, MONT_N);
+  else for (int j = 0; j < MONT_N; ++j) o[j] = 0u;
 }
 
 }  // namespace bftkv

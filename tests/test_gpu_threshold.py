@@ -160,6 +160,33 @@ def test_partial_sign_with_negative_fragments(gpu_ctx):
     assert list(st) == [1, 1, 1, 0, 0] and vals[3] == pow(5, -1, n) and vals[4] == pow(7, -1, n)
 
 
+def test_modular_inverse_on_unreduced_arguments_and_moduli_of_every_width(gpu_ctx):
+    """bftkv_gpu_modinv against Python's inverse: arguments far above a small modulus (big.Int.ModInverse reduces them; a
+    subtract-until-smaller loop would never return), every modulus width from 2 bits to 2048, shared factors, modulus 1."""
+    import math
+    import random
+    rng = random.Random(12)
+    mods, vals, idx = [], [], []
+    for bits in (1, 2, 9, 30, 31, 60, 61, 160, 255, 256, 257, 1024, 2047, 2048):
+        for _ in range(6):
+            m = rng.getrandbits(bits) | 1 | (1 << (bits - 1))
+            mods.append(m)
+            for x in (rng.randrange(m), rng.getrandbits(2048), (1 << 2048) - 1, 0, 1, m, m - 1, m + 1, 3 * rng.getrandbits(700)):
+                vals.append(x); idx.append(len(mods) - 1)
+    f = rng.getrandbits(300) | 1
+    mods.append(f * (rng.getrandbits(1700) | 1))
+    for x in (f, f * rng.getrandbits(1000), rng.getrandbits(2048)):
+        vals.append(x); idx.append(len(mods) - 1)
+    got, st = gpu_ctx.modinv(vals, mods, idx)
+    for x, i, g, s in zip(vals, idx, got, st):
+        m = mods[i]
+        if math.gcd(x, m) != 1:
+            assert (int(s), g) == (1, 0), (x, m)
+        else:
+            assert (int(s), g) == (0, pow(x, -1, m)), (x, m)
+    assert 0 in st and 1 in st
+
+
 def bench_needs_big(x):
     """k_lagrange_inv's rule for one operation: does any term's numerator or denominator leave 31 bits?"""
     x = [int(v) for v in x]
