@@ -599,14 +599,15 @@ __global__ void __launch_bounds__(64) k_limbs_mod_q(uint32_t n_ops, const uint32
   const U256 q = u256_from_limbs(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N);
   const uint32_t* v = in_limbs + (uint64_t)op * MONT_N;
   U256 acc = u256_zero();
+  bool q_small = true;
+  for (int i = 1; i < 8; ++i) q_small = q_small && q.w[i] == 0;
   for (int j = MONT_N - 1; j >= 0; --j) {
     for (int k = 0; k < MONT_W; ++k) {
       uint32_t c = u256_shl1(acc);
       if (c || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
     }
     U256 l = u256_zero();
-    l.w[0] = v[j];
-    while (u256_cmp(l, q) >= 0) u256_sub(l, q);
+    l.w[0] = q_small ? v[j] % q.w[0] : v[j];          // (a limb exceeds q only under a modulus of one word: divide, never subtract in a loop)
     u256_addmod(acc, l, q);
   }
   u256_to_limbs(acc, out_limbs + (uint64_t)op * MONT_N);
