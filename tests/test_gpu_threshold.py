@@ -503,6 +503,48 @@ def test_one_op_entries_on_random_shapes_and_unreduced_operands(gpu_ctx):
         b.close()
 
 
+def test_degenerate_moduli_and_operands_return_at_once(gpu_ctx):
+    """Moduli of two, three and nine bits under operands of the full byte width (every reduction divides or runs a fixed number of
+    rounds: none subtracts its way down), zero operands, a single share, an exponent of zero; even and zero moduli are refused per
+    caller.  Answers are Python's."""
+    import time
+    from bftkv_amd import Batcher
+    big = (1 << 2048) - 1
+    b = Batcher(gpu_ctx, max_items=8, max_wait_us=50, n_lanes=1)
+    t0 = time.time()
+    try:
+        for m in (3, 5, 511, 1237):
+            rc, st, got = b.modmul_product([big, big - 2, 1 << 2047], m)
+            assert (rc, st, got) == (0, 0, (big * (big - 2) * (1 << 2047)) % m), m
+            rc, st, got = b.modexp(big, big, m, exp_len=256)
+            assert (rc, st, got) == (0, 0, pow(big, big, m)), m
+            rc, st, got = b.modexp(big, 0, m, exp_len=4)
+            assert (rc, st, got) == (0, 0, 1 % m), m
+            xs, ys = [1, 2, 3], [big, 0, big - 1]
+            rc, st, got = b.lagrange_combine(xs, ys, m)
+            try:
+                want = T.calculate_secret(list(zip(xs, ys)), m)
+            except ValueError:
+                want = None
+            assert (rc, st, got) == ((0, 0, want) if want is not None else (0, 1, 0)), m
+            rc, st, got = b.lagrange_combine([7], [big], m)                      # one share: the secret is that share
+            assert (rc, st, got) == (0, 0, big % m), m
+        p = int(KAT["sss"]["pb"], 16)
+        for q in (3, 5, 1237):
+            xs, ri, vi = [1, 2], [big, p - 1], [q - 1, 1]
+            rc, st, got = b.dsa_calculate_r(xs, ri, vi, p, q, qbytes=2)
+            try:
+                want = T.calculate_r([(x, r.to_bytes(256, "big"), v) for x, r, v in zip(xs, ri, vi)], p, q)
+            except ValueError:
+                want = None
+            assert (rc, st, got) == ((0, 0, want) if want is not None else (0, 1, 0)), q
+        for m in (0, 1, 2, 1 << 2047):                                          # zero, one and even moduli: refused for this caller alone
+            assert b.modmul_product([3, 5], m)[0] != 0 and b.lagrange_combine([1, 2], [3, 4], m)[0] != 0 and b.modexp(3, 5, m)[0] != 0
+    finally:
+        b.close()
+    assert time.time() - t0 < 30
+
+
 def test_lagrange_coefficients_beyond_31_bits(gpu_ctx):
     """sss.Lagrange has no bound on its integers (big.Int); the kernels' fast path holds them in 31 bits -- enough for the
     reference's own n = 10, not for the clusters BASELINE names.  64 and 256 nodes: real dealings recovered through the
