@@ -1,7 +1,8 @@
 """CPU: the Go shim against the C header it binds, statically (there is no Go toolchain in the build image, so the shim has
 never met a compiler).  Every `C.bftkv_*(...)` call in shim/**/*.go must name a function include/bftkv_gpu.h declares and pass
 as many arguments as the prototype takes; every `C.BFTKV_*` constant must be #defined there; every field the shim sets on a
-C struct must be a member of it; braces and parentheses balance; every import of a file is used in it."""
+C struct must be a member of it; braces and parentheses balance; every import of a file is used in it; the C type of every argument
+this reading can type (114 of 116) is the prototype's."""
 import os
 import re
 
@@ -228,3 +229,139 @@ def test_no_variable_is_declared_and_never_used():
             for name in names:
                 if name != "_":
                     assert len(re.findall(r"\b%s\b" % re.escape(name), body)) >= 2, (p, name, body.split("\n")[0])
+
+
+# ---- cgo is strict about argument types: C.uint32_t where the prototype says uint64_t does not compile ------------------------
+def proto_param_types():
+    h = open(os.path.join(ROOT, "include", "bftkv_gpu.h")).read() + open(os.path.join(ROOT, "include", "bftkv_host.h")).read()
+    h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(bftkv_(?:gpu|host)_[a-z_0-9]+)\s*\(([^()]*)\)\s*;", h):
+        params = m.group(2).strip()
+        types = []
+        for p in ([] if params in ("", "void") else split_args(params)):
+            p = re.sub(r"\bconst\b", " ", p).strip()
+            stars = p.count("*")
+            words = p.replace("*", " ").split()
+            base = words[0] if len(words) == 1 else " ".join(words[:-1])       # the last word is the parameter's name
+            types.append(base.replace("struct ", "") + "*" * stars)
+        out[m.group(1)] = types
+    return out
+
+
+def go_c_type(t):
+    """'*C.uint8_t' -> 'uint8_t*', 'C.int' -> 'int', 'unsafe.Pointer' -> 'void*'; None for a Go type."""
+    t = t.strip()
+    if t == "unsafe.Pointer":
+        return "void*"
+    m = re.fullmatch(r"(\**)C\.(\w+)", t)
+    return None if not m else m.group(2) + "*" * len(m.group(1))
+
+
+def package_facts(paths):
+    """Helper functions' return types and struct fields' types of one Go package (only those that are C types)."""
+    funcs, fields = {}, {}
+    for p in paths:
+        src = strip_go(open(p).read())
+        for m in re.finditer(r"^func (?:\([^)]*\) )?(\w+)\(([^)]*)\)\s*([^\s{(][^{]*?)?\s*\{", src, flags=re.M):
+            ret = go_c_type(m.group(3) or "")
+            if ret:
+                funcs[m.group(1)] = ret
+        for m in re.finditer(r"^type \w+ struct \{\n(.*?)^\}", src, flags=re.S | re.M):
+            for ln in m.group(1).split("\n"):
+                f = re.match(r"\s*((?:\w+\s*,\s*)*\w+)\s+(\S+)\s*$", ln)
+                if f and go_c_type(f.group(2)):
+                    for name in f.group(1).split(","):
+                        fields.setdefault(name.strip(), set()).add(go_c_type(f.group(2)))
+    return funcs, fields
+
+
+def local_type(fn_src, name):
+    """The C type of a local variable or parameter `name` of the function whose text (up to the call) is fn_src; None if unknown."""
+    n = re.escape(name)
+    for pat, shape in ((r"\bvar\s+(?:\w+\s*,\s*)*%s(?:\s*,\s*\w+)*\s+(\[\w*\])?(\**C\.\w+|unsafe\.Pointer)" % n, "var"),
+                       (r"\b%s\s*:=\s*make\(\[\](\**C\.\w+)" % n, "slice"),
+                       (r"\b%s\s*:=\s*(C\.\w+)\(" % n, "conv"),
+                       (r"\b%s\s*:=\s*\((\*+C\.\w+)\)\(" % n, "conv"),
+                       (r"[(,]\s*(?:\w+\s*,\s*)*%s(?:\s*,\s*\w+)*\s+(\**C\.\w+|unsafe\.Pointer)\s*[,)]" % n, "param")):
+        m = None
+        for m in re.finditer(pat, fn_src):
+            pass                                                            # the last declaration before the call
+        if m:
+            if shape == "var":
+                return ("array" if m.group(1) else "value"), go_c_type(m.group(2))
+            return ("array" if shape == "slice" else "value"), go_c_type(m.group(1))
+    return None
+
+
+def infer(arg, fn_src, funcs, fields):
+    """The C type of one cgo call argument, or None where this rough reading cannot tell."""
+    arg = arg.strip()
+    m = re.match(r"^(C\.\w+)\(", arg)
+    if m and arg.endswith(")"):
+        return go_c_type(m.group(1))
+    m = re.match(r"^\((\*+C\.\w+)\)\(", arg)
+    if m:
+        return go_c_type(m.group(1))
+    if arg.startswith("unsafe.Pointer("):
+        return "void*"
+    m = re.match(r"^(\w+)\(", arg)
+    if m and arg.endswith(")"):
+        return funcs.get(m.group(1))
+    m = re.fullmatch(r"&(\w+)(\[0\])?", arg)
+    if m:
+        lt = local_type(fn_src, m.group(1))
+        if lt and (lt[0] == "array") == bool(m.group(2)):
+            return lt[1] + "*"
+        if lt is None and not m.group(2) and m.group(1) in fields and len(fields[m.group(1)]) == 1:
+            return next(iter(fields[m.group(1)])) + "*"
+        return None
+    m = re.fullmatch(r"&(?:\w+\.)+(\w+)", arg)
+    if m and len(fields.get(m.group(1), ())) == 1:
+        return next(iter(fields[m.group(1)])) + "*"
+    m = re.fullmatch(r"(?:\w+\.)+(\w+)", arg)
+    if m and len(fields.get(m.group(1), ())) == 1:
+        return next(iter(fields[m.group(1)]))
+    if re.fullmatch(r"\w+", arg) and not arg.isdigit() and arg != "nil":
+        lt = local_type(fn_src, arg)
+        return lt[1] if lt and lt[0] == "value" else None
+    return None
+
+
+INTEGERS = {"int", "uint8_t", "uint16_t", "uint32_t", "uint64_t", "int32_t", "int64_t", "size_t"}
+
+
+def test_c_call_argument_types_match_the_prototypes():
+    """What this reading can type -- conversions C.T(x), casts (*C.T)(p), the package's pointer helpers, &local, &local[0], struct
+    fields holding C handles, parameters -- must be the prototype's type exactly (const aside), as cgo demands; integer literals only
+    where the prototype takes an integer, nil only where it takes a pointer."""
+    protos = proto_param_types()
+    by_dir = {}
+    for p in go_files():
+        by_dir.setdefault(os.path.dirname(p), []).append(p)
+    typed = total = 0
+    for paths in by_dir.values():
+        funcs, fields = package_facts(paths)
+        for path in paths:
+            src = strip_go(open(path).read())
+            for m in re.finditer(r"\bC\.(bftkv_(?:gpu|host)_[a-z_0-9]+)\s*\(", src):
+                name = m.group(1)
+                start = max(src.rfind("\nfunc ", 0, m.start()), 0)
+                fn_src = src[start:m.start()]
+                for i, (arg, want) in enumerate(zip(call_args(src, m.end() - 1), protos[name])):
+                    total += 1
+                    where = "%s: %s argument %d (%s)" % (os.path.relpath(path, ROOT), name, i + 1, arg)
+                    if arg.strip().isdigit():
+                        assert want in INTEGERS, where + ": an integer literal for " + want
+                        typed += 1
+                        continue
+                    if arg.strip() == "nil":
+                        assert want.endswith("*"), where + ": nil for " + want
+                        typed += 1
+                        continue
+                    got = infer(arg, fn_src, funcs, fields)
+                    if got is None:
+                        continue
+                    typed += 1
+                    assert got == want, where + ": passes %s, the prototype takes %s" % (got, want)
+    assert total >= 100 and typed >= 0.9 * total, (typed, total)
