@@ -159,9 +159,11 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
                                                               const uint32_t* __restrict__ a_in, const uint32_t* __restrict__ y_limbs /*[n_ops][k][76] or null*/,
                                                               const uint32_t* __restrict__ mod_idx, ModTab mt,
                                                               uint32_t* __restrict__ lambda_out /*[n_ops][k][76] or null*/,
-                                                              uint32_t* __restrict__ sum_out /*[n_ops][76] or null*/) {
+                                                              uint32_t* __restrict__ sum_out /*[n_ops][76] or null*/,
+                                                              const uint8_t* __restrict__ status /*k_lagrange_inv's: bit 1 = left to the big path*/) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   QUAD_SETUP();
+  if (!__any(active && !(status[op] & 2u))) return;      // every row of this wave is rewritten by k_lagrange_finish (64 nodes: all of them)
   const uint32_t mi = mod_idx[op];
   uint32_t n[L], r2[L], acc[L], t[L], u[L];
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
 //   k_modinv           D^-1 mod m -- ONE big inverse per operation (Montgomery's trick).  The reference inverts every b_j
 //                      (ModInverse returns nil for one without inverse and the next Mul dereferences it): all b_j are
 //                      invertible exactly when their product is, so "no inverse" is the same outcome for the operation
-//   k_lagrange_finish  quad / op: lambda_j = +-a_j Pre_j Suf_j D^-1 mod m (Suf_j = B_(j+1) ... B_(k-1), built backwards),
+//   k_lagrange_finish  quad / op: lambda_j = a_j Pre_j Suf_j (+-D^-1) mod m (Suf_j = B_(j+1) ... B_(k-1), built backwards),
 //                      written out and / or folded into S = sum_j lambda_j y_j mod m; sets the operation's final status
 __device__ __forceinline__ bool limbs_mul_small(uint32_t* v, uint32_t& len, uint64_t f) {      // v *= f (f < 2^32); false: beyond 76 limbs
   uint64_t carry = 0;
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(64) k_lagrange_big(uint32_t n_ops, uint32_t k_
   sign[t] = neg ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_prep(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ b_big, const uint8_t* __restrict__ status,
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_prep(uint32_t n_ops, uint32_t k_shares, uint32_t* __restrict__ b_big /*in: b_j; out: B_j*/, const uint8_t* __restrict__ status,
                                                              const uint8_t* __restrict__ big_st, const uint32_t* __restrict__ mod_idx, ModTab mt,
                                                              uint32_t* __restrict__ pre /*[n_ops][k][76], Montgomery form*/, uint32_t* __restrict__ d_plain /*[n_ops][76]*/) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
@@ -294,10 +296,14 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_prep(uint32_t n_ops, uin
 #pragma unroll
       for (int k = 0; k < L; ++k) pre[sj * MONT_N + qlane * L + k] = acc[k];
     }
-    const uint32_t* bp = b_big + sj * MONT_N + qlane * L;
+    uint32_t* bp = b_big + sj * MONT_N + qlane * L;
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = mine ? bp[k] : 0u;
-    MONT(t, r2);                                                     // B_j = b_j R
+    MONT(t, r2);                                                     // B_j = b_j R, kept for k_lagrange_finish's suffix products
+    if (mine) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) bp[k] = t[k];
+    }
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = t[k];
     MONT(t, acc);                                                    // Pre_(j+1)
@@ -311,8 +317,13 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_prep(uint32_t n_ops, uin
   if (mine) store_mod_result(d_plain + (uint64_t)op * MONT_N + qlane * L, t, n, qlane);
 }
 
-__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_finish(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ a_big, const uint32_t* __restrict__ b_big,
-                                                               const uint8_t* __restrict__ sign, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ d_inv /*[n_ops][76] plain*/,
+// Products per term: a_j (plain, exact) * Pre_j R -> plain; * Suf_j R -> plain; * (+-D^-1) R^2 -> lambda_j R; then lambda_j R * y_j
+// -> a term of the sum, lambda_j R * 1 -> lambda_j; Suf_(j-1) R = B_j * Suf_j R.  The sign rides on the inverse: the operation's two
+// scratch rows hold D^-1 R^2 and -D^-1 R^2 (`d_inv` in: D^-1 plain; both rows are rewritten here and read back by the lanes that
+// wrote them).  Five or six products per term where the first form took nine or ten.
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_finish(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ a_big, const uint32_t* __restrict__ bt_big /*B_j = b_j R*/,
+                                                               const uint8_t* __restrict__ sign, const uint32_t* __restrict__ pre, uint32_t* d_inv /*[n_ops][76]*/,
+                                                               uint32_t* d_neg /*[n_ops][76] scratch*/,
                                                                const uint8_t* __restrict__ inv_st /*[n_ops]: 1 = D has no inverse*/, const uint8_t* __restrict__ big_st,
                                                                const uint32_t* __restrict__ y_limbs, const uint32_t* __restrict__ mod_idx, ModTab mt,
                                                                uint32_t* __restrict__ lambda_out, uint32_t* __restrict__ sum_out, uint8_t* __restrict__ status) {
@@ -323,46 +334,52 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_finish(uint32_t n_ops, u
   const uint8_t bad = flagged ? (big_st[op] ? 2 : (inv_st[op] ? 1 : 0)) : 0;
   const bool mine = flagged && !bad;
   const uint32_t mi = mod_idx[op];
-  uint32_t n[L], r2[L], di[L], suf[L], acc[L], t[L], u[L];
+  const uint64_t row = (uint64_t)op * MONT_N + qlane * L;
+  uint32_t n[L], suf[L], acc[L], t[L], u[L];
 #pragma unroll
-  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; acc[k] = 0; }
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; u[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
   const uint32_t n0inv = mt.n0inv[mi];
 #pragma unroll
-  for (int k = 0; k < L; ++k) a_lds[k] = mine ? d_inv[(uint64_t)op * MONT_N + qlane * L + k] : 0u;
-  MONT(di, r2);                                                      // D^-1 R
+  for (int k = 0; k < L; ++k) a_lds[k] = mine ? d_inv[row + k] : 0u;
+  MONT(t, u);                                                        // D^-1 R
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+  MONT(suf, u);                                                      // D^-1 R^2
+  // m - 1 = -1 (m is odd: m - 1 is m with its lowest bit cleared)
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = n[k] & ~((qlane == 0 && k == 0) ? 1u : 0u);
+  MONT(t, u);                                                        // (m - 1) R
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = suf[k];
+  MONT(acc, t);                                                      // -D^-1 R^2
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) { d_inv[row + k] = suf[k]; d_neg[row + k] = acc[k]; }
+  }
 #pragma unroll
   for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-  MONT(suf, r2);                                                     // R mod m
+  MONT(suf, u);                                                      // R mod m: the empty suffix product
+#pragma unroll
+  for (int k = 0; k < L; ++k) acc[k] = 0;
   for (uint32_t jj = 0; jj < k_shares; ++jj) {
     const uint32_t j = k_shares - 1 - jj;
     const uint64_t sj = (uint64_t)op * k_shares + j;
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = mine ? a_big[sj * MONT_N + qlane * L + k] : 0u;
-    MONT(t, r2);                                                     // |a_j| R
-#pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = mine ? pre[sj * MONT_N + qlane * L + k] : 0u;
-    MONT(u, t);                                                      // |a_j| Pre_j R
-#pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = u[k];
-    MONT(t, suf);                                                    // ... Suf_j
+    for (int k = 0; k < L; ++k) { a_lds[k] = mine ? a_big[sj * MONT_N + qlane * L + k] : 0u; u[k] = mine ? pre[sj * MONT_N + qlane * L + k] : 0u; }
+    MONT(t, u);                                                      // |a_j| Pre_j          (< 3m: |a_j| < R)
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = t[k];
-    MONT(u, di);                                                     // |lambda_j| R
-    // leave the domain WITH the sign: times 1, or times m - 1 = -1 (m is odd: m - 1 is m with its lowest bit cleared)
-    const bool neg = mine && sign[sj];
+    MONT(u, suf);                                                    // |a_j| Pre_j Suf_j
+    const uint32_t* dsel = (mine && sign[sj]) ? d_neg : d_inv;
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = neg ? (n[k] & ~((qlane == 0 && k == 0) ? 1u : 0u)) : ((qlane == 0 && k == 0) ? 1u : 0u);
-    MONT(t, u);                                                      // lambda_j, plain, < 2m
-#pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
-    MONT(u, r2);                                                     // lambda_j R
+    for (int k = 0; k < L; ++k) { a_lds[k] = u[k]; t[k] = mine ? dsel[row + k] : 0u; }
+    MONT(u, t);                                                      // lambda_j R, sign included
     if (lambda_out) {
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-      uint32_t c[L];
-      MONT(c, u);
-      canonicalize(c, qlane);
-      if (mine) store_mod_result(lambda_out + sj * MONT_N + qlane * L, c, n, qlane);
+      MONT(t, u);
+      canonicalize(t, qlane);
+      if (mine) store_mod_result(lambda_out + sj * MONT_N + qlane * L, t, n, qlane);
     }
     if (sum_out) {
 #pragma unroll
@@ -372,20 +389,17 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_finish(uint32_t n_ops, u
       for (int k = 0; k < L; ++k) acc[k] += t[k];
       canonicalize(acc, qlane);
     }
-    // Suf_(j-1) = Suf_j B_j
+    // Suf_(j-1) = B_j Suf_j
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = mine ? b_big[sj * MONT_N + qlane * L + k] : 0u;
-    MONT(t, r2);
-#pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = t[k];
+    for (int k = 0; k < L; ++k) a_lds[k] = mine ? bt_big[sj * MONT_N + qlane * L + k] : 0u;
     MONT(t, suf);
 #pragma unroll
     for (int k = 0; k < L; ++k) suf[k] = t[k];
   }
   if (sum_out) {
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = acc[k];
-    MONT(t, r2);
+    for (int k = 0; k < L; ++k) { a_lds[k] = acc[k]; u[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+    MONT(t, u);
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
     MONT(u, t);

@@ -538,6 +538,16 @@ def test_degenerate_moduli_and_operands_return_at_once(gpu_ctx):
             except ValueError:
                 want = None
             assert (rc, st, got) == ((0, 0, want) if want is not None else (0, 1, 0)), q
+        # share indices at the ends of int32 (differences of 2^32 - 1), and an index of zero (its product is 0 for every other term)
+        for xs in ([-(1 << 31), (1 << 31) - 1, 5], [0, 3, -7, (1 << 31) - 1], [-(1 << 31), -(1 << 31) + 1]):
+            for m in (p, 1237, (1 << 255) - 19):
+                ys = [big % m, 1, m - 1, 12345][:len(xs)]
+                rc, st, got = b.lagrange_combine(xs, ys, m)
+                try:
+                    want = T.calculate_secret(list(zip(xs, ys)), m)
+                except ValueError:
+                    want = None
+                assert (rc, st, got) == ((0, 0, want) if want is not None else (0, 1, 0)), (xs, m)
         for m in (0, 1, 2, 1 << 2047):                                          # zero, one and even moduli: refused for this caller alone
             assert b.modmul_product([3, 5], m)[0] != 0 and b.lagrange_combine([1, 2], [3, 4], m)[0] != 0 and b.modexp(3, 5, m)[0] != 0
     finally:
