@@ -97,7 +97,7 @@ __device__ __forceinline__ int64_t egcd_inv64(int64_t a, int64_t m) {   // a^-1 
 
 __global__ void __launch_bounds__(64) k_lagrange_inv(uint32_t n_ops, uint32_t k_shares, const int32_t* __restrict__ xs /*[n_ops][k]*/,
                                                      const uint32_t* __restrict__ mod_idx, ModTab mt,
-                                                     uint32_t* __restrict__ inv_limbs /*[n_ops][k][76]*/, uint32_t* __restrict__ a_out /*[n_ops][k]*/,
+                                                     uint32_t* __restrict__ inv_limbs /*[n_ops][k][76]: a_j * (b_j^-1 mod m), an exact integer below 2^31 m*/,
                                                      uint8_t* __restrict__ status /*[n_ops]*/) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_ops * k_shares) return;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) k_lagrange_inv(uint32_t n_ops, uint32_t k_
     tinv = egcd_inv64((int64_t)r, ab);
     if (tinv < 0) st = 1;
   }
-  if (st) { atomicOr((unsigned int*)(status + (op & ~3u)), (unsigned int)st << (8 * (op & 3))); for (int i = 0; i < MONT_N; ++i) out[i] = 0; a_out[t] = 0; return; }
+  if (st) { atomicOr((unsigned int*)(status + (op & ~3u)), (unsigned int)st << (8 * (op & 3))); for (int i = 0; i < MONT_N; ++i) out[i] = 0; return; }
   if (ab == 1) {
     for (int i = 0; i < MONT_N; ++i) out[i] = (i == 0) ? 1u : 0u;
   } else {
@@ -151,12 +151,16 @@ __global__ void __launch_bounds__(64) k_lagrange_inv(uint32_t n_ops, uint32_t k_
       out[i] = (uint32_t)(v + (borrow << MONT_W)) & MONT_MASK;
     }
   }
-  a_out[t] = (uint32_t)a;
+  // times a_j (0 <= a_j < 2^31) as an integer: below 2^31 m < R, so k_lagrange_terms takes it as the plain operand of a product and
+  // the reduction happens there (one Montgomery product per term saved, two where the coefficients are written out)
+  uint64_t carry = 0;
+  for (int i = 0; i < MONT_N; ++i) { const uint64_t v = (uint64_t)out[i] * (uint64_t)a + carry; out[i] = (uint32_t)v & MONT_MASK; carry = v >> MONT_W; }
 }
 
-// Per op (quad): lambda_j = a_j * inv_j mod m (optionally written out), S = sum_j lambda_j * y_j mod m.
-__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ inv_limbs,
-                                                              const uint32_t* __restrict__ a_in, const uint32_t* __restrict__ y_limbs /*[n_ops][k][76] or null*/,
+// Per op (quad): lambda_j = (a_j inv_j) mod m (optionally written out), S = sum_j lambda_j * y_j mod m.  Two products per term
+// (the exact integer a_j inv_j into the domain, times y_j), three where the coefficients are written out.
+__global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, uint32_t k_shares, const uint32_t* __restrict__ ainv_limbs,
+                                                              const uint32_t* __restrict__ y_limbs /*[n_ops][k][76] or null*/,
                                                               const uint32_t* __restrict__ mod_idx, ModTab mt,
                                                               uint32_t* __restrict__ lambda_out /*[n_ops][k][76] or null*/,
                                                               uint32_t* __restrict__ sum_out /*[n_ops][76] or null*/,
@@ -171,36 +175,24 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
   const uint32_t n0inv = mt.n0inv[mi];
   for (uint32_t j = 0; j < k_shares; ++j) {
     const uint64_t sj = (uint64_t)op * k_shares + j;
-    const uint32_t* ip = inv_limbs + sj * MONT_N + qlane * L;
-    const uint32_t av = a_in[sj];
+    const uint32_t* ip = ainv_limbs + sj * MONT_N + qlane * L;
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = ip[k];
-    MONT(t, r2);                                                     // inv * R
-#pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0) ? (k == 0 ? (av & MONT_MASK) : (k == 1 ? (av >> MONT_W) : 0u)) : 0u;
-    MONT(u, t);                                                      // lambda = a * inv (plain, < 2m)
+    MONT(u, r2);                                                     // lambda_j R  (a_j inv_j < 2^31 m: the result is below m(1 + 2^-49))
     if (lambda_out) {
-      // canonical value below m: one more round trip through the Montgomery domain
-#pragma unroll
-      for (int k = 0; k < L; ++k) a_lds[k] = u[k];
-      MONT(t, r2);
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
-      uint32_t c[L];
-      MONT(c, t);
-      canonicalize(c, qlane);
-      if (active) store_mod_result(lambda_out + sj * MONT_N + qlane * L, c, n, qlane);
+      MONT(t, u);                                                    // lambda_j, plain
+      canonicalize(t, qlane);
+      if (active) store_mod_result(lambda_out + sj * MONT_N + qlane * L, t, n, qlane);
     }
     if (sum_out) {
       const uint32_t* yp = y_limbs + sj * MONT_N + qlane * L;
 #pragma unroll
-      for (int k = 0; k < L; ++k) a_lds[k] = u[k];
-      MONT(t, r2);                                                   // lambda * R
-#pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = yp[k];
-      MONT(u, t);                                                    // lambda * y (plain, < 2m)
+      MONT(t, u);                                                    // lambda_j * y_j (plain, < 2m)
 #pragma unroll
-      for (int k = 0; k < L; ++k) acc[k] += u[k];
+      for (int k = 0; k < L; ++k) acc[k] += t[k];
       canonicalize(acc, qlane);
     }
   }
