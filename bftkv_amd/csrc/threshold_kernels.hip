@@ -597,26 +597,26 @@ __global__ void __launch_bounds__(64) k_u256_inv_modq(uint32_t n_ops, const uint
   }
   if (!skip) u256_to_limbs(w, out_limbs + (uint64_t)op * MONT_N);
 }
-// thread per op: out = in mod q  (in: 76 limbs, q <= 256 bits)
-__global__ void __launch_bounds__(64) k_limbs_mod_q(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,
-                                                    ModTab mt, uint32_t* __restrict__ out_limbs) {
-  const uint32_t op = blockIdx.x * blockDim.x + threadIdx.x;
-  if (op >= n_ops) return;
-  const U256 q = u256_from_limbs(mt.n_limbs + (uint64_t)mod_idx[op] * MONT_N);
-  const uint32_t* v = in_limbs + (uint64_t)op * MONT_N;
-  U256 acc = u256_zero();
-  bool q_small = true;
-  for (int i = 1; i < 8; ++i) q_small = q_small && q.w[i] == 0;
-  for (int j = MONT_N - 1; j >= 0; --j) {
-    for (int k = 0; k < MONT_W; ++k) {
-      uint32_t c = u256_shl1(acc);
-      if (c || u256_cmp(acc, q) >= 0) u256_sub(acc, q);
-    }
-    U256 l = u256_zero();
-    l.w[0] = q_small ? v[j] % q.w[0] : v[j];          // (a limb exceeds q only under a modulus of one word: divide, never subtract in a loop)
-    u256_addmod(acc, l, q);
-  }
-  u256_to_limbs(acc, out_limbs + (uint64_t)op * MONT_N);
+// quad per op: out = in mod q (in: 76 limbs below R, q: the modulus of `mt` -- the order of CalculateR's group).  Two products of the
+// multiplier that is already here (in * R mod q, then out of the domain): ~450 instructions per operation and a chain of two
+// products per wave, where a thread per operation shifting 2128 bits through 256-bit compares took 85,000 instructions in a row.
+__global__ void __launch_bounds__(RSA_BLOCK) k_limbs_mod_q(uint32_t n_ops, const uint32_t* __restrict__ in_limbs, const uint32_t* __restrict__ mod_idx,
+                                                           ModTab mt, uint32_t* __restrict__ out_limbs) {
+  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
+  QUAD_SETUP();
+  const uint32_t mi = mod_idx[op];
+  uint32_t n[L], r2[L], t[L], u[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { n[k] = mt.n_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; r2[k] = mt.r2_limbs[(uint64_t)mi * MONT_N + qlane * L + k]; }
+  const uint32_t n0inv = mt.n0inv[mi];
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = in_limbs[(uint64_t)op * MONT_N + qlane * L + k];
+  MONT(t, r2);                                                       // in * R mod q (< 2q)
+#pragma unroll
+  for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
+  MONT(u, t);
+  canonicalize(u, qlane);
+  if (active) store_mod_result(out_limbs + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
 }
 
 }  // namespace bftkv
