@@ -21,14 +21,14 @@ typedef struct {
 } corpus;
 
 typedef struct {
-  bftkv_gpu_batcher* b; int qh; const corpus* c; int tid, n_threads; double seconds; volatile int* stop;
+  bftkv_gpu_batcher* b; int qh; const corpus* c; int tid, n_threads; double seconds; int* stop;
   uint64_t calls, wrong; double* lat; uint64_t lat_cap, lat_skip;
 } worker;
 
 static void* run(void* p) {
   worker* w = (worker*)p;
   uint32_t i = (uint32_t)w->tid;
-  while (!*w->stop) {
+  while (!__atomic_load_n(w->stop, __ATOMIC_RELAXED)) {
     const uint32_t k = i % w->c->n_items;
     uint8_t err = 0xEE, fenced = 0;
     const double t0 = now_s();
@@ -37,7 +37,7 @@ static void* run(void* p) {
     const double dt = now_s() - t0;
     if (rc != 0 || fenced || (err == 0) != (w->c->want_ok[k] != 0)) ++w->wrong;
     if (w->calls < w->lat_cap) w->lat[w->calls] = dt;       /* (the warm-up's samples are dropped at the end) */
-    ++w->calls;
+    __atomic_store_n(&w->calls, w->calls + 1, __ATOMIC_RELAXED);     /* (main samples it at the end of the warm-up) */
     i += (uint32_t)w->n_threads;
   }
   return NULL;
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
          (unsigned long long)st0[3], c.n_items, n_keys);
   for (unsigned s = 0; s < n_sweep; ++s) {
     const int T = sweep[s];
-    volatile int stop = 0;
+    int stop = 0;
     worker* ws = calloc((size_t)T, sizeof *ws);
     pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
     for (int t = 0; t < T; ++t) {
@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     struct timespec warm = {0, 700000000};
     nanosleep(&warm, NULL);
     uint64_t base_calls = 0;
-    for (int t = 0; t < T; ++t) { ws[t].lat_skip = ws[t].calls; base_calls += ws[t].calls; }
+    for (int t = 0; t < T; ++t) { ws[t].lat_skip = __atomic_load_n(&ws[t].calls, __ATOMIC_RELAXED); base_calls += ws[t].lat_skip; }
     struct rusage ru0, ru1;
     getrusage(RUSAGE_SELF, &ru0);
     uint64_t tm0[8] = {0}, tm1[8] = {0}, stw[4] = {0, 0, 0, 0};
@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
     const double t0 = now_s();
     struct timespec nap = {2, 0};
     nanosleep(&nap, NULL);
-    stop = 1;
+    __atomic_store_n(&stop, 1, __ATOMIC_RELAXED);
     const double dt = now_s() - t0;
     for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
     getrusage(RUSAGE_SELF, &ru1);

@@ -28,7 +28,7 @@ typedef struct {
 } ops;
 
 typedef struct {
-  bftkv_gpu_batcher* b; const ops* o; int kind, tid, n_threads; volatile int* stop;
+  bftkv_gpu_batcher* b; const ops* o; int kind, tid, n_threads; int* stop;
   uint64_t calls, wrong; double* lat; uint64_t lat_cap, lat_skip;
 } worker;
 
@@ -56,7 +56,7 @@ static int one(bftkv_gpu_batcher* b, const ops* o, int kind, uint32_t i) {
 static void* run(void* p) {
   worker* w = (worker*)p;
   uint32_t i = (uint32_t)w->tid;
-  while (!*w->stop) {
+  while (!__atomic_load_n(w->stop, __ATOMIC_RELAXED)) {
     const uint32_t k = i % w->o->n;
     /* the mix: a DistSign of every algorithm in turn -- RSA ends in one product, threshold DSA in one CalculateR and one calculateS */
     const int kind = w->kind != K_MIX ? w->kind : (int)((i / (uint32_t)w->n_threads) % 3 == 0 ? K_RSA : (i / (uint32_t)w->n_threads) % 3 == 1 ? K_R : K_S);
@@ -65,7 +65,7 @@ static void* run(void* p) {
     const double dt = now_s() - t0;
     if (!ok) ++w->wrong;
     if (w->calls < w->lat_cap) w->lat[w->calls] = dt;
-    ++w->calls;
+    __atomic_store_n(&w->calls, w->calls + 1, __ATOMIC_RELAXED);     /* (main samples it at the end of the warm-up) */
     i += (uint32_t)w->n_threads;
   }
   return NULL;
@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
   for (int kind = 0; kind < N_KINDS; ++kind) {
     for (unsigned s = 0; s < n_sweep; ++s) {
       const int T = sweep[s];
-      volatile int stop = 0;
+      int stop = 0;
       worker* ws = calloc((size_t)T, sizeof *ws);
       pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
       for (int t = 0; t < T; ++t) {
@@ -124,13 +124,13 @@ int main(int argc, char** argv) {
       struct timespec warm = {0, 300000000};
       nanosleep(&warm, NULL);
       uint64_t base_calls = 0;
-      for (int t = 0; t < T; ++t) { ws[t].lat_skip = ws[t].calls; base_calls += ws[t].calls; }
+      for (int t = 0; t < T; ++t) { ws[t].lat_skip = __atomic_load_n(&ws[t].calls, __ATOMIC_RELAXED); base_calls += ws[t].lat_skip; }
       uint64_t stw[4] = {0, 0, 0, 0};
       bftkv_gpu_batcher_stats(b, stw);
       const double t0 = now_s();
       struct timespec nap = {(time_t)seconds, (long)((seconds - (double)(time_t)seconds) * 1e9)};
       nanosleep(&nap, NULL);
-      stop = 1;
+      __atomic_store_n(&stop, 1, __ATOMIC_RELAXED);
       for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
       const double dt = now_s() - t0;      /* (includes the last calls in flight: they are counted) */
       uint64_t calls = 0, wrong = 0, nl = 0;
