@@ -8,7 +8,8 @@
 # 2. csrc/capi.hip compiled for the host only with -fsanitize=thread and linked against it;
 # 3. tools/serving/batcher_load.c (1..256 callers of one entry) and tools/fakehip/stress.c (every batcher entry, host-buffer calls on
 #    forks and a keyring / quorum writer at once) run on a corpus whose signatures nobody checks.
-# Exit status 0 = every call returned, nothing failed open, and TSan printed no report.
+# Exit status 0 = every call returned, nothing failed open, and TSan printed no report.  BFTKV_TSAN_QUICK=1: the mixed stress run
+# alone (tests/test_host_concurrency.py runs that form in the CPU suite).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 S=${1:-/tmp/bftkv_tsan}; SECS=${2:-20}
@@ -46,9 +47,14 @@ with open(sys.argv[2], "wb") as fh:
 PY
 python "$R/tools/fakehip/make_extras.py" "$S/extras.bin"
 export LD_LIBRARY_PATH=$RTD:$S TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1"
-./batcher_load load.bin 256 200 4 1,8,64,256 > load.out 2> load.err || true
-./stress load.bin extras.bin "$SECS" 8 3 1000 > stress.out 2> stress.err || { echo "stress: a call failed open or did not return"; cat stress.out; exit 1; }
-./stress load.bin extras.bin "$SECS" 8 1 0 > stress_1lane.out 2> stress_1lane.err || { echo "stress (one lane): failed"; cat stress_1lane.out; exit 1; }
+CALLERS=8; PAUSE=1000
+if [ -n "$BFTKV_TSAN_QUICK" ]; then CALLERS=4; PAUSE=400; fi
+: > load.err; : > stress_1lane.err; : > stress_1lane.out
+if [ -z "$BFTKV_TSAN_QUICK" ]; then
+  ./batcher_load load.bin 256 200 4 1,8,64,256 > load.out 2> load.err || true
+  ./stress load.bin extras.bin "$SECS" 8 1 0 > stress_1lane.out 2> stress_1lane.err || { echo "stress (one lane): failed"; cat stress_1lane.out; exit 1; }
+fi
+./stress load.bin extras.bin "$SECS" $CALLERS 3 $PAUSE > stress.out 2> stress.err || { echo "stress: a call failed open or did not return"; cat stress.out; exit 1; }
 cat stress.out stress_1lane.out
 REPORTS=$(grep -h "SUMMARY: ThreadSanitizer" load.err stress.err stress_1lane.err | sort | uniq -c || true)
 if [ -n "$REPORTS" ]; then echo "$REPORTS"; echo "ThreadSanitizer reports above (full text in $S/*.err)"; exit 1; fi
