@@ -39,6 +39,9 @@ using namespace bftkv;
 
 namespace {
 
+// results to the caller's arrays: memcpy's pointers must be valid even for n = 0, and an empty vector's data() may be null
+inline void copy_out(void* dst, const void* src, size_t n) { if (n) memcpy(dst, src, n); }
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -1178,7 +1181,7 @@ int bftkv_gpu_host_pipeline_trace(bftkv_gpu_ctx* c, float* out, uint32_t cap, ui
   if (!c || !n_out) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   *n_out = (uint32_t)c->hb_trace.size();
-  if (out) memcpy(out, c->hb_trace.data(), sizeof(float) * std::min<size_t>(cap, c->hb_trace.size()));
+  if (out) copy_out(out, c->hb_trace.data(), sizeof(float) * std::min<size_t>(cap, c->hb_trace.size()));
   return 0;
 }
 

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                     reason="needs hipcc and clang's ThreadSanitizer runtime")
 def test_every_batcher_entry_under_thread_sanitizer(tmp_path):
     env = dict(os.environ, BFTKV_TSAN_QUICK="1")
+    env.pop("LD_PRELOAD", None)        # (tools/sanitize_host.sh runs this suite under another sanitizer's runtime)
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan_host.sh"), str(tmp_path), "4"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "ThreadSanitizer: no report" in r.stdout
