@@ -635,7 +635,9 @@ class Batcher:
     def stats(self):
         st = (C.c_uint64 * 4)()
         self.lib.bftkv_gpu_batcher_stats(self.h, st)
-        return {"calls": st[0], "batches": st[1], "max_batch": st[2], "lanes": st[3]}
+        ns = (C.c_uint64 * 8)()
+        self.lib.bftkv_gpu_batcher_times(self.h, ns)
+        return {"calls": st[0], "batches": st[1], "max_batch": st[2], "lanes": st[3], "cert_fast": ns[7]}
 
 
 def _ints_to_be(vals, nbytes: int) -> np.ndarray:

@@ -117,6 +117,18 @@ struct bftkv_gpu_ctx {
   uint64_t ring_epoch = 0, dsa_ring_epoch_seen = ~0ull;   // bftkv_gpu_keyring_set calls / the one the window width was chosen for
   uint32_t dsa_wbits_want = 0;
   uint64_t cert_clock = 0;     // compound calls over request certificates (host_capi.inc cert_cache_gc)
+  // Request certificates whose ReadEntity verdict is "valid" (cert_signature_core), by their bytes: a later request of the same
+  // client is then ONE staged signature verification on a lane of the micro-batcher (batcher_capi.inc) instead of a compound call
+  // on the root under its lock.  cert_fast_mu guards the map (a leaf lock).  A hit names the certificate's GROUP; the group's
+  // entity index in the uploaded table is read from kt_group_ent, which -- like kt_cert_epoch -- changes only under KtWrite
+  // (upload_key_table), i.e. never during a fork's device call.  cert_epoch (under mu) counts the times the certificate rows
+  // were dropped and the groups renumbered.
+  struct CertFast { uint64_t issuer_id; int group; uint64_t epoch; };
+  std::mutex cert_fast_mu;
+  std::unordered_map<std::string, CertFast> cert_fast;
+  size_t cert_fast_bytes = 0;
+  uint64_t cert_epoch = 0, kt_cert_epoch = 0;
+  std::vector<uint32_t> kt_group_ent;
   KeyTableDev kt{};
 
   std::vector<QuorumHost> quorums;
@@ -939,6 +951,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   // certificate entities: one entity index per distinct certificate (cert_group), never merged with the keyring's
   int last_group = -1;
   uint32_t group_ent = 0;
+  std::vector<uint32_t> group_ents;         // certificate group -> entity index (kt_group_ent)
   for (auto& e : c->certs) {
     if (e.cert_group != last_group) { group_ent = add(e, true); last_group = e.cert_group; }
     else {
@@ -950,6 +963,10 @@ int upload_key_table(bftkv_gpu_ctx* c) {
       rows.push_back(&e);
     }
     const_cast<KeyEntry&>(e).entity_index = group_ent;
+    if (e.cert_group >= 0) {
+      if (group_ents.size() <= (size_t)e.cert_group) group_ents.resize((size_t)e.cert_group + 1, 0xFFFFFFFEu);
+      group_ents[(size_t)e.cert_group] = group_ent;
+    }
   }
   // issuer lookup index: ids ascending, ties in table order (std::stable_sort over row numbers)
   std::vector<uint32_t> sorted_slot(key_id.size());
@@ -1006,6 +1023,8 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->kt.dsa_slot = c->k_dsaslot.as<uint32_t>();
   c->kt.dsa_comb = c->dsa_comb.as<uint32_t>();
   c->kt.dsa_wbits = c->dsa_wbits;
+  c->kt_group_ent = std::move(group_ents);
+  c->kt_cert_epoch = c->cert_epoch;
   ++c->keyring_gen;
   return 0;
 }
@@ -1249,6 +1268,8 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   c->ring = std::move(ring);
   c->certs.clear();
   c->cert_valid.clear();
+  ++c->cert_epoch;
+  { std::lock_guard<std::mutex> fl(c->cert_fast_mu); c->cert_fast.clear(); c->cert_fast_bytes = 0; }
   ++c->ring_epoch;
   return upload_key_table(c);
 }

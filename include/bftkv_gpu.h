@@ -283,8 +283,10 @@ int bftkv_gpu_batcher_signature_verify(bftkv_gpu_batcher* b, const uint8_t* tbs,
  *                     a parsed certificate can tell that it IS this one); either may be NULL.
  * The entity is registered in the root context's key table as a certificate-only entity (bounded and recycled: at most 1024
  * distinct certificates, certificate DSA keys share a bounded set of table slots) and its ReadEntity verdict is remembered
- * by certificate bytes, so a client's second request costs one signature verification.  Calls of this kind are batched
- * like the others but run on the ROOT context (registration changes the key table; the lanes' calls in flight drain first). */
+ * by certificate bytes, so a client's second request costs one signature verification.  The FIRST request with a certificate
+ * runs on the ROOT context (registration changes the key table; the lanes' calls in flight drain first); once ReadEntity's
+ * verdict on those bytes is "valid", later requests carrying the same bytes are one staged signature verification on a lane,
+ * against the entity registered for them (resolved by the bytes, never by the 64-bit key id), several in flight at once. */
 int bftkv_gpu_batcher_cert_verify(bftkv_gpu_batcher* b, const uint8_t* cert, uint64_t cert_len, const uint8_t* tbs, uint64_t tbs_len,
                                   const uint8_t* sig, uint64_t sig_len, uint8_t* err_out, uint8_t* fenced_out,
                                   uint64_t* issuer_id_out, uint8_t* fingerprint_out);
@@ -353,7 +355,9 @@ int bftkv_gpu_batcher_modexp(bftkv_gpu_batcher* b, const uint8_t* base, uint32_t
 int bftkv_gpu_batcher_stats(bftkv_gpu_batcher* b, uint64_t stats[4]);
 /* where the callers' time went, nanoseconds summed over all calls so far: [0] hashing their payloads, [1] leaders waiting
  * for a lane, [2] leaders assembling batches, [3] leaders inside device calls, of which [4] enqueueing and [5] waiting
- * for the results; [6] = device calls whose wait fell back to a stream synchronisation (a count) */
+ * for the results; [6] = device calls whose wait fell back to a stream synchronisation (a count); [7] = certificate
+ * requests (bftkv_gpu_batcher_cert_verify) answered for a certificate accepted before -- from the register, or by one staged
+ * signature verification on a lane -- instead of a compound call on the root context (a count) */
 int bftkv_gpu_batcher_times(bftkv_gpu_batcher* b, uint64_t ns[8]);
 
 /* ---- diagnostics of the last verify call: one status per packet event, in stream order -------- */

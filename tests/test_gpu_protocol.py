@@ -925,6 +925,20 @@ def test_batcher_cert_verify_for_principals_outside_the_keyring(gpu_ctx):
             assert not fenced and err == wants[i][0], (cases[i][0], err, wants[i])
         st = b.stats()
         assert st["calls"] >= len(cases) + 24 * 12 and st["batches"] < st["calls"]
+        # certificates accepted once are not walked again: their later requests were single signature verifications on the lanes
+        # (or, for the issuer alone, answers from the register) -- and gave the oracle's verdicts above all the same
+        assert st["cert_fast"] >= 24 * 12 // 3, st
+        # ... and the register follows the key table: after a keyring change the same requests take the compound route again
+        gpu_ctx.keyring_set(H.abi_keys(kr))
+        before = b.stats()["cert_fast"]
+        for (name, cert, tb, sig), (w, iid) in zip(cases, wants):
+            err, fenced, got_id, fp = b.cert_verify(cert, tb, sig)
+            assert not fenced and err == w, (name, err, w)
+        assert b.stats()["cert_fast"] - before <= 6, "only a certificate repeated within this round may come from the register"
+        for (name, cert, tb, sig), (w, iid) in zip(cases, wants):
+            err, fenced, got_id, fp = b.cert_verify(cert, tb, sig)
+            assert not fenced and err == w and (not iid or got_id == iid), (name, err, w)
+        assert b.stats()["cert_fast"] - before >= 8
         # fail closed
         rc, err, _ = Batcher.cert_verify(b, client, tbs, S(cl.client), raw=True)
         assert rc == 0 and err == 0
