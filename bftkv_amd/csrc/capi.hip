@@ -119,12 +119,12 @@ struct bftkv_gpu_ctx {
   uint64_t cert_clock = 0;     // compound calls over request certificates (host_capi.inc cert_cache_gc)
   // Request certificates whose ReadEntity verdict is "valid" (cert_signature_core), by their bytes: a later request of the same
   // client is then ONE staged signature verification on a lane of the micro-batcher (batcher_capi.inc) instead of a compound call
-  // on the root under its lock.  cert_fast_mu guards the map (a leaf lock).  A hit names the certificate's GROUP; the group's
-  // entity index in the uploaded table is read from kt_group_ent, which -- like kt_cert_epoch -- changes only under KtWrite
-  // (upload_key_table), i.e. never during a fork's device call.  cert_epoch (under mu) counts the times the certificate rows
+  // on the root under its lock.  cert_fast_mu guards the map (a leaf lock; lookups share it).  A hit names the certificate's GROUP
+  // and the epoch of that answer; the lane turns the group into an entity index through kt_group_ent, which -- like kt_cert_epoch
+  // -- changes only under KtWrite (upload_key_table), i.e. never during a fork's device call: no lock on that side.  cert_epoch (under mu) counts the times the certificate rows
   // were dropped and the groups renumbered.
   struct CertFast { uint64_t issuer_id; int group; uint64_t epoch; };
-  std::mutex cert_fast_mu;
+  std::shared_mutex cert_fast_mu;
   std::unordered_map<std::string, CertFast> cert_fast;
   size_t cert_fast_bytes = 0;
   uint64_t cert_epoch = 0, kt_cert_epoch = 0;
@@ -1269,7 +1269,7 @@ int bftkv_gpu_keyring_set(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey* keys, uint32
   c->certs.clear();
   c->cert_valid.clear();
   ++c->cert_epoch;
-  { std::lock_guard<std::mutex> fl(c->cert_fast_mu); c->cert_fast.clear(); c->cert_fast_bytes = 0; }
+  { std::unique_lock<std::shared_mutex> fl(c->cert_fast_mu); c->cert_fast.clear(); c->cert_fast_bytes = 0; }
   ++c->ring_epoch;
   return upload_key_table(c);
 }
