@@ -60,3 +60,18 @@ def test_headers_are_plain_c():
         r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", os.path.join(inc, h)],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr.decode()
+
+
+@pytest.mark.parametrize("src", ["tools/serving/batcher_load.c", "tools/serving/threshold_load.c", "tools/serving/cert_load.c", "tools/fakehip/stress.c"])
+def test_plain_c_callers_of_the_serving_entries_compile_and_link(src, tmp_path):
+    """The load generators bench.py and the profiles run on the GPU box (and the sanitizer stress driver) are plain C against
+    include/bftkv_gpu.h alone: they must build without warnings and resolve every symbol in the library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not on PATH")
+    exe = str(tmp_path / "a.out")
+    r = subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, src),
+                        "-L", os.path.join(ROOT, "bftkv_amd"), "-lbftkv_gpu", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "bftkv_amd"), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
