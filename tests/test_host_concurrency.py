@@ -26,6 +26,9 @@ def test_every_batcher_entry_under_thread_sanitizer(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]
     got = json.loads(line)
     assert got["failed_open"] == 0
+    # the register of accepted request certificates (host logic, no kernel needed): the second request with a certificate comes
+    # from the register, a keyring change forgets it, the two requests after it repeat that
+    assert got["register"] == [0, 1, 0, 1], got["register"]
     kinds = ("collective", "signature", "certificate", "modmul_product", "lagrange_combine", "dsa_calculate_r", "modexp", "host_buffer_call",
              "keyring_set", "quorum_create_destroy")
     for kind in kinds:
