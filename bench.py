@@ -568,6 +568,43 @@ def load_or_make(args, tag, rank, make):
     return d
 
 
+def cert_serving_leg(threads="1,64,256", clients=64):
+    """One Issuer(sig) + VerifyWithCertificate per CALL for clients OUTSIDE the server's keyring -- Server.sign's verification
+    (protocol/server.go:199-207), bftkv_gpu_batcher_cert_verify -- measured like serving_leg: plain-C load generator
+    (tools/serving/cert_load.c) in its own process on a corpus signed on the CPU (tools/serving/make_cert_corpus.py).  None / an
+    "error" entry when a tool is missing or fails: a side measurement never takes the line down."""
+    import shutil
+    import tempfile
+    if shutil.which("gcc") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bftkv_cert_serving")
+    try:
+        exe, path, lib_dir = os.path.join(tmp, "cert_load"), os.path.join(tmp, "certs.bin"), os.path.join(ROOT, "bftkv_amd")
+        cc = subprocess.run(["gcc", "-O2", "-std=gnu99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "serving", "cert_load.c"),
+                             "-L", lib_dir, "-lbftkv_gpu", "-lpthread", "-Wl,-rpath," + lib_dir, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if cc.returncode != 0:
+            return {"error": "gcc: " + cc.stderr.decode(errors="replace")[-300:]}
+        mk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "serving", "make_cert_corpus.py"), path, str(clients)], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, timeout=120)
+        if mk.returncode != 0:
+            return {"error": "make_cert_corpus: " + mk.stderr.decode(errors="replace")[-300:]}
+        r = subprocess.run([exe, path, "256", "0", threads, "1.0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        if r.returncode != 0:
+            return {"error": "cert_load rc=%d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"what": "one bftkv_gpu_batcher_cert_verify per call (%d clients outside the keyring, %d-byte certificates, RSA-2048): first sight "
+                        "of a certificate = compound call on the root (registration + what ReadEntity verifies), later requests = one staged "
+                        "signature verification on a lane; every answer checked" % (d["clients"], d["certificate_bytes"]),
+                "first_sight_ms_per_certificate": d["first_sight"]["ms_per_certificate"], "wrong_answers_first_sight": d["first_sight"]["wrong"],
+                "runs": [{"caller_threads": x["threads"], "calls_per_s": x["calls_per_s"], "latency_ms": x["latency_ms"], "wrong_answers": x["wrong"],
+                          "device_calls": x["device_calls"]} for x in d["runs"]],
+                "tool": "tools/serving/cert_load.c"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def serving_leg(args, cl, z, want_ok, n_writes=4096, threads="1,64,256", lanes=0):
     """One CollectiveSignature.Verify per CALL from many caller threads through the micro-batcher -- the shape the reference
     actually has (one goroutine per request, transport/http/http.go:85,143 -> protocol/server.go:562-620) -- measured by the
@@ -780,6 +817,8 @@ def bench_cfg2(args, D):
                                    "note": "see end_to_end (kept under its round-3 name; verifies_per_sec here counts packets)"}
         if D.world == 1 and not args.no_serving:
             out["serving"] = serving_leg(args, cl, z, want_ok)
+            if isinstance(out["serving"], dict):
+                out["serving"]["request_certificates"] = cert_serving_leg()
         if D.world == 1 and not args.no_cpu_baseline:
             cerr, cnver, ops, best, nt, st1 = cpu_collective(cl, z["tb"], z["to"], z["sb"], z["so"], budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
@@ -1505,6 +1544,9 @@ def line_summary(out):
     if runs and "verify_calls_per_s" in runs[0]:          # cfg 2: one Verify per call
         s["serving_verify_calls_per_s"] = {str(r["caller_threads"]): r["verify_calls_per_s"] for r in runs}
         s["serving_p99_ms"] = {str(r["caller_threads"]): r["latency_ms"]["p99"] for r in runs}
+        cr = g(out, "serving", "request_certificates", "runs")
+        if cr:                                            # Server.sign's Issuer + VerifyWithCertificate, one per call
+            s["serving_cert_verify_calls_per_s"] = {str(r["caller_threads"]): r["calls_per_s"] for r in cr}
     elif runs:                                            # cfg 5: one share-combine per call, per scheme
         s["serving_ops_per_s_256_callers"] = {r["scheme"]: r["ops_per_s"] for r in runs if r.get("caller_threads") == 256}
     if out.get("single_flight"):
