@@ -255,6 +255,49 @@ def keyring_and_quorum():
         note("quorum_destroy(bad)", lib.bftkv_gpu_quorum_destroy(ctx, rng.choice([-1, 12345, h.value])))
 
 
+def _cert_seeds():
+    import json
+    g = os.path.join(ROOT, "tests", "golden")
+    ref = json.load(open(os.path.join(g, "reference_inputs.json")))
+    return [bytes.fromhex(c) for c in ref["certs"]], [bytes.fromhex(x["sig"]) for x in ref["gpg"][:40]]
+
+
+CERTS, SIGS = _cert_seeds()
+
+
+def cert_calls():
+    """request certificates (fixtures, mutated or not -- the register keeps what it has accepted, so repeats take the lane route) with
+    signatures that are the fixtures', mutated, empty or absent"""
+    cert = bytearray(rng.choice(CERTS))
+    r = rng.random()
+    if r < 0.3 and cert:
+        for _ in range(rng.randrange(1, 4)):
+            cert[rng.randrange(len(cert))] = rng.randrange(256)
+    elif r < 0.4:
+        cert = cert[:rng.randrange(len(cert) + 1)]
+    elif r < 0.5:
+        cert += rng.choice(CERTS)
+    cert = bytes(cert)
+    tb = rng.randbytes(rng.choice([0, 1, 63, 64, 65, 300]))
+    sig = rng.choice([None, b"", rng.choice(SIGS), rng.choice(SIGS) + rng.choice(SIGS), rng.randbytes(rng.choice([1, 20, 287, 600]))])
+    e, f, iid = C.c_uint8(0), C.c_uint8(0), C.c_uint64(0)
+    fp = (C.c_uint8 * 20)()
+    if rng.random() < 0.75:
+        rc = lib.bftkv_gpu_batcher_cert_verify(batcher, cert, len(cert), tb, len(tb), sig, len(sig) if sig is not None else 0, C.byref(e), C.byref(f),
+                                               C.byref(iid), fp)
+        name = "batcher_cert_verify"
+    else:
+        cap = rng.choice([0, 1, 8, 256])
+        roles = (C.c_uint32 * max(cap, 1))()
+        off, ln, nr = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        rc = lib.bftkv_gpu_batcher_cert_entity(batcher, cert, len(cert), C.byref(e), C.byref(f), C.byref(iid), fp, C.byref(off), C.byref(ln), roles, cap,
+                                               C.byref(nr))
+        name = "batcher_cert_entity"
+        assert off.value + ln.value <= len(cert), (name, off.value, ln.value, len(cert))
+    assert rc == 0 or e.value != 0, (name, rc, e.value)      # fail closed
+    note(name, rc)
+
+
 # a usable quorum for the verify calls
 ids0 = np.arange(1, 5, dtype=np.uint64)
 qc0 = (N.QC * 1)()
@@ -266,7 +309,7 @@ assert lib.bftkv_gpu_quorum_create(ctx, qc0, 1, C.byref(quorum)) == 0
 t0 = time.time()
 n = 0
 while time.time() - t0 < budget:
-    rng.choice([threshold_batched, threshold_batched, threshold_one, verify_calls, verify_calls, keyring_and_quorum])()
+    rng.choice([threshold_batched, threshold_batched, threshold_one, verify_calls, verify_calls, keyring_and_quorum, cert_calls, cert_calls])()
     n += 1
 lib.bftkv_gpu_batcher_destroy(batcher)
 lib.bftkv_gpu_destroy(ctx)
