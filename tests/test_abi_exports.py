@@ -75,3 +75,18 @@ def test_plain_c_callers_of_the_serving_entries_compile_and_link(src, tmp_path):
                         "-L", os.path.join(ROOT, "bftkv_amd"), "-lbftkv_gpu", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "bftkv_amd"), "-o", exe],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_the_stand_in_runtime_is_test_infrastructure_only():
+    """tools/fakehip (a HIP runtime whose kernels do not run, for the sanitizer builds) is never part of the product: nothing under
+    bftkv_amd/, the build entry or the bench names it, and the library the package loads depends on the real runtime."""
+    import subprocess
+    for top in ("bftkv_amd", "__graft_entry__.py", "bench.py", "include"):
+        p = os.path.join(ROOT, top)
+        files = [p] if os.path.isfile(p) else [os.path.join(d, f) for d, _, fs in os.walk(p) for f in fs if not f.endswith((".so", ".pyc"))]
+        for f in files:
+            with open(f, "rb") as fh:
+                assert b"fakehip" not in fh.read(), f
+    ge.build()
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "bftkv_amd", "libbftkv_gpu.so")], capture_output=True, text=True).stdout
+    assert "libamdhip64.so" in needed and "fake" not in needed, needed
