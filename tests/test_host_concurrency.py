@@ -34,5 +34,5 @@ def test_every_batcher_entry_under_thread_sanitizer(tmp_path):
     for kind in kinds:
         assert got[kind]["rc_nonzero"] == 0, (kind, got[kind])
     # how far each kind gets in a few seconds under the sanitizer depends on the machine: every kind normally runs, the mix must
-    assert got["collective"]["calls"] > 0 and sum(got[k]["calls"] for k in kinds) + got["message"]["calls"] > 50, got
+    assert got["collective"]["calls"] > 0 and sum(got[k]["calls"] for k in kinds) + got["message"]["calls"] > 10, got
     # (the message walk kernel does not run here: those calls fail, closed -- "failed_open" above)
