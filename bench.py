@@ -49,6 +49,7 @@ DSA_BYTES = 99                 # per DSA-2048/256 signature veri
 # limb MACs actually executed (mont28.h): a general Montgomery product = 76x76 (a*b) + 76x76 (m*n) = 11,552; a squaring forms
 # only the triangles of a*a: 4 lanes x (4 x 190 + 1,444) = 8,816.  e = 65537: 16 squarings + 2 products.
 MACS_PER_RSA_VERIFY = 16 * 8816 + 2 * 11552
+LINE_MAX = 6144                # bytes of the ONE stdout line (round 5's had grown to 25 KB and the driver's parser returned nothing)
 
 
 def macs_per_dsa_verify(table_bits):
@@ -106,6 +107,9 @@ def parse_args(argv=None):
                     "otherwise never sees a timed region of tens of milliseconds.  0 disables")
     ap.add_argument("--corpus-cache", default="", help="path prefix of an .npz cache of the generated corpus (profiling reruns)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, sharding and exchange step only (no GPU, no number)")
+    ap.add_argument("--full-json", default=None, help="where the FULL record goes (sweeps, per-thread serving runs, timelines, notes, commands, "
+                    "every other config's record): default bench_full.json next to bench.py (bench_full_cfgN.json with --config N).  stdout "
+                    "carries ONE line of at most %d bytes -- the contract's keys, roofline, cpu_baseline, int_mac and a per-config summary" % LINE_MAX)
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = 200 if (args.config in (None, 2) and not args.dry_run) else 64 if args.config == 5 else 10
@@ -440,7 +444,9 @@ def cpu_collective(cl, tb, to, sb, so, budget_s=25.0):
             best = (dt, nt)
         res = (cerr, cnver, ops)
     CPU_SWEEP.clear()
-    CPU_SWEEP.update({"candidates": cands, "timed": timed, "truncated_by_budget": len(timed) < len(cands), "budget_s": budget_s})
+    # untuned: the budget ended the sweep while the widest count timed was still the best one (a wider one might have been better)
+    CPU_SWEEP.update({"candidates": cands, "timed": timed, "truncated_by_budget": len(timed) < len(cands), "budget_s": budget_s,
+                      "untuned": bool(len(timed) < len(cands) and best[1] == timed[-1]["threads"])})
     return res[0], res[1], res[2], best[0], best[1], ops1 / t1
 
 
@@ -462,12 +468,17 @@ def measured_traffic(cfg, kernel):
     return None, os.path.relpath(cands[-1], ROOT)
 
 
-def roofline(cfg, kernel, alg_bytes, launch_ms, note):
+def roofline(cfg, kernel, alg_bytes, launch_ms, note, **extra):
+    """`launch_ms` is the dominant kernel's SINGLE-FLIGHT launch duration (HIP events on its own stream, nothing of a neighbouring step
+    beside it) wherever the timed region keeps steps in flight whose kernels overlap: a span measured across overlapped launches is
+    not the kernel's cost and goes under `in_flight_span_ms` (extra)."""
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms else 0.0
     traffic, src = measured_traffic(cfg, kernel)
-    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg_bytes),
-            "launch_ms": launch_ms, "note": note}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(alg_bytes),
+           "launch_ms": launch_ms, "note": note}
+    out.update(extra)
+    return out
 
 
 def int_mac(macs, launch_ms, sclk_mhz=None):
@@ -692,7 +703,7 @@ def bench_cfg2(args, D):
         rows = np.unpackbits(gathered[-1].reshape(D.world, -1), axis=1, bitorder="little")[:, :items]
         tot = D.sum_ints([int(want_ok.sum())])[0]
         return {"dry_run": True, "config": 2, "n_gpus": D.world, "world_size": D.world, "steps": args.steps, "warmup": args.warmup,
-                "allgathers_in_step_loop": V.gathers, "gather_rows": int(rows.shape[0]),
+                "parallelism": "shard-by-write x%d, all-gather of verdict bitmaps" % D.world, "allgathers_in_step_loop": V.gathers, "gather_rows": int(rows.shape[0]),
                 "gathered_ok": int(rows.sum()), "sum_of_rank_ok": tot,
                 "own_row_matches": bool((rows[D.rank] == want_ok).all()), "elapsed_s": elapsed} if D.rank == 0 else None
 
@@ -743,8 +754,11 @@ def bench_cfg2(args, D):
                                       "at the library's turnstile, the duration runs from a launch's turn to its end)" % (len(timed_rsa), V.n_ctx),
                           "single_flight": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]},
                           "single_flight_is": "3 non-overlapped calls on one context right after the timed region"},
-            "roofline": roofline(2, "k_rsa_modexp", alg_bytes, rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see int_mac; "
-                                 "launch_ms = average HIP-event duration of the timed region's launches (%d in flight)" % V.n_ctx),
+            "roofline": roofline(2, "k_rsa_modexp", alg_bytes, iso_rsa or rsa_ms, "path is integer-VALU bound, not HBM bound (DESIGN.md); see "
+                                 "int_mac; launch_ms = the kernel's single-flight launch duration (HIP events on its stream, 3 non-overlapped "
+                                 "calls right after the timed region); in_flight_launch_ms = average over the timed region's launches (%d "
+                                 "batches in flight, the modexps taking turns at the turnstile)" % V.n_ctx,
+                                 in_flight_launch_ms=rsa_ms, launch_ms_basis="single_flight"),
             "int_mac": int_mac_block(counters["pubkey_ops"] * MACS_PER_RSA_VERIFY, ms_step, rsa_ms, iso_rsa, sclk, V.n_ctx),
             "sustained": sustained,
             "corpus_build_s": t_corpus,
@@ -936,6 +950,11 @@ def bench_cfg3(args, D):
     run(V.n_ctx)                 # one untimed step per verifier context: its arena is allocated at its first call
     elapsed = timed_region(D, run, args.steps, args.warmup, V.reset_timing)
     sclk = V.ctxs[0].last_sclk_mhz()
+    timed_rsa, timed_dsa, timed_hash, timed_total = list(V.rsa_ms), list(V.dsa_ms), list(V.hash_ms), list(V.total_ms)
+    iso = []
+    for _ in range(3):           # single-flight: non-overlapped calls on one context (the in-flight spans above overlap each other)
+        V.submit(0); V.complete(0)
+        iso.append(dict(V.last_tm))
     err, nver, bits = V.results(0)
     gather_ok = V.check_gather(err, bits)
     counters = V.ctxs[0].last_counters()
@@ -946,10 +965,11 @@ def bench_cfg3(args, D):
     win = winners[0]
     sustained = soak(D, run, args.soak_seconds, elapsed / args.steps * 1e3, tot_ref_ops)
     if D.rank == 0:
-        rsa_ms, dsa_ms = float(np.mean(V.rsa_ms)), float(np.mean(V.dsa_ms))
+        rsa_ms, dsa_ms = float(np.mean(timed_rsa)), float(np.mean(timed_dsa))                 # spans with V.n_ctx steps in flight
+        iso_rsa, iso_dsa = float(np.mean([t["rsa"] for t in iso])), float(np.mean([t["dsa"] for t in iso]))
         n_rsa_ops = int(counters["pubkey_ops"]) - n_dsa_ops
         dsa_bits = V.ctxs[0].dsa_window_bits()        # the width the tables were built at decides the MAC count of a verification
-        dom = "k_dsa_modexp" if dsa_ms >= rsa_ms else "k_rsa_modexp"
+        dom = "k_dsa_modexp" if iso_dsa >= iso_rsa else "k_rsa_modexp"
         alg_bytes = int(rc.tbss_off[-1]) + n_rsa_ops * RSA_BYTES + n_dsa_ops * DSA_BYTES + (n_replies + 7) // 8
         out = base_line(args, D, "pgp_mixed_rsa_dsa_signature_verifies_per_sec", "verifies/s", tot_ref_ops * args.steps / elapsed, elapsed, "u32",
                         "%d-replica quorum (half RSA-2048, half DSA-2048/256), %d signed read replies <x,v,t,sig,ss> over %d variables per GPU "
@@ -968,12 +988,18 @@ def bench_cfg3(args, D):
             "sustained": sustained,
             "reads_answered_fraction": float(np.mean(win >= 0)), "replies_accepted_fraction": float((err == 0).mean()),
             "allgather": {"calls_in_timed_region": args.steps, "bytes_per_rank": (n_replies + 7) // 8, "rows_consistent": gather_ok},
-            "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_dsa_mul+k_dsa_modexp": dsa_ms, "hash_stream": float(np.mean(V.hash_ms)),
-                          "step_device_span": float(np.mean(V.total_ms)), "measured": "HIP events of the %d timed steps" % len(V.rsa_ms),
+            "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_dsa_mul+k_dsa_modexp": dsa_ms, "hash_stream": float(np.mean(timed_hash)),
+                          "step_device_span": float(np.mean(timed_total)),
+                          "measured": "HIP events of the %d timed steps, %d in flight: SPANS that overlap the neighbouring steps' kernels, not "
+                                      "kernel costs (those are single_flight)" % (len(timed_rsa), V.n_ctx),
+                          "single_flight": {k: float(np.mean([t[k] for t in iso])) for k in iso[0]},
+                          "single_flight_is": "3 non-overlapped calls on one context right after the timed region",
                           "last_call": V.last_tm},
-            "roofline": roofline(3, dom, alg_bytes, max(rsa_ms, dsa_ms), "integer-VALU bound; see int_mac"),
+            "roofline": roofline(3, dom, alg_bytes, max(iso_rsa, iso_dsa), "integer-VALU bound; see int_mac; launch_ms = the dominant kernel's "
+                                 "single-flight duration (HIP events, one call on the device)",
+                                 in_flight_span_ms=max(rsa_ms, dsa_ms), launch_ms_basis="single_flight"),
             "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * macs_per_dsa_verify(dsa_bits), elapsed / args.steps * 1e3,
-                                     rsa_ms + dsa_ms, None, sclk, V.n_ctx),
+                                     rsa_ms + dsa_ms, iso_rsa + iso_dsa, sclk, V.n_ctx),
             "dsa_tables": {"window_bits": dsa_bits, "products_per_verify": macs_per_dsa_verify(dsa_bits) // 11552,
                            "dsa_keys": sum(1 for r in cl.replicas if r.algo == cb.PK_DSA),
                            "gb_pinned": (sum(1 for r in cl.replicas if r.algo == cb.PK_DSA) * 2 * ((256 + dsa_bits - 1) // dsa_bits) *
@@ -1347,9 +1373,12 @@ def bench_cfg5(args, D):
         out.update({
             "per_scheme_ops_per_sec_per_gpu": {names[i]: N / (sp[i] * 1e-3) for i in range(4)},
             "kernel_ms": {names[i]: float(sp[i]) for i in range(4)},
-            "roofline": roofline(5, "k_multiexp", alg_r, float(sp[3]),
-                                 "launch span of the CalculateR call (k_lagrange_inv/terms, 2 x k_multiexp, k_u256_inv_modq, k_limbs_mod_q); "
-                                 "10k operations are 625 waves: latency-, not bandwidth- or MAC-bound"),
+            "roofline": roofline(5, "k_multiexp", alg_r, single_r_ms,
+                                 "launch_ms = single-flight span of the CalculateR call (k_lagrange_inv/terms, 2 x k_multiexp, k_u256_inv_modq, "
+                                 "k_limbs_mod_q) with ONE step on the device; compare it with single_flight.ms_per_step -- the headline's "
+                                 "ms_per_step has %d independent steps in flight, whose chains overlap on the SIMDs (in_flight_span_ms is such an "
+                                 "overlapped span, not a cost); 10k operations are 625 waves: latency-, not bandwidth- or MAC-bound" % n_ctx,
+                                 in_flight_span_ms=float(sp[3]), launch_ms_basis="single_flight", single_flight_ms_per_step=single_ms),
             "int_mac": int_mac_block(N * macs_per_calculate_r(K_DSA, 64), elapsed / args.steps * 1e3, float(sp[3]), None, None, n_ctx),
             "int_mac_counts": "CalculateR only (the dominant call): %d limb MACs per operation = 2 x k_multiexp (8 bases then the final "
                               "power; 4-bit windows over the 64 windows of a 256-bit q: 715 general products and 512 squarings)" % macs_per_calculate_r(K_DSA, 64),
@@ -1409,7 +1438,7 @@ def bench_cfg5(args, D):
                                    "per_scheme_ops_per_sec": {names[i]: N / bt[i] for i in range(4)},
                                    "gpu_results_identical_to_cpu": same,
                                    "sweep": {"candidates": cands, "timed": [{"threads": t} for t in timed_nt], "truncated_by_budget": len(timed_nt) < len(cands),
-                                             "budget_s": args.cpu_budget}}
+                                             "untuned": bool(len(timed_nt) < len(cands) and best[1] == timed_nt[-1]), "budget_s": args.cpu_budget}}
     for cx in reversed(ctxs):
         cx.close()
     return out if D.rank == 0 else None
@@ -1474,12 +1503,14 @@ def summarize(out):
     keep["int_mac"] = {k: im.get(k) for k in ("achieved", "frac", "frac_of_theoretical", "basis")}
     rf = out.get("roofline") or {}
     keep["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launch_ms")}
+    keep["roofline"].update({k: rf[k] for k in ("launch_ms_basis", "in_flight_span_ms", "in_flight_launch_ms", "single_flight_ms_per_step") if k in rf})
     cb_ = out.get("cpu_baseline")
     if cb_:
         keep["cpu_baseline"] = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
         if "sweep" in cb_:
             keep["cpu_baseline"]["threads_timed"] = [t["threads"] for t in cb_["sweep"]["timed"]]
             keep["cpu_baseline"]["sweep_truncated_by_budget"] = cb_["sweep"]["truncated_by_budget"]
+            keep["cpu_baseline"]["untuned"] = bool(cb_["sweep"].get("untuned", False))
         keep["identity"] = {k: v for k, v in cb_.items() if "identical" in k}
     for k in ("verdicts_match_construction", "kernel_ms", "per_scheme_ops_per_sec_per_gpu", "packets_per_sec", "quorum_verdicts_per_sec",
               "reply_verdicts_per_sec", "read_verdicts_per_sec", "dsa_tables", "single_flight", "serving"):
@@ -1502,6 +1533,8 @@ def other_configs(args, D):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    import tempfile
+    full = {}
     for cfg, extra in plan:
         # (cfg 5 keeps its `serving` leg: one share-combine per call through the micro-batcher, ~20 s)
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--soak-seconds", "0",
@@ -1509,21 +1542,35 @@ def other_configs(args, D):
               (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
         t0 = time.time()
         key = "cfg%d" % cfg
+        fd, side = tempfile.mkstemp(prefix="bench_full_cfg%d_" % cfg, suffix=".json")       # the child's FULL record (its stdout line is the short one)
+        os.close(fd)
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+            p = subprocess.run(cmd + ["--full-json", side], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 res[key] = {"error": "rc %d" % p.returncode, "stderr_tail": p.stderr[-1200:]}
             else:
-                out = json.loads(lines[-1])
+                with open(side) as fh:
+                    out = json.load(fh)
+                full[key] = out
                 res[key] = out if cfg == 1 else summarize(out)
         except subprocess.TimeoutExpired:
             res[key] = {"error": "timeout after 900 s"}
         except Exception as e:          # noqa: BLE001 -- reported in the line
             res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            try:
+                os.unlink(side)
+            except OSError:
+                pass
         res[key]["wall_s"] = time.time() - t0
         res[key]["command"] = " ".join(["python", "bench.py"] + cmd[2:])
+    OTHER_FULL.clear()
+    OTHER_FULL.update(full)
     return res
+
+
+OTHER_FULL = {}          # the complete records of the configs run behind the headline (full record only)
 
 
 def line_summary(out):
@@ -1561,6 +1608,172 @@ def line_summary(out):
                 e["one_op_per_call_256_callers_ops_per_s"] = {r["scheme"]: r["ops_per_s"] for r in th}
             s[k] = e
     return s
+
+
+def _sig(v, nd=5):
+    """floats to `nd` significant digits (the full record keeps every digit); containers recursively"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _sig(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, nd) for x in v]
+    return str(v)
+
+
+def _cut(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def config_digest(v):
+    """One config's few figures for the stdout line: value, ms_per_step, the dominant kernel's roofline entry (single-flight launch_ms),
+    int_mac fraction, CPU baseline (with `untuned` where the budget cut its sweep short of a maximum), identity flags."""
+    if not isinstance(v, dict):
+        return None
+    e = {x: v.get(x) for x in ("value", "unit", "ms_per_step", "error") if v.get(x) is not None}
+    if "error" in e:
+        e["error"] = _cut(e["error"], 160)
+    rf = v.get("roofline") or {}
+    if rf:
+        e["roofline"] = {k: rf.get(k) for k in ("kernel", "frac", "launch_ms", "traffic") if rf.get(k) is not None}
+        for k in ("in_flight_span_ms", "in_flight_launch_ms"):
+            if rf.get(k) is not None:
+                e["roofline"][k] = rf[k]
+    im = v.get("int_mac") or {}
+    if im.get("frac") is not None:
+        e["int_mac_frac"] = im["frac"]
+        sf = (im.get("single_flight") or {}).get("frac")
+        if sf is not None:
+            e["int_mac_frac_single_flight"] = sf
+    cb_ = v.get("cpu_baseline") or {}
+    if cb_.get("value") is not None:
+        e["cpu_baseline"] = {k: cb_[k] for k in ("value", "cores", "threads", "kind") if k in cb_}
+        untuned = cb_.get("untuned", (cb_.get("sweep") or {}).get("untuned"))
+        if untuned:
+            e["cpu_baseline"]["untuned"] = True
+    ident = dict(v.get("identity") or {})
+    ident.update({k: x for k, x in cb_.items() if "identical" in k})
+    ident.update({k: x for k, x in (v.get("gpu_identity") or {}).items() if "identical" in k})
+    if ident:
+        e["identity"] = ident
+    sfl = v.get("single_flight") or {}
+    if sfl.get("ms_per_step") is not None:
+        e["single_flight_ms_per_step"] = sfl["ms_per_step"]
+        if sfl.get("value") is not None:
+            e["single_flight_value"] = sfl["value"]
+    for k in ("quorum_verdicts_per_sec", "reply_verdicts_per_sec", "read_verdicts_per_sec", "threads"):
+        if v.get(k) is not None:
+            e[k] = v[k]
+    dt = v.get("dsa_tables") or {}
+    if dt:
+        e["dsa_tables"] = {k: dt[k] for k in ("window_bits", "dsa_keys", "gb_pinned") if k in dt}
+    th = [r for r in ((v.get("serving") or {}).get("runs") or []) if isinstance(r, dict) and r.get("caller_threads") == 256 and "scheme" in r]
+    if th:
+        e["one_op_per_call_256_callers_ops_per_s"] = {_cut(r["scheme"], 28): r["ops_per_s"] for r in th}
+    return e
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line: at most LINE_MAX bytes.  The contract's keys; `roofline` (dominant kernel, single-flight launch_ms),
+    `cpu_baseline`, `int_mac`; the two rates BASELINE.json's metric names (signature verifies/s = `value`, quorum verdicts/s);
+    `summary` with one digest per config and the serving / host-buffer headline figures.  Everything else is in the full record
+    (`full_record`).  Dry-run lines (tests of the launcher; no number) pass through unchanged."""
+    if out.get("dry_run"):
+        return out
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in out}
+    if "data" in line:
+        line["data"] = _cut(line["data"], 160)
+    cfg = dict(out.get("config") or {})
+    if "workload" in cfg:
+        cfg["workload"] = _cut(cfg["workload"], 240)
+    if "parallelism" in cfg:
+        cfg["parallelism"] = _cut(cfg["parallelism"], 100)
+    line["config"] = cfg
+    for k in ("packets_per_sec", "quorum_verdicts_per_sec", "reply_verdicts_per_sec", "read_verdicts_per_sec", "verdicts_match_construction",
+              "reference_pubkey_ops_per_step_per_gpu", "device", "threads", "writes_per_sec"):
+        if k in out:
+            line[k] = out[k]
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launch_ms_basis",
+                                                   "in_flight_launch_ms", "in_flight_span_ms", "single_flight_ms_per_step",
+                                                   "algorithmic_bytes_per_launch", "traffic_source") if k in rf}
+    cb_ = out.get("cpu_baseline")
+    if cb_:
+        c = {k: cb_[k] for k in ("value", "unit", "cores", "threads", "kind") if k in cb_}
+        c["sample"] = _cut(cb_.get("sample", ""), 200)
+        c.update({k: v for k, v in cb_.items() if "identical" in k})
+        if "single_thread_verifies_per_sec" in cb_:
+            c["single_thread"] = cb_["single_thread_verifies_per_sec"]
+        sw = cb_.get("sweep") or {}
+        if sw:
+            c["threads_timed"] = [t["threads"] for t in sw.get("timed", [])]
+            c["untuned"] = bool(sw.get("untuned", False))
+        line["cpu_baseline"] = c
+    im = out.get("int_mac")
+    if im:
+        line["int_mac"] = {k: im[k] for k in ("achieved", "peak", "frac", "peak_theoretical", "frac_of_theoretical", "sclk_mhz_in_kernel") if k in im}
+        line["int_mac"]["unit"] = "u32 MAC/s (v_mad_u64_u32 lanes)"
+        line["int_mac"]["basis"] = "ms_per_step"
+        if im.get("single_flight"):
+            line["int_mac"]["single_flight_frac"] = im["single_flight"].get("frac")
+    s = {}
+    if "end_to_end" in out:
+        ee = out["end_to_end"]
+        s["host_buffers"] = {"ms_per_call_alone": ee.get("ms_per_step"), "ms_per_call_three_callers": (ee.get("three_callers") or {}).get("ms_per_call"),
+                             "verifies_per_sec_three_callers": (ee.get("three_callers") or {}).get("verifies_per_sec"),
+                             "pcie_floor_ms": ee.get("pcie_floor_ms_at_63GBps"), "bytes_over_pcie": ee.get("bytes_over_pcie")}
+        if ee.get("segments"):
+            s["host_buffers"]["segments"] = ee["segments"]
+    sv = out.get("serving") if isinstance(out.get("serving"), dict) else {}
+    runs = sv.get("runs") or []
+    if runs and "verify_calls_per_s" in runs[0]:
+        s["serving_verify_calls_per_s"] = {str(r["caller_threads"]): r["verify_calls_per_s"] for r in runs}
+        s["serving_p99_ms"] = {str(r["caller_threads"]): r["latency_ms"]["p99"] for r in runs}
+        cr = (sv.get("request_certificates") or {}).get("runs") if isinstance(sv.get("request_certificates"), dict) else None
+        if cr:
+            s["serving_cert_verify_calls_per_s"] = {str(r["caller_threads"]): r["calls_per_s"] for r in cr}
+    elif runs:
+        s["serving_ops_per_s_256_callers"] = {_cut(r["scheme"], 28): r["ops_per_s"] for r in runs if r.get("caller_threads") == 256}
+    if (out.get("single_flight") or {}).get("ms_per_step") is not None:
+        s["single_flight_ms_per_step"] = out["single_flight"]["ms_per_step"]
+    if (out.get("kernel_ms") or {}).get("single_flight"):
+        s["kernel_ms_single_flight"] = {k: v for k, v in out["kernel_ms"]["single_flight"].items() if isinstance(v, (int, float))}
+    if out.get("sustained"):
+        s["sustained"] = {k: out["sustained"].get(k) for k in ("steps", "ms_per_step", "value")}
+    if out.get("dsa_tables"):
+        s["dsa_tables"] = {k: out["dsa_tables"][k] for k in ("window_bits", "dsa_keys", "gb_pinned") if k in out["dsa_tables"]}
+    oc = out.get("other_configs") or {}
+    for k, v in oc.items():
+        if isinstance(v, dict) and v.get("dry_run"):
+            s[k] = v                                    # (dry-run rehearsal of the N > 1 extras: small records, kept whole)
+        elif isinstance(v, dict):
+            s[k] = config_digest(v)
+        elif k == "error":
+            s["other_configs_error"] = _cut(v, 160)
+    line["summary"] = s
+    if full_path:
+        line["full_record"] = os.path.relpath(full_path, ROOT) if os.path.abspath(full_path).startswith(ROOT + os.sep) else full_path
+    exact = {k: line[k] for k in ("value", "ms_per_step") if k in line}       # the contract's own figures keep every digit
+    line = _sig(line)
+    line.update(exact)
+    # a bound, not a hope: drop the least important digests until the line fits
+    for victim in ("kernel_ms_single_flight", "sustained", "serving_p99_ms", "serving_cert_verify_calls_per_s", "dsa_tables"):
+        if len(json.dumps(line)) <= LINE_MAX:
+            break
+        line["summary"].pop(victim, None)
+    if len(json.dumps(line)) > LINE_MAX:
+        for k in list(line["summary"]):
+            if k.startswith("cfg") and isinstance(line["summary"][k], dict):
+                line["summary"][k] = {x: line["summary"][k][x] for x in ("value", "unit", "ms_per_step", "error") if x in line["summary"][k]}
+    if len(json.dumps(line)) > LINE_MAX:
+        line["config"] = {"workload": _cut(line["config"].get("workload", ""), 120)}
+        line["summary"] = {"truncated": True}
+    return line
 
 
 def multi_rank_extras(args, D, emit):
@@ -1639,12 +1852,36 @@ def main():
                 printed[0] = True
                 if extra is not None:
                     out["other_configs"] = extra
-                if not args.dry_run:
-                    try:
-                        out["summary"] = line_summary(out)    # LAST key: the few numbers a reader of the line's tail should see
-                    except Exception as e:                    # noqa: BLE001 -- a digest must never take the line down
-                        out["summary"] = {"error": repr(e)[:200]}
-                os.write(json_fd, (json.dumps(out) + "\n").encode())
+                if args.dry_run:
+                    os.write(json_fd, (json.dumps(out) + "\n").encode())
+                    return
+                try:
+                    out["summary"] = line_summary(out)
+                except Exception as e:                    # noqa: BLE001 -- a digest must never take the record down
+                    out["summary"] = {"error": repr(e)[:200]}
+                # the FULL record: a side file and stderr; stdout gets the short line (LINE_MAX bytes at most)
+                path = args.full_json or os.path.join(ROOT, "bench_full.json" if default_run else "bench_full_cfg%d.json" % args.config)
+                full = dict(out)
+                if OTHER_FULL:
+                    full["other_configs_full"] = dict(OTHER_FULL)
+                try:
+                    with open(path, "w") as fh:
+                        json.dump(full, fh)
+                        fh.write("\n")
+                except OSError as e:
+                    sys.stderr.write("bench.py: full record not written to %s: %s\n" % (path, e))
+                    path = None
+                sys.stderr.write("bench.py: full record%s:\n%s\n" % (" (%s)" % path if path else "", json.dumps(out)))
+                sys.stderr.flush()
+                try:
+                    line = json.dumps(compact_line(out, path))
+                except Exception as e:                    # noqa: BLE001 -- the contract's keys at the very least
+                    keep = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                    "scaling", "vs_baseline", "dtype", "data")}
+                    keep["config"] = {"workload": _cut((out.get("config") or {}).get("workload", ""), 200)}
+                    keep["compact_line_error"] = repr(e)[:200]
+                    line = json.dumps(keep)
+                os.write(json_fd, (line + "\n").encode())
         if out is not None and everything:
             out["other_configs"] = other_configs(args, D)
             out["other_configs_note"] = ("BASELINE.json configs[0] (cfg1, CPU restatement) and configs[2..4] (cfg3/4/5 at full size on this "

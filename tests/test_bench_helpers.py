@@ -136,3 +136,71 @@ def test_line_summary_digests_every_committed_line_shape():
         json.dumps(s)
     assert {"serving_verify_calls_per_s", "serving_ops_per_s_256_callers", "single_flight_ms_per_step", "host_buffers_ms_per_call", "cfg4", "cfg5"} <= seen
     assert "error" not in bench.line_summary({"metric": "m", "value": 1.0, "serving": {"runs": []}, "other_configs": {"cfg9": "text"}})
+
+
+def test_stdout_line_is_bounded_and_carries_what_the_driver_parses():
+    """Round 5's default line had grown to 25 KB and the driver's parser returned nothing (BENCH_r05.json: parsed null).  The stdout
+    emitter (bench.compact_line) over that very record, and over every other committed full record: at most LINE_MAX = 6144 bytes,
+    json round-trips, the contract's keys, `roofline.frac`, `cpu_baseline.value`, `config.workload` present; value and ms_per_step
+    keep every digit."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    line = json.dumps(bench.compact_line(full, os.path.join(root, "bench_full.json")))
+    assert len(line) < 6144 == bench.LINE_MAX
+    r = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in r, k
+    assert r["value"] == full["value"] and r["ms_per_step"] == full["ms_per_step"]
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["bound"] == "hbm" and r["roofline"]["kernel"] == "k_rsa_modexp"
+    assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] >= 1 and r["cpu_baseline"]["kind"] == "port"
+    assert r["cpu_baseline"]["gpu_verdicts_identical_to_cpu"] is True and r["cpu_baseline"]["untuned"] is False
+    assert "10000 RSA-2048 signed writes" in r["config"]["workload"] and r["int_mac"]["frac"] > 0.5
+    assert r["quorum_verdicts_per_sec"] > 0                       # BASELINE.json's metric names both rates
+    s = r["summary"]
+    assert {"cfg1", "cfg3", "cfg4", "cfg5", "host_buffers", "serving_verify_calls_per_s"} <= set(s)
+    assert s["cfg5"]["single_flight_ms_per_step"] > s["cfg5"]["ms_per_step"]            # both in the same cell
+    assert s["cfg3"]["identity"]["read_answers_identical_to_oracle"] is True and s["cfg3"]["cpu_baseline"]["value"] > 0
+    assert r["full_record"] == "bench_full.json"
+    # every other committed full record, whatever its config
+    for p in sorted(glob.glob(os.path.join(root, "profiles", "r0[56]_*bench*.json"))):
+        d = json.load(open(p))
+        if "metric" not in d:
+            continue
+        t = json.dumps(bench.compact_line(d, None))
+        assert len(t) < bench.LINE_MAX, p
+        assert json.loads(t)["value"] == d["value"]
+    # a record bloated far beyond anything seen still fits: digests are dropped in order of importance, never the contract's keys
+    fat = json.loads(json.dumps(full))
+    fat["other_configs"].update({"cfg%d" % k: dict(fat["other_configs"]["cfg5"]) for k in range(6, 30)})
+    t = json.dumps(bench.compact_line(fat, None))
+    assert len(t) < bench.LINE_MAX and json.loads(t)["roofline"]["frac"] > 0 and json.loads(t)["cpu_baseline"]["value"] > 0
+
+
+def test_roofline_launch_ms_is_a_single_flight_duration_in_every_committed_r06_line():
+    """Round 5's cfg-3 entry carried an overlapped three-in-flight span (62.7 ms) as the kernel's launch_ms against a 44.8 ms step.  Every
+    roofline entry of the round-6 records: launch_ms <= ms_per_step of the basis it names (the step itself, or -- cfg 5, whose headline
+    keeps 16 independent steps in flight -- the single-flight step it is measured in); overlapped spans sit under in_flight_*."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = 0
+    for p in sorted(glob.glob(os.path.join(root, "profiles", "r06_*bench*.json"))):
+        d = json.load(open(p))
+        entries = [d] + [v for v in (d.get("other_configs") or {}).values() if isinstance(v, dict)]
+        entries += [v for v in (d.get("summary") or {}).values() if isinstance(v, dict) and "roofline" in v]
+        for e in entries:
+            rf = e.get("roofline")
+            if not rf or rf.get("launch_ms") is None or e.get("ms_per_step") is None:
+                continue
+            basis = rf.get("single_flight_ms_per_step") or e.get("single_flight_ms_per_step") or e["ms_per_step"]
+            assert rf["launch_ms"] <= max(basis, e["ms_per_step"]) * 1.001, (p, rf, e["ms_per_step"])
+            seen += 1
+    if not glob.glob(os.path.join(root, "profiles", "r06_*bench*.json")):
+        import pytest
+        pytest.skip("no round-6 record committed yet")
+    assert seen >= 1

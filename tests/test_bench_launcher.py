@@ -27,6 +27,7 @@ def _run(extra, env=None):
     # ... and nothing else on stdout: whatever libraries print (gloo's connection notes here, RCCL's version banner on the GPU box)
     # goes to stderr -- bench.py points file descriptor 1 there and writes its line to the descriptor stdout had
     assert out.stdout.strip() == lines[0], out.stdout[:400]
+    assert len(lines[0]) < 6144           # the bound of every stdout line (bench.LINE_MAX): round 5's 25 KB line came back unparsed
     return json.loads(lines[0])
 
 
@@ -128,3 +129,21 @@ def test_default_line_of_a_multi_rank_run_carries_cfg4_and_cfg5(world):
     assert c4["config"] == 4 and c4["world_size"] == world and c4["writes_per_step"] == c4["share_per_rank"] * world
     assert c4["gathered_ok"] == c4["sum_of_rank_ok"] and c4["ranks_whose_own_rows_match"] == world
     assert c5["config"] == 5 and c5["operation_ranges"][-1][1] == 10000 and c5["exchange_steps"] == 0
+    # the N > 1 line names its rank count where the contract puts it (`config.parallelism` of a measured line; the dry line's
+    # `config` is the config number, so the key sits beside it)
+    assert ("x%d" % world) in r["parallelism"]
+
+
+def test_measured_multi_rank_line_fits_the_bound_and_names_the_rank_count():
+    """The N > 1 form of a MEASURED line (the one-rank forced-RCCL rehearsal of round 5, cfg 4 and cfg 5 behind the headline in the same
+    process group) through the stdout emitter: at most LINE_MAX bytes, `config.parallelism` with the rank count, roofline and summary kept."""
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_multi_rank_form_one_rank_forced_rccl.json")))
+    for world in (1, 8):
+        d["n_gpus"] = world
+        d["config"]["parallelism"] = "shard-by-write x%d, RCCL all-gather of verdict bitmaps on the verifier's stream" % world
+        line = json.dumps(bench.compact_line(d, os.path.join(ROOT, "bench_full.json")))
+        assert len(line) < bench.LINE_MAX == 6144
+        r = json.loads(line)
+        assert ("x%d" % world) in r["config"]["parallelism"] and r["n_gpus"] == world
+        assert r["roofline"]["frac"] > 0 and {"cfg4", "cfg5"} <= set(r["summary"]) and r["full_record"] == "bench_full.json"
