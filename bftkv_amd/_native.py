@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r", "bftkv_gpu_selftest_reduce",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_dsa_window_bits", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_dsa_window_bits", "bftkv_gpu_set_dsa_table_budget", "bftkv_gpu_dsa_table_bytes", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
@@ -71,6 +71,8 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_keyring_set.argtypes = [vp, C.POINTER(PubKey), u32]
     lib.bftkv_gpu_set_dsa_window_bits.argtypes = [vp, u32]
     lib.bftkv_gpu_dsa_window_bits.argtypes = [vp, C.POINTER(u32)]
+    lib.bftkv_gpu_set_dsa_table_budget.argtypes = [vp, C.c_uint64]
+    lib.bftkv_gpu_dsa_table_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(u32)]
     lib.bftkv_gpu_set_hash_policy.argtypes = [vp, C.c_int, C.c_int]
     lib.bftkv_gpu_message_verify.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
@@ -258,6 +260,16 @@ class Context:
         b = C.c_uint32(0)
         self._check(self.lib.bftkv_gpu_dsa_window_bits(self.h, C.byref(b)), "dsa_window_bits")
         return int(b.value)
+
+    def set_dsa_table_budget(self, nbytes: int) -> None:
+        """Bound on the HBM the DSA tables may hold (0 = the free-memory policy); applies at the next keyring_set."""
+        self._check(self.lib.bftkv_gpu_set_dsa_table_budget(self.h, int(nbytes)), "set_dsa_table_budget")
+
+    def dsa_table_bytes(self):
+        """(bytes of HBM the DSA tables hold, limbs per table entry: 76, or 112 with a key whose p exceeds 2048 bits)"""
+        b, e = C.c_uint64(0), C.c_uint32(0)
+        self._check(self.lib.bftkv_gpu_dsa_table_bytes(self.h, C.byref(b), C.byref(e)), "dsa_table_bytes")
+        return int(b.value), int(e.value)
 
     # ---- quorum
     def quorum_create(self, qcs) -> int:

@@ -53,6 +53,14 @@ struct DevBuf {
     if (e == hipSuccess) cap = want;
     return e;
   }
+  // exactly `bytes` (the DSA table arena: GBs, sized by its own policy -- ensure()'s quarter on top would be tens of GB)
+  hipError_t ensure_exact(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   template <typename T> T* as() const { return (T*)p; }
 };
@@ -61,7 +69,7 @@ struct KeyEntry {
   uint64_t key_id = 0, entity_id = 0;
   uint8_t algo = 0, flags = 0;
   uint32_t bits = 0, e = 0, n0 = 0, qbits = 0;
-  std::vector<uint32_t> nl, r2, r2w, qw, dtab, qpow;    // r2w: R^2 mod n for the 80-limb form (<= 2048-bit RSA)
+  std::vector<uint32_t> nl, r2, r2w, qw, dtab, qpow, qconst;    // r2w: R^2 mod n for the 80-limb form (<= 2048-bit RSA); qpow: 2^(28 j) mod q rows, qconst: mod-q Montgomery constants (DSA)
   std::string material;
   bool cert_only = false;
   int cert_group = -1;          // certificates: entries of one certificate share a group
@@ -116,6 +124,9 @@ struct bftkv_gpu_ctx {
   std::set<std::string> dsa_cert_materials;        // ... those of certificate-only keys (bounded, recycled: sync_dsa_tables)
   uint64_t ring_epoch = 0, dsa_ring_epoch_seen = ~0ull;   // bftkv_gpu_keyring_set calls / the one the window width was chosen for
   uint32_t dsa_wbits_want = 0;
+  uint32_t dsa_entry_limbs = DSA_N_SMALL;      // limbs of a table entry, arena-wide: DSA_N_BIG once the node keyring holds a DSA key with p beyond 2048 bits
+  size_t dsa_budget_bytes = 0;                 // bftkv_gpu_set_dsa_table_budget: the arena never grows past this (0: the free-HBM policy)
+  bool have_dsa3072 = false;
   uint64_t cert_clock = 0;     // compound calls over request certificates (host_capi.inc cert_cache_gc)
   // Request certificates whose ReadEntity verdict is "valid" (cert_signature_core), by their bytes: a later request of the same
   // client is then ONE staged signature verification on a lane of the micro-batcher (batcher_capi.inc) instead of a compound call
@@ -660,8 +671,11 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
     // (the LDS-DMA form of this kernel measured the same and spilled: removed in round 5, profiles/r04_cfg3_ab_dsa_dma*.json)
-    hipLaunchKernelGGL(k_dsa_modexp, dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+    hipLaunchKernelGGL((k_dsa_modexp<MONT_L, MONT_TPI>), dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
                        c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
+    if (c->have_dsa3072)      // keys with p beyond 2048 bits: the same work list through the 8-lane form (rows of the other class ride along)
+      hipLaunchKernelGGL((k_dsa_modexp<MONT_L3072, MONT_TPI_BIG>), dim3((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG)), dim3(RSA_BLOCK), 0, s,
+                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
   };
   if (total) launch_compare(start0);
   HIPCHK(c, rec(8, s));
@@ -717,7 +731,7 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
   e.bits = (uint32_t)hostbn::bit_length(k.n, k.n_len);
   e.e = 0; e.n0 = 0; e.qbits = 0;
   e.r2w.clear();
-  e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(2 * MONT_N, 0); e.qpow.clear();
+  e.nl.assign(MONT_NMAX, 0); e.r2.assign(MONT_NMAX, 0); e.qw.assign(8, 0); e.dtab.assign(2 * DSA_N_BIG, 0); e.qpow.clear(); e.qconst.clear();
   if (k.pk_algo == PK_RSA || k.pk_algo == PK_RSA_SIGN_ONLY) {
     if (hostbn::bit_length(k.e, k.e_len) > 32) return fail(c, BFTKV_E_UNSUPPORTED, "RSA public exponent wider than 32 bits");  // x/crypto refuses > 24 bits
     for (uint32_t j = 0; j < k.e_len; ++j) e.e = (e.e << 8) | k.e[j];
@@ -733,39 +747,43 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
     }
   } else if (k.pk_algo == PK_DSA) {
     // n = p, e = q.  Montgomery domain mod p; g and y in Montgomery form seed the fixed-base tables.
+    // Size class of p: 76 limbs over 4 lanes (<= 2048 bits, R = 2^2128) or 112 limbs over 8 lanes (<= 3072 bits, R = 2^3136).
     e.qbits = (uint32_t)hostbn::bit_length(k.e, k.e_len);
-    const int nwords = (28 * MONT_N + 31) / 32 + 1;
+    const int NLp = e.bits <= 2048 ? (int)DSA_N_SMALL : (int)DSA_N_BIG;
+    const uint32_t cap_bits = e.bits <= 2048 ? 2048u : 3072u;
+    const int nwords = (28 * NLp + 31) / 32 + 1;
     std::vector<uint32_t> p(nwords), g(nwords), y(nwords), q(nwords);
     hostbn::from_be(k.e, k.e_len, q.data(), nwords);
-    bool ok = e.bits >= 2 && e.bits <= 2048 && e.qbits >= 32 && e.qbits <= 256 && (q[0] & 1u) &&
-              hostbn::mont_setup(k.n, k.n_len, MONT_N, e.nl.data(), e.r2.data(), &e.n0);
-    if (ok && (hostbn::bit_length(k.g, k.g_len) > 2048 || hostbn::bit_length(k.y, k.y_len) > 2048)) ok = false;
+    bool ok = e.bits >= 2 && e.bits <= 3072 && e.qbits >= 32 && e.qbits <= 256 && (q[0] & 1u) &&
+              hostbn::mont_setup(k.n, k.n_len, NLp, e.nl.data(), e.r2.data(), &e.n0);
+    if (ok && (hostbn::bit_length(k.g, k.g_len) > cap_bits || hostbn::bit_length(k.y, k.y_len) > cap_bits)) ok = false;
     if (ok) {
       hostbn::from_be(k.n, k.n_len, p.data(), nwords);
       hostbn::from_be(k.g, k.g_len, g.data(), nwords);
       hostbn::from_be(k.y, k.y_len, y.data(), nwords);
       hostbn::reduce(g.data(), p.data(), nwords);
       hostbn::reduce(y.data(), p.data(), nwords);
-      hostbn::to_mont_limbs(g.data(), p.data(), nwords, MONT_N, &e.dtab[0]);
-      hostbn::to_mont_limbs(y.data(), p.data(), nwords, MONT_N, &e.dtab[MONT_N]);
+      hostbn::to_mont_limbs(g.data(), p.data(), nwords, NLp, &e.dtab[0]);
+      hostbn::to_mont_limbs(y.data(), p.data(), nwords, NLp, &e.dtab[DSA_N_BIG]);
       for (int j = 0; j < 8; ++j) e.qw[j] = q[j];
-      // 2^(28 j) mod q, j = 0 .. 75, as radix-2^28 limbs (k_dsa_modexp folds v mod p to v mod q with them)
-      e.qpow.assign(DSA_QTAIL_WORDS, 0);
+      // 2^(28 j) mod q, one row per limb of p, as radix-2^28 limbs (k_dsa_modexp folds v mod p to v mod q with them)
+      e.qpow.assign((size_t)NLp * 10, 0);
       uint32_t x[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0}, q9[9];
       for (int j = 0; j < 9; ++j) q9[j] = j < 8 ? q[j] : 0;
-      for (int j = 0; j < MONT_N; ++j) {
+      for (int j = 0; j < NLp; ++j) {
         hostbn::to_limbs28(x, 9, &e.qpow[(size_t)j * 10], 10);
         for (int b = 0; b < MONT_W; ++b) hostbn::dbl_mod(x, q9, 9);
       }
       // mod-q Montgomery constants (u256_montmul): 2^512 mod q and -q^-1 mod 2^32
+      e.qconst.assign(12, 0);
       uint32_t r2q[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int b = 0; b < 512; ++b) hostbn::dbl_mod(r2q, q9, 9);
-      for (int j = 0; j < 8; ++j) e.qpow[DSA_QPOW_WORDS + j] = r2q[j];
+      for (int j = 0; j < 8; ++j) e.qconst[j] = r2q[j];
       uint32_t inv = 1;
       for (int it = 0; it < 5; ++it) inv *= 2u - q[0] * inv;     // Newton: q^-1 mod 2^32
-      e.qpow[DSA_QPOW_WORDS + 8] = 0u - inv;
+      e.qconst[8] = 0u - inv;
     } else {
-      e.bits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 2048 bits): ST_UNSUPPORTED
+      e.bits = 0xFFFFFFFFu;   // fenced key shapes (even p or q, q > 256 bits, p > 3072 bits): ST_UNSUPPORTED
     }
   }
   return 0;
@@ -773,23 +791,37 @@ int make_key_entry(bftkv_gpu_ctx* c, const bftkv_gpu_pubkey& k, bool cert_only, 
 
 // Fixed-base tables for the DSA rows of the table being uploaded.  A table depends only on (p, g, y), so it is
 // keyed by the row's key material and survives re-uploads (certificate batches re-upload the table per request).
-// Window width 8 while the slots fit 4096 keys (20 GB); a larger DSA population restarts the cache at width 4.
-// Certificate-only DSA keys (they arrive inside unauthenticated requests) get a bounded number of table slots -- 8 at the
-// 16-bit width (637 MB and a 2 ms build each), 1024 below -- recycled among themselves; a certificate key beyond that is marked
-// unsupported for this upload (its signatures are fenced: the reference path decides).  The window width follows the NODE
-// keyring's DSA population alone and is re-evaluated only when that keyring changes, so neither a flood of certificates nor
-// jitter in the free-memory reading can force the node keys' tables to be rebuilt.  `bits_changed`: rows were marked.
+// Certificate-only DSA keys (they arrive inside unauthenticated requests) get a bounded number of table slots -- 8 at every
+// width above 8 bits (14 bits: 189 MB and a build each), 1024 at the 5 MB width, fewer where a caller's budget leaves less room --
+// recycled among themselves; a certificate key beyond that is marked unsupported for this upload (its signatures are fenced: the
+// reference path decides).  The window width AND the entry size (76 limbs, or 112 once a key with p beyond 2048 bits is in the
+// ring) follow the NODE keyring's DSA population alone and are re-evaluated only when that keyring changes, so neither a flood
+// of certificates nor jitter in the free-memory reading can force the node keys' tables to be rebuilt: a certificate-only key with
+// p beyond 2048 bits in an arena of 76-limb entries is fenced.  `bits_changed`: rows were marked.
 int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, const std::vector<uint8_t>& algo,
                     std::vector<uint32_t>& bits, bool* bits_changed) {
   std::vector<uint32_t> slot(rows.size() ? rows.size() : 1, 0xFFFFFFFFu);
   *bits_changed = false;
+  auto stride_bytes = [&](uint32_t w, uint32_t E) -> size_t { return (size_t)dsa_slot_stride(w, E) * sizeof(uint32_t); };
+  size_t ring_dsa = 0;
+  bool ring_big = false;
+  for (size_t i = 0; i < rows.size(); ++i)
+    if (algo[i] == PK_DSA && bits[i] != 0xFFFFFFFFu && !rows[i]->cert_only) { ++ring_dsa; ring_big = ring_big || bits[i] > 2048; }
   auto assign = [&](std::vector<uint32_t>& new_slots, std::vector<uint32_t>& new_rows) {
     new_slots.clear(); new_rows.clear();
-    // certificate-only DSA keys (they arrive in unauthenticated requests) share a bounded set of table slots, recycled by recency:
-    // 8 at the widths of 16 bits and more, below that about 8 GB of them (14 bits: 45, 12 bits: 156), at most 1024
-    const size_t cert_cap = c->dsa_wbits >= 16 ? 8 : std::min<size_t>(1024, std::max<size_t>(8, (8ull << 30) / (dsa_slot_stride(c->dsa_wbits) * sizeof(uint32_t))));
+    // certificate-only DSA keys share a bounded set of table slots, recycled by recency
+    size_t cert_cap = c->dsa_wbits > 8 ? 8 : 1024;
+    if (c->dsa_budget_bytes) {
+      const size_t per = stride_bytes(c->dsa_wbits, c->dsa_entry_limbs), ring_need = per * ring_dsa;
+      cert_cap = std::min(cert_cap, c->dsa_budget_bytes > ring_need ? (c->dsa_budget_bytes - ring_need) / per : 0);
+    }
     for (size_t i = 0; i < rows.size(); ++i) {
       if (algo[i] != PK_DSA || bits[i] == 0xFFFFFFFFu) continue;
+      if (bits[i] > 2048 && c->dsa_entry_limbs != DSA_N_BIG) {      // (only a certificate key can get here: the ring decides the entry size)
+        bits[i] = 0xFFFFFFFFu; *bits_changed = true;
+        const_cast<KeyEntry*>(rows[i])->dsa_unslotted = true;
+        continue;
+      }
       auto it = c->dsa_comb_slot.find(rows[i]->material);
       if (it == c->dsa_comb_slot.end()) {
         uint32_t id = (uint32_t)c->dsa_comb_slot.size();
@@ -827,78 +859,101 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
       slot[i] = it->second;
     }
   };
-  std::vector<uint32_t> new_slots, new_rows;
-  assign(new_slots, new_rows);
-  const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
   // Window width by DSA population and free HBM -- HBM capacity traded for multiplications, GRADED (round 5: the policy used to
   // fall from 16 bits straight to 8 at 65 keys, 31 -> 63 products per signature).  2 * ceil(256 / w) - 1 products and
-  // 2 * ceil(256 / w) * (2^w - 1) * 304 bytes per key:
+  // 2 * ceil(256 / w) * (2^w - 1) * 304 bytes per key (448 bytes per entry once the arena holds 3072-bit keys):
   //     w   18      16      15      14      13      12      10      8
   //   prod  29      31      35      37      39      43      51      63
   //   /key  2.39 GB 637 MB  358 MB  189 MB  100 MB  55 MB   16 MB   5 MB
-  // The widest width whose tables for every key of the ring -- with the half again the buffer grows by -- fit the budget: 45 % of
-  // the free HBM for 18 bits (as since round 3), a quarter for the others.  (17 bits has 16 windows like 16; 19 / 20 can be
-  // pinned, never chosen.)  4 bits beyond 4096 keys.
-  auto policy = [&](size_t n_keys) -> uint32_t {
+  // Without a budget: the widest width whose tables for every key of the ring -- with the half again the buffer grows by -- fit
+  // 45 % of the free HBM for 18 bits (as since round 3), a quarter for the others.  With a caller's budget
+  // (bftkv_gpu_set_dsa_table_budget: a service that shares the GPU): the widest width whose tables for every key of the ring fit
+  // the budget, and the arena is never allocated beyond it.  (17 bits has 16 windows like 16; 19 / 20 can be pinned, never
+  // chosen.)  4 bits beyond 4096 keys.
+  auto policy = [&](size_t n_keys, uint32_t E) -> uint32_t {
     if (c->dsa_wbits_pinned) return c->dsa_wbits_pinned;
     if (const char* e = getenv("BFTKV_DSA_WBITS")) {            // experiments: the width without touching the caller
       const uint32_t b = (uint32_t)atoi(e);
       if (b == 4 || (b >= 8 && b <= 20)) return b;
     }
     if (n_keys > 4096) return 4u;
+    static const uint32_t widths[] = {18, 16, 15, 14, 13, 12, 10};
+    if (c->dsa_budget_bytes) {
+      for (uint32_t w : widths)
+        if (std::max<size_t>(n_keys, 1) * stride_bytes(w, E) <= c->dsa_budget_bytes) return w;
+      return std::max<size_t>(n_keys, 1) * stride_bytes(8, E) <= c->dsa_budget_bytes ? 8u : 4u;
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t room = free_b + c->dsa_comb.cap;
-      static const uint32_t widths[] = {18, 16, 15, 14, 13, 12, 10};
       for (uint32_t w : widths) {
-        const size_t need = (n_keys + 1) * dsa_slot_stride(w) * sizeof(uint32_t) * 3 / 2;
+        const size_t need = (n_keys + 1) * stride_bytes(w, E) * 3 / 2;
         if (need < (w == 18 ? room / 100 * 45 : room / 4)) return w;
       }
     }
     return 8u;
   };
+  uint32_t want_E = c->dsa_entry_limbs;
   if (c->dsa_ring_epoch_seen != c->ring_epoch || c->dsa_wbits_want == 0) {      // the node keyring changed (or first upload)
-    size_t ring_dsa = 0;
-    for (size_t i = 0; i < rows.size(); ++i) ring_dsa += algo[i] == PK_DSA && bits[i] != 0xFFFFFFFFu && !rows[i]->cert_only;
-    c->dsa_wbits_want = policy(ring_dsa);
+    want_E = ring_big ? DSA_N_BIG : DSA_N_SMALL;
+    c->dsa_wbits_want = policy(ring_dsa, want_E);
     c->dsa_ring_epoch_seen = c->ring_epoch;
   }
   const uint32_t want_wbits = c->dsa_wbits_pinned ? c->dsa_wbits_pinned : c->dsa_wbits_want;
+  std::vector<uint32_t> new_slots, new_rows;
   bool restart = false;
-  // tables of keys that left the keyring stay cached by key material (a key that comes back costs nothing) -- as long as they
-  // are few and the wide layouts do not crowd the HBM: past 45 % of what is free (with the buffer's growth margin) they go
-  bool crowded = false;
-  if (want_wbits >= 12 && c->dsa_comb_slot.size() > live) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      crowded = c->dsa_comb_slot.size() * dsa_slot_stride(want_wbits) * sizeof(uint32_t) * 3 / 2 > (free_b + c->dsa_comb.cap) / 100 * 45;
-  }
-  if (want_wbits != c->dsa_wbits || c->dsa_comb_slot.size() > 2 * live + 256 || crowded) {   // width change, mostly stale, or crowded: restart
+  if (want_wbits != c->dsa_wbits || want_E != c->dsa_entry_limbs) {       // width or entry size change: every table is rebuilt
     restart = true;
     c->dsa_comb_slot.clear();
     c->dsa_cert_materials.clear();
     c->dsa_wbits = want_wbits;
+    c->dsa_entry_limbs = want_E;
+  }
+  assign(new_slots, new_rows);
+  const size_t live = [&] { size_t n = 0; for (uint32_t v : slot) n += v != 0xFFFFFFFFu; return n; }();
+  // tables of keys that left the keyring stay cached by key material (a key that comes back costs nothing) -- as long as they
+  // are few and the wide layouts do not crowd the HBM: past 45 % of what is free (with the buffer's growth margin), or past the
+  // caller's budget, they go
+  bool crowded = false;
+  if (!restart && c->dsa_comb_slot.size() > live) {
+    const size_t held = c->dsa_comb_slot.size() * stride_bytes(c->dsa_wbits, c->dsa_entry_limbs);
+    size_t free_b = 0, total_b = 0;
+    if (c->dsa_budget_bytes) crowded = held > c->dsa_budget_bytes;
+    else if (c->dsa_wbits >= 12 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) crowded = held * 3 / 2 > (free_b + c->dsa_comb.cap) / 100 * 45;
+  }
+  if (!restart && (c->dsa_comb_slot.size() > 2 * live + 256 || crowded)) {   // mostly stale, or crowded: restart
+    restart = true;
+    c->dsa_comb_slot.clear();
+    c->dsa_cert_materials.clear();
     for (size_t i = 0; i < rows.size(); ++i) slot[i] = 0xFFFFFFFFu;
     assign(new_slots, new_rows);
   }
   if (getenv("BFTKV_DEBUG_DSA")) {
     size_t n_cert_rows = 0, n_dsa = 0, n_fenced = 0;
     for (size_t i = 0; i < rows.size(); ++i) { n_cert_rows += rows[i]->cert_only; n_dsa += algo[i] == PK_DSA; n_fenced += algo[i] == PK_DSA && bits[i] == 0xFFFFFFFFu; }
-    fprintf(stderr, "[dsa tables] rows %zu (cert %zu, dsa %zu, dsa without slot %zu) width %u want %u slots %zu cert-slots %zu new %zu restart %d clock %llu\n", rows.size(),
-            n_cert_rows, n_dsa, n_fenced, c->dsa_wbits, want_wbits, c->dsa_comb_slot.size(), c->dsa_cert_materials.size(), new_slots.size(), (int)restart,
-            (unsigned long long)c->cert_clock);
+    fprintf(stderr, "[dsa tables] rows %zu (cert %zu, dsa %zu, dsa without slot %zu) width %u want %u entry limbs %u slots %zu cert-slots %zu new %zu restart %d clock %llu budget %zu\n", rows.size(),
+            n_cert_rows, n_dsa, n_fenced, c->dsa_wbits, want_wbits, c->dsa_entry_limbs, c->dsa_comb_slot.size(), c->dsa_cert_materials.size(), new_slots.size(), (int)restart,
+            (unsigned long long)c->cert_clock, c->dsa_budget_bytes);
   }
   int rc;
   if ((rc = upload(c, c->k_dsaslot, slot))) return rc;
   c->kt.dsa_slot = c->k_dsaslot.as<uint32_t>();
   c->kt.dsa_wbits = c->dsa_wbits;
+  c->kt.dsa_entry_limbs = c->dsa_entry_limbs;
   if (new_slots.empty()) return 0;
-  const size_t per_key = dsa_slot_stride(c->dsa_wbits) * sizeof(uint32_t);
+  const uint32_t E = c->dsa_entry_limbs;
+  const size_t per_key = stride_bytes(c->dsa_wbits, E);
   const size_t need = per_key * c->dsa_comb_slot.size();
+  // (a restart whose tables are much smaller than the arena -- a narrower width, a budget -- gives the memory back first)
+  if (restart && (c->dsa_comb.cap > 2 * need + (64u << 20) || (c->dsa_budget_bytes && c->dsa_comb.cap > c->dsa_budget_bytes))) c->dsa_comb.release();
   if (need > c->dsa_comb.cap) {           // grow, keeping the tables already built
     DevBuf bigger;
-    // room to grow by half -- but a pinned width beyond 18 bits (4.46 / 8.3 GB per key) only by two more keys
-    HIPCHK(c, bigger.ensure(need + (c->dsa_wbits > 18 ? std::min(need / 2, 2 * per_key) : need / 2)));
+    // room to grow by half -- but a pinned width beyond 18 bits (4.46 / 8.3 GB per key) only by two more keys, and never past a
+    // caller's budget (the ring's own tables always fit it: the policy chose the width that way; a pinned width is the caller's word)
+    size_t want = need + (c->dsa_wbits > 18 ? std::min(need / 2, 2 * per_key) : need / 2);
+    if (c->dsa_budget_bytes) want = std::max(need, std::min(want, c->dsa_budget_bytes));
+    if (restart) c->dsa_comb.release();      // (nothing to keep: the old tables go before the new ones are allocated)
+    HIPCHK(c, bigger.ensure_exact(want));
     // every whole slot the old buffer holds (new and recycled slots are built below, in place)
     const size_t keep = restart ? 0 : std::min(need, (c->dsa_comb.cap / per_key) * per_key);
     if (keep && c->dsa_comb.p) HIPCHK(c, hipMemcpyAsync(bigger.p, c->dsa_comb.p, keep, hipMemcpyDeviceToDevice, c->stream));
@@ -907,17 +962,32 @@ int sync_dsa_tables(bftkv_gpu_ctx* c, const std::vector<const KeyEntry*>& rows, 
     c->dsa_comb = bigger;
   }
   c->kt.dsa_comb = c->dsa_comb.as<uint32_t>();
-  for (size_t k = 0; k < new_slots.size(); ++k)      // the slot's 2^(28 j) mod q table (host-computed, 3 KB)
-    HIPCHK(c, hipMemcpyAsync((char*)c->dsa_comb.p + per_key * new_slots[k] + dsa_comb_limbs_per_key(c->dsa_wbits) * sizeof(uint32_t),
-                             rows[new_rows[k]]->qpow.data(), DSA_QTAIL_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  DevBuf d_slots, d_rows;
-  if ((rc = upload(c, d_slots, new_slots)) || (rc = upload(c, d_rows, new_rows))) { d_slots.release(); d_rows.release(); return rc; }
-  const uint32_t parts = c->dsa_wbits > 12 ? 1u << (c->dsa_wbits - 12u) : 1u;        // at most 4,096 entries per quad
-  const uint32_t n_quads = (uint32_t)new_slots.size() * 2u * dsa_nwin(c->dsa_wbits) * parts;
-  hipLaunchKernelGGL(k_dsa_build_comb, dim3((n_quads + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
-                     (uint32_t)new_slots.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
-  hipError_t e = hipStreamSynchronize(c->stream);
-  d_slots.release(); d_rows.release();
+  for (size_t k = 0; k < new_slots.size(); ++k) {    // the slot's 2^(28 j) mod q rows and mod-q constants (host-computed, 3 - 4.5 KB)
+    char* tail = (char*)c->dsa_comb.p + per_key * new_slots[k] + dsa_comb_limbs_per_key(c->dsa_wbits, E) * sizeof(uint32_t);
+    const KeyEntry* ke = rows[new_rows[k]];
+    HIPCHK(c, hipMemcpyAsync(tail, ke->qpow.data(), ke->qpow.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tail + dsa_qpow_words(E) * sizeof(uint32_t), ke->qconst.data(), ke->qconst.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  // one build per size class of p: <19, 4> for p <= 2048 bits, <14, 8> beyond
+  hipError_t e = hipSuccess;
+  for (int big = 0; big < 2 && e == hipSuccess; ++big) {
+    std::vector<uint32_t> cs, cr;
+    for (size_t k = 0; k < new_slots.size(); ++k)
+      if ((bits[new_rows[k]] > 2048) == (big == 1)) { cs.push_back(new_slots[k]); cr.push_back(new_rows[k]); }
+    if (cs.empty()) continue;
+    DevBuf d_slots, d_rows;
+    if ((rc = upload(c, d_slots, cs)) || (rc = upload(c, d_rows, cr))) { d_slots.release(); d_rows.release(); return rc; }
+    const uint32_t parts = c->dsa_wbits > 12 ? 1u << (c->dsa_wbits - 12u) : 1u;        // at most 4,096 entries per group
+    const uint32_t n_groups = (uint32_t)cs.size() * 2u * dsa_nwin(c->dsa_wbits) * parts;
+    if (big)
+      hipLaunchKernelGGL((k_dsa_build_comb<MONT_L3072, MONT_TPI_BIG>), dim3((n_groups + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG)), dim3(RSA_BLOCK), 0, c->stream,
+                         (uint32_t)cs.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
+    else
+      hipLaunchKernelGGL((k_dsa_build_comb<MONT_L, MONT_TPI>), dim3((n_groups + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, c->stream,
+                         (uint32_t)cs.size(), d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), c->kt, c->dsa_comb.as<uint32_t>(), parts);
+    e = hipStreamSynchronize(c->stream);
+    d_slots.release(); d_rows.release();
+  }
   if (e != hipSuccess) return fail(c, BFTKV_E_DEVICE, "k_dsa_build_comb", e);
   return 0;
 }
@@ -992,10 +1062,11 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   if ((rc = sync_dsa_tables(c, rows, algo, bits, &bits_changed))) return rc;
   if (bits_changed && (rc = upload(c, c->k_bits, bits))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_dsa_keys = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
+  c->have_dsa_keys = c->have_dsa3072 = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
   for (size_t i = 0; i < algo.size(); ++i) {
     if (flags[i] & KEYF_AMBIGUOUS) c->have_ambiguous = true;
     if (algo[i] == PK_DSA) c->have_dsa_keys = true;
+    if (algo[i] == PK_DSA && bits[i] != 0xFFFFFFFFu && bits[i] > 2048) c->have_dsa3072 = true;
     if ((algo[i] == PK_RSA || algo[i] == PK_RSA_SIGN_ONLY) && bits[i] != 0xFFFFFFFFu) {
       if (bits[i] > 3072) c->have_rsa4096 = true; else if (bits[i] > 2048) c->have_rsa3072 = true;
     }
@@ -1023,6 +1094,7 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   c->kt.dsa_slot = c->k_dsaslot.as<uint32_t>();
   c->kt.dsa_comb = c->dsa_comb.as<uint32_t>();
   c->kt.dsa_wbits = c->dsa_wbits;
+  c->kt.dsa_entry_limbs = c->dsa_entry_limbs;
   c->kt_group_ent = std::move(group_ents);
   c->kt_cert_epoch = c->cert_epoch;
   ++c->keyring_gen;
@@ -1036,9 +1108,9 @@ int fork_refresh(bftkv_gpu_ctx* c) {
   if (c->seen_keyring_gen != r->keyring_gen) {
     c->kt = r->kt;
     c->n_keys = r->n_keys; c->n_entities = r->n_entities; c->n_ring_entities = r->n_ring_entities;
-    c->have_dsa_keys = r->have_dsa_keys; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096; c->have_ambiguous = r->have_ambiguous;
+    c->have_dsa_keys = r->have_dsa_keys; c->have_dsa3072 = r->have_dsa3072; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096; c->have_ambiguous = r->have_ambiguous;
     c->h_key_id = r->h_key_id; c->h_entity_id = r->h_entity_id; c->h_key_entity = r->h_key_entity; c->h_key_flags = r->h_key_flags;
-    c->n_dsa_slots = r->dsa_comb_slot.size(); c->dsa_wbits = r->dsa_wbits;
+    c->n_dsa_slots = r->dsa_comb_slot.size(); c->dsa_wbits = r->dsa_wbits; c->dsa_entry_limbs = r->dsa_entry_limbs;
     c->keyring_gen = r->keyring_gen;          // the fork's membership tables follow the root's generations
     c->seen_keyring_gen = r->keyring_gen;
   }
@@ -1232,6 +1304,24 @@ int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && !dsa_width_ok(bits))) return BFTKV_E_INVALID;
   ctx_lock lk(c->mu);
   c->dsa_wbits_pinned = bits;
+  return 0;
+}
+
+int bftkv_gpu_set_dsa_table_budget(bftkv_gpu_ctx* c, uint64_t bytes) {
+  if (!c) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  if (c->root) return fail(c, BFTKV_E_STATE, "a forked context cannot change the key table (use its root)");
+  c->dsa_budget_bytes = (size_t)bytes;
+  c->dsa_wbits_want = 0;          // the next upload re-evaluates the width (sync_dsa_tables)
+  return 0;
+}
+
+int bftkv_gpu_dsa_table_bytes(bftkv_gpu_ctx* c, uint64_t* bytes_out, uint32_t* entry_limbs_out) {
+  if (!c) return BFTKV_E_INVALID;
+  ctx_lock lk(c->mu);
+  const bftkv_gpu_ctx* r = c->root ? c->root : c;
+  if (bytes_out) *bytes_out = (uint64_t)r->dsa_comb.cap;
+  if (entry_limbs_out) *entry_limbs_out = r->dsa_entry_limbs;
   return 0;
 }
 

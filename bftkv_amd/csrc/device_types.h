@@ -69,29 +69,34 @@ struct KeyTableDev {
   // DSA keys only (zero otherwise)
   const uint32_t* q_words;    // [n_keys][8] subgroup order q, little-endian 32-bit words
   const uint32_t* q_bits;     // [n_keys]
-  const uint32_t* dsa_tab;    // [n_keys][2][76] g*R, y*R mod p (Montgomery form): seeds of the fixed-base tables
+  const uint32_t* dsa_tab;    // [n_keys][2][DSA_N_BIG] g*R, y*R mod p (Montgomery form; R = 2^2128, or 2^3136 for p beyond 2048 bits): seeds of the fixed-base tables
   // Fixed-base window tables, resident in HBM for as long as the key is known (k_dsa_build_comb):
-  //   dsa_comb[slot][base in {g, y}][window w][digit d-1][76] = base^(d * 2^(wbits*w)) * R mod p,  d = 1 .. 2^wbits - 1
+  //   dsa_comb[slot][base in {g, y}][window w][digit d-1][E] = base^(d * 2^(wbits*w)) * R mod p,  d = 1 .. 2^wbits - 1
   // so g^u1 * y^u2 is at most 2 * 256/wbits - 1 table multiplications and no squarings (the entries of the window multiplied
   // by last, dsa_plain_window, are stored without the factor R: that product leaves the Montgomery domain).  The slot ends with
-  //   q_pow28[76][10] = 2^(28 j) mod q as radix-2^28 limbs, which folds v (mod p) down to v mod q.
+  //   q_pow28[E][10] = 2^(28 j) mod q as radix-2^28 limbs, which folds v (mod p) down to v mod q.
+  // E = dsa_entry_limbs, the limbs of an entry, ONE value for the whole arena: 76 (4 lanes x 19) while every DSA key has p <= 2048
+  // bits, 112 (8 lanes x 14: k_dsa_modexp<14, 8>) from the moment a key with p up to 3072 bits is known -- the smaller keys then
+  // leave the upper 36 limbs of their entries unused (the arena restarts when E changes).
   const uint32_t* dsa_slot;   // [n_keys] table slot of a DSA key (0xFFFFFFFF otherwise)
   const uint32_t* dsa_comb;
   uint32_t dsa_wbits;         // 18 (2.39 GB per key), 16 (637 MB), 8 (4.96 MB) or 4 (0.58 MB per key, very large DSA keyrings)
+  uint32_t dsa_entry_limbs;   // E above: DSA_N_SMALL or DSA_N_BIG
   uint32_t hash_policy;       // bits 0-1 MD5, bits 2-3 RIPEMD-160: 0 unknown (fenced), 1 available, 2 not available (bftkv_gpu_set_hash_policy)
 };
 // windows per 256-bit exponent: the top one is narrower when the width does not divide 256 (18 bits: 14 full windows + 4 bits;
 // its table is laid out like the others, only its first 15 entries are ever read)
 constexpr uint32_t dsa_nwin(uint32_t wbits) { return (256u + wbits - 1u) / wbits; }
-constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits) {
-  return 2ull * dsa_nwin(wbits) * ((1u << wbits) - 1u) * 76u;
+constexpr uint32_t DSA_N_SMALL = 76, DSA_N_BIG = 112;        // limbs of p: 4 x 19 (<= 2048 bits), 8 x 14 (<= 3072 bits)
+constexpr uint64_t dsa_comb_limbs_per_key(uint32_t wbits, uint32_t entry_limbs) {
+  return 2ull * dsa_nwin(wbits) * ((1u << wbits) - 1u) * entry_limbs;
 }
-constexpr uint32_t DSA_QPOW_WORDS = 76 * 10;
+constexpr uint32_t dsa_qpow_words(uint32_t entry_limbs) { return entry_limbs * 10u; }
 // ... followed by the mod-q Montgomery constants: 2^512 mod q (8 words), -q^-1 mod 2^32 (1 word), 3 words padding
-constexpr uint32_t DSA_QTAIL_WORDS = DSA_QPOW_WORDS + 12;
+constexpr uint32_t dsa_qtail_words(uint32_t entry_limbs) { return dsa_qpow_words(entry_limbs) + 12u; }
 // the (base, window) whose entries are stored in plain instead of Montgomery form: the one k_dsa_modexp multiplies by last
 constexpr bool dsa_plain_window(uint32_t base, uint32_t w, uint32_t nwin) { return base == 1u && w == nwin - 1u; }
-constexpr uint64_t dsa_slot_stride(uint32_t wbits) { return dsa_comb_limbs_per_key(wbits) + DSA_QTAIL_WORDS; }
+constexpr uint64_t dsa_slot_stride(uint32_t wbits, uint32_t entry_limbs) { return dsa_comb_limbs_per_key(wbits, entry_limbs) + dsa_qtail_words(entry_limbs); }
 
 constexpr uint8_t KEYF_USABLE_SIGN = 1, KEYF_CAN_SIGN = 2, KEYF_PRIMARY = 4;
 // key only exists inside a request's certificate: invisible to keyring lookups, reachable when the lookup is

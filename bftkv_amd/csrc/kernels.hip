@@ -1595,6 +1595,13 @@ __global__ void __launch_bounds__(256) k_rsa_compare(SigRec* __restrict__ recs, 
 // Per DSA signature, as soon as it is parsed (runs beside the RSA modexp and the hashing): range checks,
 // w = s^-1 mod q, u2 = r*w.  dsa_u row = { w (all zero: signature already refused), u2, r }.
 constexpr int DSA_U_WORDS = 24;
+// a key's table slot, and the mod-q Montgomery constants behind its tables and its 2^(28 j) mod q rows (device_types.h)
+__device__ __forceinline__ const uint32_t* dsa_slot_base(const KeyTableDev& kt, uint32_t key) {
+  return kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(kt.dsa_wbits, kt.dsa_entry_limbs);
+}
+__device__ __forceinline__ const uint32_t* dsa_qconst(const KeyTableDev& kt, uint32_t key) {
+  return dsa_slot_base(kt, key) + dsa_comb_limbs_per_key(kt.dsa_wbits, kt.dsa_entry_limbs) + dsa_qpow_words(kt.dsa_entry_limbs);
+}
 __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_blob, const SigRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ dsa_list, const uint32_t* __restrict__ pk_count,
                                                 const uint32_t* __restrict__ pk_start,
@@ -1617,7 +1624,7 @@ __global__ void __launch_bounds__(64) k_dsa_inv(const uint8_t* __restrict__ sig_
   ok = ok && u256_modinv_odd(s_, q, w);
   U256 u2 = u256_zero();
   if (ok) {
-    const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+    const uint32_t* qc = dsa_qconst(kt, key);
     U256 r2;
     for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
     u2 = u256_mulmod_mont(w, r, q, qc[8], r2);
@@ -1697,7 +1704,7 @@ __global__ void __launch_bounds__(INV_BLOCK) k_dsa_inv_batched(const uint8_t* __
     U256 q, r2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) q.w[i] = kt.q_words[(uint64_t)key * 8 + i];
-    const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+    const uint32_t* qc = dsa_qconst(kt, key);
 #pragma unroll
     for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
     const uint32_t q0inv = qc[8];
@@ -1779,48 +1786,51 @@ __global__ void __launch_bounds__(64) k_dsa_mul(SigRec* __restrict__ recs, const
   U256 z;
   u256_from_be((const uint8_t*)(digests + (uint64_t)ri * 16), zlen, z);
   while (u256_cmp(z, q) >= 0) u256_sub(z, q);        // z < 2^bits(q) < 2q: at most one round
-  const uint32_t* qc = kt.dsa_comb + (uint64_t)kt.dsa_slot[rec.key_slot] * dsa_slot_stride(kt.dsa_wbits) + dsa_comb_limbs_per_key(kt.dsa_wbits) + DSA_QPOW_WORDS;
+  const uint32_t* qc = dsa_qconst(kt, (uint32_t)rec.key_slot);
   U256 r2;
   for (int i = 0; i < 8; ++i) r2.w[i] = qc[i];
   const U256 u1 = u256_mulmod_mont(w, z, q, qc[8], r2);
   for (int i = 0; i < 8; ++i) o[i] = u1.w[i];
 }
 
-// Fixed-base window tables for one DSA key (see KeyTableDev::dsa_comb).  One quad per (slot, base, window, part):
+// Fixed-base window tables for one DSA key (see KeyTableDev::dsa_comb).  One group per (slot, base, window, part):
 // B = seed^(2^(wbits*w)) by repeated squaring; the part's first entry B^(d0) by square-and-multiply over d0; then the
 // part's entries by repeated multiplication with B.  `parts` splits the 2^wbits - 1 digits of a window so that the 16-bit
-// layout (65,535 entries per window) is built by 16x more quads with 16x shorter chains.
+// layout (65,535 entries per window) is built by 16x more groups with 16x shorter chains.
+// <19, 4>: keys with p <= 2048 bits; <14, 8>: p <= 3072 bits (the host hands each instantiation the new slots of its class).
 // Runs once per new DSA key (bftkv_gpu_keyring_set / certificate upload), never on the verify path.
+template <int L, int TPI>
 __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, const uint32_t* __restrict__ new_slots /*[n_new]*/,
                                                               const uint32_t* __restrict__ slot_key /*[n_new] key table row*/,
                                                               KeyTableDev kt, uint32_t* __restrict__ comb, uint32_t parts) {
-  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
-  constexpr int L = MONT_L;
+  constexpr int NL = L * TPI, GROUPS = RSA_BLOCK / TPI;
+  __shared__ uint32_t a_sh[GROUPS * NL];
+  const uint32_t E = kt.dsa_entry_limbs;
   const uint32_t wbits = kt.dsa_wbits, nwin = dsa_nwin(wbits), nent = (1u << wbits) - 1u;
   const uint32_t n_quads = n_new * 2u * nwin * parts;
-  const uint32_t quad = threadIdx.x >> 2;
-  const int qlane = threadIdx.x & 3;
-  const uint32_t gq0 = blockIdx.x * QUADS_PER_BLOCK + quad;
+  const uint32_t quad = threadIdx.x / TPI;
+  const int qlane = threadIdx.x % TPI;
+  const uint32_t gq0 = blockIdx.x * GROUPS + quad;
   const bool active = gq0 < n_quads;
   const uint32_t gq = active ? gq0 : (n_quads - 1);
   const uint32_t part = gq % parts, gw = gq / parts;
   const uint32_t which = gw / (2u * nwin), base = (gw / nwin) & 1u, w = gw % nwin;
   const uint32_t key = slot_key[which];
-  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
-  const uint32_t* a_rd = a_sh + quad * MONT_N;
+  uint32_t* a_lds = a_sh + quad * NL + qlane * L;
+  const uint32_t* a_rd = a_sh + quad * NL;
   uint32_t n[L], b[L], y[L], t[L], one[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
-  const uint32_t* sp = kt.dsa_tab + ((uint64_t)key * 2 + base) * MONT_N + qlane * L;
+  const uint32_t* sp = kt.dsa_tab + ((uint64_t)key * 2 + base) * DSA_N_BIG + qlane * L;
   const uint32_t* rp = kt.r2_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
 #pragma unroll
   for (int k = 0; k < L; ++k) { n[k] = np[k]; y[k] = sp[k]; }
   const uint32_t n0inv = kt.n0inv[key];
   const uint32_t nsq = wbits * w;
-  for (uint32_t i = 0; i < wbits * (nwin - 1); ++i) {     // uniform trip count; quads past their own count keep y
+  for (uint32_t i = 0; i < wbits * (nwin - 1); ++i) {     // uniform trip count; groups past their own count keep y
 #pragma unroll
     for (int k = 0; k < L; ++k) { a_lds[k] = y[k]; b[k] = y[k]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (i < nsq) {
 #pragma unroll
@@ -1834,29 +1844,29 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, co
 #pragma unroll
   for (int k = 0; k < L; ++k) { a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u; b[k] = rp[k]; }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  mont_mul(one, a_rd, b, n, n0inv, qlane);
+  mont_mul<L, TPI>(one, a_rd, b, n, n0inv, qlane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
   for (int k = 0; k < L; ++k) b[k] = one[k];
-  for (int bit = (int)wbits - 1; bit >= 0; --bit) {         // b = B^d0, left-to-right (uniform trip count, per-quad select)
+  for (int bit = (int)wbits - 1; bit >= 0; --bit) {         // b = B^d0, left-to-right (uniform trip count, per-group select)
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = b[k];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int k = 0; k < L; ++k) { b[k] = t[k]; a_lds[k] = y[k]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if ((d0 >> bit) & 1u) {
 #pragma unroll
       for (int k = 0; k < L; ++k) b[k] = t[k];
     }
   }
-  uint32_t* out = comb + (uint64_t)new_slots[which] * dsa_slot_stride(wbits) + ((uint64_t)(base * nwin + w) * nent) * MONT_N + qlane * L;
+  uint32_t* out = comb + (uint64_t)new_slots[which] * dsa_slot_stride(wbits, E) + ((uint64_t)(base * nwin + w) * nent) * E + qlane * L;
   // The window k_dsa_modexp multiplies by LAST (base 1, top window) is stored in plain form, B^d instead of B^d R: that
-  // product then leaves the Montgomery domain by itself.  One more product per entry here, for the waves that hold such a quad.
+  // product then leaves the Montgomery domain by itself.  One more product per entry here, for the waves that hold such a group.
   const bool plain = dsa_plain_window(base, w, nwin);
   const bool any_plain = __any(plain);
   for (uint32_t j = 0; j < per; ++j) {
@@ -1865,66 +1875,78 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_build_comb(uint32_t n_new, co
 #pragma unroll
       for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      mont_mul(t, a_rd, b, n, n0inv, qlane);          // B^d R * 1 * R^-1
+      mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);          // B^d R * 1 * R^-1
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      canonicalize(t, qlane);
+      canonicalize<L, TPI>(t, qlane);
     }
     if (active && d >= 1) {
 #pragma unroll
-      for (int k = 0; k < L; ++k) out[(uint64_t)(d - 1) * MONT_N + k] = plain ? t[k] : b[k];
+      for (int k = 0; k < L; ++k) out[(uint64_t)(d - 1) * E + k] = plain ? t[k] : b[k];
     }
 #pragma unroll
     for (int k = 0; k < L; ++k) a_lds[k] = y[k];     // a = B for the chain
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    mont_mul(t, a_rd, b, n, n0inv, qlane);
+    mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int k = 0; k < L; ++k) b[k] = t[k];
   }
 }
 
-__device__ __forceinline__ uint64_t quad_sum64(uint64_t v) {
+template <int TPI>
+__device__ __forceinline__ uint64_t grp_sum64(uint64_t v) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   v += ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_QUAD_SWAP1, 0xF, 0xF, false) << 32) |
        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, DPP_QUAD_SWAP1, 0xF, 0xF, false);
   lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
   v += ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_QUAD_SWAP2, 0xF, 0xF, false) << 32) |
        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, DPP_QUAD_SWAP2, 0xF, 0xF, false);
+  if constexpr (TPI == 8) {     // the other quad of the group
+    lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+    v += ((uint64_t)(uint32_t)__shfl_xor((int)hi, 4) << 32) | (uint32_t)__shfl_xor((int)lo, 4);
+  }
   return v;
 }
 
 // v = g^u1 * y^u2 mod p from the per-key fixed-base tables: one table multiplication per non-zero
-// window digit of u1 and u2 but the first (<= 2 * 256/wbits - 1), no squarings.  A table row is 304 B read straight from
-// HBM/MALL into the quad's LDS slot; a wave skips a (window, base) step when all 16 digits are zero.
-// The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each quad lane
-// folds its 19 limbs, the quad adds up, 35 shift-subtract steps finish), then (v mod q) == r.
+// window digit of u1 and u2 but the first (<= 2 * 256/wbits - 1), no squarings.  A table row (304 B; 448 B for a 3072-bit p) is
+// read straight from HBM/MALL into the group's LDS slot; a wave skips a (window, base) step when all its digits are zero.
+// The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each group lane
+// folds its L limbs, the group adds up, 35 shift-subtract steps finish), then (v mod q) == r.
+// <19, 4> takes the rows of the DSA work list whose key has p <= 2048 bits, <14, 8> those with p <= 3072 bits (launched only
+// when such a key is in the table); rows of the other class ride along untouched, and a wave without a row of its class returns.
+template <int L, int TPI>
 __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
                                                           const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
                                                           const uint32_t* __restrict__ dsa_u) {
-  __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
-  constexpr int L = MONT_L;
+  constexpr int NL = L * TPI, GROUPS = RSA_BLOCK / TPI;
+  constexpr bool BIG = NL > (int)DSA_N_SMALL;
+  __shared__ uint32_t a_sh[GROUPS * NL];
   const uint32_t count = pk_count[1], start = pk_start[1];
-  if (start + blockIdx.x * QUADS_PER_BLOCK >= count) return;
-  const uint32_t quad = threadIdx.x >> 2;
-  const int qlane = threadIdx.x & 3;
-  const uint32_t gq = start + blockIdx.x * QUADS_PER_BLOCK + quad;
+  if (start + blockIdx.x * GROUPS >= count) return;
+  const uint32_t quad = threadIdx.x / TPI;
+  const int qlane = threadIdx.x % TPI;
+  const uint32_t gq = start + blockIdx.x * GROUPS + quad;
   const bool active = gq < count;
   const uint32_t di = active ? gq : (count - 1);
   const uint32_t ri = dsa_list[di];
   const SigRec rec = recs[ri];
   const uint32_t key = (uint32_t)rec.key_slot;
-  uint32_t* a_lds = a_sh + quad * MONT_N + qlane * L;
-  const uint32_t* a_rd = a_sh + quad * MONT_N;
+  const bool mine = active && (kt.mod_bits[key] > 2048u) == BIG;      // this instantiation's size class
+  if (!__any(mine)) return;
+  uint32_t* a_lds = a_sh + quad * NL + qlane * L;
+  const uint32_t* a_rd = a_sh + quad * NL;
   uint32_t n[L], b[L], y[L], t[L];
   const uint32_t* np = kt.n_limbs + (uint64_t)key * MONT_NMAX + qlane * L;
+  const uint32_t E = kt.dsa_entry_limbs;
   const uint32_t wbits = kt.dsa_wbits, nwin = dsa_nwin(wbits), nent = (1u << wbits) - 1u;
-  const uint32_t* slot_base = kt.dsa_comb + (uint64_t)kt.dsa_slot[key] * dsa_slot_stride(wbits);
+  const uint32_t* slot_base = dsa_slot_base(kt, key);
   const uint32_t* tab = slot_base + qlane * L;
 #pragma unroll
-  for (int k = 0; k < L; ++k) n[k] = np[k];
+  for (int k = 0; k < L; ++k) n[k] = mine ? np[k] : (qlane == 0 && k == 0 ? 1u : 0u);     // (a row of the other class: modulus 1, digits 0)
   const uint32_t n0inv = kt.n0inv[key];
   const uint32_t* up = dsa_u + (uint64_t)di * DSA_U_WORDS;
-  const bool live = active && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
+  const bool live = mine && rec.status == ST_PENDING_RSA;     // refused rows ride along with all-zero digits
   auto digit = [&](uint32_t step) -> uint32_t {
     const uint32_t bitpos = (step >> 1) * wbits, wi = bitpos >> 5, sh = bitpos & 31u;
     if (!live) return 0u;
@@ -1933,7 +1955,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & nent;
   };
   auto entry = [&](uint32_t step, uint32_t d) -> const uint32_t* {
-    return tab + ((uint64_t)((step & 1u) * nwin + (step >> 1)) * nent + (d ? d - 1 : 0)) * MONT_N;
+    return tab + ((uint64_t)((step & 1u) * nwin + (step >> 1)) * nent + (d ? d - 1 : 0)) * E;
   };
   // The chain is 2*nwin - 1 products at most (31 for 16-bit windows): a signature's first non-zero digit just takes its
   // table entry as the starting value, and the last window's entries are stored in plain form (k_dsa_build_comb) so that
@@ -1944,11 +1966,13 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   for (int k = 0; k < L; ++k) y[k] = 0;
   for (uint32_t step = 0; step <= last; ++step) {
     const uint32_t d = digit(step);
-    const bool need = (step == last) || d != 0;      // the last product always happens: a zero digit multiplies by the plain 1
+    const bool need = mine && ((step == last) || d != 0);      // the last product always happens: a zero digit multiplies by the plain 1
     if (!__any(need)) continue;
     const uint32_t* tp = entry(step, d);
+    if (mine) {
 #pragma unroll
-    for (int k = 0; k < L; ++k) a_lds[k] = tp[k];    // a zero digit reads entry 1 and (but for the last step) drops the product
+      for (int k = 0; k < L; ++k) a_lds[k] = tp[k];    // a zero digit reads entry 1 and (but for the last step) drops the product
+    }
     if (step == last && __any(d == 0)) {
       if (d == 0) {
 #pragma unroll
@@ -1959,7 +1983,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
     if (__any(need && started)) {
 #pragma unroll
       for (int k = 0; k < L; ++k) b[k] = y[k];
-      mont_mul(t, a_rd, b, n, n0inv, qlane);
+      mont_mul<L, TPI>(t, a_rd, b, n, n0inv, qlane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (__any(need && !started)) {                   // first non-zero digit of some signature: the entry is its starting value
@@ -1977,25 +2001,27 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   // y = g^u1 y^u2 mod p, possibly + p (mont_mul leaves values below p(1 + 2^-79)): the mod-q fold below needs the residue
 #pragma unroll
   for (int k = 0; k < L; ++k) t[k] = y[k];
-  canonicalize(t, qlane);
-  reduce_once(t, n, qlane);
+  canonicalize<L, TPI>(t, qlane);
+  reduce_once<L, TPI>(t, n, qlane);
   uint32_t diff = 0;
 #pragma unroll
   for (int k = 0; k < L; ++k) diff |= t[k];
-  diff = quad_or(diff);                      // 0: v = 0, and r > 0 can never match
-  // v mod q: sum_j v_j * (2^(28 j) mod q) over 10 radix-2^28 columns (76 terms of < 2^56 each)
+  diff = grp_or<TPI>(diff);                  // 0: v = 0, and r > 0 can never match
+  // v mod q: sum_j v_j * (2^(28 j) mod q) over 10 radix-2^28 columns (NL terms of < 2^56 each)
   uint64_t col[10];
 #pragma unroll
   for (int j = 0; j < 10; ++j) col[j] = 0;
-  const uint32_t* pw = slot_base + dsa_comb_limbs_per_key(wbits) + (qlane * L) * 10;
+  const uint32_t* pw = slot_base + dsa_comb_limbs_per_key(wbits, E) + (qlane * L) * 10;
+  if (mine) {
 #pragma unroll
-  for (int k = 0; k < L; ++k) {
+    for (int k = 0; k < L; ++k) {
 #pragma unroll
-    for (int j = 0; j < 10; ++j) col[j] = mad64(t[k], pw[k * 10 + j], col[j]);
+      for (int j = 0; j < 10; ++j) col[j] = mad64(t[k], pw[k * 10 + j], col[j]);
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 10; ++j) col[j] = quad_sum64(col[j]);
-  // columns -> 32-bit words W (value < q * 2^34.3)
+  for (int j = 0; j < 10; ++j) col[j] = grp_sum64<TPI>(col[j]);
+  // columns -> 32-bit words W (value < q * 2^34.3; 112 limbs: q * 2^34.9)
   uint32_t W[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) W[i] = 0;
@@ -2012,7 +2038,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ r
   U256 q, rr, acc;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { q.w[i] = kt.q_words[(uint64_t)key * 8 + i]; rr.w[i] = up[16 + i]; }
-  // acc = top part (value >> 35 < 2^bits(q) <= 2q), then 35 double-and-reduce steps for the low bits
+  // acc = top part (value >> 35 < q), then 35 double-and-reduce steps for the low bits
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc.w[i] = (W[i + 1] >> 3) | (W[i + 2] << 29);
   if (u256_cmp(acc, q) >= 0) u256_sub(acc, q);

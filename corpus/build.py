@@ -95,9 +95,9 @@ def _hashed_area(issuer: int, extra: bytes = b"") -> bytes:
     return (b"\x05\x02" + struct.pack(">I", CREATION_TIME) + extra + b"\x09\x10" + struct.pack(">Q", issuer))
 
 
-def sig_prefix(sig_type: int, pk_algo: int, hashed: bytes) -> bytes:
+def sig_prefix(sig_type: int, pk_algo: int, hashed: bytes, hash_id: int = HASH_SHA256) -> bytes:
     """The first 6+hl bytes of a v4 signature body (also the start of the hash suffix)."""
-    return bytes([4, sig_type, pk_algo, HASH_SHA256]) + struct.pack(">H", len(hashed)) + hashed
+    return bytes([4, sig_type, pk_algo, hash_id]) + struct.pack(">H", len(hashed)) + hashed
 
 
 def hash_suffix(prefix: bytes) -> bytes:
@@ -142,10 +142,16 @@ def make_sig_packet(kp: KeyPair, prefix: bytes, digest: bytes, rng: Optional[DRB
     return _hdr(2, len(body)) + body
 
 
-def detach_sign(kp: KeyPair, signed: bytes, rng: Optional[DRBG] = None) -> bytes:
-    """openpgp.DetachSign(w, priv, r, nil) shape (crypto_pgp.go:353)."""
-    prefix = sig_prefix(0x00, kp.algo, _hashed_area(kp.key_id))
-    digest = hashlib.sha256(signed + hash_suffix(prefix)).digest()
+HASH_NAMES = {2: "sha1", 8: "sha256", 9: "sha384", 10: "sha512", 11: "sha224"}      # RFC 4880 9.4 ids -> hashlib
+
+
+def detach_sign(kp: KeyPair, signed: bytes, rng: Optional[DRBG] = None, hash_id: int = HASH_SHA256) -> bytes:
+    """openpgp.DetachSign(w, priv, r, nil) shape (crypto_pgp.go:353; nil config = SHA-256).  ``hash_id`` other than SHA-256 is what
+    a packet.Config{DefaultHash: ...} signer emits -- DSA only (the RSA EMSA prefix of make_sig_packet is SHA-256's): the digest is
+    cut to the leftmost ceil(bits(q) / 8) bytes by the signer and by the verifier alike."""
+    assert hash_id == HASH_SHA256 or kp.algo == PK_DSA
+    prefix = sig_prefix(0x00, kp.algo, _hashed_area(kp.key_id), hash_id)
+    digest = hashlib.new(HASH_NAMES[hash_id], signed + hash_suffix(prefix)).digest()
     return make_sig_packet(kp, prefix, digest, rng)
 
 
@@ -219,11 +225,18 @@ def quorum_numbers(n: int) -> Tuple[int, int, int, int]:
 
 
 def make_cluster(n: int, dsa_fraction: float = 0.0, seed: int = MASTER_SEED, n_outsiders: int = 2,
-                 key_offset: int = 0) -> Cluster:
+                 key_offset: int = 0, dsa_kind: str = "dsa2048") -> Cluster:
+    """``dsa_kind``: the DSA replicas' group size -- 'dsa2048' (q 256 bits, BASELINE's configs), 'dsa1024' (q 160), 'dsa1536'
+    (q 224), 'dsa3072' (q 256), or a sequence of kinds dealt round-robin to the DSA replicas."""
     rng = DRBG("cluster", seed, n, dsa_fraction)
     n_dsa = int(round(n * dsa_fraction))
     rsa = load_keys("rsa2048", key_offset + (n - n_dsa) + 1 + n_outsiders)[key_offset:]
-    dsa = load_keys("dsa2048", n_dsa) if n_dsa else []
+    if isinstance(dsa_kind, str):
+        dsa = load_keys(dsa_kind, n_dsa) if n_dsa else []
+    else:
+        kinds = list(dsa_kind)
+        pools = {k: load_keys(k, (n_dsa + len(kinds) - 1) // len(kinds)) for k in kinds}
+        dsa = [pools[kinds[i % len(kinds)]][i // len(kinds)] for i in range(n_dsa)]
     # seeded assignment of which replica indices are DSA
     idx = list(range(n))
     for i in range(n - 1, 0, -1):

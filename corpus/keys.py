@@ -130,6 +130,9 @@ def gen_dsa(index: int, L: int = 2048, N: int = 256, seed: int = MASTER_SEED) ->
     return {"p": p, "q": q, "g": g, "x": priv}
 
 
+DSA_Q_BITS = {1024: 160, 1536: 224, 2048: 256, 3072: 256}      # FIPS 186-3 pairs as GnuPG picks them (g10/keygen.c: > 2047 bits 256, > 1024 bits 224, else 160)
+
+
 _GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -138,15 +141,21 @@ def _cache_path(kind: str) -> str:
 
 
 def load_keys(kind: str, count: int) -> List[Dict[str, int]]:
-    """kind: 'rsa2048', 'rsa3072', 'rsa4096' or 'dsa2048'.  Returns the first ``count`` keys, generating and extending
-    the on-disk cache when it is short."""
+    """kind: 'rsa2048', 'rsa3072', 'rsa4096', 'dsa2048' (q 256 bits), or the other DSA sizes in use -- 'dsa1024' (q 160 bits: the
+    group size of the reference's era and of its threshold tests, crypto/threshold/dsa/dsa_test.go:26-28), 'dsa1536' (q 224 bits,
+    what gpg 2.2 makes of a 1536-bit request) and 'dsa3072' (q 256 bits).  Returns the first ``count`` keys, generating and
+    extending the on-disk cache when it is short."""
     path = _cache_path(kind)
     keys: List[Dict[str, str]] = []
     if os.path.exists(path):
         with open(path) as f:
             keys = json.load(f)["keys"]
     if len(keys) < count:
-        gen = (lambda i: gen_rsa(i, bits=int(kind[3:]))) if kind.startswith("rsa") else gen_dsa
+        if kind.startswith("rsa"):
+            gen = lambda i: gen_rsa(i, bits=int(kind[3:]))                     # noqa: E731
+        else:
+            L = int(kind[3:])
+            gen = lambda i: gen_dsa(i, L=L, N=DSA_Q_BITS[L])                   # noqa: E731
         for i in range(len(keys), count):
             k = gen(i)
             keys.append({name: "%x" % v for name, v in k.items()})

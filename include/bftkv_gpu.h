@@ -112,6 +112,18 @@ int bftkv_gpu_set_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t bits);
 /* The width the DSA tables of the current key table were built at (0: the table holds no DSA key): a verification is
  * 2 * ceil(256 / bits) - 1 table multiplications at most. */
 int bftkv_gpu_dsa_window_bits(bftkv_gpu_ctx* ctx, uint32_t* bits_out);
+/* A bound on the HBM the DSA tables may hold -- for a service that shares the GPU (the default policy takes up to 45 % of the
+ * FREE memory: 76.5 GB for 32 keys on an idle MI355X).  With a budget the policy picks the widest window whose tables for every
+ * DSA key of the node keyring fit `bytes` (32 keys: 8 GB -> 14 bits, 37 multiplications per signature; 24 GB -> 16 bits, 31;
+ * 77 GB -> 18 bits, 29; keys with p beyond 2048 bits: entries are 448 instead of 304 bytes), the arena is never allocated beyond
+ * it, cached tables of keys that left the keyring are dropped before it is exceeded, and certificate-only DSA keys (request
+ * certificates, crypto/pgp/crypto_pgp.go:332-344) get only the slots the budget leaves (none: their signatures are fenced).
+ * bytes = 0 returns to the free-memory policy.  A width pinned with bftkv_gpu_set_dsa_window_bits wins over the budget.
+ * Replaces the environment variable BFTKV_DSA_WBITS (kept for experiments).  Takes effect at the next bftkv_gpu_keyring_set. */
+int bftkv_gpu_set_dsa_table_budget(bftkv_gpu_ctx* ctx, uint64_t bytes);
+/* Bytes of HBM the DSA tables hold right now (the arena's allocation) and the entry size in limbs (76: every key has p <= 2048
+ * bits; 112: a key with p up to 3072 bits is in the node keyring).  Either pointer may be null. */
+int bftkv_gpu_dsa_table_bytes(bftkv_gpu_ctx* ctx, uint64_t* bytes_out, uint32_t* entry_limbs_out);
 
 /* ---- transport message signatures: the signature half of PGPMessage.Decrypt (crypto/pgp/crypto_pgp.go:453-471) ----
  * Every request and reply is an OpenPGP message encrypted to the peer and signed by the sender

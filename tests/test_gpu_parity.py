@@ -1516,3 +1516,139 @@ def test_big_batch_with_other_hashes_still_runs_their_digests(gpu_ctx):
     err2, _, _ = gpu_ctx.collective_verify(qh, tbT, toT, sbT, soT)            # and cut into pieces by the size rule
     assert (err2 == err).all()
     gpu_ctx.quorum_destroy(qh)
+
+
+# ---- DSA at the group sizes gpg and the reference use (a17; tests/golden/make_gpg_dsa_sizes_vectors.py) ---------------------------
+def _dsa_sizes():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gpg_dsa_sizes_vectors.json")))
+
+
+def _verify_singles(ctx, kr, payloads, sigs):
+    """one detached signature per item through bftkv_gpu_signature_verify; returns (err, fenced, per-item statuses)"""
+    tb, to = _cat(payloads)
+    sb, so = _cat(sigs)
+    err = ctx.signature_verify(tb, to, sb, so)
+    fenced = np.array(ctx.last_fenced).copy()
+    st, st_item = ctx.last_statuses()
+    return err, fenced, [list(st[st_item == i]) for i in range(len(payloads))]
+
+
+def test_dsa_1024_160_and_3072_256_gpg_vectors_on_gpu(gpu_ctx):
+    """gpg-made dsa1024 (q 160 bits) and dsa3072 (q 256 bits) keys and signatures under SHA-1 / 224 / 256 / 384 / 512 (digest as wide
+    as q, or cut to its leftmost bits(q) / 8 bytes), intact and with a tampered payload: the device's verdict is gpg's and the
+    oracle's, the per-packet status is the oracle's, and NOTHING is fenced -- neither size is handed back to the reference path."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    vec = _dsa_sizes()
+    ring = pgp.read_entities(bytes.fromhex(vec["A_pubring"]))
+    kr = col.Keyring(keyring=ring)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    pl = [bytes.fromhex(v["payload"]) for v in vec["A"]]
+    sg = [bytes.fromhex(v["sig"]) for v in vec["A"]]
+    n = len(pl)
+    err, fenced, sts = _verify_singles(gpu_ctx, kr, pl + [p + b"!" for p in pl], sg + sg)
+    assert not fenced.any()
+    for i, v in enumerate(vec["A"]):
+        assert (err[i] == 0) == v["gpg_good"] and (err[n + i] == 0) == v["gpg_tampered_good"], v
+        for k, payload in ((i, pl[i]), (n + i, pl[i] + b"!")):
+            r = pgp.check_detached_signature(ring, payload, sg[i], 0)
+            assert sts[k] == r.statuses, (v["key"], v["digest"], sts[k], r.statuses)
+    assert (err[:n] == 0).all() and (err[n:] != 0).all()
+    by_key = {k: sum(1 for v in vec["A"] if v["key"] == k) for k in ("dsa1024", "dsa3072")}
+    assert by_key == {"dsa1024": 16, "dsa3072": 12}
+
+
+def test_generator_dsa_sizes_judged_by_gpg_on_gpu(gpu_ctx):
+    """Generator keys of 1024/160, 1536/224 and 3072/256 bits with Go-shaped signatures under SHA-1 / SHA-256 / SHA-512, intact and
+    tampered (payload; a bit of s): verdicts are gpg's, statuses the oracle's, nothing fenced."""
+    from oracle import collective as col
+    from oracle import openpgp as pgp
+    vec = _dsa_sizes()
+    ring = pgp.read_entities(bytes.fromhex(vec["B_pubring"]))
+    kr = col.Keyring(keyring=ring)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    pl = [bytes.fromhex(v["payload"]) for v in vec["B"]]
+    sg = [bytes.fromhex(v["sig"]) for v in vec["B"]]
+    err, fenced, sts = _verify_singles(gpu_ctx, kr, pl, sg)
+    assert not fenced.any()
+    good = {}
+    for i, v in enumerate(vec["B"]):
+        assert (err[i] == 0) == v["gpg_good"], v
+        r = pgp.check_detached_signature(ring, pl[i], sg[i], 0)
+        assert sts[i] == r.statuses, (v["p_bits"], v["q_bits"], v["hash_id"], v["tamper"], sts[i], r.statuses)
+        if err[i] == 0:
+            good[v["p_bits"]] = good.get(v["p_bits"], 0) + 1
+    assert good == {1024: 18, 1536: 12, 3072: 12}
+
+
+@pytest.mark.parametrize("wbits", (0, 8, 13))
+def test_mixed_dsa_group_sizes_in_one_quorum(gpu_ctx, wbits):
+    """One 16-replica clique whose members hold RSA-2048 keys and DSA keys of FOUR group sizes (1024/160, 1536/224, 2048/256,
+    3072/256), writes with the usual mutations: error bytes, exit counts and per-packet statuses against the oracle, nothing fenced.
+    Table widths: the library's choice, 8 and 13 bits (every size class builds and reads its own fixed-base tables)."""
+    cl = cb.make_cluster(16, dsa_fraction=0.75, dsa_kind=("dsa1024", "dsa3072", "dsa1536", "dsa2048"))
+    assert sorted({r.p.bit_length() for r in cl.replicas if r.algo == cb.PK_DSA}) == [1024, 1536, 2048, 3072]
+    rates = {cb.MUT_BAD_MPI: 0.15, cb.MUT_ONE_SHORT: 0.15, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1}
+    c = cb.make_write_corpus(cl, 96, mutation_rates=rates, seed=606 + wbits)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    gpu_ctx.set_dsa_window_bits(wbits)
+    try:
+        gpu_ctx.keyring_set(H.abi_keys(kr))
+        qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+        err, nver, _ = gpu_ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+        assert not np.array(gpu_ctx.last_fenced).any()
+        st, st_item = gpu_ctx.last_statuses()
+        n_dsa_ok = 0
+        dsa_ids = {r.key_id for r in cl.replicas if r.algo == cb.PK_DSA}
+        for i in range(c.n_items):
+            r = H.oracle_collective(kr, q, c, i)
+            assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (i, err[i], r.err)
+            got = list(st[st_item == i])
+            assert got[:len(r.statuses)] == r.statuses, (i, got, r.statuses)
+            n_dsa_ok += sum(1 for kid in r.verified if kid in dsa_ids)
+        assert n_dsa_ok > 300 and 0 < int((err == 0).sum()) < c.n_items
+        gpu_ctx.quorum_destroy(qh)
+    finally:
+        gpu_ctx.set_dsa_window_bits(0)
+
+
+def test_dsa_table_budget_bounds_the_hbm_the_tables_hold():
+    """bftkv_gpu_set_dsa_table_budget (a service that shares the GPU): 32 DSA-2048 keys (BASELINE configs[2]'s keyring) under 8 GB /
+    24 GB / no budget get 14- / 16- / 18-bit tables (37 / 31 / 29 multiplications per signature), the arena's allocation stays within
+    the budget, and the verdicts stay the oracle's at every width.  Its own context: the arena is tens of GB."""
+    import torch  # noqa: F401
+    from bftkv_amd import Context
+    cl = cb.make_cluster(64, dsa_fraction=0.5)
+    assert sum(1 for r in cl.replicas if r.algo == cb.PK_DSA) == 32
+    c = cb.make_write_corpus(cl, 24, seed=77, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_ONE_SHORT: 0.2})
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    want = [H.oracle_collective(kr, q, c, i) for i in range(c.n_items)]
+    ctx = Context(0)
+    try:
+        picked = {}
+        for budget in (8 << 30, 24 << 30, 0):
+            ctx.set_dsa_table_budget(budget)
+            ctx.keyring_set(H.abi_keys(kr))
+            qh = ctx.quorum_create(H.abi_qcs(q))
+            bits = ctx.dsa_window_bits()
+            held, entry = ctx.dsa_table_bytes()
+            picked[budget] = bits
+            assert entry == 76
+            if budget:
+                assert held <= budget, (budget, held)
+            err, nver, _ = ctx.collective_verify(qh, c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off)
+            st, st_item = ctx.last_statuses()
+            for i, r in enumerate(want):
+                assert (err[i] == 0) == (r.err is None) and nver[i] == len(r.verified), (budget, i)
+                assert list(st[st_item == i][:len(r.statuses)]) == r.statuses, (budget, i)
+            assert not np.array(ctx.last_fenced).any()
+            ctx.quorum_destroy(qh)
+        assert picked[8 << 30] == 14 and picked[24 << 30] == 16 and picked[0] in (16, 18), picked
+        # a budget too small for anything but the narrowest tables still verifies (4.96 MB per key at 8 bits)
+        ctx.set_dsa_table_budget(200 << 20)
+        ctx.keyring_set(H.abi_keys(kr))
+        assert ctx.dsa_window_bits() == 8 and ctx.dsa_table_bytes()[0] <= 200 << 20
+    finally:
+        ctx.close()
