@@ -40,7 +40,7 @@ EXPORTS = [
     "bftkv_gpu_stream", "bftkv_gpu_modmul_product", "bftkv_gpu_lagrange_combine", "bftkv_gpu_dsa_calculate_r", "bftkv_gpu_selftest_reduce",
     "bftkv_gpu_comm_unique_id", "bftkv_gpu_comm_init", "bftkv_gpu_allgather_verdicts", "bftkv_gpu_sss_distribute", "bftkv_gpu_modinv",
     "bftkv_gpu_batcher_create", "bftkv_gpu_batcher_destroy", "bftkv_gpu_batcher_collective_verify",
-    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_dsa_window_bits", "bftkv_gpu_set_dsa_table_budget", "bftkv_gpu_dsa_table_bytes", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
+    "bftkv_gpu_batcher_signature_verify", "bftkv_gpu_batcher_stats", "bftkv_gpu_set_dsa_window_bits", "bftkv_gpu_dsa_window_bits", "bftkv_gpu_set_dsa_table_budget", "bftkv_gpu_dsa_table_bytes", "bftkv_gpu_collective_verify_segments", "bftkv_gpu_message_verify", "bftkv_gpu_batcher_message_verify",
     "bftkv_gpu_modexp_ops", "bftkv_gpu_allgather_errs_dev", "bftkv_gpu_set_early_exit", "bftkv_gpu_last_sclk_mhz", "bftkv_gpu_modmul_product_dev", "bftkv_gpu_lagrange_combine_dev",
     "bftkv_gpu_dsa_calculate_r_dev", "bftkv_gpu_sss_distribute_dev", "bftkv_gpu_modinv_dev",
     "bftkv_gpu_ctx_fork", "bftkv_gpu_batcher_create_lanes", "bftkv_gpu_batcher_times", "bftkv_gpu_comm_library", "bftkv_gpu_comm_selftest",
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib.bftkv_gpu_quorum_create.argtypes = [vp, C.POINTER(QC), u32, C.POINTER(C.c_int)]
     lib.bftkv_gpu_quorum_destroy.argtypes = [vp, C.c_int]
     lib.bftkv_gpu_collective_verify.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, vp, u8p, u8p]
+    lib.bftkv_gpu_collective_verify_segments.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u32, vp, u8p, u64p, u8p, vp, u8p, u8p]
     lib.bftkv_gpu_collective_verify_dev.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, C.c_uint64, u8p, vp, u8p, u8p]
     lib.bftkv_gpu_collective_verify_small.argtypes = [vp, C.c_int, u32, u8p, u64p, u8p, u64p, u8p, u8p]
     lib.bftkv_gpu_signature_verify_small.argtypes = [vp, u32, u8p, u64p, u8p, u64p, u64p, u8p, u8p]
@@ -310,6 +311,22 @@ class Context:
     # (bftkv_gpu_*_verify_small -- midstates from the host, one stream, 8-lane modexp, every packet verified) first, and the two
     # answers must be identical item by item.
     check_small = False
+
+    def collective_verify_segments(self, quorum: int, prefix_blob, prefix_off, shared_blob, shared_off, seg_of_item, ss_blob, ss_off):
+        """bftkv_gpu_collective_verify_segments: payload i = prefix i || shared segment seg_of_item[i] (0xFFFFFFFF: none)."""
+        n = len(prefix_off) - 1
+        prefix_blob, shared_blob, ss_blob = _u8(prefix_blob), _u8(shared_blob), _u8(ss_blob)
+        prefix_off, shared_off, ss_off = _u64(prefix_off), _u64(shared_off), _u64(ss_off)
+        seg = np.ascontiguousarray(seg_of_item, dtype=np.uint32)
+        err = np.zeros(n, dtype=np.uint8)
+        nver = np.zeros(n, dtype=np.uint32)
+        verdict = np.zeros(n, dtype=np.uint8)
+        self.last_fenced = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.bftkv_gpu_collective_verify_segments(self.h, quorum, n, _ptr(prefix_blob), _ptr(prefix_off), _ptr(shared_blob),
+                                                                  _ptr(shared_off), len(shared_off) - 1, _ptr(seg), _ptr(ss_blob), _ptr(ss_off),
+                                                                  _ptr(err), _ptr(nver), _ptr(verdict), _ptr(self.last_fenced)),
+                    "collective_verify_segments")
+        return err, nver, verdict
 
     def _cross_check(self, n: int) -> bool:
         return bool(self.check_small) and 0 < n <= 4096

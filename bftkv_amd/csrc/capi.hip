@@ -150,6 +150,8 @@ struct bftkv_gpu_ctx {
   DevBuf counts, base, total, item_flags, walk_scratch, cert_ent, sig_class, mid, mid64, hash_mask, recs, digests, r, xr, pk_list, pk_list3072, pk_list4096, r3072, r4096, pk_count, dsa_list, dsa_u, ids_tmp;
   DevBuf o_err, o_nver, o_verdict, o_fenced;
   DevBuf in_tbs, in_tbs_off, in_ss, in_ss_off;
+  hipEvent_t seg_ev = nullptr;             // unsplit segmented call: the offsets are on the device (main stream -> hash stream)
+  DevBuf in_prefix, in_prefix_off, in_shared, in_shared_off, in_seg;     // bftkv_gpu_collective_verify_segments: what crosses PCIe instead of whole payloads
   DevBuf st_tmp, item_tmp, bits_tmp, plan_cut;
   DevBuf chunk_arena, chunk_ctr;    // linearised partial-length signature bodies (parse_one) and their counters (k_walk / k_scan_counts)
   uint32_t multiexp_parts = 0;        // experiment knob (BFTKV_MULTIEXP_PARTS): quads per CalculateR operation, 0 = default policy
@@ -1207,7 +1209,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot, &c->k_r2w,
                     &c->chunk_arena, &c->chunk_ctr, &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
                     &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
-                    &c->in_ss, &c->in_ss_off, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut, &c->txt_mid32, &c->txt_mid64, &c->txt_tail, &c->txt_len})
+                    &c->in_ss, &c->in_ss_off, &c->in_prefix, &c->in_prefix_off, &c->in_shared, &c->in_shared_off, &c->in_seg, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut, &c->txt_mid32, &c->txt_mid64, &c->txt_tail, &c->txt_len})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }
   c->in_pack.release();
@@ -1222,6 +1224,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   if (c->hb_ring) { if (c->stream_c) (void)hipStreamSynchronize(c->stream_c); delete (HbRing*)c->hb_ring; }
   for (hipEvent_t e : c->hb_ev) (void)hipEventDestroy(e);
   if (c->hb_ev0) (void)hipEventDestroy(c->hb_ev0);
+  if (c->seg_ev) (void)hipEventDestroy(c->seg_ev);
   if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
   if (c->stream_c2) { (void)hipStreamSynchronize(c->stream_c2); (void)hipStreamDestroy(c->stream_c2); }
   rccl_release(c);
@@ -1473,12 +1476,21 @@ int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* c, int quorum, uint32_t n_ite
 
 struct HbPiece { uint32_t i0, i1; };
 
+// Segmented payloads (bftkv_gpu_collective_verify_segments): payload i = prefix[prefix_off[i] .. prefix_off[i+1]) || shared segment
+// seg[i] (0xFFFFFFFF: none).  Only the prefixes and each distinct segment cross PCIe; k_expand_segments lays the payloads out in
+// in_tbs exactly as the unsegmented call receives them, on the copy stream, behind the copy of the piece's prefixes.
+struct HbSeg { const uint8_t* prefix; const uint64_t* prefix_off; const uint8_t* shared; const uint64_t* shared_off; uint32_t n_shared; const uint32_t* seg; };
+
 // One contiguous range of the caller's buffers on its way to the device: `half` 0 = signature streams, 1 = payloads of piece k.
 struct HbCopy { uint32_t piece; int half; const uint8_t* src; uint8_t* dst; uint64_t len; };
 
-static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n_items) {
+static uint32_t hb_forced_pieces(const bftkv_gpu_ctx* c) {
   static const int env = getenv("BFTKV_HB_PIECES") ? atoi(getenv("BFTKV_HB_PIECES")) : 0;
-  const uint32_t forced = c->hb_pieces ? c->hb_pieces : (uint32_t)std::max(env, 0);     // bftkv_gpu_set_host_pipeline, else the environment
+  return c->hb_pieces ? c->hb_pieces : (uint32_t)std::max(env, 0);     // bftkv_gpu_set_host_pipeline, else the environment
+}
+
+static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n_items) {
+  const uint32_t forced = hb_forced_pieces(c);
   if (forced == 1) return 1;
   if (forced > 1) return std::max<uint32_t>(1, std::min<uint32_t>(std::min(forced, HB_PIPE_MAX_PIECES), n_items));
   if (bytes < HB_PIPE_MIN_BYTES || n_items < 64) return 1;
@@ -1488,8 +1500,9 @@ static uint32_t hb_pieces_for(const bftkv_gpu_ctx* c, uint64_t bytes, uint32_t n
 
 static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                        const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                       uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces) {
+                                       uint8_t* verdict_out, uint8_t* fenced_out, uint32_t n_pieces, const HbSeg* sg = nullptr) {
   // caller holds c->mu and, on a fork, the root's key-table lock (shared)
+  // sg: `tbs` is null, tbs_off are the offsets of the EXPANDED payloads (computed by the caller from sg)
   // One pipelined call per device COPIES at a time: such a call is bound by the PCIe link, which concurrent callers would only
   // share (three at once: 7.2 ms per call against 5.2 alone, their 45 streams queueing on the runtime's four hardware queues).
   // The turn ends when this call's last byte is on its way (copiers joined): the next caller's first pieces cross the link
@@ -1506,14 +1519,18 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   // launches and dependent small kernels, so a piece of >= ~40 MB is done before the next one has arrived and the call ends one
   // such piece behind the last byte; smaller pieces fall behind the copy (their fixed part does not shrink), larger ones leave
   // more work for the end.  (A small LAST piece was tried: the piece before it is then large and late -- worse.)
+  // (Round 6 measured a cut at whole modexp ROUNDS instead -- 768 blocks of 64 signatures are resident at a time, and a piece of 1.79
+  // rounds pays for 2 -- and lost: the kernel's time steps by thirds of a round (a CU holds 3 blocks), an estimate that lands a piece
+  // just past a boundary costs more than the rule saves; docs/history.md.)
   std::vector<HbPiece> pc;
   {
-    const uint64_t total = tl + sl;
+    const uint64_t* const poff = sg ? sg->prefix_off : tbs_off;       // bytes that cross the link per item
+    const uint64_t total = poff[n_items] + sl;
     uint32_t i = 0;
     for (uint32_t k = 0; k < n_pieces && i < n_items; ++k) {
       const uint64_t want = total / n_pieces * (k + 1);
       uint32_t lo = i + 1, hi = n_items;
-      while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (tbs_off[m] + ss_off[m] < want) lo = m + 1; else hi = m; }
+      while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (poff[m] + ss_off[m] < want) lo = m + 1; else hi = m; }
       const uint32_t j = (k + 1 == n_pieces) ? n_items : lo;
       pc.push_back({i, j});
       i = j;
@@ -1547,7 +1564,14 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   const size_t off_bytes = sizeof(uint64_t) * ((size_t)n_items + 1);
   const size_t o_toff = (o_nv + sizeof(uint32_t) * (size_t)n_items + 15) & ~(size_t)15, o_soff = o_toff + off_bytes;
   const size_t o_tot = o_soff + off_bytes;                  // per piece: [packet events, overflow] (k_scan_counts)
-  const size_t out_bytes = o_tot + 8 * (size_t)HB_PIPE_MAX_PIECES;
+  // segmented calls: prefix offsets, item -> segment map, segment offsets and (when small) the segments themselves, staged likewise
+  const uint64_t seg_shl = sg && sg->n_shared ? sg->shared_off[sg->n_shared] : 0;
+  const bool seg_stage_blob = sg && seg_shl <= (4u << 20);
+  const size_t o_poff = (o_tot + 8 * (size_t)HB_PIPE_MAX_PIECES + 15) & ~(size_t)15;
+  const size_t o_seg = o_poff + (sg ? off_bytes : 0);
+  const size_t o_shoff = (o_seg + (sg ? sizeof(uint32_t) * (size_t)n_items : 0) + 15) & ~(size_t)15;
+  const size_t o_shb = o_shoff + (sg ? sizeof(uint64_t) * ((size_t)sg->n_shared + 1) : 0);
+  const size_t out_bytes = o_shb + (seg_stage_blob ? (size_t)seg_shl : 0) + 16;
   if (c->hb_out_cap < out_bytes) {
     if (c->hb_out) { (void)hipHostFree(c->hb_out); c->hb_out = nullptr; c->hb_out_cap = 0; }
     HIPCHK(c, hipHostMalloc((void**)&c->hb_out, out_bytes + out_bytes / 4, hipHostMallocDefault));
@@ -1560,12 +1584,47 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   memcpy(c->hb_out + o_soff, ss_off, off_bytes);
   HIPCHK(c, hipMemcpyAsync(c->in_tbs_off.p, c->hb_out + o_toff, off_bytes, hipMemcpyHostToDevice, c->stream_c));
   HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, c->hb_out + o_soff, off_bytes, hipMemcpyHostToDevice, c->stream_c));
+  if (sg) {      // the distinct segments, the prefix offsets and the item -> segment map go first (a few hundred KB)
+    const uint64_t shl = sg->n_shared ? sg->shared_off[sg->n_shared] : 0;
+    HIPCHK(c, c->in_prefix.ensure(sg->prefix_off[n_items] + 64));
+    HIPCHK(c, c->in_prefix_off.ensure(off_bytes));
+    HIPCHK(c, c->in_shared.ensure(shl + 64));
+    HIPCHK(c, c->in_shared_off.ensure(sizeof(uint64_t) * ((size_t)sg->n_shared + 1)));
+    HIPCHK(c, c->in_seg.ensure(sizeof(uint32_t) * (size_t)n_items));
+    // (through the pinned buffer like the offsets above: four copies from pageable memory cost 0.4 ms before the first piece moved)
+    memcpy(c->hb_out + o_poff, sg->prefix_off, off_bytes);
+    memcpy(c->hb_out + o_seg, sg->seg, sizeof(uint32_t) * (size_t)n_items);
+    HIPCHK(c, hipMemcpyAsync(c->in_prefix_off.p, c->hb_out + o_poff, off_bytes, hipMemcpyHostToDevice, c->stream_c));
+    HIPCHK(c, hipMemcpyAsync(c->in_seg.p, c->hb_out + o_seg, sizeof(uint32_t) * (size_t)n_items, hipMemcpyHostToDevice, c->stream_c));
+    if (sg->n_shared) {
+      memcpy(c->hb_out + o_shoff, sg->shared_off, sizeof(uint64_t) * ((size_t)sg->n_shared + 1));
+      HIPCHK(c, hipMemcpyAsync(c->in_shared_off.p, c->hb_out + o_shoff, sizeof(uint64_t) * ((size_t)sg->n_shared + 1), hipMemcpyHostToDevice, c->stream_c));
+    }
+    if (shl && seg_stage_blob) {
+      memcpy(c->hb_out + o_shb, sg->shared, shl);
+      HIPCHK(c, hipMemcpyAsync(c->in_shared.p, c->hb_out + o_shb, shl, hipMemcpyHostToDevice, c->stream_c));
+    } else if (shl) HIPCHK(c, hipMemcpyAsync(c->in_shared.p, sg->shared, shl, hipMemcpyHostToDevice, c->stream_c));
+  }
+  // Segmented: a piece's payloads are laid out by k_expand_segments on the piece's own HASH stream, once that stream has waited for
+  // the copy of the piece's prefixes (payload_ready below) -- right where they are consumed.  (On the copy stream, behind the
+  // copy, it held the DMA engine back: a kernel squeezed in beside a machine-filling modexp takes 0.3 ms, and the next copy of
+  // that stream waits for it -- 43 GB/s over the call instead of 51.)
+  auto expand_piece = [&](uint32_t k, hipStream_t st) {
+    if (!sg) return;
+    const uint32_t nk = pc[k].i1 - pc[k].i0;
+    if (nk) hipLaunchKernelGGL(k_expand_segments, dim3((nk + 3) / 4), dim3(256), 0, st, c->in_prefix.as<uint8_t>(), c->in_prefix_off.as<uint64_t>(),
+                               c->in_shared.as<uint8_t>(), c->in_shared_off.as<uint64_t>(), c->in_seg.as<uint32_t>(), c->in_tbs_off.as<uint64_t>(),
+                               pc[k].i0, nk, c->in_tbs.as<uint8_t>());
+  };
   // copy plan: piece 0's signature streams first (its modexp can start), then for every piece the payloads BEFORE the signature
   // streams of the next one -- when a piece's streams have arrived, everything of it has, and nothing waits for a payload
   std::vector<HbCopy> plan;
   for (uint32_t k = 0; k < P; ++k) {
     const uint64_t s0 = ss_off[pc[k].i0], s1 = ss_off[pc[k].i1], t0 = tbs_off[pc[k].i0], t1 = tbs_off[pc[k].i1];
-    const HbCopy cs{k, 0, ss + s0, c->in_ss.as<uint8_t>() + s0, s1 - s0}, ct{k, 1, tbs + t0, c->in_tbs.as<uint8_t>() + t0, t1 - t0};
+    const HbCopy cs{k, 0, ss + s0, c->in_ss.as<uint8_t>() + s0, s1 - s0};
+    const HbCopy ct = sg ? HbCopy{k, 1, sg->prefix + sg->prefix_off[pc[k].i0], c->in_prefix.as<uint8_t>() + sg->prefix_off[pc[k].i0],
+                                  sg->prefix_off[pc[k].i1] - sg->prefix_off[pc[k].i0]}
+                         : HbCopy{k, 1, tbs + t0, c->in_tbs.as<uint8_t>() + t0, t1 - t0};
     if (k == 0) { plan.push_back(cs); plan.push_back(ct); } else { plan.push_back(ct); plan.push_back(cs); }
   }
   std::vector<std::atomic<int>> flag(2 * (size_t)P);      // 1: the range is enqueued and its event recorded, -1: the copy failed
@@ -1697,7 +1756,8 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   // beside the three modexp waves per SIMD of piece k; it then sits at the head of a hardware queue it shares with piece k's
   // hash stream, whose digests -- and with them the piece's compare and tally -- wait behind it: +0.5..0.9 ms per piece, 5.7
   // against 5.2 ms per call.  BFTKV_HB_EARLY_MIDS=1 turns it on (it pays together with BFTKV_HB_MODEXP_LDS_PAD, two modexp waves per SIMD).
-  static const bool early_mids = getenv("BFTKV_HB_EARLY_MIDS") && atoi(getenv("BFTKV_HB_EARLY_MIDS")) != 0;
+  static const bool early_mids_env = getenv("BFTKV_HB_EARLY_MIDS") && atoi(getenv("BFTKV_HB_EARLY_MIDS")) != 0;
+  const bool early_mids = early_mids_env && !sg;        // (segmented payloads exist only behind the piece's payload hook)
   uint32_t next_mid = early_mids ? 1 : P;
   auto launch_early_mids = [&]() -> int {
     while (next_mid < P) {
@@ -1740,6 +1800,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
       for (uint32_t it = 0; (q = hipEventQuery(c->hb_ev[2 * k + 1])) == hipErrorNotReady; ++it) { if ((it & 31u) == 31u) std::this_thread::yield(); else __builtin_ia32_pause(); }
       if (q != hipSuccess) return fail(w, BFTKV_E_DEVICE, "host-buffer pipeline: payload copy event", q);
       HIPCHK(w, hipStreamWaitEvent(sh, c->hb_ev[2 * k + 1], 0));
+      expand_piece(k, sh);
       return 0;
     };
     hipError_t e;
@@ -1833,7 +1894,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
 
 static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                  uint8_t* verdict_out, uint8_t* fenced_out);
+                                  uint8_t* verdict_out, uint8_t* fenced_out, const HbSeg* sg = nullptr);
 
 int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                 const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
@@ -1848,21 +1909,51 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, 
   return rc;
 }
 
+int bftkv_gpu_collective_verify_segments(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* prefix, const uint64_t* prefix_off,
+                                         const uint8_t* shared, const uint64_t* shared_off, uint32_t n_shared, const uint32_t* seg_of_item,
+                                         const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
+                                         uint8_t* verdict_out, uint8_t* fenced_out) {
+  const HbSeg sg{prefix, prefix_off, shared, shared_off, n_shared, seg_of_item};
+  const int rc = collective_verify_host(c, quorum, n_items, nullptr, nullptr, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, &sg);
+  if (rc && n_items) {     // fail closed, as bftkv_gpu_collective_verify
+    if (err_out) memset(err_out, BFTKV_ERR_INSUFFICIENT_SIGNATURES, n_items);
+    if (verdict_out) memset(verdict_out, 0, n_items);
+    if (nver_out) memset(nver_out, 0, sizeof(uint32_t) * (size_t)n_items);
+    if (fenced_out) memset(fenced_out, 0, n_items);
+  }
+  return rc;
+}
+
 static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items, const uint8_t* tbs, const uint64_t* tbs_off,
                                   const uint8_t* ss, const uint64_t* ss_off, uint8_t* err_out, uint32_t* nver_out,
-                                  uint8_t* verdict_out, uint8_t* fenced_out) {
-  if (!c || (n_items && (!tbs_off || !ss_off))) return BFTKV_E_INVALID;
+                                  uint8_t* verdict_out, uint8_t* fenced_out, const HbSeg* sg) {
+  if (!c || (n_items && (!ss_off || (!sg && !tbs_off)))) return BFTKV_E_INVALID;
+  if (sg && n_items && (!sg->prefix_off || !sg->seg || (sg->n_shared && (!sg->shared_off || (!sg->shared && sg->shared_off[sg->n_shared]))))) return BFTKV_E_INVALID;
   if (n_items == 0) return 0;
   ctx_lock lk(c->mu);      // one lock for copy-in, pipeline and copy-out: callers may share a context
   KtRead kr(c);
   if (kr.rc) return kr.rc;
   HIPCHK(c, hipSetDevice(c->device));
   int rco;
+  std::vector<uint64_t> toff_seg;        // segmented: the offsets of the payloads as the device lays them out
+  if (sg) {
+    if ((rco = check_offsets(c, sg->prefix_off, n_items, "prefix_off not monotone from 0"))) return rco;
+    if (sg->n_shared && (rco = check_offsets(c, sg->shared_off, sg->n_shared, "shared_off not monotone from 0"))) return rco;
+    toff_seg.resize((size_t)n_items + 1);
+    toff_seg[0] = 0;
+    for (uint32_t i = 0; i < n_items; ++i) {
+      const uint32_t g = sg->seg[i];
+      if (g != 0xFFFFFFFFu && g >= sg->n_shared) return fail(c, BFTKV_E_INVALID, "segment index beyond n_shared");
+      toff_seg[i + 1] = toff_seg[i] + (sg->prefix_off[i + 1] - sg->prefix_off[i]) + (g == 0xFFFFFFFFu ? 0 : sg->shared_off[g + 1] - sg->shared_off[g]);
+    }
+    tbs_off = toff_seg.data();
+  }
   if ((rco = check_offsets(c, tbs_off, n_items, "tbs_off not monotone from 0")) || (rco = check_offsets(c, ss_off, n_items, "ss_off not monotone from 0")))
     return rco;
   const uint64_t tl = tbs_off[n_items], sl = ss_off[n_items];
-  if (const uint32_t pieces = hb_pieces_for(c, tl + sl, n_items); pieces > 1)
-    return collective_verify_pipelined(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, pieces);
+  const uint64_t link_bytes = (sg ? sg->prefix_off[n_items] : tl) + sl;       // what crosses PCIe decides whether the call is cut into pieces
+  if (const uint32_t pieces = hb_pieces_for(c, link_bytes, n_items); pieces > 1)
+    return collective_verify_pipelined(c, quorum, n_items, tbs, tbs_off, ss, ss_off, err_out, nver_out, verdict_out, fenced_out, pieces, sg);
   HIPCHK(c, c->in_tbs.ensure(tl + 64));
   HIPCHK(c, c->in_ss.ensure(sl + 64));
   HIPCHK(c, c->in_tbs_off.ensure(sizeof(uint64_t) * (n_items + 1)));
@@ -1877,9 +1968,35 @@ static int collective_verify_host(bftkv_gpu_ctx* c, int quorum, uint32_t n_items
   HIPCHK(c, hipMemcpyAsync(c->in_ss_off.p, ss_off, sizeof(uint64_t) * (n_items + 1), hipMemcpyHostToDevice, c->stream));
   // the signed payloads go over PCIe while the modexp runs (run_pipeline calls this once the modexp is launched)
   const std::function<int(hipStream_t)> upload_tbs = [&](hipStream_t sh) -> int {
-    if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, sh));
+    if (!sg) {
+      if (tl) HIPCHK(c, hipMemcpyAsync(c->in_tbs.p, tbs, tl, hipMemcpyHostToDevice, sh));
+      return 0;
+    }
+    // segmented: prefixes, the distinct segments and the map, then the payloads laid out on the device (in_tbs_off went ahead on the
+    // main stream: this stream waits for it)
+    const uint64_t pl = sg->prefix_off[n_items], shl = sg->n_shared ? sg->shared_off[sg->n_shared] : 0;
+    const size_t off_bytes = sizeof(uint64_t) * ((size_t)n_items + 1);
+    HIPCHK(c, c->in_prefix.ensure(pl + 64));
+    HIPCHK(c, c->in_prefix_off.ensure(off_bytes));
+    HIPCHK(c, c->in_shared.ensure(shl + 64));
+    HIPCHK(c, c->in_shared_off.ensure(sizeof(uint64_t) * ((size_t)sg->n_shared + 1)));
+    HIPCHK(c, c->in_seg.ensure(sizeof(uint32_t) * (size_t)n_items));
+    if (pl) HIPCHK(c, hipMemcpyAsync(c->in_prefix.p, sg->prefix, pl, hipMemcpyHostToDevice, sh));
+    HIPCHK(c, hipMemcpyAsync(c->in_prefix_off.p, sg->prefix_off, off_bytes, hipMemcpyHostToDevice, sh));
+    if (shl) HIPCHK(c, hipMemcpyAsync(c->in_shared.p, sg->shared, shl, hipMemcpyHostToDevice, sh));
+    if (sg->n_shared) HIPCHK(c, hipMemcpyAsync(c->in_shared_off.p, sg->shared_off, sizeof(uint64_t) * ((size_t)sg->n_shared + 1), hipMemcpyHostToDevice, sh));
+    HIPCHK(c, hipMemcpyAsync(c->in_seg.p, sg->seg, sizeof(uint32_t) * (size_t)n_items, hipMemcpyHostToDevice, sh));
+    if (!c->seg_ev) HIPCHK(c, hipEventCreateWithFlags(&c->seg_ev, hipEventDisableTiming));
+    HIPCHK(c, hipStreamWaitEvent(sh, c->seg_ev, 0));
+    hipLaunchKernelGGL(k_expand_segments, dim3((n_items + 3) / 4), dim3(256), 0, sh, c->in_prefix.as<uint8_t>(), c->in_prefix_off.as<uint64_t>(),
+                       c->in_shared.as<uint8_t>(), c->in_shared_off.as<uint64_t>(), c->in_seg.as<uint32_t>(), c->in_tbs_off.as<uint64_t>(), 0u, n_items,
+                       c->in_tbs.as<uint8_t>());
     return 0;
   };
+  if (sg) {      // (the offsets are on the main stream: the hash stream's expansion kernel must see them)
+    if (!c->seg_ev) HIPCHK(c, hipEventCreateWithFlags(&c->seg_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->seg_ev, c->stream));
+  }
   int rc = collective_verify_impl(c, quorum, n_items, c->in_tbs.as<uint8_t>(), c->in_tbs_off.as<uint64_t>(), c->in_ss.as<uint8_t>(),
                                   c->in_ss_off.as<uint64_t>(), c->o_err.as<uint8_t>(), c->o_nver.as<uint32_t>(), c->o_verdict.as<uint8_t>(),
                                   fenced_out ? c->o_fenced.as<uint8_t>() : nullptr, &upload_tbs, sl);

@@ -2351,6 +2351,41 @@ __global__ void k_fenced_out(const uint8_t* __restrict__ item_flags, const uint3
   if (i < n) out[i] = (((item_flags[i] & 4) || (item_hash_mask[i] & ITEM_FENCED)) ? 1 : 0) | ((item_hash_mask[i] & rehash_bits) ? 2 : 0);
 }
 
+// Segmented payloads (bftkv_gpu_collective_verify_segments): payload i = prefix_i || shared[seg_i].  The signed bytes of a bftkv
+// write end in chunk(Cert) (packet/packet.go:192-212) -- the SAME client certificate behind every write of that client -- so the
+// caller sends each distinct tail once and this kernel lays the payloads out in HBM as the unsegmented call would have received
+// them: everything downstream (midstates, digests, the text-mode hashes) reads the same bytes at the same offsets.
+// One wave per item; destination dwords are written whole (a lane per dword, the source funnelled through v_alignbyte), the up
+// to three bytes before the first and after the last aligned dword one by one.  Source buffers carry 64 bytes of slack.
+__device__ __forceinline__ void wave_copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t len, uint32_t lane) {
+  if (len == 0) return;
+  const uint64_t head = ((4u - ((uintptr_t)dst & 3u)) & 3u) < len ? ((4u - ((uintptr_t)dst & 3u)) & 3u) : len;
+  if (lane < head) dst[lane] = src[lane];
+  const uint64_t body = (len - head) & ~(uint64_t)3;
+  uint32_t* __restrict__ d4 = (uint32_t*)(dst + head);
+  const uint8_t* sp = src + head;
+  const uint32_t mis = (uint32_t)((uintptr_t)sp & 3u);
+  const uint32_t* __restrict__ s4 = (const uint32_t*)(sp - mis);          // aligned down: stays inside the (256-byte aligned) buffer
+  for (uint64_t w = lane; w < body / 4; w += 64) {
+    const uint32_t lo = s4[w], hi = mis ? s4[w + 1] : 0u;                // (the dword past the end is the buffer's slack at worst)
+    d4[w] = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+  }
+  const uint64_t done = head + body;
+  if (lane < len - done) dst[done + lane] = src[done + lane];
+}
+__global__ void __launch_bounds__(256) k_expand_segments(const uint8_t* __restrict__ prefix, const uint64_t* __restrict__ prefix_off,
+                                                         const uint8_t* __restrict__ shared, const uint64_t* __restrict__ shared_off,
+                                                         const uint32_t* __restrict__ seg, const uint64_t* __restrict__ tbs_off,
+                                                         uint32_t i0, uint32_t n, uint8_t* __restrict__ out) {
+  const uint32_t item = i0 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63u;
+  if (item >= i0 + n) return;
+  const uint64_t p0 = prefix_off[item], pl = prefix_off[item + 1] - p0;
+  uint8_t* dst = out + tbs_off[item];
+  wave_copy_bytes(dst, prefix + p0, pl, lane);
+  const uint32_t sg = seg[item];
+  if (sg != 0xFFFFFFFFu) wave_copy_bytes(dst + pl, shared + shared_off[sg], shared_off[sg + 1] - shared_off[sg], lane);
+}
+
 __global__ void k_err_from_verdict(const uint8_t* __restrict__ v, uint32_t n, uint8_t* __restrict__ e) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) e[i] = (v[i] & V_IS_SUFFICIENT) ? 0 : 2;   // BFTKV_ERR_NONE : BFTKV_ERR_INSUFFICIENT_SIGNATURES

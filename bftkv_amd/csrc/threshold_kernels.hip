@@ -167,6 +167,21 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
                                                               const uint8_t* __restrict__ status /*k_lagrange_inv's: bit 1 = left to the big path*/) {
   __shared__ uint32_t a_sh[QUADS_PER_BLOCK * MONT_N];
   QUAD_SETUP();
+  // Rows of flagged operations are zeroes from here on: k_lagrange_finish rewrites them when the big path follows, and when it does
+  // not (a device-resident caller whose promised index bound did not hold) the caller reads a fenced status beside zeroes, never
+  // stale pool memory (fail closed: ADVICE r05)
+  const bool flagged = active && (status[op] & 2u);
+  if (flagged) {
+    if (sum_out) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) sum_out[(uint64_t)op * MONT_N + qlane * L + k] = 0u;
+    }
+    if (lambda_out)
+      for (uint32_t j = 0; j < k_shares; ++j) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) lambda_out[((uint64_t)op * k_shares + j) * MONT_N + qlane * L + k] = 0u;
+      }
+  }
   if (!__any(active && !(status[op] & 2u))) return;      // every row of this wave is rewritten by k_lagrange_finish (64 nodes: all of them)
   const uint32_t mi = mod_idx[op];
   uint32_t n[L], r2[L], acc[L], t[L], u[L];
@@ -184,7 +199,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
       for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
       MONT(t, u);                                                    // lambda_j, plain
       canonicalize(t, qlane);
-      if (active) store_mod_result(lambda_out + sj * MONT_N + qlane * L, t, n, qlane);
+      if (active && !flagged) store_mod_result(lambda_out + sj * MONT_N + qlane * L, t, n, qlane);
     }
     if (sum_out) {
       const uint32_t* yp = y_limbs + sj * MONT_N + qlane * L;
@@ -204,7 +219,7 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_lagrange_terms(uint32_t n_ops, ui
     for (int k = 0; k < L; ++k) a_lds[k] = (qlane == 0 && k == 0) ? 1u : 0u;
     MONT(u, t);
     canonicalize(u, qlane);
-    if (active) store_mod_result(sum_out + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
+    if (active && !flagged) store_mod_result(sum_out + (uint64_t)op * MONT_N + qlane * L, u, n, qlane);
   }
 }
 
@@ -685,6 +700,14 @@ __global__ void __launch_bounds__(64) k_modinv(uint32_t n_ops, const uint32_t* _
   uint32_t* o = out_limbs + (uint64_t)op * MONT_N;
   if (ok) sg_to28(&inv, o, MONT_N);
   else for (int j = 0; j < MONT_N; ++j) o[j] = 0u;
+}
+
+// status bytes as the header documents them: 0, 1 (no inverse) or 2 (fenced; wins when both were recorded)
+__global__ void k_status_normalise(uint8_t* __restrict__ status, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t v = status[i];
+  if (v != 0xFFu) status[i] = (v & 2u) ? 2u : (v & 1u);
 }
 
 }  // namespace bftkv

@@ -42,6 +42,51 @@ class SigParse(C.Structure):
                 ("hashed_len", C.c_uint16), ("mpi_bits", C.c_uint16 * 2), ("mpi_off", C.c_uint32 * 2), ("issuer", C.c_uint64)]
 
 
+def split_tails(blob, off, tails: Sequence[bytes]):
+    """Payloads that end in one of the byte strings `tails` (TBSS ends in chunk(sig.Cert), packet/packet.go:192-212: the signer's
+    certificate) -> the arguments of Context.collective_verify_segments: (prefix_blob, prefix_off, shared_blob, shared_off,
+    seg_of_item).  A payload that ends in none of them stays whole (segment 0xFFFFFFFF); the longest matching tail wins."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64).astype(np.int64)
+    n = len(off) - 1
+    lens = off[1:] - off[:-1]
+    seg = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    cut = np.zeros(n, dtype=np.int64)
+    order = sorted(range(len(tails)), key=lambda k: -len(tails[k]))
+    for k in order:
+        t = np.frombuffer(tails[k], dtype=np.uint8)
+        L = len(t)
+        if L == 0:
+            continue
+        cand = np.nonzero((lens >= L) & (seg == 0xFFFFFFFF))[0]
+        if cand.size == 0:
+            continue
+        # compare the last L bytes of every candidate with the tail, a slab at a time
+        for lo in range(0, cand.size, 1024):
+            c = cand[lo:lo + 1024]
+            idx = (off[c + 1] - L)[:, None] + np.arange(L, dtype=np.int64)[None, :]
+            hit = (blob[idx] == t[None, :]).all(axis=1)
+            seg[c[hit]] = k
+            cut[c[hit]] = L
+    keep = lens - cut
+    prefix_off = np.zeros(n + 1, dtype=np.uint64)
+    prefix_off[1:] = np.cumsum(keep, dtype=np.uint64)
+    mask = np.ones(blob.size, dtype=bool)
+    hit = np.nonzero(cut)[0]
+    if hit.size:
+        # drop [end - cut, end) of every matched payload
+        starts = off[hit + 1] - cut[hit]
+        delta = np.zeros(blob.size + 1, dtype=np.int32)
+        np.add.at(delta, starts, 1)
+        np.add.at(delta, off[hit + 1], -1)
+        mask = np.cumsum(delta[:-1]) == 0
+    prefix_blob = blob[mask]
+    shared_off = np.zeros(len(tails) + 1, dtype=np.uint64)
+    shared_off[1:] = np.cumsum([len(t) for t in tails], dtype=np.uint64)
+    shared_blob = np.frombuffer(b"".join(tails) or b"\0", dtype=np.uint8)[:int(shared_off[-1])].copy()
+    return prefix_blob, prefix_off, shared_blob, shared_off, seg
+
+
 def parse_signature(body: bytes) -> SigParse:
     """bftkv_host_parse_signature: the verifier's Signature.parse / SignatureV3.parse on one packet body, on the host."""
     out = SigParse()

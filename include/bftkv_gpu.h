@@ -178,7 +178,22 @@ int bftkv_gpu_collective_verify(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items
                                 const uint8_t* tbs_blob, const uint64_t* tbs_off,
                                 const uint8_t* ss_blob, const uint64_t* ss_off,
                                 uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out, uint8_t* fenced_out);
-/* same, every pointer a DEVICE pointer (inputs already resident in HBM); asynchronous on the
+/* The same call for payloads that share their tails.  What a replica verifies is TBSS = Serialize(x, v, t, sig)
+ * (packet/packet.go:170-190), and writeSignature ends it in chunk(Cert) (packet.go:192-212): the signer's whole certificate -- 8 KB
+ * at 64 replicas, 28 KB at 256 -- the SAME bytes behind every write of one client.  A bulk caller holding host buffers (revoke /
+ * audit sweeps, protocol/client.go:304-353; Server.write batches, server.go:286-300) hands them over once:
+ *   payload i = prefix_blob[prefix_off[i] .. prefix_off[i+1])  ||  shared_blob[shared_off[g] .. shared_off[g+1]),  g = seg_of_item[i]
+ * (g = 0xFFFFFFFF: no tail).  Only the prefixes, the n_shared distinct tails and the signature streams cross PCIe (cfg 2: 146 MB
+ * instead of 226 MB per 10,000 writes); a kernel lays the payloads out in HBM as bftkv_gpu_collective_verify would have received
+ * them, so every result byte -- error, exit count, verdict bits, fence flag, per-packet status -- is that call's on the
+ * concatenated payloads (tests/test_gpu_host_pipeline.py).  Pipelined across PCIe like it; bftkv_gpu_set_host_pipeline applies. */
+int bftkv_gpu_collective_verify_segments(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
+                                         const uint8_t* prefix_blob, const uint64_t* prefix_off,
+                                         const uint8_t* shared_blob, const uint64_t* shared_off, uint32_t n_shared,
+                                         const uint32_t* seg_of_item,
+                                         const uint8_t* ss_blob, const uint64_t* ss_off,
+                                         uint8_t* err_out, uint32_t* n_verified_out, uint8_t* verdict_out, uint8_t* fenced_out);
+/* same as bftkv_gpu_collective_verify, every pointer a DEVICE pointer (inputs already resident in HBM); asynchronous on the
  * context's stream until bftkv_gpu_sync */
 int bftkv_gpu_collective_verify_dev(bftkv_gpu_ctx* ctx, int quorum, uint32_t n_items,
                                     const uint8_t* tbs_blob, const uint64_t* tbs_off,

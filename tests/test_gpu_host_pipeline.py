@@ -142,3 +142,88 @@ def test_pipelined_call_fails_closed(gpu_ctx):
     finally:
         gpu_ctx.set_host_pipeline(0)
         gpu_ctx.quorum_destroy(qh)
+
+
+@pytest.mark.parametrize("early", [True, False], ids=["early-exit", "every-packet"])
+def test_segmented_payloads_give_the_unsegmented_answers(gpu_ctx, early):
+    """bftkv_gpu_collective_verify_segments: payload i = prefix_i || shared[seg_i] (TBSS ends in chunk(Cert), packet.go:192-212, the
+    same certificate behind every write of a client).  Everything a caller can observe equals the call on the concatenated payloads
+    -- error bytes, exit counts, verdict bits, fence flags, per-packet statuses, counters -- unsplit and cut into pieces, by both
+    copy routes; with two distinct tails, payloads without a tail, empty prefixes, tails at every alignment, and text-mode / SHA-512
+    signatures whose hashes run over the seam."""
+    from bftkv_amd import host as HM
+    cl = cb.make_cluster(10, dsa_fraction=0.3)
+    rates = {cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_BAD_TAG: 0.1}
+    c = cb.make_write_corpus(cl, 240, mutation_rates=rates)
+    cert = cl.client.entity
+    # a second "client": the same payloads with another tail appended would not verify, so its items are built to be judged
+    # anyway -- what matters is that both routes see the same bytes.  Tails of odd lengths at odd offsets; some items keep no tail.
+    other = bytes(range(251)) * 5 + b"\x01\x02\x03"
+    rng = np.random.default_rng(5)
+    payloads, tails = [], []
+    for i in range(c.n_items):
+        t = c.tbss(i)
+        if i % 7 == 3:
+            payloads.append(t[:len(t) - len(cert)] + other); tails.append(1)      # another certificate behind the same prefix
+        elif i % 11 == 5:
+            payloads.append(t[:int(rng.integers(1, 200))]); tails.append(None)     # a payload that ends in neither
+        elif i == 17:
+            payloads.append(cert); tails.append(0)                                 # empty prefix
+        else:
+            payloads.append(t); tails.append(0)
+    tb, to = np.frombuffer(b"".join(payloads), dtype=np.uint8), np.zeros(len(payloads) + 1, dtype=np.uint64)
+    to[1:] = np.cumsum([len(p) for p in payloads], dtype=np.uint64)
+    pb, po, shb, sho, seg = HM.split_tails(tb, to, [cert, other])
+    assert [None if g == 0xFFFFFFFF else int(g) for g in seg] == tails and int(po[-1]) < int(to[-1]) // 3
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    gpu_ctx.set_early_exit(early)
+
+    def observe_seg():
+        err, nver, verdict = gpu_ctx.collective_verify_segments(qh, pb, po, shb, sho, seg, c.ss_blob, c.ss_off)
+        st, st_item = gpu_ctx.last_statuses()
+        return err.copy(), nver.copy(), verdict.copy(), gpu_ctx.last_fenced.copy(), st.copy(), st_item.copy(), dict(gpu_ctx.last_counters())
+    try:
+        gpu_ctx.set_host_pipeline(1)
+        base = _observe(gpu_ctx, qh, tb, to, c.ss_blob, c.ss_off)
+        assert (base[0] == 0).any() and (base[0] == 2).any()
+        for pieces, copy in ((1, ""), (2, "ring"), (3, "direct"), (8, "direct"), (8, "ring")):
+            gpu_ctx.set_host_pipeline(pieces, copy)
+            got = observe_seg()
+            for name, a, b in zip(("err", "n_verified", "verdict", "fenced", "statuses", "status items"), base, got):
+                assert np.array_equal(a, b), (pieces, copy, name)
+            assert got[6] == base[6], (pieces, got[6], base[6])
+        # the reference's verdicts on the intact writes
+        from oracle import collective as col
+        from oracle.packet import SignaturePacket
+        for i in range(c.n_items):
+            if tails[i] == 0 and i != 17:
+                r = col.collective_verify(kr, payloads[i], SignaturePacket(Type=1, Data=c.ss_data(i) or None), q)
+                assert (got[0][i] == 0) == (r.err is None) and got[1][i] == len(r.verified), i
+        # bad arguments are refused and fail closed: a segment index beyond n_shared
+        bad = seg.copy(); bad[3] = 2
+        with pytest.raises(Exception):
+            gpu_ctx.collective_verify_segments(qh, pb, po, shb, sho, bad, c.ss_blob, c.ss_off)
+    finally:
+        gpu_ctx.set_host_pipeline(0)
+        gpu_ctx.set_early_exit(True)
+        gpu_ctx.quorum_destroy(qh)
+
+
+def test_server_write_verify_sends_each_certificate_once(gpu_ctx):
+    """bftkv_host_server_write_verify (Server.write's verification, server.go:286-300) hands TBSS over as prefix + certificate
+    segment: the verdicts are the oracle's on the full request bytes."""
+    from bftkv_amd import host as HM
+    from oracle import collective as col
+    from oracle.packet import SignaturePacket
+    cl = cb.make_cluster(7)
+    c = cb.make_write_corpus(cl, 64, mutation_rates={cb.MUT_BAD_MPI: 0.2, cb.MUT_ONE_SHORT: 0.2}, keep_requests=True)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    hq = HM.Quorum.from_qcs(H.abi_qcs(q))
+    err = HM.Server(gpu_ctx).write_verify(hq, c.requests)
+    for i in range(c.n_items):
+        r = col.collective_verify(kr, c.tbss(i), SignaturePacket(Type=1, Data=c.ss_data(i) or None), q)
+        assert (err[i] == 0) == (r.err is None), i
+    assert 0 < int((np.array(err) == 0).sum()) < c.n_items
