@@ -681,7 +681,8 @@ __global__ void __launch_bounds__(RSA_BLOCK) k_sss_distribute(uint32_t n_ops_tot
 // big.Int.ModInverse inside rsaContext.Sign for negative key fragments (crypto/threshold/rsa/rsa.go:164-167), and the one inverse
 // per operation of the big Lagrange path.  The arithmetic is safegcd.inc (its header has the algorithm and the step bound; the CPU
 // suite runs the same text against Python's inverse): at most 208 rounds of 30 steps whatever the operands, no reduction loop.
-#define SG_FN __device__
+#define SG_FN __device__ __forceinline__
+#define SG_UNROLL _Pragma("unroll")
 #include "safegcd.inc"
 
 // `gate` / `gate_not` (the big Lagrange path): only operations whose gate byte has bit 2 set and whose gate_not byte is zero are

@@ -1,10 +1,13 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r06d
-run() { echo "== $*"; env "$@" timeout 300 python tools/hostbuf_rate.py 2>/dev/null | tail -1; }
-{
-run BFTKV_HB_COPIERS=2
-run BFTKV_HB_COPIERS=2 BFTKV_HB_PIECES=4
-run BFTKV_HB_PIECES=2
-run GPU_MAX_HW_QUEUES=8
-} > gpurun_out/r06d/hostbuf_ab4.txt 2>&1
-cat gpurun_out/r06d/hostbuf_ab4.txt
+R=$PWD
+mkdir -p gpurun_out/r06e
+python tools/threshold_rate.py --ops 4000 --nodes 64 --k 22 > gpurun_out/r06e/rates_64_after.json 2>/dev/null
+python tools/threshold_rate.py --ops 4000 --nodes 256 --k 86 > gpurun_out/r06e/rates_256_after.json 2>/dev/null
+python tools/threshold_rate.py --ops 10000 > gpurun_out/r06e/rates_10_after.json 2>/dev/null
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r06e/trace64b -o t -- python $R/tools/threshold_rate.py --ops 4000 --nodes 64 --k 22 > /dev/null 2>&1
+cd $R
+find gpurun_out/r06e -size +4M -delete
+cat gpurun_out/r06e/rates_64_after.json; cat gpurun_out/r06e/rates_256_after.json
+head -8 gpurun_out/r06e/trace64b/t_kernel_stats.csv
+timeout 1200 python -m pytest tests/test_gpu_threshold.py -m gpu -x -q 2>&1 | tail -3
