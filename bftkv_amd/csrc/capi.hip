@@ -162,6 +162,7 @@ struct bftkv_gpu_ctx {
   uint32_t lagrange_x_bound = 0;      // bftkv_gpu_set_lagrange_x_bound: device-resident callers promise 0 <= x <= bound (0: no promise)
   bool early_exit = true;              // CollectiveSignature.Verify stops verifying where the reference stops reading (bftkv_gpu_set_early_exit)
   std::vector<DevBuf*> scratch_pool;   // threshold entry points' temporaries (threshold_capi.inc)
+  std::unordered_map<std::string, std::vector<uint32_t>> modrow_cache;   // ... and the host-computed rows of ONE modulus (n, R^2, -n^-1, R_wide^2), by its bytes
   std::map<std::string, std::array<DevBuf, 4>> modtab_cache;   // Montgomery tables of the threshold entry points, by modulus bytes
   uint32_t* h_mail = nullptr;          // pinned + mapped: [0] packet count of the call in flight (k_scan_counts)
   uint32_t* d_mail = nullptr;

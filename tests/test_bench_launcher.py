@@ -138,7 +138,16 @@ def test_measured_multi_rank_line_fits_the_bound_and_names_the_rank_count():
     """The N > 1 form of a MEASURED line (the one-rank forced-RCCL rehearsal of round 5, cfg 4 and cfg 5 behind the headline in the same
     process group) through the stdout emitter: at most LINE_MAX bytes, `config.parallelism` with the rank count, roofline and summary kept."""
     import bench
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_multi_rank_form_one_rank_forced_rccl.json")))
+    for name in ("r05_bench_multi_rank_form_one_rank_forced_rccl.json", "r06_bench_multi_rank_form_one_rank_forced_rccl.json"):
+        _check_multi_rank_record(bench, json.load(open(os.path.join(ROOT, "profiles", name))))
+    # what the round-6 rehearsal really printed (BFTKV_FORCE_RCCL=1 BFTKV_BENCH_EXTRAS_IN_PROCESS=1 python bench.py --gpus 1 ...)
+    line = open(os.path.join(ROOT, "profiles", "r06_bench_multi_rank_form_stdout_line.json")).read().strip()
+    r = json.loads(line)
+    assert len(line) < bench.LINE_MAX and "x1" in r["config"]["parallelism"] and {"cfg4", "cfg5"} <= set(r["summary"])
+    assert r["roofline"]["launch_ms"] <= r["ms_per_step"] and r["summary"]["cfg4"]["roofline"]["launch_ms"] <= r["summary"]["cfg4"]["ms_per_step"]
+
+
+def _check_multi_rank_record(bench, d):
     for world in (1, 8):
         d["n_gpus"] = world
         d["config"]["parallelism"] = "shard-by-write x%d, RCCL all-gather of verdict bitmaps on the verifier's stream" % world
