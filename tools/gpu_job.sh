@@ -1,6 +1,10 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r06g
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-json gpurun_out/r06g/bench_full.json > gpurun_out/r06g/line.json 2> gpurun_out/r06g/stderr.txt; echo rc=$? bytes=$(wc -c < gpurun_out/r06g/line.json)
-bash tools/profile_bench.sh r06_cfg2 2 5 > /dev/null 2>&1
-bash tools/profile_bench.sh r06_cfg3 3 3 > /dev/null 2>&1
-ls gpurun_out/prof_r06_cfg2 gpurun_out/prof_r06_cfg3
+mkdir -p gpurun_out/r06d
+run() { echo "== $*"; env "$@" timeout 300 python tools/hostbuf_rate.py 2>/dev/null | tail -1; }
+{
+run A=1
+run A=2
+run GPU_MAX_HW_QUEUES=8
+} > gpurun_out/r06d/hostbuf_ab5.txt 2>&1
+cat gpurun_out/r06d/hostbuf_ab5.txt
+timeout 900 python -m pytest tests/test_gpu_host_pipeline.py -m gpu -x -q 2>&1 | tail -3
