@@ -260,21 +260,7 @@ Turnstile g_turnstile[16];
 // host-buffer pipeline (collective_verify_pipelined)
 constexpr uint64_t HB_PIPE_MIN_BYTES = 24ull << 20;      // below this a call is latency-, not PCIe-bound: one piece
 constexpr uint32_t HB_PIPE_MAX_PIECES = 8;
-// per device: pipelined host-buffer calls take turns on the PCIe link (collective_verify_pipelined).  Not a mutex: the turn is
-// taken by the calling thread and given up by whichever copier thread issues the call's last copy.
-struct HbLink {
-  std::mutex m; std::condition_variable cv; bool busy = false;
-  void acquire() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !busy; }); busy = true; }
-  void release() { { std::lock_guard<std::mutex> l(m); busy = false; } cv.notify_one(); }
-};
-struct HbLinkHold {      // gives the turn up exactly once: the last copier does, or the caller's scope on any early way out
-  HbLink& l; std::atomic<bool> held{false};
-  explicit HbLinkHold(HbLink& link) : l(link) {}
-  void acquire() { l.acquire(); held.store(true); }
-  void release() { if (held.exchange(false)) l.release(); }
-  ~HbLinkHold() { release(); }
-};
-HbLink g_hb_link[16];
+std::mutex g_hb_mu[16];           // per device: pipelined host-buffer calls take turns (collective_verify_pipelined)
 constexpr size_t HB_TR = 10;      // floats per piece in the timeline (bftkv_gpu_host_pipeline_trace)
 // The caller's memory is pageable.  hipMemcpyAsync from it either pins the pages in place (the runtime caches such pins: fast
 // for a buffer it has seen, ~17 GB/s for a fresh one, profiles/r04_h2d_rates_microbench.txt) and returns only when the copy is
@@ -1522,10 +1508,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   // share (three at once: 7.2 ms per call against 5.2 alone, their 45 streams queueing on the runtime's four hardware queues).
   // The turn ends when this call's last byte is on its way (copiers joined): the next caller's first pieces cross the link
   // while this call's last piece is still being verified.
-  // (round 6: the turn is taken when this call's copies are about to start -- its pieces, buffers and offsets are prepared while the
-  // previous caller still copies -- and ends when the last copy has been issued, by the copier thread itself: the caller's thread is
-  // still enqueuing the last piece then.)
-  HbLinkHold link_turn(g_hb_link[(unsigned)c->device & 15u]);
+  std::unique_lock<std::mutex> link_turn(g_hb_mu[(unsigned)c->device & 15u]);
   const auto t_call = std::chrono::steady_clock::now();
   auto us_now = [&] { return (float)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_call).count() * 1e-3f; };
   bftkv_gpu_ctx* const root = c->root ? c->root : c;
@@ -1654,8 +1637,6 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   tr.assign(8 + HB_TR * (size_t)P, 0.f);
   tr[0] = (float)P; tr[1] = use_ring ? 1.f : 0.f;
   std::vector<std::thread> copiers;
-  std::atomic<int> copiers_left{0};
-  link_turn.acquire();
   bool spawn_failed = false;
   // (a thread the system refuses must end the call with an error, not the process: the copiers' loops are written so that the
   // ones that did start finish by themselves once `dead` is set)
@@ -1684,7 +1665,6 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
       }
     }
     const int nth = (int)std::min<size_t>(HbRing::THREADS, chunks.size());
-    copiers_left.store(nth);
     for (int t = 0; t < nth; ++t)
       try_spawn(copiers, [&, t, nth] {
         (void)hipSetDevice(c->device);
@@ -1710,7 +1690,6 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
           if (ch.last) { flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release); tr[8 + HB_TR * cp.piece + cp.half] = us_now(); }
           if (!dead.load()) ticket.store(i + 1, std::memory_order_release);
         }
-        if (copiers_left.fetch_sub(1) == 1) link_turn.release();      // the call's last copy is on its way: the next caller's turn
       });
   } else {
     // Two helper threads take the ranges of the plan alternately, each on its own stream: a copy from pageable memory returns
@@ -1721,7 +1700,6 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
     // One is the default.)
     static const int n_copiers = getenv("BFTKV_HB_COPIERS") ? std::max(1, std::min(2, atoi(getenv("BFTKV_HB_COPIERS")))) : 1;
     if (n_copiers > 1) { HIPCHK(c, hipEventRecord(c->hb_ev[2 * (size_t)P], c->stream_c)); HIPCHK(c, hipStreamWaitEvent(c->stream_c2, c->hb_ev[2 * (size_t)P], 0)); }
-    copiers_left.store(n_copiers);
     for (int t = 0; t < n_copiers; ++t)
       try_spawn(copiers, [&, t] {
         (void)hipSetDevice(c->device);
@@ -1737,7 +1715,6 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
           flag[2 * cp.piece + cp.half].store(dead.load() ? -1 : 1, std::memory_order_release);
           tr[8 + HB_TR * cp.piece + cp.half] = us_now();
         }
-        if (copiers_left.fetch_sub(1) == 1) link_turn.release();      // the call's last copy is on its way: the next caller's turn
       });
   }
   if (spawn_failed) {
@@ -1853,7 +1830,7 @@ static int collective_verify_pipelined(bftkv_gpu_ctx* c, int quorum, uint32_t n_
   }
   if (first_rc) dead.store(true);
   for (auto& t : copiers) t.join();
-  link_turn.release();        // (already given up by the last copier, unless a thread could not be started)
+  link_turn.unlock();
   tr[2] = us_now();
   // one synchronisation: every piece that was enqueued, and the copy stream (the caller's buffers must not be read after return)
   hipError_t se = hipStreamSynchronize(c->stream_c);
