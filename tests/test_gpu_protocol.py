@@ -1238,3 +1238,45 @@ def test_read_entity_on_random_certificates_with_real_signatures(gpu_ctx):
             hist[v] = hist.get(v, 0) + 1
     assert not bad, bad[:3]
     assert min(hist.get(True, 0), hist.get(False, 0), hist.get(None, 0)) >= 40, hist
+
+
+def test_request_certificates_with_dsa_keys_of_other_sizes(gpu_ctx):
+    """A principal whose certificate travels in the request (server.go:199-207) holds a DSA key of 1024/160 or 3072/256 bits.  The
+    smaller group is verified like any other key.  A 3072-bit p needs the arena's wide entries, which only the NODE keyring decides
+    (an unauthenticated certificate must not make the node's tables be rebuilt): with no such key in the ring the request is FENCED --
+    no verdict, the reference path decides --, with one in the ring it is verified, and every verdict given is the oracle's."""
+    from bftkv_amd import Batcher
+    from corpus.keys import DRBG
+    from oracle import openpgp as pgp
+    tbs = cb.serialize_tbs(b"variable", b"value", 9)
+    strangers = {}
+    for kind in ("dsa1024", "dsa3072"):
+        kp = cb.make_keypair(cb.PK_DSA, cb.load_keys(kind, 4)[3], "d-%s <%s@bftkv.example>" % (kind, kind))
+        cb.build_entity(kp, [], DRBG("stranger", kind))
+        strangers[kind] = kp
+
+    def want_of(kp, data):
+        cert = kp.entity
+        ents = pgp.entity_checks(cert)
+        assert ents and ents[0]["valid"]
+        sig = cb.detach_sign(kp, data, DRBG("cert-sizes"))
+        e = col.signature_verify_with_certificate(tbs, opk.SignaturePacket(1, 0, False, sig, cert), pgp.read_entities(cert)[0])
+        return sig, (0 if e is None else 1)
+
+    for ring_kind, expect_3072_fenced in (("dsa2048", True), (("dsa2048", "dsa3072"), False)):
+        cl = cb.make_cluster(6, dsa_fraction=0.5, dsa_kind=ring_kind)
+        gpu_ctx.keyring_set(H.abi_keys(H.oracle_keyring(cl)))
+        assert gpu_ctx.dsa_table_bytes()[1] == (76 if expect_3072_fenced else 112)
+        b = Batcher(gpu_ctx, max_items=16)
+        try:
+            for kind, kp in strangers.items():
+                for data in (tbs, tbs + b"!"):
+                    sig, want = want_of(kp, data)
+                    for _ in range(2):          # first sight (the compound route), then the register
+                        err, fenced, got_id, _ = b.cert_verify(kp.entity, tbs, sig)
+                        if kind == "dsa3072" and expect_3072_fenced:
+                            assert fenced, (ring_kind, kind)
+                        else:
+                            assert not fenced and err == want and got_id == kp.key_id, (ring_kind, kind, err, want)
+        finally:
+            b.close()
