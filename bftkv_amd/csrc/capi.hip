@@ -126,7 +126,8 @@ struct bftkv_gpu_ctx {
   uint32_t dsa_wbits_want = 0;
   uint32_t dsa_entry_limbs = DSA_N_SMALL;      // limbs of a table entry, arena-wide: DSA_N_BIG once the node keyring holds a DSA key with p beyond 2048 bits
   size_t dsa_budget_bytes = 0;                 // bftkv_gpu_set_dsa_table_budget: the arena never grows past this (0: the free-HBM policy)
-  bool have_dsa3072 = false;
+  bool have_dsa3072 = false, have_dsa2048 = false;      // the key table holds a usable DSA key with p beyond / up to 2048 bits
+  DevBuf dsa_idx;
   uint64_t cert_clock = 0;     // compound calls over request certificates (host_capi.inc cert_cache_gc)
   // Request certificates whose ReadEntity verdict is "valid" (cert_signature_core), by their bytes: a later request of the same
   // client is then ONE staged signature verification on a lane of the micro-batcher (batcher_capi.inc) instead of a compound call
@@ -515,6 +516,7 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
   if (c->have_rsa4096) HIPCHK(c, c->r4096.ensure(sizeof(uint32_t) * EM_LOW_LIMBS * tr));
   HIPCHK(c, c->dsa_list.ensure(sizeof(uint32_t) * tr));
   if (c->have_dsa_keys) HIPCHK(c, c->dsa_u.ensure(sizeof(uint32_t) * DSA_U_WORDS * tr));
+  if (c->have_dsa3072 && c->have_dsa2048) HIPCHK(c, c->dsa_idx.ensure(sizeof(uint32_t) * 4 * (size_t)tr + 16));      // k_dsa_split: two class lists per phase
   // fill pass only for items whose event list overflowed the scratch (a no-op grid otherwise)
   hipLaunchKernelGGL(k_walk<true>, dim3(n_items), dim3(64), 0, s, d_ss, d_ss_off, n_items, c->counts.as<uint32_t>(),
                      c->base.as<uint32_t>(), c->recs.as<SigRec>(), c->item_flags.as<uint8_t>(), (WalkEnt*)nullptr, walk_cap, (uint32_t*)nullptr);
@@ -674,11 +676,22 @@ int run_pipeline(bftkv_gpu_ctx* c, uint32_t n_items, const uint8_t* d_tbs, const
     hipLaunchKernelGGL(k_dsa_mul, dim3((total + 63) / 64), dim3(64), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(),
                        cnt_p, start, c->kt, c->digests.as<uint32_t>(), c->dsa_u.as<uint32_t>());
     // (the LDS-DMA form of this kernel measured the same and spilled: removed in round 5, profiles/r04_cfg3_ab_dsa_dma*.json)
-    hipLaunchKernelGGL((k_dsa_modexp<MONT_L, MONT_TPI>), dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
-                       c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
-    if (c->have_dsa3072)      // keys with p beyond 2048 bits: the same work list through the 8-lane form (rows of the other class ride along)
+    // a key table with DSA keys of both size classes: the list's positions sorted by class first (phase 1: counters [20], [21];
+    // phase 2: [22], [23]), each instantiation over its own compact list; one class only: that instantiation over the list itself
+    const uint32_t* idx_s = nullptr; const uint32_t* idx_b = nullptr; const uint32_t* cnt_cls = nullptr;
+    if (c->have_dsa3072 && c->have_dsa2048) {
+      uint32_t* cc = cnt_p + (start == start0 ? 20 : 22);
+      uint32_t* is = c->dsa_idx.as<uint32_t>() + (start == start0 ? 0 : 2 * (size_t)total);
+      hipLaunchKernelGGL(k_dsa_split, dim3((total + 255) / 256), dim3(256), 0, s, c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt,
+                         is, is + total, cc);
+      idx_s = is; idx_b = is + total; cnt_cls = cc;
+    }
+    if (c->have_dsa2048)
+      hipLaunchKernelGGL((k_dsa_modexp<MONT_L, MONT_TPI>), dim3((total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK), dim3(RSA_BLOCK), 0, s,
+                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>(), idx_s, cnt_cls);
+    if (c->have_dsa3072)      // keys with p beyond 2048 bits: the 8-lane form
       hipLaunchKernelGGL((k_dsa_modexp<MONT_L3072, MONT_TPI_BIG>), dim3((total + RSA_BLOCK / MONT_TPI_BIG - 1) / (RSA_BLOCK / MONT_TPI_BIG)), dim3(RSA_BLOCK), 0, s,
-                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>());
+                         c->recs.as<SigRec>(), c->dsa_list.as<uint32_t>(), cnt_p, start, c->kt, c->dsa_u.as<uint32_t>(), idx_b, cnt_cls ? cnt_cls + 1 : nullptr);
   };
   if (total) launch_compare(start0);
   HIPCHK(c, rec(8, s));
@@ -1065,11 +1078,12 @@ int upload_key_table(bftkv_gpu_ctx* c) {
   if ((rc = sync_dsa_tables(c, rows, algo, bits, &bits_changed))) return rc;
   if (bits_changed && (rc = upload(c, c->k_bits, bits))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_dsa_keys = c->have_dsa3072 = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
+  c->have_dsa_keys = c->have_dsa3072 = c->have_dsa2048 = c->have_rsa3072 = c->have_rsa4096 = c->have_ambiguous = false;
   for (size_t i = 0; i < algo.size(); ++i) {
     if (flags[i] & KEYF_AMBIGUOUS) c->have_ambiguous = true;
     if (algo[i] == PK_DSA) c->have_dsa_keys = true;
     if (algo[i] == PK_DSA && bits[i] != 0xFFFFFFFFu && bits[i] > 2048) c->have_dsa3072 = true;
+    if (algo[i] == PK_DSA && (bits[i] == 0xFFFFFFFFu || bits[i] <= 2048)) c->have_dsa2048 = true;
     if ((algo[i] == PK_RSA || algo[i] == PK_RSA_SIGN_ONLY) && bits[i] != 0xFFFFFFFFu) {
       if (bits[i] > 3072) c->have_rsa4096 = true; else if (bits[i] > 2048) c->have_rsa3072 = true;
     }
@@ -1111,7 +1125,7 @@ int fork_refresh(bftkv_gpu_ctx* c) {
   if (c->seen_keyring_gen != r->keyring_gen) {
     c->kt = r->kt;
     c->n_keys = r->n_keys; c->n_entities = r->n_entities; c->n_ring_entities = r->n_ring_entities;
-    c->have_dsa_keys = r->have_dsa_keys; c->have_dsa3072 = r->have_dsa3072; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096; c->have_ambiguous = r->have_ambiguous;
+    c->have_dsa_keys = r->have_dsa_keys; c->have_dsa3072 = r->have_dsa3072; c->have_dsa2048 = r->have_dsa2048; c->have_rsa3072 = r->have_rsa3072; c->have_rsa4096 = r->have_rsa4096; c->have_ambiguous = r->have_ambiguous;
     c->h_key_id = r->h_key_id; c->h_entity_id = r->h_entity_id; c->h_key_entity = r->h_key_entity; c->h_key_flags = r->h_key_flags;
     c->n_dsa_slots = r->dsa_comb_slot.size(); c->dsa_wbits = r->dsa_wbits; c->dsa_entry_limbs = r->dsa_entry_limbs;
     c->keyring_gen = r->keyring_gen;          // the fork's membership tables follow the root's generations
@@ -1209,7 +1223,7 @@ void bftkv_gpu_destroy(bftkv_gpu_ctx* c) {
   (void)hipStreamSynchronize(c->stream_d);
   for (DevBuf* b : {&c->k_id, &c->k_entity, &c->k_algo, &c->k_flags, &c->k_bits, &c->k_e, &c->k_n, &c->k_r2, &c->k_n0, &c->k_q, &c->k_qbits, &c->k_dsatab, &c->k_dsaslot, &c->dsa_comb, &c->k_sorted_id, &c->k_sorted_slot, &c->k_r2w,
                     &c->chunk_arena, &c->chunk_ctr, &c->counts, &c->base, &c->total, &c->item_flags, &c->walk_scratch, &c->cert_ent, &c->sig_class, &c->mid, &c->mid64, &c->hash_mask, &c->recs, &c->digests, &c->r, &c->xr,
-                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
+                    &c->pk_list, &c->pk_list3072, &c->pk_list4096, &c->r3072, &c->r4096, &c->pk_count, &c->dsa_list, &c->dsa_u, &c->dsa_idx, &c->ids_tmp, &c->o_err, &c->o_nver, &c->o_verdict, &c->o_fenced, &c->in_tbs, &c->in_tbs_off,
                     &c->in_ss, &c->in_ss_off, &c->in_prefix, &c->in_prefix_off, &c->in_shared, &c->in_shared_off, &c->in_seg, &c->st_tmp, &c->item_tmp, &c->bits_tmp, &c->plan_cut, &c->txt_mid32, &c->txt_mid64, &c->txt_tail, &c->txt_len})
     b->release();
   for (auto& q : c->quorums) { q.member.release(); q.ids.release(); }

@@ -1908,27 +1908,45 @@ __device__ __forceinline__ uint64_t grp_sum64(uint64_t v) {
   return v;
 }
 
+// A key table that holds DSA keys of BOTH size classes: the positions of the DSA work list [start, count) sorted by class into two
+// compact index lists, so that each instantiation of k_dsa_modexp runs waves full of its own rows (one list for both, rows of the
+// other class riding along, cost a four-size ring 11.8 ms where the two pure rings take 5.6 and 9.4: profiles/r06_dsa_rates_…).
+__global__ void __launch_bounds__(256) k_dsa_split(const SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
+                                                   const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
+                                                   uint32_t* __restrict__ idx_small, uint32_t* __restrict__ idx_big, uint32_t* __restrict__ cls_count /*[2]*/) {
+  const uint32_t di = pk_start[1] + blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = di < pk_count[1];
+  const bool big = in && kt.mod_bits[(uint32_t)recs[dsa_list[di]].key_slot] > 2048u;
+  const uint32_t a = wave_alloc(cls_count, in && !big);
+  if (in && !big) idx_small[a] = di;
+  const uint32_t b = wave_alloc(cls_count + 1, big);
+  if (big) idx_big[b] = di;
+}
+
 // v = g^u1 * y^u2 mod p from the per-key fixed-base tables: one table multiplication per non-zero
 // window digit of u1 and u2 but the first (<= 2 * 256/wbits - 1), no squarings.  A table row (304 B; 448 B for a 3072-bit p) is
 // read straight from HBM/MALL into the group's LDS slot; a wave skips a (window, base) step when all its digits are zero.
 // The tail finishes dsa.Verify in place: v mod q through the per-key table 2^(28 j) mod q (each group lane
 // folds its L limbs, the group adds up, 35 shift-subtract steps finish), then (v mod q) == r.
 // <19, 4> takes the rows of the DSA work list whose key has p <= 2048 bits, <14, 8> those with p <= 3072 bits (launched only
-// when such a key is in the table); rows of the other class ride along untouched, and a wave without a row of its class returns.
+// when such a key is in the table); a table that holds both classes hands each its own compact index list (k_dsa_split).
 template <int L, int TPI>
 __global__ void __launch_bounds__(RSA_BLOCK) k_dsa_modexp(SigRec* __restrict__ recs, const uint32_t* __restrict__ dsa_list,
                                                           const uint32_t* __restrict__ pk_count, const uint32_t* __restrict__ pk_start, KeyTableDev kt,
-                                                          const uint32_t* __restrict__ dsa_u) {
+                                                          const uint32_t* __restrict__ dsa_u, const uint32_t* __restrict__ cls_idx = nullptr,
+                                                          const uint32_t* __restrict__ cls_count = nullptr) {
   constexpr int NL = L * TPI, GROUPS = RSA_BLOCK / TPI;
   constexpr bool BIG = NL > (int)DSA_N_SMALL;
   __shared__ uint32_t a_sh[GROUPS * NL];
-  const uint32_t count = pk_count[1], start = pk_start[1];
+  // cls_idx (a key table that MIXES the size classes, k_dsa_split): the work-list positions of this class, compacted -- a wave then
+  // holds rows of its own class only
+  const uint32_t count = cls_idx ? *cls_count : pk_count[1], start = cls_idx ? 0u : pk_start[1];
   if (start + blockIdx.x * GROUPS >= count) return;
   const uint32_t quad = threadIdx.x / TPI;
   const int qlane = threadIdx.x % TPI;
   const uint32_t gq = start + blockIdx.x * GROUPS + quad;
   const bool active = gq < count;
-  const uint32_t di = active ? gq : (count - 1);
+  const uint32_t di = cls_idx ? cls_idx[active ? gq : (count - 1)] : (active ? gq : (count - 1));
   const uint32_t ri = dsa_list[di];
   const SigRec rec = recs[ri];
   const uint32_t key = (uint32_t)rec.key_slot;

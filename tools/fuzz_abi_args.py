@@ -197,8 +197,18 @@ def verify_calls():
     err, fen, nver, ver = buf(n, "zero"), buf(n, "zero"), np.zeros(max(n, 1), dtype=np.uint32), buf(n, "zero")
     u64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
     q = rng.choice([quorum.value, quorum.value, -1, 99, 0x7FFFFFFF])
-    which = rng.randrange(5)
-    if which == 0:
+    which = rng.randrange(6)
+    if which == 5:
+        # segmented payloads: hostile prefix / shared offsets, segment indices past n_shared, no segments at all
+        n_sh = rng.choice([0, 1, 3])
+        sh_len = rng.choice([0, 1, 300, 9000])
+        sh, sho = buf(sh_len), offsets(n_sh, sh_len)
+        seg = np.array([rng.choice([0, 1, 2, 3, 0xFFFFFFFF, 0x7FFFFFFF]) for _ in range(max(n, 1))], dtype=np.uint32)
+        rc = lib.bftkv_gpu_collective_verify_segments(ctx, q, n, p8(tb), u64(to), p8(sh), u64(sho), n_sh, seg.ctypes.data_as(vp), p8(ss), u64(so),
+                                                      p8(err), nver.ctypes.data_as(vp), p8(ver), p8(fen))
+        assert rc == 0 or n == 0 or all(int(e) != 0 for e in err[:n]), ("collective_verify_segments", rc)      # fail closed
+        note("collective_verify_segments", rc)
+    elif which == 0:
         note("collective_verify", lib.bftkv_gpu_collective_verify(ctx, q, n, p8(tb), u64(to), p8(ss), u64(so), p8(err), nver.ctypes.data_as(vp), p8(ver), p8(fen)))
     elif which == 1:
         note("signature_verify", lib.bftkv_gpu_signature_verify(ctx, n, p8(tb), u64(to), p8(ss), u64(so), None, p8(err), p8(fen)))
