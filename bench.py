@@ -1911,7 +1911,9 @@ def main():
                 except OSError as e:
                     sys.stderr.write("bench.py: full record not written to %s: %s\n" % (path, e))
                     path = None
-                sys.stderr.write("bench.py: full record%s:\n%s\n" % (" (%s)" % path if path else "", json.dumps(out)))
+                # (on ONE stderr line that does not start with a brace: a reader that takes the last line beginning with "{" of whatever
+                # it captured must find the stdout line, not this one)
+                sys.stderr.write("bench.py: full record%s: %s\n" % (" (%s)" % path if path else "", json.dumps(out)))
                 sys.stderr.flush()
                 try:
                     line = json.dumps(compact_line(out, path))
