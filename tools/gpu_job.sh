@@ -1,7 +1,11 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r06h
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_protocol.py -m gpu -x -q -k "dsa or cfg3 or gpg or other_sizes or cert" 2>&1 | tail -5
-for k in dsa2048 dsa3072 dsa1024,dsa3072,dsa1536,dsa2048; do
-  timeout 600 python tools/dsa_rate.py --json --replicas 16 --dsa-fraction 1.0 --dsa-kind $k --bits 14 --writes 600 --tile 24 2>/dev/null | tail -1
-done > gpurun_out/r06h/dsa_rates_by_group_size_split.jsonl
-cat gpurun_out/r06h/dsa_rates_by_group_size_split.jsonl
+mkdir -p gpurun_out/r06i
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -8 > gpurun_out/r06i/gpu_suite.txt; cat gpurun_out/r06i/gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/r06i/smoke.txt
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-json gpurun_out/r06i/bench_full.json > gpurun_out/r06i/line.json 2> gpurun_out/r06i/stderr.txt; echo rc=$? bytes=$(wc -c < gpurun_out/r06i/line.json)
+for w in 14 16; do BFTKV_DSA_WBITS=$w timeout 600 python bench.py --config 3 --steps 10 --warmup 2 --soak-seconds 0 --no-cpu-baseline --full-json gpurun_out/r06i/cfg3_w$w.json > gpurun_out/r06i/cfg3_w${w}_line.json 2>/dev/null; done
+python - <<'PY'
+import json
+for w in (14,16):
+    d=json.load(open('gpurun_out/r06i/cfg3_w%d.json'%w)); print(w, d['ms_per_step'], d['value'], d['dsa_tables'], d['roofline']['launch_ms'], d['int_mac']['frac'])
+PY
