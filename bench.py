@@ -1040,11 +1040,13 @@ def bench_cfg3(args, D):
             "int_mac": int_mac_block(n_rsa_ops * MACS_PER_RSA_VERIFY + n_dsa_ops * macs_per_dsa_verify(dsa_bits), elapsed / args.steps * 1e3,
                                      rsa_ms + dsa_ms, iso_rsa + iso_dsa, sclk, V.n_ctx),
             "dsa_tables": {"window_bits": dsa_bits, "products_per_verify": macs_per_dsa_verify(dsa_bits) // 11552,
+                           "gb_allocated": V.ctxs[0].dsa_table_bytes()[0] / 1e9,       # the arena as the library holds it (bftkv_gpu_dsa_table_bytes)
                            "dsa_keys": sum(1 for r in cl.replicas if r.algo == cb.PK_DSA),
                            "gb_pinned": (sum(1 for r in cl.replicas if r.algo == cb.PK_DSA) * 2 * ((256 + dsa_bits - 1) // dsa_bits) *
                                          ((1 << dsa_bits) - 1) * 304 / 1e9) if dsa_bits else 0.0,
                            "note": "width chosen by the library for this keyring and the free HBM (bftkv_gpu_dsa_window_bits: the widest of 18 / 16 / "
-                                   "15 / 14 / 13 / 12 / 10 / 8 bits whose tables fit the budget); BFTKV_DSA_WBITS pins it"},
+                                   "15 / 14 / 13 / 12 / 10 / 8 bits whose tables fit); bftkv_gpu_set_dsa_table_budget bounds it (32 keys: 8 GB -> 14 "
+                                   "bits, 24 GB -> 16); gb_pinned = the tables of the ring's keys, gb_allocated = the arena with its growth margin"},
             "corpus_build_s": t_corpus,
         })
         if D.world == 1 and not args.no_cpu_baseline:
