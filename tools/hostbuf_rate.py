@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch  # noqa: F401
+    import torch
     import bench
     from bftkv_amd import Context, host as HM
     from corpus import build as cb
@@ -32,6 +32,10 @@ def main():
     err, nver, _ = ctx0.collective_verify(qh, z["tb"], z["to"], z["sb"], z["so"])
     ctx0.set_host_pipeline(0)
     pb, po, shb, sho, seg = HM.split_tails(z["tb"], z["to"], [cl.client.entity])
+    if os.environ.get("HOSTBUF_PINNED") == "1":      # the caller's buffers page-locked (what bftkv_gpu_host_alloc would hand a caller)
+        pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+        z = {k: (pin(v) if isinstance(v, np.ndarray) and v.ndim == 1 and v.size > 1 else v) for k, v in dict(z).items()}
+        pb, po, shb, sho, seg = pin(pb), pin(po), pin(shb), pin(sho), pin(seg)
 
     def plain(cx):
         e, nv, _ = cx.collective_verify(qh, z["tb"], z["to"], z["sb"], z["so"])
