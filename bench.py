@@ -154,6 +154,8 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dry = args.dry_run
         self.dist = None
+        # "library": bftkv_gpu_allgather_errs_dev on the verifier's stream; "torch": the fallback of comm_init (BFTKV_BENCH_EXCHANGE=torch forces it)
+        self.exchange = "torch" if os.environ.get("BFTKV_BENCH_EXCHANGE") == "torch" else "library"
         if self.dry:
             self.dev = torch.device("cpu")
         else:
@@ -211,23 +213,37 @@ class Dist:
         (bftkv_gpu_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins."""
         from bftkv_amd import Context
         torch = self.torch
-        for cx in ctxs:
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if self.rank == 0:
-                uid = torch.from_numpy(Context.comm_unique_id().copy())
-            if self.dist:
-                u = uid.to(self.dev)
-                self.dist.broadcast(u, src=0)
-                uid = u.cpu()
-            cx.comm_init(self.world, self.rank, uid.numpy())
-        # before anything is timed: every rank's row of a gathered, rank-stamped buffer must be that rank's, on every context
-        # (bftkv_gpu_comm_selftest; collective).  A failure names the rank and RCCL's own error string and ends the run.
-        for k, cx in enumerate(ctxs):
-            try:
+        if self.exchange == "torch":
+            return
+        failed = None
+        try:
+            for cx in ctxs:
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    uid = torch.from_numpy(Context.comm_unique_id().copy())
+                if self.dist:
+                    u = uid.to(self.dev)
+                    self.dist.broadcast(u, src=0)
+                    uid = u.cpu()
+                cx.comm_init(self.world, self.rank, uid.numpy())
+            # before anything is timed: every rank's row of a gathered, rank-stamped buffer must be that rank's, on every context
+            # (bftkv_gpu_comm_selftest; collective).
+            for k, cx in enumerate(ctxs):
                 cx.comm_selftest(4096)
-            except Exception as e:      # noqa: BLE001
-                sys.stderr.write("bench.py: rank %d of %d: exchange self-test failed on context %d: %s\n" % (self.rank, self.world, k, e))
-                raise
+        except Exception as e:      # noqa: BLE001
+            failed = e
+            sys.stderr.write("bench.py: rank %d of %d: the library's own RCCL exchange could not be set up: %s\n" % (self.rank, self.world, e))
+        # Every rank learns whether ANY rank failed.  The multi-GPU path has never met more than one GPU (one per box here): if the
+        # library's communicator cannot be had, the exchange step falls back to torch.distributed's all-gather of the same bitmaps
+        # (still RCCL over xGMI, but host-synchronised per step) and the line says so -- a number with a caveat instead of none.
+        if self.world > 1:
+            if self.sum_ints([1 if failed else 0])[0]:
+                self.exchange = "torch"
+                if self.rank == 0:
+                    sys.stderr.write("bench.py: exchange step through torch.distributed.all_gather_into_tensor (fallback)\n")
+                return
+        elif failed:
+            raise failed
         if self.world > 1:
             path, pre = Context.comm_library()
             seen = self.sum_ints([1])[0]
@@ -323,7 +339,17 @@ class Verifier:
         cx.collective_verify_dev(self.qhs[k], self.n_items, self.d_tbs.data_ptr(), self.d_tbs_off.data_ptr(), self.d_ss.data_ptr(),
                                  self.d_ss_off.data_ptr(), self.ss_len, e.data_ptr(), nv.data_ptr(), vd.data_ptr())
         # exchange step, enqueued behind the tally on the verifier's own stream: no host synchronisation in between
-        cx.allgather_errs_dev(e.data_ptr(), self.n_items, self.slots, bits.data_ptr())
+        if self.D.exchange == "library":
+            cx.allgather_errs_dev(e.data_ptr(), self.n_items, self.slots, bits.data_ptr())
+        else:       # fallback (Dist.comm_init): wait for the verdicts, pack and gather with torch.distributed -- same bitmap layout
+            from bftkv_amd import dist as BD
+            cx.sync()
+            local = BD.pack_verdicts(e == 0, self.slots)
+            if self.D.dist:
+                self.D.dist.all_gather_into_tensor(bits, local)
+            else:
+                bits.copy_(local)
+            self.D.torch.cuda.current_stream().synchronize()
         self.gathers += 1
 
     def complete(self, i):
@@ -745,7 +771,8 @@ def bench_cfg2(args, D):
             "sufficient_fraction": float((err == 0).mean()),
             "verdicts_match_construction": bool(((err == 0) == want_ok).all()),
             "allgather": {"calls_in_timed_region": args.steps, "bytes_per_rank": (items + 7) // 8, "rows_consistent": gather_ok,
-                          "via": "bftkv_gpu_allgather_errs_dev (library RCCL, verifier stream)"},
+                          "via": "bftkv_gpu_allgather_errs_dev (library RCCL, verifier stream)" if D.exchange == "library" else
+                                 "torch.distributed.all_gather_into_tensor (FALLBACK: the library's communicator could not be set up; host-synchronised per step)"},
             "kernel_ms": {"k_rsa_modexp": rsa_ms, "k_rsa_modexp_min_max": [float(np.min(timed_rsa)), float(np.max(timed_rsa))],
                           "hash_stream": float(np.mean(timed_hash)), "step_device_span": float(np.mean(timed_total)),
                           "step_over_modexp": ms_step / iso_rsa if iso_rsa else None,
@@ -1738,6 +1765,10 @@ def compact_line(out, full_path=None):
               "reference_pubkey_ops_per_step_per_gpu", "device", "threads", "writes_per_sec"):
         if k in out:
             line[k] = out[k]
+    ag = out.get("allgather") or {}
+    if ag:
+        line["exchange"] = {"rows_consistent": ag.get("rows_consistent"), "bytes_per_rank": ag.get("bytes_per_rank"),
+                            "via": "library RCCL on the verifier's stream" if str(ag.get("via", "")).startswith("bftkv_gpu") else "torch.distributed (fallback)"}
     rf = out.get("roofline")
     if rf:
         line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launch_ms_basis",
