@@ -1652,3 +1652,40 @@ def test_dsa_table_budget_bounds_the_hbm_the_tables_hold():
         assert ctx.dsa_window_bits() == 8 and ctx.dsa_table_bytes()[0] <= 200 << 20
     finally:
         ctx.close()
+
+
+def test_dsa_group_sizes_at_volume(gpu_ctx):
+    """The four DSA group sizes at volume: a 16-replica all-DSA clique (1024/160, 3072/256, 1536/224, 2048/256 dealt round-robin), 300
+    signed writes with the usual mutations tiled 64 x in the call (~300 k signature packets, both k_dsa_modexp instantiations over
+    the class lists of k_dsa_split).  Tile 0 is the C restatement's answer on every write (error byte, exit count) and the Python
+    oracle's per-packet statuses on a sample; every other tile equals tile 0 -- items are independent."""
+    from oracle.cbind import COracle
+    cl = cb.make_cluster(16, dsa_fraction=1.0, dsa_kind=("dsa1024", "dsa3072", "dsa1536", "dsa2048"))
+    rates = {cb.MUT_BAD_MPI: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_UNKNOWN_ISSUER: 0.05, cb.MUT_DUP_SIGNER: 0.05, cb.MUT_BAD_TAG: 0.05}
+    c = cb.make_write_corpus(cl, 300, mutation_rates=rates, seed=6066)
+    kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
+    co = COracle()
+    co.set_keyring(kr)
+    co.set_quorum(q)
+    cerr, cnver, _ = co.collective_verify(c.tbss_blob, c.tbss_off, c.ss_blob, c.ss_off, 4)
+    gpu_ctx.keyring_set(H.abi_keys(kr))
+    assert gpu_ctx.dsa_table_bytes()[1] == 112
+    qh = gpu_ctx.quorum_create(H.abi_qcs(q))
+    T = 64
+    tb, sb = np.tile(c.tbss_blob, T), np.tile(c.ss_blob, T)
+    step_t, step_s = np.uint64(c.tbss_off[-1]), np.uint64(c.ss_off[-1])
+    to = np.concatenate([(np.arange(T, dtype=np.uint64)[:, None] * step_t + c.tbss_off[None, :-1].astype(np.uint64)).reshape(-1), [np.uint64(T) * step_t]]).astype(np.uint64)
+    so = np.concatenate([(np.arange(T, dtype=np.uint64)[:, None] * step_s + c.ss_off[None, :-1].astype(np.uint64)).reshape(-1), [np.uint64(T) * step_s]]).astype(np.uint64)
+    err, nver, vd = gpu_ctx.collective_verify(qh, tb, to, sb, so)
+    st, st_item = gpu_ctx.last_statuses()
+    assert not np.array(gpu_ctx.last_fenced).any()
+    err, nver, vd = err.reshape(T, -1), nver.reshape(T, -1), vd.reshape(T, -1)
+    assert ((err[0] == 0) == (cerr == 0)).all() and (nver[0] == cnver).all()
+    assert (err == err[0][None, :]).all() and (nver == nver[0][None, :]).all() and (vd == vd[0][None, :]).all()
+    per_tile = len(st) // T
+    assert len(st) == per_tile * T and (st.reshape(T, per_tile) == st[:per_tile][None, :]).all()
+    for i in range(0, c.n_items, 15):
+        r = H.oracle_collective(kr, q, c, i)
+        assert list(st[:per_tile][st_item[:per_tile] == i][:len(r.statuses)]) == r.statuses, i
+    assert 0 < int((err[0] == 0).sum()) < c.n_items and int(gpu_ctx.last_counters()["dsa_ops"]) > 150000
+    gpu_ctx.quorum_destroy(qh)

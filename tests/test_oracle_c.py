@@ -12,9 +12,10 @@ from tests import helpers as H
 RATES = {cb.MUT_BAD_MPI: 0.1, cb.MUT_UNKNOWN_ISSUER: 0.1, cb.MUT_DUP_SIGNER: 0.1, cb.MUT_ONE_SHORT: 0.15, cb.MUT_BAD_TAG: 0.1}
 
 
-@pytest.mark.parametrize("n,dsa,items", [(4, 0.0, 40), (10, 0.3, 30)])
-def test_c_oracle_matches_python_oracle(n, dsa, items):
-    cl = cb.make_cluster(n, dsa_fraction=dsa)
+@pytest.mark.parametrize("n,dsa,items,kind", [(4, 0.0, 40, "dsa2048"), (10, 0.3, 30, "dsa2048"),
+                                              (12, 0.75, 24, ("dsa1024", "dsa3072", "dsa1536", "dsa2048"))])      # DSA of every group size in use
+def test_c_oracle_matches_python_oracle(n, dsa, items, kind):
+    cl = cb.make_cluster(n, dsa_fraction=dsa, dsa_kind=kind)
     c = cb.make_write_corpus(cl, items, mutation_rates=RATES)
     kr, q = H.oracle_keyring(cl), H.clique_quorum(cl)
     co = COracle()
