@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+CALLS = int(os.environ.get("HOSTBUF_CALLS", "6"))      # calls per caller thread in the three-caller leg
+
+
 def main():
     import torch
     import bench
@@ -60,7 +63,7 @@ def main():
             fn(ctxs[k]); fn(ctxs[k])
             gate.wait()
             t0 = time.perf_counter()
-            for _ in range(6):
+            for _ in range(CALLS):
                 fn(ctxs[k])
             spans[k] = (t0, time.perf_counter())
         th = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
@@ -69,8 +72,9 @@ def main():
         for t in th:
             t.join()
         span = max(b for _, b in spans.values()) - min(a for a, _ in spans.values())
-        out[name] = {"alone_ms": round(min(ts) * 1e3, 3), "alone_median_ms": round(float(np.median(ts)) * 1e3, 3), "three_callers_ms_per_call": round(span / 18 * 1e3, 3),
-                     "pieces": tr["pieces"] if tr else None,
+        tr3 = ctx0.host_pipeline_trace()
+        out[name] = {"alone_ms": round(min(ts) * 1e3, 3), "alone_median_ms": round(float(np.median(ts)) * 1e3, 3), "three_callers_ms_per_call": round(span / (3 * CALLS) * 1e3, 3),
+                     "pieces": tr["pieces"] if tr else None, "pieces_last_call_of_three_callers": tr3["pieces"] if tr3 else None,
                      "piece_modexp_ms": [round((p["gpu_modexp_end"] - p["gpu_modexp_start"]) / 1e3, 3) for p in tr["per_piece_us"]] if tr else None,
                      "copies_done_us": round(tr["copy_stream_drained_us"]) if tr else None, "done_us": round(tr["done_us"]) if tr else None}
     print(json.dumps(out))
